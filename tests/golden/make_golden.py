@@ -1,0 +1,547 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, read-only).  It imports the
+reference's modules unmodified, with two stub modules (`gym`, `wandb`; plus `pyglet`
+for the env files) placed in sys.modules because those third-party packages are not
+installed and are not on the arithmetic path.  One harness patch
+is applied: ReplayBuffer.episode_lengths is cast to int64 after construction to restore
+the pinned numpy-1.22 semantics of `uint8 - int` (replay_buffer.py:69,152; SURVEY.md
+section 4 quirk 1).
+
+Only DATA is written: inputs, expected outputs, seeds and version stamps (.npz / .json).
+No reference source, bytecode or pickled module travels.  Weights are produced by
+oracle.dtqn_oracle.init_params (numpy PCG64, key order = state_dict order) and loaded
+into the reference network with load_state_dict, so both sides regenerate them from the
+seed; a checksum of the weights is stored to catch generator drift.
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import random
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+
+# --------------------------------------------------------------------------- #
+# stubs for absent third-party modules
+# --------------------------------------------------------------------------- #
+def install_stubs():
+    gym = types.ModuleType("gym")
+
+    class Env:
+        def seed(self, seed=None):
+            return [seed]
+
+    class _Space:
+        def seed(self, seed=None):
+            return [seed]
+
+    class Discrete(_Space):
+        def __init__(self, n):
+            self.n = n
+
+    class MultiDiscrete(_Space):
+        def __init__(self, nvec):
+            self.nvec = np.asarray(nvec)
+            self.shape = self.nvec.shape
+
+    class MultiBinary(_Space):
+        def __init__(self, n):
+            self.n = n
+
+    class Box(_Space):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Discrete, spaces.MultiDiscrete, spaces.MultiBinary, spaces.Box = Discrete, MultiDiscrete, MultiBinary, Box
+    gym.Env, gym.Wrapper, gym.spaces = Env, Wrapper, spaces
+    utils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding")
+    utils.seeding = seeding
+    gym.utils = utils
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.utils": utils, "gym.utils.seeding": seeding})
+    sys.modules["wandb"] = types.ModuleType("wandb")
+    pyglet = types.ModuleType("pyglet")
+    canvas = types.ModuleType("pyglet.canvas")
+    xlib = types.ModuleType("pyglet.canvas.xlib")
+
+    class NoSuchDisplayException(Exception):
+        pass
+
+    xlib.NoSuchDisplayException = NoSuchDisplayException
+    sys.modules.update({"pyglet": pyglet, "pyglet.canvas": canvas, "pyglet.canvas.xlib": xlib})
+
+
+install_stubs()
+sys.path.insert(0, REF)
+
+from dtqn.networks.dtqn import DTQN as RefDTQN                      # noqa: E402
+from dtqn.agents.dtqn import DtqnAgent as RefAgent                  # noqa: E402
+from dtqn.buffers.replay_buffer import ReplayBuffer as RefBuffer    # noqa: E402
+from utils.context import Context as RefContext                     # noqa: E402
+from utils.epsilon_anneal import LinearAnneal as RefAnneal          # noqa: E402
+from utils.logging_utils import RunningAverage as RefRunAvg         # noqa: E402
+import utils.random as ref_random                                   # noqa: E402
+
+from oracle import dtqn_oracle as O                                  # noqa: E402
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+STAMP = {"torch": torch.__version__, "numpy": np.__version__,
+         "reference": "kevslinger/DTQN @ 2024_08_07", "ref_pins": "torch==1.11.0 numpy==1.22.4"}
+
+
+def checksum(params):
+    return float(sum(float(v.double().abs().sum()) for k, v in sorted(params.items())))
+
+
+def make_ref_net(cfg: O.NetCfg, params):
+    net = RefDTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size,
+                  cfg.num_heads, cfg.num_layers, cfg.history_len, dropout=0.0, gate=cfg.gate,
+                  identity=cfg.identity, pos=cfg.pos, discrete=cfg.discrete,
+                  vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=0)
+    assert list(net.state_dict().keys()) == O.state_dict_keys(cfg), "state_dict key order drifted"
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == O.param_shapes(cfg)[k], k
+    net.load_state_dict({k: v.clone() for k, v in params.items()})
+    return net
+
+
+def synth_episodes(rng, n_eps, T, cfg: O.NetCfg, min_len=3):
+    """Synthetic replay content in the shape of SURVEY.md section 8d."""
+    eps = []
+    for _ in range(n_eps):
+        n = int(rng.integers(min_len, T + 1))
+        if cfg.discrete:
+            obs = rng.integers(0, cfg.vocab_sizes - 1, size=(n + 1, cfg.obs_dim)).astype(np.int64)
+        else:
+            obs = rng.uniform(-1, 1, size=(n + 1, cfg.obs_dim)).astype(np.float32)
+        act = rng.integers(0, cfg.num_actions, size=n)
+        rew = rng.choice(np.array([0, 0, 0, 1, -1], dtype=np.float32), size=n)
+        done = np.zeros(n, dtype=bool)
+        done[-1] = True
+        eps.append((obs, act, rew, done))
+    return eps
+
+
+def make_ref_agent(cfg: O.NetCfg, pol_params, tgt_params, B, T, buf_eps, mask, lr=3e-4, gamma=0.99,
+                   history=None, tuf=10_000):
+    history = cfg.history_len if history is None else history
+    it = iter([pol_params, tgt_params])
+    agent = RefAgent(lambda: make_ref_net(cfg, next(it)), buffer_size=buf_eps * T, device=torch.device("cpu"),
+                     env_obs_length=cfg.obs_dim, max_env_steps=T, obs_mask=mask, num_actions=cfg.num_actions,
+                     is_discrete_env=cfg.discrete, learning_rate=lr, batch_size=B, context_len=cfg.history_len,
+                     gamma=gamma, history=history, target_update_frequency=tuf, bag_size=0)
+    # DqnAgent.__init__ hard-copies policy -> target (dqn.py:49); restore the distinct target weights
+    agent.target_network.load_state_dict({k: v.clone() for k, v in tgt_params.items()})
+    agent.replay_buffer.episode_lengths = agent.replay_buffer.episode_lengths.astype(np.int64)  # quirk 1
+    return agent
+
+
+def fill_agent(agent, episodes):
+    for obs, act, rew, done in episodes:
+        agent.context_reset(obs[0])
+        for t in range(len(act)):
+            agent.observe(obs[t + 1], int(act[t]), float(rew[t]), bool(done[t]))
+        agent.replay_buffer.flush()
+
+
+def run_ref_updates(agent, n_updates):
+    """Run agent.train() n_updates times, capturing the sampled batch, pre-clip grads and stats."""
+    rec = {"batches": [], "grads": [], "norms": [], "stats": [], "pre": [], "post": [], "m": [], "v": []}
+    tparams = [p for p in agent.policy_network.parameters() if p.requires_grad]
+    flat = lambda ts: np.concatenate([t.detach().numpy().ravel() for t in ts])
+    orig_sample = agent.replay_buffer.sample
+
+    def sample(bs):
+        out = orig_sample(bs)
+        rec["batches"].append([np.array(a) for a in out])
+        return out
+
+    agent.replay_buffer.sample = sample
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm, **kw):
+        params = list(params)
+        rec["grads"].append([None if p.grad is None else p.grad.detach().clone() for p in params])
+        n = orig_clip(params, max_norm, **kw)
+        rec["norms"].append(float(n))
+        return n
+
+    torch.nn.utils.clip_grad_norm_ = clip
+    try:
+        for _ in range(n_updates):
+            rec["pre"].append(flat(tparams))
+            agent.train()
+            rec["post"].append(flat(tparams))
+            rec["m"].append(flat([agent.optimizer.state[p]["exp_avg"] for p in tparams]))
+            rec["v"].append(flat([agent.optimizer.state[p]["exp_avg_sq"] for p in tparams]))
+            rec["stats"].append({
+                "td_error": agent.td_errors.q[-1], "grad_norm": agent.grad_norms.q[-1],
+                "qvalue_max": agent.qvalue_max.q[-1], "qvalue_mean": agent.qvalue_mean.q[-1],
+                "qvalue_min": agent.qvalue_min.q[-1], "target_max": agent.target_max.q[-1],
+                "target_mean": agent.target_mean.q[-1], "target_min": agent.target_min.q[-1]})
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+        agent.replay_buffer.sample = orig_sample
+    return rec
+
+
+def batch_to_npz(prefix, b):
+    names = ["obss", "actions", "rewards", "next_obss", "next_actions", "dones", "ep_lens"]
+    return {f"{prefix}{n}": np.asarray(a) for n, a in zip(names, b)}
+
+
+def ref_q(net, obss, actions, discrete):
+    with torch.no_grad():
+        o = torch.as_tensor(obss, dtype=torch.long if discrete else torch.float32)
+        a = torch.as_tensor(actions, dtype=torch.long)
+        return net(o, a).numpy()
+
+
+def td_case(cfg: O.NetCfg, seed, B, T, n_eps, mask, n_updates, store_grads=True, store_params=True,
+            lr=3e-4, history=None, tuf=10_000, trace=False):
+    """One learner fixture: reference agent runs n_updates TD updates on a synthetic buffer."""
+    random.seed(seed)
+    ref_random.RNG.rng = np.random.Generator(np.random.PCG64(seed))
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    pol = O.init_params(cfg, seed=seed, perturb=True)
+    tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+    agent = make_ref_agent(cfg, pol, tgt, B, T, n_eps + 2, mask, lr=lr, history=history, tuf=tuf)
+    fill_agent(agent, synth_episodes(rng, n_eps, T, cfg))
+    # Q-values of the three forwards on the first batch, BEFORE any update
+    state = random.getstate()
+    first = [np.array(a) for a in agent.replay_buffer.sample(B)]
+    random.setstate(state)
+    agent.eval_off()
+    out = {"cfg": json.dumps(cfg.to_json()), "seed": seed, "B": B, "T": T, "mask": mask,
+           "lr": lr, "gamma": 0.99, "history": cfg.history_len if history is None else history, "tuf": tuf,
+           "n_updates": n_updates, "pol_checksum": checksum(pol), "tgt_checksum": checksum(tgt),
+           "stamp": json.dumps(STAMP)}
+    out["q_all"] = ref_q(agent.policy_network, first[0], first[1], cfg.discrete)
+    out["q_next_pol"] = ref_q(agent.policy_network, first[3], first[4], cfg.discrete)
+    out["q_next_tgt"] = ref_q(agent.target_network, first[3], first[4], cfg.discrete)
+    rec = run_ref_updates(agent, n_updates)
+    assert all(np.array_equal(a, b) for a, b in zip(first, rec["batches"][0]))
+    for i, b in enumerate(rec["batches"]):
+        out.update(batch_to_npz(f"batch{i}_", b))
+    keys = O.trainable_keys(cfg)
+    named = dict(agent.policy_network.named_parameters())          # de-duplicated, registration order
+    pnames = [n for n, p in agent.policy_network.named_parameters()]
+    out["stats"] = json.dumps(rec["stats"])
+    out["grad_norms"] = np.array(rec["norms"], dtype=np.float64)
+    if store_grads:
+        # pre-clip gradients of update 0, concatenated in oracle.trainable_keys order
+        gl = {n: g for n, g in zip(pnames, rec["grads"][0]) if g is not None}
+        assert sorted(gl) == sorted(keys)
+        out["grad0_flat"] = np.concatenate([gl[k].numpy().ravel() for k in keys])
+    sd = agent.policy_network.state_dict()
+    if store_params:
+        out["final_flat"] = np.concatenate([sd[k].numpy().ravel() for k in keys])
+    out["final_checksum"] = checksum({k: sd[k] for k in keys})
+    # parameters after the FIRST update (exact pin of Adam step k=1 and of the clip coefficient)
+    if store_grads and store_params:
+        out["post0_flat"] = rec["post"][0]
+    # teacher-forcing trace: state before/after every update, so each Adam step can be checked from
+    # the reference's own pre-state (free-running comparisons are chaotic, see tests/test_oracle_golden.py)
+    if trace:
+        for i in range(n_updates):
+            out[f"pre{i}_flat"], out[f"post{i}_flat"] = rec["pre"][i], rec["post"][i]
+            out[f"m{i}_flat"], out[f"v{i}_flat"] = rec["m"][i], rec["v"][i]
+            if i > 0:
+                out[f"grad{i}_flat"] = np.concatenate([g.numpy().ravel() for g in rec["grads"][i] if g is not None])
+    out["q_all_final"] = ref_q(agent.policy_network, first[0], first[1], cfg.discrete)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# fixture groups
+# --------------------------------------------------------------------------- #
+def gen_G1():
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    out = td_case(cfg, seed=11, B=32, T=200, n_eps=60, mask=-5, n_updates=3)
+    np.savez_compressed(os.path.join(HERE, "G1_cfg1_td.npz"), **out)
+
+
+def variant_cfgs():
+    """24 cases: the full gate x identity x pos factorial (12), each with two of the six
+    (a_embed, obs kind) pairs in rotation, so every pair is seen under four network variants."""
+    obs_kinds = [dict(obs_dim=3, discrete=False, vocab_sizes=0, mask=-5),
+                 dict(obs_dim=10, discrete=True, vocab_sizes=9, mask=8),
+                 dict(obs_dim=1, discrete=True, vocab_sizes=22, mask=21)]
+    pairs = [(a, ok) for a in (0, 4) for ok in obs_kinds]
+    cases = []
+    combo = 0
+    for gate in ("res", "gru"):
+        for identity in (False, True):
+            for pos in ("learned", "sin", "none"):
+                for j in range(2):
+                    a_embed, ok = pairs[(2 * combo + j + combo // 3) % 6]
+                    cfg = O.NetCfg(obs_dim=ok["obs_dim"], num_actions=4, embed_per_obs_dim=8,
+                                   action_dim=a_embed, inner_embed_size=16, num_heads=2, num_layers=2,
+                                   history_len=8, gate=gate, identity=identity, pos=pos,
+                                   discrete=ok["discrete"], vocab_sizes=ok["vocab_sizes"])
+                    cases.append((cfg, ok["mask"]))
+                combo += 1
+    return cases
+
+
+def gen_G2():
+    out = {}
+    names = []
+    for idx, (cfg, mask) in enumerate(variant_cfgs()):
+        name = f"v{idx:02d}"
+        names.append(name)
+        # history < context on every third case pins the [:, -history:] slice (dtqn.py:240-241)
+        hist = 5 if idx % 3 == 0 else None
+        c = td_case(cfg, seed=100 + idx, B=2, T=12, n_eps=6, mask=mask, n_updates=3, history=hist, tuf=2,
+                    store_params=(idx % 4 == 0), trace=(idx in (0, 13, 22)))
+        for k, v in c.items():
+            out[f"{name}/{k}"] = v
+    out["names"] = json.dumps(names)
+    np.savez_compressed(os.path.join(HERE, "G2_variants_td.npz"), **out)
+
+
+def gen_G3():
+    """cfg 3/4/5 shapes, outputs + stats only, B=2."""
+    cfgs = {
+        "cfg3": (O.NetCfg(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2,
+                          history_len=50, discrete=True, vocab_sizes=9), 8, 50),
+        "cfg4": (O.NetCfg(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, num_layers=2,
+                          history_len=128, discrete=True, vocab_sizes=12), 11, 250),
+        "cfg5": (O.NetCfg(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, num_layers=2,
+                          history_len=256, discrete=True, vocab_sizes=22), 21, 256),
+    }
+    out = {}
+    for name, (cfg, mask, T) in cfgs.items():
+        c = td_case(cfg, seed=31, B=2, T=T, n_eps=5, mask=mask, n_updates=1, store_grads=False,
+                    store_params=False)
+        for k, v in c.items():
+            out[f"{name}/{k}"] = v
+    out["names"] = json.dumps(list(cfgs))
+    np.savez_compressed(os.path.join(HERE, "G3_cfg345_td.npz"), **out)
+
+
+def gen_G4():
+    """Variable-length actor forward (dtqn/agents/dtqn.py:81-107): Q[:, -1] at seq len 1,2,17,50."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    cfg_a = O.NetCfg(obs_dim=3, num_actions=3, action_dim=8, inner_embed_size=64, num_heads=8, num_layers=2,
+                     history_len=50, gate="gru", pos="sin")
+    out = {"stamp": json.dumps(STAMP)}
+    for tag, c in (("res", cfg), ("gru_a8_sin", cfg_a)):
+        params = O.init_params(c, seed=41, perturb=True)
+        net = make_ref_net(c, params)
+        net.train()
+        rng = np.random.Generator(np.random.PCG64(41))
+        out[f"{tag}/cfg"] = json.dumps(c.to_json())
+        out[f"{tag}/checksum"] = checksum(params)
+        for n in (1, 2, 17, 50):
+            obs = rng.uniform(-1, 1, size=(1, n, 3)).astype(np.float32)
+            act = rng.integers(0, 3, size=(1, n, 1))
+            out[f"{tag}/n{n}_obs"] = obs
+            out[f"{tag}/n{n}_act"] = act
+            out[f"{tag}/n{n}_q"] = ref_q(net, obs, act, False)
+    np.savez_compressed(os.path.join(HERE, "G4_actor_varlen.npz"), **out)
+
+
+def gen_G5():
+    """ReplayBuffer: scripted store/flush sequence (with wrap-around and an in-progress episode)
+    -> full array dump + sample() under random.seed (replay_buffer.py:71-168)."""
+    out = {"stamp": json.dumps(STAMP)}
+    for tag, (O_len, mask, T, L, dtype) in {"cont": (3, -5, 12, 5, np.float32), "disc": (2, 7, 9, 4, np.int64)}.items():
+        buf = RefBuffer(buffer_size=5 * T, env_obs_length=O_len, obs_mask=mask, max_episode_steps=T, context_len=L)
+        buf.episode_lengths = buf.episode_lengths.astype(np.int64)
+        rng = np.random.Generator(np.random.PCG64(51))
+        script = []
+        for ep in range(8):                                     # 8 episodes into 5 slots -> wraps
+            n = int(rng.integers(2, T + 1)) if ep != 3 else T   # one full-length episode
+            o0 = (rng.uniform(-1, 1, O_len).astype(np.float32) if dtype == np.float32
+                  else rng.integers(0, mask, O_len))
+            buf.store_obs(o0)
+            script.append(("store_obs", np.asarray(o0, dtype=np.float64)))
+            steps = n if ep != 7 else 3                          # episode 7 stays in progress (no flush)
+            for t in range(steps):
+                o = (rng.uniform(-1, 1, O_len).astype(np.float32) if dtype == np.float32
+                     else rng.integers(0, mask, O_len))
+                a, r, d = int(rng.integers(0, 4)), float(rng.choice([0.0, 1.0, -1.0])), bool(t == n - 1)
+                buf.store(o, a, r, d, t + 1)
+                script.append(("store", np.concatenate([np.asarray(o, dtype=np.float64), [a, r, d, t + 1]])))
+            if ep != 7:
+                buf.flush()
+                script.append(("flush", np.zeros(0)))
+        out[f"{tag}/script_ops"] = json.dumps([s[0] for s in script])
+        out[f"{tag}/script_args"] = np.array([np.pad(s[1], (0, O_len + 4 - len(s[1]))) for s in script])
+        out[f"{tag}/meta"] = json.dumps(dict(obs_len=O_len, mask=mask, T=T, L=L, buffer_size=5 * T,
+                                             discrete=dtype != np.float32))
+        out[f"{tag}/obss"], out[f"{tag}/actions"] = buf.obss.copy(), buf.actions.copy()
+        out[f"{tag}/rewards"], out[f"{tag}/dones"] = buf.rewards.copy(), buf.dones.copy()
+        out[f"{tag}/episode_lengths"] = buf.episode_lengths.copy()
+        out[f"{tag}/pos"] = np.array(buf.pos)
+        out[f"{tag}/can_sample_4"] = buf.can_sample(4)
+        out[f"{tag}/can_sample_7"] = buf.can_sample(7)
+        out[f"{tag}/can_sample_8"] = buf.can_sample(8)
+        random.seed(77)
+        for i in range(3):
+            s = buf.sample(6)
+            out.update(batch_to_npz(f"{tag}/sample{i}_", s))
+    np.savez_compressed(os.path.join(HERE, "G5_replay.npz"), **out)
+
+
+def gen_G6():
+    """Env traces: CarFlag / Memory (obs, reward, done, info.is_success) for fixed seeds and action
+    scripts (envs/car_flag.py:70-159, envs/memory_cards.py:64-116), without the TimeLimit wrapper
+    (gym 0.18's TimeLimit is third-party; the build restates its step-count semantics)."""
+    car = load_by_path("ref_car_flag", os.path.join(REF, "envs/car_flag.py"))
+    mem = load_by_path("ref_memory", os.path.join(REF, "envs/memory_cards.py"))
+    out = {"stamp": json.dumps(STAMP)}
+    for seed in (1, 7):
+        env = car.CarFlag(discrete=True)
+        env.seed(seed)
+        rng = np.random.Generator(np.random.PCG64(seed + 5))
+        obs_l, rew_l, done_l, suc_l, act_l, reset_l = [], [], [], [], [], []
+        for ep in range(6):
+            o = env.reset()
+            reset_l.append(len(obs_l))
+            obs_l.append(np.asarray(o, dtype=np.float64)); rew_l.append(0.0); done_l.append(False); suc_l.append(False); act_l.append(-1)
+            # episodes alternate between a random policy and "always push right/left"
+            for t in range(200):
+                a = int(rng.integers(0, 3)) if ep % 3 == 0 else (2 if ep % 3 == 1 else 0)
+                o, r, d, info = env.step(a)
+                obs_l.append(np.asarray(o, dtype=np.float64)); rew_l.append(float(r)); done_l.append(bool(d))
+                suc_l.append(bool(info["is_success"])); act_l.append(a)
+                if d:
+                    break
+        out[f"carflag_s{seed}/obs"] = np.array(obs_l); out[f"carflag_s{seed}/rew"] = np.array(rew_l)
+        out[f"carflag_s{seed}/done"] = np.array(done_l); out[f"carflag_s{seed}/success"] = np.array(suc_l)
+        out[f"carflag_s{seed}/act"] = np.array(act_l); out[f"carflag_s{seed}/resets"] = np.array(reset_l)
+
+        env = mem.Memory(num_pairs=5)
+        env.seed(seed)
+        obs_l, rew_l, done_l, suc_l, act_l, reset_l = [], [], [], [], [], []
+        for ep in range(6):
+            o = env.reset()
+            reset_l.append(len(obs_l))
+            obs_l.append(np.array(o, dtype=np.float64)); rew_l.append(0.0); done_l.append(False); suc_l.append(False); act_l.append(-1)
+            for t in range(50):
+                if ep % 2 == 0:
+                    a = int(rng.integers(0, 10))
+                else:   # cheating policy that reads env.state -> exercises the success branch
+                    cur = env.current_card
+                    cand = [i for i in range(10) if env.state[i] == env.state[cur] and i != cur]
+                    a = cand[0]
+                o, r, d, info = env.step(a)
+                obs_l.append(np.array(o, dtype=np.float64)); rew_l.append(float(r)); done_l.append(bool(d))
+                suc_l.append(bool(info.get("is_success", False))); act_l.append(a)
+                if d:
+                    break
+        out[f"memory_s{seed}/obs"] = np.array(obs_l); out[f"memory_s{seed}/rew"] = np.array(rew_l)
+        out[f"memory_s{seed}/done"] = np.array(done_l); out[f"memory_s{seed}/success"] = np.array(suc_l)
+        out[f"memory_s{seed}/act"] = np.array(act_l); out[f"memory_s{seed}/resets"] = np.array(reset_l)
+    np.savez_compressed(os.path.join(HERE, "G6_env_traces.npz"), **out)
+
+
+def gen_G7():
+    """LinearAnneal, RunningAverage and Context traces (utils/epsilon_anneal.py:28-34,
+    utils/logging_utils.py:10-24, utils/context.py:36-96 incl. the int-truncation quirk)."""
+    out = {"stamp": json.dumps(STAMP)}
+    eps = RefAnneal(1.0, 0.1, 50)
+    vals = []
+    for _ in range(400):
+        vals.append(eps.val)
+        eps.anneal()
+    out["anneal_1.0_0.1_50"] = np.array(vals)
+    ra = RefRunAvg(5)
+    xs = np.random.Generator(np.random.PCG64(3)).normal(size=17)
+    means = []
+    for x in xs:
+        ra.add(float(x))
+        means.append(ra.mean())
+    out["runavg_in"], out["runavg_mean"] = xs, np.array(means)
+    out["runavg_empty_mean"] = RefRunAvg(5).mean()
+    # Context: continuous env with integer mask -5 -> int64 storage truncates floats (quirk 2)
+    for tag, (mask, olen, disc) in {"cont": (-5, 3, False), "disc": (8, 2, True)}.items():
+        ref_random.RNG.rng = np.random.Generator(np.random.PCG64(9))
+        ctx = RefContext(4, mask, 3, olen)
+        rng = np.random.Generator(np.random.PCG64(10))
+        o0 = rng.uniform(-1, 1, olen) if not disc else rng.integers(0, 8, olen)
+        ctx.reset(o0)
+        obs_tr, act_tr, ts_tr, ins = [ctx.obs.copy()], [ctx.action.copy()], [ctx.timestep], [np.asarray(o0, dtype=np.float64)]
+        for t in range(7):
+            o = rng.uniform(-1, 1, olen) if not disc else rng.integers(0, 8, olen)
+            a = int(rng.integers(0, 3))
+            ctx.add_transition(o, a, 1.0, False)
+            obs_tr.append(ctx.obs.copy()); act_tr.append(ctx.action.copy()); ts_tr.append(ctx.timestep)
+            ins.append(np.concatenate([np.asarray(o, dtype=np.float64), [a]]))
+        out[f"ctx_{tag}/obs"] = np.array(obs_tr); out[f"ctx_{tag}/action"] = np.array(act_tr)
+        out[f"ctx_{tag}/timestep"] = np.array(ts_tr)
+        out[f"ctx_{tag}/in0"] = ins[0]; out[f"ctx_{tag}/ins"] = np.array(ins[1:])
+        out[f"ctx_{tag}/obs_dtype"] = str(ctx.obs.dtype)
+    np.savez_compressed(os.path.join(HERE, "G7_misc.npz"), **out)
+
+
+def time_reference():
+    """the reference's own DtqnAgent.train() on CPU, cfg 1 and 2."""
+    res = {"stamp": STAMP, "nproc": os.cpu_count(), "runs": []}
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    for B in (32, 256):
+        for threads in (8, 1):
+            torch.set_num_threads(threads)
+            random.seed(1)
+            ref_random.RNG.rng = np.random.Generator(np.random.PCG64(1))
+            rng = np.random.Generator(np.random.PCG64(1))
+            pol = O.init_params(cfg, seed=1)
+            agent = make_ref_agent(cfg, pol, pol, B, 200, 300, -5)
+            fill_agent(agent, synth_episodes(rng, 290, 200, cfg, min_len=5))
+            n_warm, n = (5, 40) if B == 32 else (2, 8)
+            for _ in range(n_warm):
+                agent.train()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                agent.train()
+                ts.append(time.perf_counter() - t0)
+            ts = np.array(ts) * 1e3
+            res["runs"].append({"config": f"cfg1-shapes B={B}", "threads": threads, "updates": n,
+                                "ms_median": float(np.median(ts)), "ms_p10": float(np.percentile(ts, 10)),
+                                "ms_p90": float(np.percentile(ts, 90)),
+                                "td_updates_per_s": float(1e3 / np.median(ts))})
+            print(res["runs"][-1])
+    torch.set_num_threads(8)
+    with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "time"]
+    torch.manual_seed(0)
+    for w in which:
+        t0 = time.time()
+        {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
+         "time": time_reference}[w]()
+        print(f"{w}: done in {time.time() - t0:.1f}s")

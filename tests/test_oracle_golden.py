@@ -1,0 +1,202 @@
+"""Pin the CPU oracle (oracle/dtqn_oracle.py) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU-only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dtqn_oracle as O
+
+from conftest import GOLDEN
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def _checksum(params):
+    return float(sum(float(v.double().abs().sum()) for k, v in sorted(params.items())))
+
+
+def _batch(z, prefix, i, discrete):
+    g = lambda n: z[f"{prefix}batch{i}_{n}"]
+    ot = torch.long if discrete else torch.float32
+    return O.Batch(
+        obss=torch.as_tensor(g("obss"), dtype=ot), actions=torch.as_tensor(g("actions"), dtype=torch.long),
+        rewards=torch.as_tensor(g("rewards"), dtype=torch.float32),
+        next_obss=torch.as_tensor(g("next_obss"), dtype=ot),
+        next_actions=torch.as_tensor(g("next_actions"), dtype=torch.long),
+        dones=torch.as_tensor(g("dones"), dtype=torch.long))
+
+
+def assert_first_step_close(got, ref, pre, grad0, lr):
+    """After ONE Adam step from zero state the update is lr * g / (|g| + eps'): elements whose
+    gradient is above the fp32 summation-noise floor must agree tightly; elements at the floor
+    (e.g. the key-bias rows of in_proj_bias, whose true gradient is exactly 0 because softmax is
+    shift-invariant) may land anywhere within +-lr of the pre-step value."""
+    d = np.abs(got - ref)
+    g = np.abs(grad0)
+    solid = g >= 1e-4 * g.max()
+    assert solid.mean() > 0.5
+    assert d[solid].max() <= 5e-7
+    assert np.abs(got - pre).max() <= 1.001 * lr
+    assert d.max() <= 2.002 * lr
+
+
+def assert_params_close(got, ref, lr, n_updates):
+    """Free-running multi-step comparison.  Adam divides by sqrt(v), so noise-floor gradients turn
+    into +-lr moves, those flip ReLU/argmax decisions on later steps, and two correct fp32
+    implementations with different reduction orders drift apart (measured here: oracle vs
+    reference 4.6e-4 max after 3 updates at cfg 1, while oracle-vs-oracle at 8 vs 1 threads is
+    8e-6).  So this check is statistical: bounded by the total Adam travel, tight in the median and
+    for >= 98 % of the elements.  Exact per-step pins are assert_first_step_close and the
+    teacher-forced traces."""
+    d = np.abs(got - ref)
+    assert d.max() <= 1.01 * lr * n_updates
+    assert (d > 1e-5).mean() <= 0.02
+    assert np.median(d) <= 2e-7
+
+
+def _set_flat(learner, keys, flat):
+    off = 0
+    for k in keys:
+        n = learner.pol[k].numel()
+        learner.pol[k].copy_(torch.from_numpy(flat[off:off + n]).reshape(learner.pol[k].shape))
+        off += n
+
+
+def _check_trace(z, prefix, cfg, pol, tgt, lr, gamma, hist, tuf):
+    """Teacher-forced: every update starts from the reference's own pre-update parameters and
+    Adam moments, so steps k = 1, 2, 3 (bias corrections, moment recursion, target sync at tuf=2,
+    shared-gate gradient accumulation) are each pinned without chaotic drift."""
+    keys = O.trainable_keys(cfg)
+    learner = O.OracleLearner(cfg, pol, lr=lr, gamma=gamma, history=hist, tuf=tuf, target=tgt)
+    for i in range(int(z[prefix + "n_updates"])):
+        pre = z[prefix + f"pre{i}_flat"]
+        _set_flat(learner, keys, pre)
+        if i > 0:
+            off = 0
+            for k in keys:
+                n = learner.pol[k].numel()
+                learner.opt.m[k].copy_(torch.from_numpy(z[prefix + f"m{i-1}_flat"][off:off + n]).reshape(learner.pol[k].shape))
+                learner.opt.v[k].copy_(torch.from_numpy(z[prefix + f"v{i-1}_flat"][off:off + n]).reshape(learner.pol[k].shape))
+                off += n
+            # target sync happened inside the reference at num_train_steps % tuf == 0
+            if i % tuf == 0:
+                for k in learner.tgt:
+                    learner.tgt[k].copy_(learner.pol[k])
+        learner.opt.step = i
+        learner.num_train_steps = i
+        learner.update(_batch(z, prefix, i, cfg.discrete))
+        flat = lambda d: np.concatenate([d[k].numpy().ravel() for k in keys])
+        m_ref, v_ref = z[prefix + f"m{i}_flat"], z[prefix + f"v{i}_flat"]
+        assert np.abs(flat(learner.opt.m) - m_ref).max() <= 1e-5 * np.abs(m_ref).max()
+        assert np.abs(flat(learner.opt.v) - v_ref).max() <= 1e-5 * np.abs(v_ref).max()
+        got, ref = flat(learner.pol), z[prefix + f"post{i}_flat"]
+        d = np.abs(got - ref)
+        # an element is well-conditioned when its moment estimate is far above the noise floor
+        solid = np.abs(m_ref) >= 1e-3 * np.abs(m_ref).max()
+        assert d[solid].max() <= 1e-6
+        assert d.max() <= 2.002 * lr
+
+
+def _check_td_case(z, prefix, q_tol=2e-6, grad_rtol=1e-4):
+    cfg = O.NetCfg(**json.loads(str(z[prefix + "cfg"])))
+    seed = int(z[prefix + "seed"])
+    pol = O.init_params(cfg, seed=seed, perturb=True)
+    tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+    assert _checksum(pol) == pytest.approx(float(z[prefix + "pol_checksum"]), rel=1e-12)
+    assert _checksum(tgt) == pytest.approx(float(z[prefix + "tgt_checksum"]), rel=1e-12)
+    hist, gamma, lr, tuf = int(z[prefix + "history"]), float(z[prefix + "gamma"]), float(z[prefix + "lr"]), int(z[prefix + "tuf"])
+    b0 = _batch(z, prefix, 0, cfg.discrete)
+    # the +1 overlap of the two windows (replay_buffer.py:160-167)
+    assert torch.equal(b0.next_obss[:, :-1], b0.obss[:, 1:])
+    with torch.no_grad():
+        q_all = O.forward(pol, cfg, b0.obss, b0.actions)
+        qnp = O.forward(pol, cfg, b0.next_obss, b0.next_actions)
+        qnt = O.forward(tgt, cfg, b0.next_obss, b0.next_actions)
+    scale = max(1.0, float(np.abs(z[prefix + "q_all"]).max()))
+    assert np.abs(q_all.numpy() - z[prefix + "q_all"]).max() <= q_tol * scale
+    assert np.abs(qnp.numpy() - z[prefix + "q_next_pol"]).max() <= q_tol * scale
+    assert np.abs(qnt.numpy() - z[prefix + "q_next_tgt"]).max() <= q_tol * scale
+    # gradients of update 0
+    if prefix + "grad0_flat" in z:
+        grads, _ = O.td_gradients(pol, tgt, cfg, b0, gamma, hist)
+        flat = np.concatenate([grads[k].numpy().ravel() for k in O.trainable_keys(cfg)])
+        ref = z[prefix + "grad0_flat"]
+        assert flat.shape == ref.shape
+        denom = np.abs(ref).max()
+        assert np.abs(flat - ref).max() <= grad_rtol * denom
+        if prefix + "post0_flat" in z:
+            one = O.OracleLearner(cfg, pol, lr=lr, gamma=gamma, history=hist, tuf=tuf, target=tgt)
+            pre = np.concatenate([one.pol[k].numpy().ravel() for k in O.trainable_keys(cfg)])
+            one.update(b0)
+            got = np.concatenate([one.pol[k].numpy().ravel() for k in O.trainable_keys(cfg)])
+            assert_first_step_close(got, z[prefix + "post0_flat"], pre, ref, lr)
+    if prefix + "pre1_flat" in z:
+        _check_trace(z, prefix, cfg, pol, tgt, lr, gamma, hist, tuf)
+    # full free-running updates: loss / stats / grad norm / final parameters
+    learner = O.OracleLearner(cfg, pol, lr=lr, gamma=gamma, history=hist, tuf=tuf, target=tgt)
+    ref_stats = json.loads(str(z[prefix + "stats"]))
+    for i in range(int(z[prefix + "n_updates"])):
+        st = learner.update(_batch(z, prefix, i, cfg.discrete))
+        for k, v in ref_stats[i].items():
+            assert st[k] == pytest.approx(v, rel=(2e-4 if i == 0 else 5e-3), abs=2e-5), (i, k)
+    keys = O.trainable_keys(cfg)
+    if prefix + "final_flat" in z:
+        flat = np.concatenate([learner.pol[k].numpy().ravel() for k in keys])
+        assert_params_close(flat, z[prefix + "final_flat"], lr, int(z[prefix + "n_updates"]))
+    assert _checksum({k: learner.pol[k] for k in keys}) == pytest.approx(float(z[prefix + "final_checksum"]), rel=1e-3)
+    with torch.no_grad():
+        qf = O.forward(learner.pol, cfg, b0.obss, b0.actions)
+    # chaotic floor (see assert_params_close): functional agreement after n free-running updates
+    assert np.abs(qf.numpy() - z[prefix + "q_all_final"]).max() <= 2e-3 * scale
+
+
+def test_G1_cfg1_full_size():
+    _check_td_case(_load("G1_cfg1_td.npz"), "")
+
+
+def test_G2_variant_matrix():
+    z = _load("G2_variants_td.npz")
+    names = json.loads(str(z["names"]))
+    assert len(names) == 24
+    seen = set()
+    for n in names:
+        cfg = json.loads(str(z[f"{n}/cfg"]))
+        seen.add((cfg["gate"], cfg["identity"], cfg["pos"]))
+        _check_td_case(z, n + "/")
+    assert len(seen) == 12
+
+
+def test_G3_cfg345_shapes():
+    z = _load("G3_cfg345_td.npz")
+    for n in json.loads(str(z["names"])):
+        _check_td_case(z, n + "/", q_tol=5e-6)
+
+
+def test_G4_actor_variable_length():
+    z = _load("G4_actor_varlen.npz")
+    for tag in ("res", "gru_a8_sin"):
+        cfg = O.NetCfg(**json.loads(str(z[f"{tag}/cfg"])))
+        params = O.init_params(cfg, seed=41, perturb=True)
+        assert _checksum(params) == pytest.approx(float(z[f"{tag}/checksum"]), rel=1e-12)
+        for n in (1, 2, 17, 50):
+            with torch.no_grad():
+                q = O.forward(params, cfg, torch.as_tensor(z[f"{tag}/n{n}_obs"]),
+                              torch.as_tensor(z[f"{tag}/n{n}_act"], dtype=torch.long))
+            ref = z[f"{tag}/n{n}_q"]
+            assert q.shape == ref.shape == (1, n, 3)
+            assert np.abs(q.numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_shared_gate_and_frozen_keys():
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, gate="gru", pos="sin")
+    keys = O.trainable_keys(cfg)
+    assert not any(k.startswith("transformer_layers.1.attn_gate") for k in keys)
+    assert "position_embedding.position_encoding" not in keys
+    assert not any(k.endswith("attn_mask") for k in keys)
+    p = O.init_params(cfg, 0)
+    assert p["transformer_layers.1.mlp_gate.w_g.weight"] is p["transformer_layers.0.mlp_gate.w_g.weight"]
