@@ -1,0 +1,183 @@
+"""ctypes binding of libdtqn_hip.so, generated from include/dtqn_hip.h at import time.
+
+The header is the single source of truth for the C ABI: the struct layouts below are parsed out of
+it (members are restricted to int32_t / uint32_t / float / pointers there), so the Python side can
+never drift from the library.  This module only knows how to LOAD a library and describe its
+structs; dtqn_amd.engine decides which library is the product one (the hipcc build for gfx950,
+and nothing else -- there is no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "dtqn_hip.h")
+
+_SCALARS = {
+    "int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "float": ctypes.c_float, "int": ctypes.c_int,
+}
+
+
+def _strip_comments(src: str) -> str:
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.sub(r"//[^\n]*", "", src)
+
+
+def parse_structs(header_path: str = HEADER) -> Dict[str, List[Tuple[str, object]]]:
+    src = _strip_comments(open(header_path).read())
+    out: Dict[str, List[Tuple[str, object]]] = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        name, body = m.group(3), m.group(2)
+        fields: List[Tuple[str, object]] = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            if "*" in decl:
+                for nm in decl.split("*")[-1].split(","):
+                    fields.append((nm.strip(), ctypes.c_void_p))
+                continue
+            toks = decl.split(" ", 1)
+            ctype = _SCALARS[toks[0]]
+            for nm in toks[1].split(","):
+                fields.append((nm.strip(), ctype))
+        out[name] = fields
+    return out
+
+
+def parse_defines(header_path: str = HEADER) -> Dict[str, int]:
+    src = _strip_comments(open(header_path).read())
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DTQN_\w+)\s+(-?\d+)\s*$", src, flags=re.M)}
+
+
+def parse_functions(header_path: str = HEADER) -> List[str]:
+    src = _strip_comments(open(header_path).read())
+    src = re.sub(r"typedef\s+struct.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    return re.findall(r"\b(dtqn_\w+)\s*\(", src)
+
+
+_STRUCTS = parse_structs()
+DEFINES = parse_defines()
+FUNCTIONS = sorted(set(parse_functions()))
+
+
+def _make(name: str):
+    return type(name, (ctypes.Structure,), {"_fields_": _STRUCTS[name]})
+
+
+DtqnNet = _make("DtqnNet")
+DtqnWJob = _make("DtqnWJob")
+DtqnReplay = _make("DtqnReplay")
+DtqnReplayRecord = _make("DtqnReplayRecord")
+DtqnTd = _make("DtqnTd")
+
+
+def load_library(path: str) -> ctypes.CDLL:
+    """dlopen `path` and declare the prototypes of every entry point the header lists.
+    Raises if the file or any declared symbol is missing."""
+    lib = ctypes.CDLL(path)
+    missing = [f for f in FUNCTIONS if not hasattr(lib, f)]
+    if missing:
+        raise OSError(f"{path} does not export {missing} (declared in include/dtqn_hip.h)")
+    vp, i32, u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32
+    P = ctypes.POINTER
+    protos = {
+        "dtqn_net_init": [P(DtqnNet)],
+        "dtqn_net_wjobs": [P(DtqnNet), P(DtqnWJob)],
+        "dtqn_net_fill_frozen": [P(DtqnNet), vp],
+        "dtqn_lds_bytes_forward": [P(DtqnNet), i32],
+        "dtqn_lds_bytes_backward": [P(DtqnNet)],
+        "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
+        "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
+        "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
+        "dtqn_td_forward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
+        "dtqn_td_backward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
+        "dtqn_td_wgrad": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_td_reduce": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_td_gradnorm": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_td_clip_adam": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
+        "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
+        "dtqn_abi_version": [],
+        "dtqn_build_info": [],
+    }
+    for name, argtypes in protos.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "dtqn_build_info" else ctypes.c_int
+    assert set(protos) == set(FUNCTIONS), sorted(set(protos) ^ set(FUNCTIONS))
+    if lib.dtqn_abi_version() != DEFINES["DTQN_ABI_VERSION"]:
+        raise OSError(f"{path}: ABI version {lib.dtqn_abi_version()} != header {DEFINES['DTQN_ABI_VERSION']}")
+    return lib
+
+
+GATES = {"res": DEFINES["DTQN_GATE_RES"], "gru": DEFINES["DTQN_GATE_GRU"]}
+POS = {"learned": DEFINES["DTQN_POS_LEARNED"], "sin": DEFINES["DTQN_POS_SIN"], "none": DEFINES["DTQN_POS_NONE"]}
+
+
+def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, inner_embed_size=64, num_heads=8,
+             num_layers=2, history_len=50, gate="res", identity=False, pos="learned", discrete=False,
+             vocab_sizes=0) -> DtqnNet:
+    """Build and initialise a DtqnNet from the reference's DTQN constructor arguments
+    (dtqn/networks/dtqn.py:41-59)."""
+    net = DtqnNet()
+    net.obs_dim, net.num_actions, net.embed_per_obs, net.action_dim = obs_dim, num_actions, embed_per_obs_dim, action_dim
+    net.d_model, net.num_heads, net.num_layers, net.ctx_len = inner_embed_size, num_heads, num_layers, history_len
+    if gate not in GATES:
+        raise ValueError("Gate must be one of `gru`, `res`")          # dtqn.py:114
+    net.gate, net.identity, net.pos = GATES[gate], int(bool(identity)), POS[str(pos)]
+    net.discrete, net.vocab = int(bool(discrete)), int(vocab_sizes or 0)
+    rc = lib.dtqn_net_init(ctypes.byref(net))
+    if rc != 0:
+        raise NotImplementedError(
+            f"dtqn_net_init rc={rc}: this DTQN variant/shape is outside the gfx950 kernels' coverage "
+            f"(D={inner_embed_size}, H={num_heads}, L={history_len}, gate={gate}); see DESIGN.md")
+    return net
+
+
+def param_table(net: DtqnNet) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
+    """state_dict key -> (offset into theta, shape), using the reference's key names
+    (SURVEY.md section 8b).  Shared GRU gates appear under every layer prefix with the same offset."""
+    D, L, A, a = net.d_model, net.ctx_len, net.num_actions, net.action_dim
+    tab: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+    if a > 0:
+        tab["action_embedding.embedding.0.weight"] = (net.off_act_emb, (A, a))
+    if net.discrete:
+        tab["obs_embedding.observation_embedding.0.weight"] = (net.off_obs_tab, (net.vocab, net.embed_per_obs))
+        tab["obs_embedding.observation_embedding.2.weight"] = (net.off_obs_w, (D - a, net.ke))
+        tab["obs_embedding.observation_embedding.2.bias"] = (net.off_obs_b, (D - a,))
+    else:
+        tab["obs_embedding.observation_embedding.weight"] = (net.off_obs_w, (D - a, net.ke))
+        tab["obs_embedding.observation_embedding.bias"] = (net.off_obs_b, (D - a,))
+    tab["position_embedding.position_encoding"] = (net.off_pos, (1, L, D))
+    gate_names = [("w_r.weight", net.go_w_r, (D, D)), ("u_r.weight", net.go_u_r, (D, D)),
+                  ("w_z.weight", net.go_w_z, (D, D)), ("w_z.bias", net.go_b_z, (D,)),
+                  ("u_z.weight", net.go_u_z, (D, D)), ("w_g.weight", net.go_w_g, (D, D)),
+                  ("u_g.weight", net.go_u_g, (D, D))]
+    for l in range(net.num_layers):
+        base = net.off_layer0 + l * net.layer_stride
+        pre = f"transformer_layers.{l}."
+        tab[pre + "layernorm1.weight"] = (base + net.lo_ln1_w, (D,))
+        tab[pre + "layernorm1.bias"] = (base + net.lo_ln1_b, (D,))
+        tab[pre + "layernorm2.weight"] = (base + net.lo_ln2_w, (D,))
+        tab[pre + "layernorm2.bias"] = (base + net.lo_ln2_b, (D,))
+        tab[pre + "attention.in_proj_weight"] = (base + net.lo_in_w, (3 * D, D))
+        tab[pre + "attention.in_proj_bias"] = (base + net.lo_in_b, (3 * D,))
+        tab[pre + "attention.out_proj.weight"] = (base + net.lo_out_w, (D, D))
+        tab[pre + "attention.out_proj.bias"] = (base + net.lo_out_b, (D,))
+        tab[pre + "ffn.0.weight"] = (base + net.lo_f1_w, (4 * D, D))
+        tab[pre + "ffn.0.bias"] = (base + net.lo_f1_b, (4 * D,))
+        tab[pre + "ffn.2.weight"] = (base + net.lo_f2_w, (D, 4 * D))
+        tab[pre + "ffn.2.bias"] = (base + net.lo_f2_b, (D,))
+        if net.gate == GATES["gru"]:
+            for gname, goff in (("attn_gate", net.off_gate_attn), ("mlp_gate", net.off_gate_mlp)):
+                for nm, off, shp in gate_names:
+                    tab[pre + f"{gname}.{nm}"] = (goff + off, shp)
+    tab["ffn.0.weight"] = (net.off_head1_w, (D, D))
+    tab["ffn.0.bias"] = (net.off_head1_b, (D,))
+    tab["ffn.2.weight"] = (net.off_head2_w, (A, D))
+    tab["ffn.2.bias"] = (net.off_head2_b, (A,))
+    return tab

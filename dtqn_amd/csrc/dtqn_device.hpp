@@ -1,0 +1,282 @@
+// Device building blocks shared by the DTQN forward / backward kernels (gfx950, wave64).
+//
+// One workgroup = DTQN_THREADS (4 waves) owns ONE sequence: its [LP x D] context tile lives in LDS
+// for the whole pass.  Dense projections run on the exact-f32 matrix core
+// (v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r is
+// D[(l>>4)*4+r][l&15]).  The contraction index is permuted so that each lane's k-slices are
+// CONTIGUOUS in memory (lane group kq owns k in [kq*K/4, (kq+1)*K/4)): A-fragments come out of
+// LDS as ds_read_b128 and weight fragments out of L2 as global_load_dwordx4, four MFMA steps per
+// load.  Attention (head_dim 8..32, L <= 64) is too skinny for MFMA and runs on the VALU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dtqn_hip.h"
+#include "dtqn_limits.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
+
+namespace dtqn {
+
+struct Thr {
+    int tid, lane, wave, i, kq;
+};
+__device__ __forceinline__ Thr make_thr() {
+    Thr t;
+    t.tid = (int)threadIdx.x;
+    t.lane = t.tid & 63;
+    t.wave = t.tid >> 6;
+    t.i = t.lane & 15;
+    t.kq = t.lane >> 4;
+    return t;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------
+// acc[m] += X[m-tile rows][K] * W[ncol][K]^T for one 16-column n-tile.
+//   Xs : LDS, row-major, leading dim lda (multiple of 4), MT*16 rows
+//   Wrow: global pointer to W[ncol][0] of THIS lane's column (or nullptr -> zero column)
+// ------------------------------------------------------------------------------------------
+template <int K, int MT>
+__device__ __forceinline__ void mma_xwT_tile(const float* Xs, int lda, const float* __restrict__ Wrow, const Thr& t,
+                                             f32x4 (&acc)[MT]) {
+    static_assert(K % 16 == 0, "K must be a multiple of 16");
+    constexpr int KS = K / 16;
+    float4 bf[KS];
+    if (Wrow != nullptr) {
+        const float4* wp = reinterpret_cast<const float4*>(Wrow + t.kq * (K / 4));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = wp[s];
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* xp = Xs + t.i * lda + t.kq * (K / 4);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 af = ld4(xp + m * 16 * lda + 4 * s);
+            acc[m] = mfma16(af.x, bf[s].x, acc[m]);
+            acc[m] = mfma16(af.y, bf[s].y, acc[m]);
+            acc[m] = mfma16(af.z, bf[s].z, acc[m]);
+            acc[m] = mfma16(af.w, bf[s].w, acc[m]);
+        }
+    }
+}
+
+// Y[rows][N] = X * W^T, W global [N][ldw]; epi(row, col, value) is called for every element the lane owns.
+template <int K, int MT, typename Epi>
+__device__ __forceinline__ void gemm_xwT(const float* Xs, int lda, const float* __restrict__ W, int ldw, int N,
+                                         const Thr& t, Epi epi) {
+    const int ntiles = (N + 15) >> 4;
+    for (int nt = t.wave; nt < ntiles; nt += DTQN_WAVES) {
+        const int col = nt * 16 + t.i;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero4();
+        mma_xwT_tile<K, MT>(Xs, lda, col < N ? W + (size_t)col * ldw : nullptr, t, acc);
+        if (col < N) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi(m * 16 + t.kq * 4 + r, col, acc[m][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// acc[m] += dY[m-tile rows][NN] * W[NN][col] for one 16-column tile of the OUTPUT (contraction
+// over the ROWS of W).  Wcol: global pointer to W[0][col] of this lane's column (or nullptr).
+// ------------------------------------------------------------------------------------------
+template <int NN, int MT>
+__device__ __forceinline__ void mma_dyw_tile(const float* dYs, int lda, const float* __restrict__ Wcol, int ldw,
+                                             const Thr& t, f32x4 (&acc)[MT]) {
+    static_assert(NN % 16 == 0, "contraction length must be a multiple of 16");
+    constexpr int Q = NN / 4;
+    float bf[Q];
+    if (Wcol != nullptr) {
+        const float* wp = Wcol + (size_t)(t.kq * Q) * ldw;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) bf[q] = wp[(size_t)q * ldw];
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) bf[q] = 0.f;
+    }
+    const float* yp = dYs + t.i * lda + t.kq * Q;
+#pragma unroll
+    for (int s = 0; s < Q / 4; ++s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 af = ld4(yp + m * 16 * lda + 4 * s);
+            acc[m] = mfma16(af.x, bf[4 * s + 0], acc[m]);
+            acc[m] = mfma16(af.y, bf[4 * s + 1], acc[m]);
+            acc[m] = mfma16(af.z, bf[4 * s + 2], acc[m]);
+            acc[m] = mfma16(af.w, bf[4 * s + 3], acc[m]);
+        }
+    }
+}
+
+// dX[rows][Kout] = dY * W, W global [NN][ldw]; epi(row, col, value).
+template <int NN, int MT, typename Epi>
+__device__ __forceinline__ void gemm_dyw(const float* dYs, int lda, const float* __restrict__ W, int ldw, int Kout,
+                                         const Thr& t, Epi epi) {
+    const int ktiles = (Kout + 15) >> 4;
+    for (int kt = t.wave; kt < ktiles; kt += DTQN_WAVES) {
+        const int col = kt * 16 + t.i;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero4();
+        mma_dyw_tile<NN, MT>(dYs, lda, col < Kout ? W + col : nullptr, ldw, t, acc);
+        if (col < Kout) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi(m * 16 + t.kq * 4 + r, col, acc[m][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over D of every row of a [LP][ld] LDS tile (eps 1e-5, biased variance;
+// torch.nn.LayerNorm as used at dtqn/networks/transformer.py:28-29).  4 lanes per row.
+// Optionally records (mean, rstd) per row to st_out[row*2..] (global).
+// ------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float* __restrict__ st_out, const Thr& t) {
+    constexpr int NV = D / 16;  // float4 chunks per lane
+    for (int base = 0; base < LP; base += DTQN_THREADS / 4) {
+        const int row = base + (t.tid >> 2), part = t.tid & 3;
+        const bool valid = row < LP;
+        const float* sp = src + (valid ? row : 0) * ld + part * 4;
+        float4 v[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = ld4(sp + 16 * j);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+        sq += __shfl_xor(sq, 1);
+        sq += __shfl_xor(sq, 2);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        if (valid) {
+            float* dp = dst + row * ld + part * 4;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float4 g = ld4(gamma + part * 4 + 16 * j), b = ld4(beta + part * 4 + 16 * j);
+                float4 o;
+                o.x = (v[j].x - mean) * rstd * g.x + b.x;
+                o.y = (v[j].y - mean) * rstd * g.y + b.y;
+                o.z = (v[j].z - mean) * rstd * g.z + b.z;
+                o.w = (v[j].w - mean) * rstd * g.w + b.w;
+                st4(dp + 16 * j, o);
+            }
+            if (st_out != nullptr && part == 0) {
+                st_out[row * 2 + 0] = mean;
+                st_out[row * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Causal multi-head self-attention on a [LP][ld] LDS tile laid out [q | k | v] (3*D columns).
+// Work item = (query row t, head h), h fastest across lanes so a wave's 8 heads x 8 rows read
+// each key row conflict-free and finish within 7 iterations of each other.  The output o[t, h]
+// OVERWRITES q[t, h] (only this item ever reads it).  Online softmax (single pass over keys);
+// optional log-sum-exp per (h, t) for the backward pass.
+//   torch.nn.MultiheadAttention as called at transformer.py:64-70: q scaled by hd^-0.5, float
+//   additive mask = strictly-upper-triangular -inf  => keys s <= t only.
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
+                                                  float* __restrict__ lse_out, const Thr& t) {
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int item = t.tid; item < LP * H; item += DTQN_THREADS) {
+        const int row = item / H, h = item - row * H;
+        float* qp = Ws + row * ld + h * HD;
+        if (row >= n) {
+#pragma unroll
+            for (int c = 0; c < HD; ++c) qp[c] = 0.f;
+            if (lse_out != nullptr) lse_out[h * LP + row] = 0.f;
+            continue;
+        }
+        float q[HD], acc[HD];
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            const float4 x = ld4(qp + c);
+            q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
+            acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
+        }
+        float m = -INFINITY, l = 0.f;
+        const float* kbase = Ws + D + h * HD;
+        for (int s = 0; s <= row; ++s) {
+            const float* kp = kbase + s * ld;
+            const float* vp = kp + D;
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 k = ld4(kp + c);
+                sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
+            }
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn);
+            const float p = expf(sc - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 v = ld4(vp + c);
+                acc[c] = fmaf(p, v.x, acc[c] * corr); acc[c + 1] = fmaf(p, v.y, acc[c + 1] * corr);
+                acc[c + 2] = fmaf(p, v.z, acc[c + 2] * corr); acc[c + 3] = fmaf(p, v.w, acc[c + 3] * corr);
+            }
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) st4(qp + c, make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv));
+        if (lse_out != nullptr) lse_out[h * LP + row] = m + logf(l);
+    }
+}
+
+// Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.
+__device__ __forceinline__ void tile_store(const float* s, int ld, float* __restrict__ g, int rows, int cols, const Thr& t) {
+    const int c4 = cols >> 2;
+    for (int idx = t.tid; idx < rows * c4; idx += DTQN_THREADS) {
+        const int r = idx / c4, c = (idx - r * c4) * 4;
+        st4(g + (size_t)r * cols + c, ld4(s + r * ld + c));
+    }
+}
+__device__ __forceinline__ void tile_load(float* s, int ld, const float* __restrict__ g, int rows, int cols, const Thr& t) {
+    const int c4 = cols >> 2;
+    for (int idx = t.tid; idx < rows * c4; idx += DTQN_THREADS) {
+        const int r = idx / c4, c = (idx - r * c4) * 4;
+        st4(s + r * ld + c, ld4(g + (size_t)r * cols + c));
+    }
+}
+
+__device__ __forceinline__ const float* layer_theta(const DtqnNet& net, const float* theta, int l) {
+    return theta + net.off_layer0 + (size_t)l * net.layer_stride;
+}
+
+}  // namespace dtqn

@@ -1,0 +1,245 @@
+// Host-side layout of the flat parameter buffer, the per-sequence activation / gradient records
+// and the weight-gradient job table (see include/dtqn_hip.h, DtqnNet).  Pure C++ (no device code).
+#include <cmath>
+#include <cstring>
+
+#include "dtqn_hip.h"
+#include "dtqn_limits.h"
+
+namespace {
+inline int up4(int x) { return (x + 3) & ~3; }
+inline int up16(int x) { return (x + 15) & ~15; }
+
+struct Cursor {
+    int pos = 0;
+    int take(int n) {
+        int at = pos;
+        pos += up4(n);
+        return at;
+    }
+};
+}  // namespace
+
+extern "C" int dtqn_abi_version(void) { return DTQN_ABI_VERSION; }
+
+extern "C" int dtqn_net_init(DtqnNet* net) {
+    if (!net) return DTQN_ERR_ARG;
+    const int O = net->obs_dim, A = net->num_actions, e = net->embed_per_obs, a = net->action_dim;
+    const int D = net->d_model, H = net->num_heads, NL = net->num_layers, L = net->ctx_len, V = net->vocab;
+    if (O < 1 || A < 1 || D < 16 || H < 1 || NL < 1 || NL > DTQN_MAX_LAYERS || L < 1) return DTQN_ERR_CONFIG;
+    if (D % 16 != 0 || D % H != 0 || a < 0 || a >= D) return DTQN_ERR_CONFIG;
+    if (net->discrete && (V < 1 || e < 1)) return DTQN_ERR_CONFIG;
+    if (net->gate != DTQN_GATE_RES && net->gate != DTQN_GATE_GRU) return DTQN_ERR_CONFIG;
+    if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
+    net->abi_version = DTQN_ABI_VERSION;
+    net->lp = up16(L);
+    net->ke = net->discrete ? O * e : O;
+    net->kep = up4(net->ke);
+    net->ap = up4(A);
+    net->head_dim = D / H;
+    net->ffn_chunk = 2 * D;
+    const int LP = net->lp;
+    // kernels cover what fits the per-sequence LDS tile (DESIGN.md "coverage")
+    if (LP > DTQN_MAX_LP || D > DTQN_MAX_D || net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
+    if (A > DTQN_MAX_ACTIONS) return DTQN_ERR_CONFIG;
+
+    // ---- theta: trainable region first ----
+    Cursor c;
+    net->off_act_emb = a > 0 ? c.take(A * a) : -1;
+    net->off_obs_tab = net->discrete ? c.take(V * e) : -1;
+    net->off_obs_w = c.take((D - a) * net->ke);
+    net->off_obs_b = c.take(D - a);
+    const bool pos_trainable = net->pos == DTQN_POS_LEARNED;
+    if (pos_trainable) net->off_pos = c.take(L * D);
+    {
+        Cursor lc;
+        net->lo_ln1_w = lc.take(D);
+        net->lo_ln1_b = lc.take(D);
+        net->lo_ln2_w = lc.take(D);
+        net->lo_ln2_b = lc.take(D);
+        net->lo_in_w = lc.take(3 * D * D);
+        net->lo_in_b = lc.take(3 * D);
+        net->lo_out_w = lc.take(D * D);
+        net->lo_out_b = lc.take(D);
+        net->lo_f1_w = lc.take(4 * D * D);
+        net->lo_f1_b = lc.take(4 * D);
+        net->lo_f2_w = lc.take(4 * D * D);
+        net->lo_f2_b = lc.take(D);
+        net->layer_stride = lc.pos;
+    }
+    net->off_layer0 = c.take(net->layer_stride * NL);
+    {
+        Cursor gc;
+        net->go_w_r = gc.take(D * D);
+        net->go_u_r = gc.take(D * D);
+        net->go_w_z = gc.take(D * D);
+        net->go_b_z = gc.take(D);
+        net->go_u_z = gc.take(D * D);
+        net->go_w_g = gc.take(D * D);
+        net->go_u_g = gc.take(D * D);
+        if (net->gate == DTQN_GATE_GRU) {
+            net->off_gate_attn = c.take(gc.pos);
+            net->off_gate_mlp = c.take(gc.pos);
+        } else {
+            net->off_gate_attn = net->off_gate_mlp = -1;
+        }
+    }
+    net->off_head1_w = c.take(D * D);
+    net->off_head1_b = c.take(D);
+    net->off_head2_w = c.take(A * D);
+    net->off_head2_b = c.take(A);
+    net->n_trainable = c.pos;
+    if (!pos_trainable) net->off_pos = c.take(L * D);
+    net->n_theta = c.pos;
+
+    // ---- activation record ----
+    const bool gru = net->gate == DTQN_GATE_GRU;
+    Cursor ac;
+    net->ao_ein = ac.take(LP * net->kep);
+    net->ao_x0 = ac.take(LP * D);
+    {
+        Cursor lc;
+        net->al_u1 = lc.take(LP * D);
+        net->al_qkv = lc.take(LP * 3 * D);
+        net->al_lse = lc.take(H * LP);
+        net->al_o = lc.take(LP * D);
+        net->al_y1 = lc.take(LP * D);
+        net->al_s1 = lc.take(LP * D);
+        net->al_st1 = lc.take(LP * 2);
+        net->al_u2 = lc.take(LP * D);
+        net->al_h = lc.take(LP * 4 * D);
+        net->al_y2 = lc.take(LP * D);
+        net->al_s2 = lc.take(LP * D);
+        net->al_st2 = lc.take(LP * 2);
+        net->al_gate1 = gru ? lc.take(4 * LP * D) : -1;
+        net->al_gate2 = gru ? lc.take(4 * LP * D) : -1;
+        net->act_layer_stride = lc.pos;
+    }
+    net->ao_layer0 = ac.take(net->act_layer_stride * NL);
+    net->ao_xf = ac.take(LP * D);
+    net->ao_hh = ac.take(LP * D);
+    net->act_stride = ac.pos;
+
+    // ---- gradient record ----
+    Cursor gc;
+    net->go_dx0 = gc.take(LP * D);
+    {
+        Cursor lc;
+        net->gl_dqkv = lc.take(LP * 3 * D);
+        net->gl_da = lc.take(LP * D);
+        net->gl_dhp = lc.take(LP * 4 * D);
+        net->gl_df = lc.take(LP * D);
+        net->gl_gate1 = gru ? lc.take(3 * LP * D) : -1;
+        net->gl_gate2 = gru ? lc.take(3 * LP * D) : -1;
+        net->grd_layer_stride = lc.pos;
+    }
+    net->go_layer0 = gc.take(net->grd_layer_stride * NL);
+    net->go_dhh = gc.take(LP * D);
+    net->go_dq = gc.take(LP * net->ap);
+    net->grd_stride = gc.pos;
+
+    // ---- small partials ----
+    Cursor sc;
+    net->so_ln = sc.take(NL * 4 * D);
+    net->so_tab = net->discrete ? sc.take(V * e) : -1;
+    net->so_act = a > 0 ? sc.take(A * a) : -1;
+    net->sp_stride = sc.pos;
+
+    // ---- weight-gradient jobs ----
+    int njobs = 0, ntiles = 0;
+    auto count = [&](int N, int K) {
+        njobs++;
+        ntiles += ((N + 31) / 32) * ((K + 31) / 32);
+    };
+    count(D - a, net->ke);
+    for (int l = 0; l < NL; ++l) {
+        count(3 * D, D);
+        count(D, D);
+        count(4 * D, D);
+        count(D, 4 * D);
+    }
+    if (gru) {
+        // shared gate weights see the tokens of every layer: one job per (layer, gate, matrix)
+        for (int l = 0; l < NL; ++l) for (int g = 0; g < 2; ++g) for (int m = 0; m < 6; ++m) count(D, D);
+    }
+    count(D, D);
+    count(A, D);
+    net->n_wjobs = njobs;
+    net->n_wtiles = ntiles;
+    return DTQN_OK;
+}
+
+extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
+    if (!net || !jobs) return DTQN_ERR_ARG;
+    const int a = net->action_dim, D = net->d_model, NL = net->num_layers, A = net->num_actions;
+    int j = 0, tile = 0;
+    auto add = [&](int x_in_act, int x_off, int ldx, int K, int dy_off, int ldy, int N, int w_off, int b_off) {
+        DtqnWJob& w = jobs[j++];
+        w.x_in_act = x_in_act;
+        w.x_off = x_off; w.ldx = ldx; w.K = K;
+        w.dy_off = dy_off; w.ldy = ldy; w.N = N;
+        w.w_off = w_off; w.b_off = b_off;
+        w.tile0 = tile;
+        w.tiles_n = (N + 31) / 32;
+        w.tiles_k = (K + 31) / 32;
+        tile += w.tiles_n * w.tiles_k;
+    };
+    // embedding linear: dY = dx0[:, a:], X = e_in
+    add(1, net->ao_ein, net->kep, net->ke, net->go_dx0 + a, D, D - a, net->off_obs_w, net->off_obs_b);
+    for (int l = 0; l < NL; ++l) {
+        const int ab = net->ao_layer0 + l * net->act_layer_stride;
+        const int gb = net->go_layer0 + l * net->grd_layer_stride;
+        const int tb = net->off_layer0 + l * net->layer_stride;
+        add(1, ab + net->al_u1, D, D, gb + net->gl_dqkv, 3 * D, 3 * D, tb + net->lo_in_w, tb + net->lo_in_b);
+        add(1, ab + net->al_o, D, D, gb + net->gl_da, D, D, tb + net->lo_out_w, tb + net->lo_out_b);
+        add(1, ab + net->al_u2, D, D, gb + net->gl_dhp, 4 * D, 4 * D, tb + net->lo_f1_w, tb + net->lo_f1_b);
+        add(1, ab + net->al_h, 4 * D, 4 * D, gb + net->gl_df, D, D, tb + net->lo_f2_w, tb + net->lo_f2_b);
+    }
+    if (net->gate == DTQN_GATE_GRU) {
+        const int LPD = net->lp * D;
+        for (int l = 0; l < NL; ++l) {
+            const int ab = net->ao_layer0 + l * net->act_layer_stride;
+            const int gb = net->go_layer0 + l * net->grd_layer_stride;
+            for (int g = 0; g < 2; ++g) {
+                const int gate_w = g == 0 ? net->off_gate_attn : net->off_gate_mlp;
+                const int ga = ab + (g == 0 ? net->al_gate1 : net->al_gate2);   // z, r, h~, r*x
+                const int gg = gb + (g == 0 ? net->gl_gate1 : net->gl_gate2);   // dz_pre, dr_pre, dh_pre
+                // y = relu(sub-layer out), x = stream before the gate
+                const int y_off = ab + (g == 0 ? net->al_y1 : net->al_y2);
+                // stream before the attention gate: post-LN -> u1 (layer input); identity -> layer input stream.
+                // stream before the mlp gate: post-LN -> u2 (= LN1 output); identity -> s1.
+                int x_off;
+                if (g == 0) x_off = net->identity ? (l == 0 ? net->ao_x0 : net->ao_layer0 + (l - 1) * net->act_layer_stride + net->al_s2) : ab + net->al_u1;
+                else x_off = net->identity ? ab + net->al_s1 : ab + net->al_u2;
+                add(1, y_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_w_r, -1);
+                add(1, x_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_u_r, -1);
+                add(1, y_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_w_z, gate_w + net->go_b_z);
+                add(1, x_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_u_z, -1);
+                add(1, y_off, D, D, gg + 2 * LPD, D, D, gate_w + net->go_w_g, -1);
+                add(1, ga + 3 * LPD, D, D, gg + 2 * LPD, D, D, gate_w + net->go_u_g, -1);
+            }
+        }
+    }
+    add(1, net->ao_xf, D, D, net->go_dhh, D, D, net->off_head1_w, net->off_head1_b);
+    add(1, net->ao_hh, D, D, net->go_dq, net->ap, A, net->off_head2_w, net->off_head2_b);
+    return (j == net->n_wjobs && tile == net->n_wtiles) ? DTQN_OK : DTQN_ERR_CONFIG;
+}
+
+extern "C" int dtqn_net_fill_frozen(const DtqnNet* net, float* theta) {
+    if (!net || !theta) return DTQN_ERR_ARG;
+    const int L = net->ctx_len, D = net->d_model;
+    if (net->pos == DTQN_POS_SIN) {
+        // position_encodings.py:23-35: P[t,2i] = sin(t * exp(2i * -ln(1e4)/D)), P[t,2i+1] = cos(same);
+        // the reference evaluates it in fp32 torch ops: exp in fp32, product in fp32, sin/cos in fp32.
+        for (int t = 0; t < L; ++t)
+            for (int i = 0; i < D; i += 2) {
+                const float div = std::exp((float)i * (float)(-std::log(10000.0) / D));
+                const float ang = (float)t * div;
+                theta[net->off_pos + t * D + i] = std::sin(ang);
+                if (i + 1 < D) theta[net->off_pos + t * D + i + 1] = std::cos(ang);
+            }
+    } else if (net->pos == DTQN_POS_NONE) {
+        std::memset(theta + net->off_pos, 0, sizeof(float) * (size_t)L * D);
+    }
+    return DTQN_OK;
+}

@@ -1,0 +1,253 @@
+/* dtqn_hip.h -- C ABI of libdtqn_hip.so, the MI355X (gfx950) engine behind dtqn_amd.
+ *
+ * The reference (kevslinger/DTQN) has no FFI / plugin layer: its hot path is Python calling
+ * torch ops.  This header is therefore the boundary a reference maintainer would bind to
+ * (ctypes stub in INTEGRATION.md): plain pointers to DEVICE memory, sizes, a hipStream_t passed
+ * as void*, int status codes.  No torch types.  The library allocates nothing: every buffer is
+ * owned by the caller (sizes come from dtqn_net_init).  All kernels are asynchronous on the
+ * given stream.  Every entry point cites the reference interface it replaces (paths relative to
+ * the reference root).
+ *
+ * Struct members are restricted to int32_t / uint32_t / float / pointers so that host bindings
+ * can be generated from this file (dtqn_amd/_binding.py parses it).
+ */
+#ifndef DTQN_HIP_H
+#define DTQN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTQN_ABI_VERSION 1
+#define DTQN_MAX_LAYERS 8
+
+/* status codes */
+#define DTQN_OK 0
+#define DTQN_ERR_CONFIG 1      /* unsupported dims / variant (the reference would accept it) */
+#define DTQN_ERR_ARG 2         /* bad argument: seq > ctx_len, NULL pointer, ... (AssertionError in dtqn.py:170-179) */
+#define DTQN_ERR_LAUNCH 3      /* hip launch error */
+
+/* gate / positional-encoding enums (dtqn/networks/dtqn.py:107-114, position_encodings.py:8-11) */
+#define DTQN_GATE_RES 0
+#define DTQN_GATE_GRU 1
+#define DTQN_POS_LEARNED 0
+#define DTQN_POS_SIN 1
+#define DTQN_POS_NONE 2
+
+/* ------------------------------------------------------------------------------------------
+ * DtqnNet: network hyper-parameters (caller fills the first block) and every derived layout
+ * (dtqn_net_init fills the rest).  Replaces the module tree built by DTQN.__init__
+ * (dtqn/networks/dtqn.py:41-156): all parameters of one network live in ONE flat fp32 buffer
+ * `theta` of n_theta floats; the first n_trainable floats are the trainable region the optimizer
+ * walks (attn_mask is never materialised: causality is implicit; frozen sin / none position
+ * tables sit after the trainable region).  Offsets are in floats; every tensor starts on a
+ * 4-float boundary and padding stays zero.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct DtqnNet {
+    /* ---- inputs (dtqn.py:41-59 ctor arguments) ---- */
+    int32_t obs_dim;          /* O: length of the observation vector */
+    int32_t num_actions;      /* A */
+    int32_t embed_per_obs;    /* e: per-dimension embedding width (discrete obs only) */
+    int32_t action_dim;       /* a: action-embedding width, 0 = none */
+    int32_t d_model;          /* D: inner_embed_size */
+    int32_t num_heads;        /* H */
+    int32_t num_layers;       /* NL */
+    int32_t ctx_len;          /* L: history_len */
+    int32_t gate;             /* DTQN_GATE_* */
+    int32_t identity;         /* identity-map reordering (transformer.py:81-101) */
+    int32_t pos;              /* DTQN_POS_* */
+    int32_t discrete;         /* discrete observations -> Embedding(V,e)+Linear (representations.py:25-52) */
+    int32_t vocab;            /* V */
+    /* ---- derived: geometry ---- */
+    int32_t abi_version;
+    int32_t lp;               /* L padded to the MFMA row tile (multiple of 16) */
+    int32_t ke;               /* embedding-linear fan-in: O (continuous) or O*e (discrete) */
+    int32_t kep;              /* ke padded to 4 */
+    int32_t ap;               /* A padded to 4 */
+    int32_t head_dim;
+    int32_t ffn_chunk;        /* columns of the 4D hidden processed per LDS pass */
+    /* ---- derived: theta layout (floats) ---- */
+    int32_t off_act_emb;      /* [A][a]            action_embedding.embedding.0.weight */
+    int32_t off_obs_tab;      /* [V][e]            obs_embedding.observation_embedding.0.weight */
+    int32_t off_obs_w;        /* [D-a][ke]         obs_embedding.observation_embedding(.2).weight */
+    int32_t off_obs_b;        /* [D-a] */
+    int32_t off_pos;          /* [L][D]            position_embedding.position_encoding */
+    int32_t off_layer0;       /* first transformer layer block */
+    int32_t layer_stride;
+    int32_t lo_ln1_w, lo_ln1_b, lo_ln2_w, lo_ln2_b;           /* offsets inside a layer block */
+    int32_t lo_in_w, lo_in_b, lo_out_w, lo_out_b;             /* attention.in_proj_* / out_proj.* */
+    int32_t lo_f1_w, lo_f1_b, lo_f2_w, lo_f2_b;               /* ffn.0.* / ffn.2.* */
+    int32_t off_gate_attn;    /* shared GRU gate (gates.py:5-31): w_r u_r w_z b_z u_z w_g u_g, each [D][D] ([D] for b_z) */
+    int32_t off_gate_mlp;
+    int32_t go_w_r, go_u_r, go_w_z, go_b_z, go_u_z, go_w_g, go_u_g;   /* offsets inside a gate block */
+    int32_t off_head1_w, off_head1_b, off_head2_w, off_head2_b;       /* ffn.0.* / ffn.2.* (Q head) */
+    int32_t n_trainable;      /* floats the optimizer updates (multiple of 4) */
+    int32_t n_theta;          /* total floats of theta */
+    /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
+    int32_t act_stride;       /* floats per sequence */
+    int32_t ao_ein, ao_x0, ao_layer0, act_layer_stride, ao_xf, ao_hh;
+    int32_t al_u1, al_qkv, al_lse, al_o, al_y1, al_s1, al_st1, al_u2, al_h, al_y2, al_s2, al_st2;
+    int32_t al_gate1, al_gate2;   /* GRU: z, r, h~, r*x, each [LP][D] */
+    /* ---- derived: per-sequence gradient record written by the backward-data kernel ---- */
+    int32_t grd_stride;
+    int32_t go_dx0, go_layer0, grd_layer_stride, go_dhh, go_dq;
+    int32_t gl_dqkv, gl_da, gl_dhp, gl_df;
+    int32_t gl_gate1, gl_gate2;   /* GRU: d z_pre, d r_pre, d h_pre, each [LP][D] */
+    /* ---- derived: per-sequence small partials (LayerNorm affine, embedding tables) ---- */
+    int32_t sp_stride;
+    int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */
+    /* ---- derived: weight-gradient job table ---- */
+    int32_t n_wjobs;
+    int32_t n_wtiles;         /* total 32x32 output tile groups over all jobs */
+} DtqnNet;
+
+/* One weight-gradient GEMM:  dW[N][K] (+)= sum over tokens dY[t][N]^T X[t][K],  db[N] = sum_t dY[t][N].
+ * x/dy offsets address the per-sequence act / grd records. */
+typedef struct DtqnWJob {
+    int32_t x_in_act;        /* 1: X lives in the act record, 0: in the grd record */
+    int32_t x_off, ldx, K;
+    int32_t dy_off, ldy, N;
+    int32_t w_off;           /* offset of dW in the flat gradient */
+    int32_t b_off;           /* offset of db, or -1 */
+    int32_t tile0;           /* first global tile-group index of this job */
+    int32_t tiles_n, tiles_k;
+} DtqnWJob;
+
+/* Fills every derived field of `net` from its inputs.  Returns DTQN_ERR_CONFIG when the variant
+ * is outside what the gfx950 kernels cover (see DESIGN.md "coverage"). */
+int dtqn_net_init(DtqnNet* net);
+/* Writes net->n_wjobs jobs (host memory). */
+int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs);
+/* Fills a HOST buffer of n_theta floats with the frozen tables (sinusoidal position encoding,
+ * position_encodings.py:23-35); trainable entries are left untouched. */
+int dtqn_net_fill_frozen(const DtqnNet* net, float* theta_host);
+/* LDS bytes the forward / backward kernels request for this net (0 = does not fit). */
+int dtqn_lds_bytes_forward(const DtqnNet* net, int training);
+int dtqn_lds_bytes_backward(const DtqnNet* net);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident episode-major replay (replaces dtqn/buffers/replay_buffer.py:19-69 storage).
+ *   obs      [E][T+1][O] f32   (discrete observations are stored as exact small floats, as the
+ *                               reference does, and converted to indices in-kernel)
+ *   actions  [E][T+1]    u8
+ *   rewards  [E][T]      f32
+ *   dones    [E][T]      u8
+ *   ep_len   [E]         i32   (the reference's uint8 wraps at 256)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct DtqnReplay {
+    float* obs;
+    uint8_t* actions;
+    float* rewards;
+    uint8_t* dones;
+    int32_t* ep_len;
+    int32_t num_episodes;     /* E = buffer_size // max_episode_steps (replay_buffer.py:27) */
+    int32_t max_steps;        /* T */
+    int32_t obs_dim;          /* O */
+    float obs_mask;           /* padding value of unwritten observations */
+} DtqnReplay;
+
+/* One producer record: what DtqnAgent.context_reset / observe push per env step
+ * (replay_buffer.py:71-92).  kind 0 = store_obs (cleanse slot `ep`, write obs at row 0),
+ * kind 1 = store (obs at row t+1, action/reward/done at row t, ep_len = t+1). */
+typedef struct DtqnReplayRecord {
+    int32_t kind;
+    int32_t ep;
+    int32_t t;
+    int32_t action;
+    float reward;
+    int32_t done;
+    int32_t obs_index;        /* row of the packed observation array that travels with the records */
+    int32_t reserved;
+} DtqnReplayRecord;
+
+/* Applies n records (device memory; staged by the host through pinned memory + hipMemcpyAsync)
+ * to the replay arrays, in order. */
+int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* recs_dev, const float* obs_rows_dev,
+                      int n, void* stream);
+/* Draws `batch` (episode, start) pairs on the device with the reference's distribution
+ * (replay_buffer.py:141-158): episode uniform over finished slots [0, n_valid) minus `exclude`,
+ * start uniform on {0..max(0, len-L)}.  Counter-based RNG keyed by (seed, *step_counter). */
+int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed,
+                       const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Inference / actor forward.  Replaces DTQN.forward (dtqn/networks/dtqn.py:158-218) for the
+ * no-grad call sites (dtqn/agents/dtqn.py:81-107 get_action).
+ *   obs      [B][n][O] f32 contiguous, actions [B][n] u8 (may be NULL when action_dim == 0)
+ *   q_out    [B][n][A] f32
+ * ------------------------------------------------------------------------------------------ */
+int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                 int batch, int n, float* q_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One TD update = DtqnAgent.train() (dtqn/agents/dtqn.py:162-269) after sampling.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct DtqnTd {
+    /* network state */
+    float* theta_pol;         /* [n_theta]  policy parameters (updated in place) */
+    float* theta_tgt;         /* [n_theta]  target parameters */
+    float* grad;              /* [n_trainable] flat gradient (mean over the local batch) */
+    float* adam_m;            /* [n_trainable] */
+    float* adam_v;            /* [n_trainable] */
+    /* sampled windows */
+    const int32_t* ep_idx;    /* [B] */
+    const int32_t* start;     /* [B] */
+    /* workspaces */
+    float* act;               /* [B][act_stride] */
+    float* grd;               /* [B][grd_stride] */
+    float* small;             /* [B][sp_stride] */
+    float* q3;                /* [3][B][LP][AP]: Q_pol(o), Q_pol(o'), Q_tgt(o') */
+    float* gsplit;            /* [n_split][n_trainable] split-K partials of the weight gradients */
+    float* norm_partial;      /* [n_norm_blocks] per-block sum of squares of grad */
+    float* stats_partial;     /* [B][8] */
+    float* stats;             /* [8 + 4]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, nonfinite flag */
+    int32_t* step_counter;    /* [2]: number of optimizer steps taken; updates since last target sync */
+    const DtqnWJob* wjobs;    /* device copy of the job table */
+    /* hyper-parameters */
+    int32_t batch;            /* B (local) */
+    int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
+    int32_t n_split;          /* token splits of the weight-gradient kernel */
+    int32_t n_norm_blocks;
+    int32_t target_update_frequency;
+    float gamma;
+    float lr;
+    float beta1;
+    float beta2;
+    float eps;
+    float grad_norm_clip;
+    float grad_scale;         /* multiplies the reduced gradient before clipping (1/world_size for DP) */
+} DtqnTd;
+
+/* The three forwards (dtqn.py:215,226,230) fused with the window gather (replay_buffer.py:160-167).
+ * Grid = 3*B workgroups.  Writes q3 and the act record of the policy(o) pass. */
+int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* Double-DQN target, MSE, dL/dQ (dtqn.py:219-243) and the data-gradient chain of loss.backward()
+ * (dtqn.py:256).  Writes the grd / small records and stats_partial. */
+int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* Weight gradients: token-contraction GEMMs over act x grd into gsplit. */
+int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* Sums gsplit / small partials into grad (mean-loss scaling is already in dL/dQ), writes
+ * norm_partial.  After this call `grad` is ready for a data-parallel all-reduce. */
+int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* Recomputes norm_partial from `grad` (used after an all-reduce changed it). */
+int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* clip_grad_norm_(1.0) + Adam + step counters + hard target sync every tuf steps
+ * (dtqn.py:257-269, dqn.py:64,208-210) + final stats.  Non-finite norm: sets stats[11] and skips
+ * the update (the host raises RuntimeError like error_if_nonfinite=True). */
+int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* Convenience: forward, backward, wgrad, reduce, clip_adam back to back (single GPU). */
+int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
+int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
+
+/* Library self-description. */
+int dtqn_abi_version(void);
+const char* dtqn_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTQN_HIP_H */

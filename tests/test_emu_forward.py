@@ -1,0 +1,73 @@
+"""Kernel-logic tests on the CPU: the HIP sources compiled against the test-only HIP emulation
+(tests/emu) versus the oracle.  These do not replace the -m gpu parity tests; they validate
+indexing / LDS layout / barrier structure / MFMA fragment maps without a GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dtqn_amd import _binding as B
+from oracle import dtqn_oracle as O
+
+from helpers import net_from_cfg, pack_theta, ptr
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import emu_build
+    return B.load_library(emu_build.build())
+
+
+def _fwd(emu, cfg, params, obs, act):
+    net = net_from_cfg(emu, cfg)
+    theta = pack_theta(net, params)
+    Bn, n = obs.shape[:2]
+    q = np.full((Bn, n, cfg.num_actions), np.nan, dtype=np.float32)
+    obs_f = np.ascontiguousarray(obs, dtype=np.float32)
+    act_u8 = np.ascontiguousarray(act.reshape(Bn, n), dtype=np.uint8)
+    rc = emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), None)
+    assert rc == 0
+    return q
+
+
+CASES = [
+    dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8),
+    dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, action_dim=4),
+    dict(obs_dim=10, num_actions=5, inner_embed_size=32, num_heads=2, history_len=12, discrete=True, vocab_sizes=9),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, identity=True, pos="sin"),
+    dict(obs_dim=1, num_actions=5, inner_embed_size=32, num_heads=4, history_len=30, discrete=True, vocab_sizes=22,
+         action_dim=8, pos="none"),
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_forward_small_variants(emu, kw):
+    cfg = O.NetCfg(**kw)
+    params = O.init_params(cfg, seed=3, perturb=True)
+    rng = np.random.default_rng(5)
+    for n in sorted({1, 2, cfg.history_len // 2, cfg.history_len}):
+        Bn = 3
+        if cfg.discrete:
+            obs = rng.integers(0, cfg.vocab_sizes, size=(Bn, n, cfg.obs_dim))
+        else:
+            obs = rng.uniform(-1, 1, size=(Bn, n, cfg.obs_dim)).astype(np.float32)
+        act = rng.integers(0, cfg.num_actions, size=(Bn, n, 1))
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs, dtype=torch.long if cfg.discrete else torch.float32),
+                            torch.as_tensor(act, dtype=torch.long)).numpy()
+        got = _fwd(emu, cfg, params, obs, act)
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(got - ref).max())
+
+
+def test_forward_cfg1_size(emu):
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    params = O.init_params(cfg, seed=11, perturb=True)
+    rng = np.random.default_rng(7)
+    obs = rng.uniform(-1, 1, size=(2, 50, 3)).astype(np.float32)
+    act = rng.integers(0, 3, size=(2, 50, 1))
+    with torch.no_grad():
+        ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act)).numpy()
+    got = _fwd(emu, cfg, params, obs, act)
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

@@ -1,0 +1,100 @@
+"""-m gpu: HIP forward (through the C ABI) vs the CPU oracle and the reference's golden vectors."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dtqn_amd import _binding as B
+from oracle import dtqn_oracle as O
+
+from conftest import GOLDEN
+from helpers import net_from_cfg, pack_theta, ptr
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL = 1e-4   # north_star: per-timestep Q-values within 1e-4 fp32 (scaled by max(1, |Q|max))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dtqn_amd import engine
+    engine.require_gpu()
+    return engine.get_lib()
+
+
+def hip_forward(lib, cfg, params, obs, act):
+    from dtqn_amd import engine
+    net = net_from_cfg(lib, cfg)
+    dev = torch.device("cuda")
+    theta = torch.from_numpy(pack_theta(net, params)).to(dev)
+    Bn, n = obs.shape[:2]
+    obs_d = torch.as_tensor(np.ascontiguousarray(obs, dtype=np.float32)).to(dev)
+    act_d = torch.as_tensor(np.ascontiguousarray(act.reshape(Bn, n), dtype=np.uint8)).to(dev)
+    q = torch.full((Bn, n, cfg.num_actions), float("nan"), device=dev)
+    rc = lib.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_d), ptr(act_d), Bn, n, ptr(q), engine.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return q.cpu().numpy()
+
+
+def test_golden_G4_actor_variable_length(lib):
+    z = np.load(os.path.join(GOLDEN, "G4_actor_varlen.npz"))
+    tag = "res"
+    cfg = O.NetCfg(**json.loads(str(z[f"{tag}/cfg"])))
+    params = O.init_params(cfg, seed=41, perturb=True)
+    for n in (1, 2, 17, 50):
+        got = hip_forward(lib, cfg, params, z[f"{tag}/n{n}_obs"], z[f"{tag}/n{n}_act"])
+        ref = z[f"{tag}/n{n}_q"]
+        assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), n
+
+
+def test_golden_G1_q_values(lib):
+    z = np.load(os.path.join(GOLDEN, "G1_cfg1_td.npz"))
+    cfg = O.NetCfg(**json.loads(str(z["cfg"])))
+    seed = int(z["seed"])
+    pol = O.init_params(cfg, seed=seed, perturb=True)
+    tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+    scale = max(1.0, np.abs(z["q_all"]).max())
+    got = hip_forward(lib, cfg, pol, z["batch0_obss"], z["batch0_actions"])
+    assert np.abs(got - z["q_all"]).max() <= Q_TOL * scale
+    got = hip_forward(lib, cfg, pol, z["batch0_next_obss"], z["batch0_next_actions"])
+    assert np.abs(got - z["q_next_pol"]).max() <= Q_TOL * scale
+    got = hip_forward(lib, cfg, tgt, z["batch0_next_obss"], z["batch0_next_actions"])
+    assert np.abs(got - z["q_next_tgt"]).max() <= Q_TOL * scale
+
+
+VARIANTS = [
+    dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8),
+    dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, action_dim=4),
+    dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, identity=True, pos="sin"),
+    dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=4, history_len=64, discrete=True, vocab_sizes=22,
+         action_dim=8, pos="none"),
+]
+
+
+@pytest.mark.parametrize("kw", VARIANTS)
+def test_variants_vs_oracle(lib, kw):
+    cfg = O.NetCfg(**kw)
+    params = O.init_params(cfg, seed=3, perturb=True)
+    rng = np.random.default_rng(5)
+    for n in sorted({1, 2, cfg.history_len // 2, cfg.history_len}):
+        Bn = 5
+        obs = (rng.integers(0, cfg.vocab_sizes, size=(Bn, n, cfg.obs_dim)) if cfg.discrete
+               else rng.uniform(-1, 1, size=(Bn, n, cfg.obs_dim)).astype(np.float32))
+        act = rng.integers(0, cfg.num_actions, size=(Bn, n, 1))
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs, dtype=torch.long if cfg.discrete else torch.float32),
+                            torch.as_tensor(act, dtype=torch.long)).numpy()
+        got = hip_forward(lib, cfg, params, obs, act)
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), (n, np.abs(got - ref).max())
+
+
+def test_seq_longer_than_context_is_rejected(lib):
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8)
+    net = net_from_cfg(lib, cfg)
+    assert lib.dtqn_forward(ctypes.byref(net), ctypes.c_void_p(8), ctypes.c_void_p(8), None, 1, 9, ctypes.c_void_p(8), None) == B.DEFINES["DTQN_ERR_ARG"]
