@@ -1,0 +1,561 @@
+// Double-DQN loss + hand-written data-gradient chain of the DTQN policy network (gfx950).
+// One workgroup per sampled sequence; dL/dx of the residual stream lives in LDS for the whole pass.
+//
+// Replaces (dtqn/agents/dtqn.py): q.gather / argmax / target gather / Bellman / mse_loss (:219-243),
+// the seven logged statistics (:245-253) and the autograd backward of forward #1 (:256) -- restricted
+// to the DATA gradients.  Every pre-activation gradient that feeds a weight matrix is written to the
+// per-sequence `grd` record; dtqn_wgrad.hip contracts those against the saved activations over all
+// B*L tokens, so no per-sequence weight-gradient partials exist.
+#include "dtqn_device.hpp"
+
+namespace dtqn {
+
+struct BwdArgs {
+    DtqnNet net;
+    const float* theta;          // policy parameters
+    const float* act;            // [B][act_stride] saved by the training forward
+    float* grd;                  // [B][grd_stride]
+    float* small;                // [B][sp_stride]
+    const float* q3;             // [3][B][LP][AP]
+    float* stats_partial;        // [B][8]
+    const float* obs;            // replay arrays (actions / rewards / dones of the sampled window)
+    const uint8_t* actions;
+    const float* rewards;
+    const uint8_t* dones;
+    long long obs_ep_stride, act_ep_stride, rew_ep_stride;
+    const int32_t* ep_idx;
+    const int32_t* start;
+    int batch, history;
+    float gamma;
+};
+
+// LayerNorm backward over the rows of a [LP][ld] tile.
+//   dy   : gradient w.r.t. the LN output            (LDS, [LP][ld])
+//   xin  : the LN input                             (LDS, [LP][ld])
+//   st   : (mean, rstd) per row                     (global, [LP][2])
+//   dst  : receives rstd*(g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy; assigned or accumulated
+//   dgb  : per-sequence partial of d gamma ([D]) followed (at +D) by d beta ([D])   (global)
+// Contains two __syncthreads(); caller must sync before (inputs ready) and after (dst ready).
+template <int D>
+__device__ __forceinline__ void layernorm_backward(const float* dy, const float* xin, float* dst, bool accumulate,
+                                                   int ld, int LP, const float* __restrict__ st,
+                                                   const float* __restrict__ gamma, float* __restrict__ dgb,
+                                                   float* red, const Thr& t) {
+    constexpr int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    // pass A: column sums  d gamma[d] = sum_r dy*xhat,  d beta[d] = sum_r dy
+    {
+        const int d = t.tid % D, part = t.tid / D;
+        if (part < PARTS) {
+            float sg = 0.f, sb = 0.f;
+            for (int r = part; r < LP; r += PARTS) {
+                const float mean = st[r * 2], rstd = st[r * 2 + 1];
+                const float g = dy[r * ld + d];
+                sg = fmaf(g, (xin[r * ld + d] - mean) * rstd, sg);
+                sb += g;
+            }
+            red[(part * 2 + 0) * D + d] = sg;
+            red[(part * 2 + 1) * D + d] = sb;
+        }
+    }
+    __syncthreads();
+    for (int idx = t.tid; idx < 2 * D; idx += DTQN_THREADS) {
+        const int which = idx / D, d = idx - which * D;
+        float s = 0.f;
+        for (int p = 0; p < PARTS; ++p) s += red[(p * 2 + which) * D + d];
+        dgb[which * D + d] = s;
+    }
+    // pass B: rows (4 lanes per row)
+    constexpr int NV = D / 16;
+    float4 o[NV];
+    int row = t.tid >> 2;
+    const int part = t.tid & 3;
+    const bool valid = row < LP;
+    row = valid ? row : 0;
+    {
+        const float mean = st[row * 2], rstd = st[row * 2 + 1];
+        const float* yp = dy + row * ld + part * 4;
+        const float* xp = xin + row * ld + part * 4;
+        float4 gq[NV], xh[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 y = ld4(yp + 16 * j), x = ld4(xp + 16 * j), gm = ld4(gamma + part * 4 + 16 * j);
+            gq[j] = make_float4(y.x * gm.x, y.y * gm.y, y.z * gm.z, y.w * gm.w);
+            xh[j] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+            c1 += (gq[j].x + gq[j].y) + (gq[j].z + gq[j].w);
+            c2 += (gq[j].x * xh[j].x + gq[j].y * xh[j].y) + (gq[j].z * xh[j].z + gq[j].w * xh[j].w);
+        }
+        c1 += __shfl_xor(c1, 1); c1 += __shfl_xor(c1, 2);
+        c2 += __shfl_xor(c2, 1); c2 += __shfl_xor(c2, 2);
+        c1 *= (1.0f / D);
+        c2 *= (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            o[j].x = rstd * (gq[j].x - c1 - xh[j].x * c2);
+            o[j].y = rstd * (gq[j].y - c1 - xh[j].y * c2);
+            o[j].z = rstd * (gq[j].z - c1 - xh[j].z * c2);
+            o[j].w = rstd * (gq[j].w - c1 - xh[j].w * c2);
+        }
+    }
+    __syncthreads();   // every lane has read dy / dst before anyone overwrites dst (dst may alias dy)
+    if (valid) {
+        float* dp = dst + row * ld + part * 4;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (accumulate) {
+                const float4 p = ld4(dp + 16 * j);
+                st4(dp + 16 * j, make_float4(p.x + o[j].x, p.y + o[j].y, p.z + o[j].z, p.w + o[j].w));
+            } else {
+                st4(dp + 16 * j, o[j]);
+            }
+        }
+    }
+}
+
+// Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each).
+//   pass 1 (item = query row t, head): delta = do . o ; dS = P*(dP - delta); dq = scale * dS k
+//   pass 2 (item = key row s, head):   dk = scale * dS^T q ; dv = P^T do      (in place over k, v)
+template <int HD>
+__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n, int h0,
+                                                         const float* __restrict__ lse_g,   // [H][LP] global
+                                                         const float* __restrict__ o_g,     // [LP][D] global
+                                                         int D, float* delta_s, float* lse_s, const Thr& t) {
+    const int HG = GW / HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int item = t.tid; item < LP * HG; item += DTQN_THREADS) {
+        const int row = item / HG, hl = item - row * HG;
+        float* dqp = W5 + row * ld + 4 * GW + hl * HD;
+        float dq[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+        float delta = 0.f, lse = 0.f;
+        if (row < n) {
+            const float* qp = W5 + row * ld + hl * HD;
+            const float* dop = W5 + row * ld + 3 * GW + hl * HD;
+            const float* op = o_g + (size_t)row * D + (h0 + hl) * HD;
+            float q[HD], dO[HD];
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 x = ld4(qp + c), g = ld4(dop + c), ov = ld4(op + c);
+                q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
+                dO[c] = g.x; dO[c + 1] = g.y; dO[c + 2] = g.z; dO[c + 3] = g.w;
+                delta = fmaf(g.x, ov.x, delta); delta = fmaf(g.y, ov.y, delta);
+                delta = fmaf(g.z, ov.z, delta); delta = fmaf(g.w, ov.w, delta);
+            }
+            lse = lse_g[(h0 + hl) * LP + row];
+            const float* kbase = W5 + GW + hl * HD;
+            for (int s = 0; s <= row; ++s) {
+                const float* kp = kbase + s * ld;
+                const float* vp = kp + GW;
+                float sc = 0.f, dp = 0.f;
+                float kk[HD];
+#pragma unroll
+                for (int c = 0; c < HD; c += 4) {
+                    const float4 k = ld4(kp + c), v = ld4(vp + c);
+                    kk[c] = k.x; kk[c + 1] = k.y; kk[c + 2] = k.z; kk[c + 3] = k.w;
+                    sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
+                    dp = fmaf(dO[c], v.x, dp); dp = fmaf(dO[c + 1], v.y, dp); dp = fmaf(dO[c + 2], v.z, dp); dp = fmaf(dO[c + 3], v.w, dp);
+                }
+                const float ds = expf(sc - lse) * (dp - delta);
+#pragma unroll
+                for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kk[c], dq[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HD; c += 4)
+            st4(dqp + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
+        delta_s[hl * LP + row] = delta;
+        lse_s[hl * LP + row] = lse;
+    }
+    __syncthreads();
+    for (int item = t.tid; item < LP * HG; item += DTQN_THREADS) {
+        const int srow = item / HG, hl = item - srow * HG;
+        float* kp = W5 + srow * ld + GW + hl * HD;
+        float* vp = kp + GW;
+        float dk[HD], dv[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
+        if (srow < n) {
+            float k[HD], v[HD];
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 x = ld4(kp + c), y = ld4(vp + c);
+                k[c] = x.x; k[c + 1] = x.y; k[c + 2] = x.z; k[c + 3] = x.w;
+                v[c] = y.x; v[c + 1] = y.y; v[c + 2] = y.z; v[c + 3] = y.w;
+            }
+            for (int row = n - 1; row >= srow; --row) {
+                const float* qp = W5 + row * ld + hl * HD;
+                const float* dop = qp + 3 * GW;
+                float sc = 0.f, dp = 0.f;
+                float qq[HD], dd[HD];
+#pragma unroll
+                for (int c = 0; c < HD; c += 4) {
+                    const float4 x = ld4(qp + c), g = ld4(dop + c);
+                    qq[c] = x.x * scale; qq[c + 1] = x.y * scale; qq[c + 2] = x.z * scale; qq[c + 3] = x.w * scale;
+                    dd[c] = g.x; dd[c + 1] = g.y; dd[c + 2] = g.z; dd[c + 3] = g.w;
+                }
+#pragma unroll
+                for (int c = 0; c < HD; ++c) { sc = fmaf(qq[c], k[c], sc); dp = fmaf(dd[c], v[c], dp); }
+                const float p = expf(sc - lse_s[hl * LP + row]);
+                const float ds = p * (dp - delta_s[hl * LP + row]);
+#pragma unroll
+                for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(p, dd[c], dv[c]); }
+            }
+        }
+        // NOTE: other items of this pass read only q / do / lse / delta, never k or v of another row
+#pragma unroll
+        for (int c = 0; c < HD; c += 4) {
+            st4(kp + c, make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]));
+            st4(vp + c, make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]));
+        }
+    }
+}
+
+template <int D, int MT, int HD>
+__global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) {
+    constexpr int LP = MT * 16;
+    constexpr int LDX = D + 4;
+    constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
+    constexpr int NG = D / GW;
+    constexpr int NC = 2 * D;                     // FFN hidden columns per pass
+    constexpr int W5C = (5 * GW > NC ? 5 * GW : NC);
+    constexpr int LD5 = W5C + 4;
+    constexpr int NTW = (D / 16 + DTQN_WAVES - 1) / DTQN_WAVES;
+    const DtqnNet& net = a.net;
+    const Thr t = make_thr();
+    const int b = (int)blockIdx.x;
+    const int L = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
+    const bool ident = net.identity != 0;
+    const float* __restrict__ theta = a.theta;
+    const float* rec = a.act + (size_t)b * net.act_stride;
+    float* grec = a.grd + (size_t)b * net.grd_stride;
+    float* srec = a.small + (size_t)b * net.sp_stride;
+
+    float* DX = reinterpret_cast<float*>(dtqn_smem);   // dL/d(residual stream)        [LP][LDX]
+    float* T2 = DX + LP * LDX;                         // narrow temp                   [LP][LDX]
+    float* W5 = T2 + LP * LDX;                         // wide temp                     [LP][LD5]
+    float* dq_s = W5 + LP * LD5;                       // dL/dQ                         [LP][AP]
+    float* delta_s = dq_s + LP * AP;                   // attention row terms           [GW/HD][LP]
+    float* lse_s = delta_s + (GW / HD) * LP;
+    float* red = lse_s + (GW / HD) * LP;               // LN column-sum scratch         [PARTS][2][D]
+    constexpr int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    float* DU = red + PARTS * 2 * D;                   // identity only: branch grad    [LP][LDX]
+
+    const int ep = a.ep_idx[b], st0 = a.start[b];
+
+    // ---------------- B0: double-DQN target, loss, dL/dQ, statistics (dtqn.py:219-253) ----------------
+    {
+        const float* q0 = a.q3 + ((size_t)0 * a.batch + b) * LP * AP;
+        const float* q1 = a.q3 + ((size_t)1 * a.batch + b) * LP * AP;
+        const float* q2 = a.q3 + ((size_t)2 * a.batch + b) * LP * AP;
+        const float inv_count = 1.0f / ((float)a.batch * (float)a.history);
+        for (int idx = t.tid; idx < LP * AP; idx += DTQN_THREADS) dq_s[idx] = 0.f;
+        __syncthreads();
+        if (t.wave == 0) {
+            float sq = 0.f, mnq = INFINITY, mxq = -INFINITY, sy = 0.f, mny = INFINITY, mxy = -INFINITY, se = 0.f;
+            for (int r = t.lane; r < LP; r += 64) {
+                if (r < L && r >= L - a.history) {
+                    const int at = (int)a.actions[(size_t)ep * a.act_ep_stride + st0 + r];
+                    const float rew = a.rewards[(size_t)ep * a.rew_ep_stride + st0 + r];
+                    const float dn = a.dones[(size_t)ep * a.rew_ep_stride + st0 + r] ? 1.f : 0.f;
+                    const float q = q0[r * AP + at];
+                    int am = 0;
+                    float best = q1[r * AP];
+                    for (int c = 1; c < A; ++c) {          // torch.argmax: first maximal index
+                        const float v = q1[r * AP + c];
+                        if (v > best) { best = v; am = c; }
+                    }
+                    const float y = rew + (1.f - dn) * (q2[r * AP + am] * a.gamma);
+                    const float diff = q - y;
+                    dq_s[r * AP + at] = 2.f * diff * inv_count;
+                    sq += q; mnq = fminf(mnq, q); mxq = fmaxf(mxq, q);
+                    sy += y; mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+                    se = fmaf(diff, diff, se);
+                }
+            }
+            for (int m = 32; m >= 1; m >>= 1) {
+                sq += __shfl_xor(sq, m); sy += __shfl_xor(sy, m); se += __shfl_xor(se, m);
+                mnq = fminf(mnq, __shfl_xor(mnq, m)); mxq = fmaxf(mxq, __shfl_xor(mxq, m));
+                mny = fminf(mny, __shfl_xor(mny, m)); mxy = fmaxf(mxy, __shfl_xor(mxy, m));
+            }
+            if (t.lane == 0) {
+                float* sp = a.stats_partial + (size_t)b * 8;
+                sp[0] = se; sp[1] = sq; sp[2] = mxq; sp[3] = mnq; sp[4] = sy; sp[5] = mxy; sp[6] = mny; sp[7] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < LP * AP; idx += DTQN_THREADS) grec[net.go_dq + idx] = dq_s[idx];
+    }
+
+    // ---------------- B1: Q head backward ----------------
+    {
+        const float* __restrict__ W2 = theta + net.off_head2_w;
+        const float* hh = rec + net.ao_hh;
+        for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+            const int r = idx / D, k = idx - r * D;
+            float g = 0.f;
+            if (hh[idx] > 0.f)
+                for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + k], g);
+            T2[r * LDX + k] = g;
+            grec[net.go_dhh + idx] = g;
+        }
+    }
+    __syncthreads();
+    gemm_dyw<D, MT>(T2, LDX, theta + net.off_head1_w, D, D, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
+    __syncthreads();
+
+    // ---------------- layers, last to first ----------------
+    for (int l = net.num_layers - 1; l >= 0; --l) {
+        const float* __restrict__ th = layer_theta(net, theta, l);
+        const float* lrec = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
+        float* lgrd = grec + net.go_layer0 + (size_t)l * net.grd_layer_stride;
+        float* lsm = srec + net.so_ln + l * 4 * D;
+
+        if (!ident) {   // x_out = LN2(s2): dL/ds2
+            tile_load(T2, LDX, lrec + net.al_s2, LP, D, t);
+            __syncthreads();
+            layernorm_backward<D>(DX, T2, DX, false, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            __syncthreads();
+        }
+        // mlp gate (res): s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0]; the skip path keeps DX
+        {
+            const float* y2 = lrec + net.al_y2;
+            for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+                const int r = idx / D, c = idx - r * D;
+                const float g = y2[idx] > 0.f ? DX[r * LDX + c] : 0.f;
+                T2[r * LDX + c] = g;
+                lgrd[net.gl_df + idx] = g;
+            }
+        }
+        __syncthreads();
+        // FFN backward: dh = df W2 (masked by h > 0), du2 = dh W1, in hidden-column passes
+        {
+            f32x4 xacc[NTW][MT];
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xacc[q][m] = zero4();
+            const float* __restrict__ W1 = th + net.lo_f1_w;
+            const float* __restrict__ W2 = th + net.lo_f2_w;
+            const float* hrec = lrec + net.al_h;
+            for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+                gemm_dyw<D, MT>(T2, LDX, W2 + c0, 4 * D, NC, t, [&](int r, int c, float v) {
+                    const float g = hrec[(size_t)r * 4 * D + c0 + c] > 0.f ? v : 0.f;
+                    W5[r * LD5 + c] = g;
+                    lgrd[net.gl_dhp + (size_t)r * 4 * D + c0 + c] = g;
+                });
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) {
+                    const int nt = t.wave + q * DTQN_WAVES;
+                    if (nt * 16 < D) mma_dyw_tile<NC, MT>(W5, LD5, W1 + (size_t)c0 * D + nt * 16 + t.i, D, t, xacc[q]);
+                }
+                __syncthreads();
+            }
+            float* dst = ident ? DU : DX;
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                const int nt = t.wave + q * DTQN_WAVES;
+                if (nt * 16 < D) {
+                    const int c = nt * 16 + t.i;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = m * 16 + t.kq * 4 + r4;
+                            if (ident) dst[r * LDX + c] = xacc[q][m][r4];
+                            else dst[r * LDX + c] += xacc[q][m][r4];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        // LayerNorm in front of / behind the FFN
+        tile_load(T2, LDX, lrec + net.al_s1, LP, D, t);
+        __syncthreads();
+        if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
+            layernorm_backward<D>(DX, T2, DX, false, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+        else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
+            layernorm_backward<D>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+        __syncthreads();
+        // attention gate (res): s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]
+        {
+            const float* y1 = lrec + net.al_y1;
+            for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+                const int r = idx / D, c = idx - r * D;
+                const float g = y1[idx] > 0.f ? DX[r * LDX + c] : 0.f;
+                T2[r * LDX + c] = g;
+                lgrd[net.gl_da + idx] = g;
+            }
+        }
+        __syncthreads();
+        // attention backward, one head group (GW columns) at a time; du1 = dqkv W_in accumulates in registers
+        {
+            f32x4 xacc[NTW][MT];
+#pragma unroll
+            for (int q = 0; q < NTW; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xacc[q][m] = zero4();
+            const float* __restrict__ Wo = th + net.lo_out_w;
+            const float* __restrict__ Win = th + net.lo_in_w;
+            const float* qkv = lrec + net.al_qkv;
+            for (int g = 0; g < NG; ++g) {
+                // q, k, v of this head group -> W5[:, 0:3GW]
+                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += DTQN_THREADS) {
+                    const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
+                    const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
+                    st4(W5 + r * LD5 + which * GW + c, ld4(qkv + (size_t)r * 3 * D + which * D + g * GW + c));
+                }
+                // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW]
+                gemm_dyw<D, MT>(T2, LDX, Wo + g * GW, D, GW, t, [&](int r, int c, float v) { W5[r * LD5 + 3 * GW + c] = v; });
+                __syncthreads();
+                attention_backward_group<HD>(W5, LD5, GW, LP, L, g * (GW / HD), lrec + net.al_lse, lrec + net.al_o, D,
+                                             delta_s, lse_s, t);
+                __syncthreads();
+                // dq | dk | dv of the group -> grd record (columns of the packed [LP][3D] layout)
+                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += DTQN_THREADS) {
+                    const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
+                    const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
+                    const float* sp = W5 + r * LD5 + (which == 0 ? 4 * GW : which * GW) + c;
+                    st4(lgrd + net.gl_dqkv + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
+                }
+#pragma unroll
+                for (int q = 0; q < NTW; ++q) {
+                    const int nt = t.wave + q * DTQN_WAVES;
+                    if (nt * 16 < D) {
+                        const float* wc = Win + nt * 16 + t.i;
+                        mma_dyw_tile<GW, MT>(W5 + 4 * GW, LD5, wc + (size_t)(0 * D + g * GW) * D, D, t, xacc[q]);
+                        mma_dyw_tile<GW, MT>(W5 + 1 * GW, LD5, wc + (size_t)(1 * D + g * GW) * D, D, t, xacc[q]);
+                        mma_dyw_tile<GW, MT>(W5 + 2 * GW, LD5, wc + (size_t)(2 * D + g * GW) * D, D, t, xacc[q]);
+                    }
+                }
+                __syncthreads();
+            }
+            float* dst = ident ? DU : DX;
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                const int nt = t.wave + q * DTQN_WAVES;
+                if (nt * 16 < D) {
+                    const int c = nt * 16 + t.i;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = m * 16 + t.kq * 4 + r4;
+                            if (ident) dst[r * LDX + c] = xacc[q][m][r4];
+                            else dst[r * LDX + c] += xacc[q][m][r4];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
+            const float* xin = l == 0 ? rec + net.ao_x0 : rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2;
+            tile_load(T2, LDX, xin, LP, D, t);
+            __syncthreads();
+            layernorm_backward<D>(DU, T2, DX, true, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- embedding: dL/dx0 -> record; table / action-embedding partials ----------------
+    tile_store(DX, LDX, grec + net.go_dx0, LP, D, t);
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
+    const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
+    if (net.discrete) {
+        const int KE = net.ke, KEP = net.kep, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim;
+        const float* __restrict__ We = theta + net.off_obs_w;
+        float* dein = W5;    // [LP][KEP]: dL/d(gathered table rows) = dx0[:, a:] W_e
+        for (int idx = t.tid; idx < LP * KEP; idx += DTQN_THREADS) {
+            const int r = idx / KEP, k = idx - r * KEP;
+            float g = 0.f;
+            if (r < L && k < KE)
+                for (int d = 0; d < D - adim; ++d) g = fmaf(DX[r * LDX + adim + d], We[(size_t)d * KE + k], g);
+            dein[idx] = g;
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < V * e; idx += DTQN_THREADS) {
+            const int v = idx / e, c = idx - v * e;
+            float g = 0.f;
+            for (int r = 0; r < L; ++r)
+                for (int j = 0; j < O; ++j) {
+                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+                    if (tok == v) g += dein[r * KEP + j * e + c];
+                }
+            srec[net.so_tab + idx] = g;
+        }
+    }
+    if (adim > 0) {
+        for (int idx = t.tid; idx < A * adim; idx += DTQN_THREADS) {
+            const int v = idx / adim, c = idx - v * adim;
+            float g = 0.f;
+            if (L == 1) {
+                if ((int)act_rows[0] == v) g = DX[c];
+            } else {
+                for (int r = 1; r < L; ++r)
+                    if ((int)act_rows[r - 1] == v) g += DX[r * LDX + c];
+            }
+            srec[net.so_act + idx] = g;
+        }
+    }
+}
+
+static size_t bwd_lds_bytes(const DtqnNet* net) {
+    const int LP = net->lp, D = net->d_model, HD = net->head_dim;
+    const int GW = D >= 64 ? 64 : D, NC = 2 * D;
+    const int W5C = 5 * GW > NC ? 5 * GW : NC;
+    const int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    size_t fl = 2 * (size_t)LP * (D + 4) + (size_t)LP * (W5C + 4) + (size_t)LP * net->ap + 2 * (size_t)(GW / HD) * LP +
+                (size_t)PARTS * 2 * D;
+    if (net->identity) fl += (size_t)LP * (D + 4);
+    return fl * sizeof(float);
+}
+
+template <int D, int MT, int HD>
+static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = bwd_lds_bytes(&a.net);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD>), dim3(a.batch), dim3(DTQN_THREADS), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+}  // namespace dtqn
+
+using namespace dtqn;
+
+extern "C" int dtqn_lds_bytes_backward(const DtqnNet* net) {
+    if (!net) return 0;
+    const size_t b = bwd_lds_bytes(net);
+    return b <= 160 * 1024 ? (int)b : 0;
+}
+
+extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+    if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
+    if (td->history < 1 || td->history > net->ctx_len) return DTQN_ERR_ARG;
+    if (net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
+    if (bwd_lds_bytes(net) > 160 * 1024) return DTQN_ERR_CONFIG;
+    BwdArgs a;
+    a.net = *net;
+    a.theta = td->theta_pol;
+    a.act = td->act; a.grd = td->grd; a.small = td->small; a.q3 = td->q3; a.stats_partial = td->stats_partial;
+    a.obs = rp->obs; a.actions = rp->actions; a.rewards = rp->rewards; a.dones = rp->dones;
+    a.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim;
+    a.act_ep_stride = rp->max_steps + 1;
+    a.rew_ep_stride = rp->max_steps;
+    a.ep_idx = td->ep_idx; a.start = td->start;
+    a.batch = td->batch; a.history = td->history; a.gamma = td->gamma;
+    const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim;
+    hipStream_t s = (hipStream_t)stream;
+#define DTQN_BWD_CASE(d, mt, hd) \
+    if (D == d && MT == mt && HD == hd) return launch_bwd<d, mt, hd>(a, s);
+    DTQN_BWD_CASE(64, 4, 8)
+    DTQN_BWD_CASE(128, 4, 16)
+    DTQN_BWD_CASE(64, 4, 16)
+    DTQN_BWD_CASE(16, 1, 8)
+    DTQN_BWD_CASE(32, 2, 8)
+    DTQN_BWD_CASE(32, 1, 16)
+#undef DTQN_BWD_CASE
+    return DTQN_ERR_CONFIG;
+}

@@ -27,7 +27,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     const int O = net->obs_dim, A = net->num_actions, e = net->embed_per_obs, a = net->action_dim;
     const int D = net->d_model, H = net->num_heads, NL = net->num_layers, L = net->ctx_len, V = net->vocab;
     if (O < 1 || A < 1 || D < 16 || H < 1 || NL < 1 || NL > DTQN_MAX_LAYERS || L < 1) return DTQN_ERR_CONFIG;
-    if (D % 16 != 0 || D % H != 0 || a < 0 || a >= D) return DTQN_ERR_CONFIG;
+    if (D % 16 != 0 || D % H != 0 || a < 0 || a >= D || (a % 4) != 0) return DTQN_ERR_CONFIG;
     if (net->discrete && (V < 1 || e < 1)) return DTQN_ERR_CONFIG;
     if (net->gate != DTQN_GATE_RES && net->gate != DTQN_GATE_GRU) return DTQN_ERR_CONFIG;
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
@@ -41,7 +41,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     const int LP = net->lp;
     // kernels cover what fits the per-sequence LDS tile (DESIGN.md "coverage")
     if (LP > DTQN_MAX_LP || D > DTQN_MAX_D || net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
-    if (A > DTQN_MAX_ACTIONS) return DTQN_ERR_CONFIG;
+    if (A > DTQN_MAX_ACTIONS || net->kep > 3 * D) return DTQN_ERR_CONFIG;
 
     // ---- theta: trainable region first ----
     Cursor c;
@@ -149,7 +149,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     int njobs = 0, ntiles = 0;
     auto count = [&](int N, int K) {
         njobs++;
-        ntiles += ((N + 31) / 32) * ((K + 31) / 32);
+        ntiles += ((N + 63) / 64) * ((K + 63) / 64);
     };
     count(D - a, net->ke);
     for (int l = 0; l < NL; ++l) {
@@ -180,8 +180,8 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
         w.dy_off = dy_off; w.ldy = ldy; w.N = N;
         w.w_off = w_off; w.b_off = b_off;
         w.tile0 = tile;
-        w.tiles_n = (N + 31) / 32;
-        w.tiles_k = (K + 31) / 32;
+        w.tiles_n = (N + 63) / 64;
+        w.tiles_k = (K + 63) / 64;
         tile += w.tiles_n * w.tiles_k;
     };
     // embedding linear: dY = dx0[:, a:], X = e_in

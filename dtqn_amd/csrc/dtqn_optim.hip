@@ -1,0 +1,249 @@
+// Gradient assembly, global-norm clip, Adam, hard target sync (gfx950; HBM/L2-bound elementwise work).
+//
+// Replaces torch.nn.utils.clip_grad_norm_(params, 1.0, error_if_nonfinite=True), optim.Adam.step and
+// DqnAgent.target_update (dtqn/agents/dtqn.py:257-269, dtqn/agents/dqn.py:64,208-210), plus the seven
+// `.item()` statistics of dtqn.py:245-253,263 (reduced on the device, read back asynchronously).
+#include "dtqn_device.hpp"
+
+namespace dtqn {
+
+constexpr int kOptThreads = 256;
+constexpr int kOptVec = 4;                 // floats per thread (one float4)
+constexpr int kOptBlockElems = kOptThreads * kOptVec;
+
+struct ReduceArgs {
+    DtqnNet net;
+    const float* gsplit;
+    const float* small;
+    const float* grd;
+    float* grad;
+    float* norm_partial;
+    int32_t* step_counter;
+    int batch, n_split;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int w = 0; w < kOptThreads / 64; ++w) s += red[w];
+    __syncthreads();
+    return s;
+}
+
+// grad[p] = sum of the weight-gradient splits, or (for LayerNorm affine / embedding tables / learned
+// position table) the sum over sequences of the backward kernel's per-sequence partials.
+__global__ __launch_bounds__(kOptThreads) void dtqn_reduce_kernel(ReduceArgs a) {
+    __shared__ float red[kOptThreads / 64];
+    const DtqnNet& net = a.net;
+    const int tid = (int)threadIdx.x;
+    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    if (blockIdx.x == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];   // publish the step count of the previous update
+    float v[kOptVec] = {0.f, 0.f, 0.f, 0.f};
+    if (p0 < net.n_trainable) {
+        const int D = net.d_model, L = net.ctx_len, LP = net.lp;
+        // which source? (all segment boundaries are multiples of 4, so a float4 never straddles two)
+        int kind = 0, src = 0;
+        const int lrel = p0 - net.off_layer0;
+        if (lrel >= 0 && lrel < net.layer_stride * net.num_layers && (lrel % net.layer_stride) < 4 * D) {
+            kind = 1; src = net.so_ln + (lrel / net.layer_stride) * 4 * D + (lrel % net.layer_stride);
+        } else if (net.discrete && p0 >= net.off_obs_tab && p0 < net.off_obs_tab + net.vocab * net.embed_per_obs) {
+            kind = 1; src = net.so_tab + (p0 - net.off_obs_tab);
+        } else if (net.action_dim > 0 && p0 >= net.off_act_emb && p0 < net.off_act_emb + net.num_actions * net.action_dim) {
+            kind = 1; src = net.so_act + (p0 - net.off_act_emb);
+        } else if (net.pos == DTQN_POS_LEARNED && p0 >= net.off_pos && p0 < net.off_pos + L * D) {
+            kind = 2; src = net.go_dx0 + (p0 - net.off_pos);
+        }
+        if (kind == 0) {
+            for (int s = 0; s < a.n_split; ++s) {
+                const float4 x = ld4(a.gsplit + (size_t)s * net.n_trainable + p0);
+                v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+            }
+        } else {
+            const float* base = kind == 1 ? a.small : a.grd;
+            const size_t stride = kind == 1 ? (size_t)net.sp_stride : (size_t)net.grd_stride;
+            // tables may end off a float4 boundary inside their padded slot: the padding of the
+            // per-sequence record is never written, so guard the tail element-wise
+            int valid = 4;
+            if (kind == 1 && net.discrete && p0 >= net.off_obs_tab && p0 < net.off_obs_tab + net.vocab * net.embed_per_obs)
+                valid = net.off_obs_tab + net.vocab * net.embed_per_obs - p0;
+            if (kind == 1 && net.action_dim > 0 && p0 >= net.off_act_emb && p0 < net.off_act_emb + net.num_actions * net.action_dim)
+                valid = net.off_act_emb + net.num_actions * net.action_dim - p0;
+            (void)LP;
+            for (int b = 0; b < a.batch; ++b) {
+                const float* sp = base + (size_t)b * stride + src;
+                for (int c = 0; c < 4; ++c)
+                    if (c < valid) v[c] += sp[c];
+            }
+        }
+        st4(a.grad + p0, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    const float ss = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), red, tid);
+    if (tid == 0) a.norm_partial[blockIdx.x] = ss;
+}
+
+struct NormArgs {
+    const float* grad;
+    float* norm_partial;
+    int n;
+};
+__global__ __launch_bounds__(kOptThreads) void dtqn_gradnorm_kernel(NormArgs a) {
+    __shared__ float red[kOptThreads / 64];
+    const int tid = (int)threadIdx.x;
+    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    float ss = 0.f;
+    if (p0 < a.n) {
+        const float4 g = ld4(a.grad + p0);
+        ss = (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+    }
+    ss = block_sum(ss, red, tid);
+    if (tid == 0) a.norm_partial[blockIdx.x] = ss;
+}
+
+struct AdamArgs {
+    float* theta;
+    float* theta_tgt;
+    const float* grad;
+    float* m;
+    float* v;
+    const float* norm_partial;
+    const float* stats_partial;
+    float* stats;
+    int32_t* step_counter;
+    int n, n_norm_blocks, batch, history, tuf;
+    float lr, beta1, beta2, eps, clip, grad_scale;
+};
+
+__global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a) {
+    __shared__ float red[kOptThreads / 64];
+    __shared__ double pw[2];
+    const int tid = (int)threadIdx.x;
+    // every block re-derives the global norm from the per-block partials (a few hundred floats)
+    float part = 0.f;
+    for (int i = tid; i < a.n_norm_blocks; i += kOptThreads) part += a.norm_partial[i];
+    const float total = block_sum(part, red, tid);
+    const float norm = sqrtf(total) * a.grad_scale;
+    const bool finite = isfinite(norm);
+    const int k = a.step_counter[0] + 1;                      // 1-based index of this optimizer step
+    if (tid == 0) {
+        pw[0] = 1.0 - pow((double)a.beta1, (double)k);
+        pw[1] = 1.0 - pow((double)a.beta2, (double)k);
+    }
+    __syncthreads();
+    const float bc1 = (float)pw[0], bc2_sqrt = (float)sqrt(pw[1]);
+    const float coef = fminf(1.0f, a.clip / (norm + 1e-6f)) * a.grad_scale;
+    const float step_size = a.lr / bc1;
+    const bool sync_target = finite && a.tuf > 0 && (k % a.tuf) == 0;
+    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    if (finite && p0 < a.n) {
+        const float4 g4 = ld4(a.grad + p0);
+        float4 m4 = ld4(a.m + p0), v4 = ld4(a.v + p0), p4 = ld4(a.theta + p0);
+        const float g[4] = {g4.x * coef, g4.y * coef, g4.z * coef, g4.w * coef};
+        float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mm[c] = mm[c] + (g[c] - mm[c]) * (1.0f - a.beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
+            vv[c] = vv[c] * a.beta2 + (1.0f - a.beta2) * g[c] * g[c];           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+            const float denom = sqrtf(vv[c]) / bc2_sqrt + a.eps;
+            pp[c] = pp[c] - step_size * (mm[c] / denom);
+        }
+        st4(a.m + p0, make_float4(mm[0], mm[1], mm[2], mm[3]));
+        st4(a.v + p0, make_float4(vv[0], vv[1], vv[2], vv[3]));
+        const float4 pn = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        st4(a.theta + p0, pn);
+        if (sync_target) st4(a.theta_tgt + p0, pn);           // hard target update every tuf steps (dqn.py:208-210)
+    }
+    if (blockIdx.x == 0) {
+        // statistics of dtqn.py:245-253,263, reduced over the per-sequence partials
+        float se = 0.f, sq = 0.f, sy = 0.f, mxq = -INFINITY, mnq = INFINITY, mxy = -INFINITY, mny = INFINITY;
+        for (int b = tid; b < a.batch; b += kOptThreads) {
+            const float* sp = a.stats_partial + (size_t)b * 8;
+            se += sp[0]; sq += sp[1]; mxq = fmaxf(mxq, sp[2]); mnq = fminf(mnq, sp[3]);
+            sy += sp[4]; mxy = fmaxf(mxy, sp[5]); mny = fminf(mny, sp[6]);
+        }
+        se = block_sum(se, red, tid); sq = block_sum(sq, red, tid); sy = block_sum(sy, red, tid);
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            mxq = fmaxf(mxq, __shfl_xor(mxq, mk)); mnq = fminf(mnq, __shfl_xor(mnq, mk));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, mk)); mny = fminf(mny, __shfl_xor(mny, mk));
+        }
+        __shared__ float mm4[4][kOptThreads / 64];
+        if ((tid & 63) == 0) { mm4[0][tid >> 6] = mxq; mm4[1][tid >> 6] = mnq; mm4[2][tid >> 6] = mxy; mm4[3][tid >> 6] = mny; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kOptThreads / 64; ++w) {
+                mxq = fmaxf(mxq, mm4[0][w]); mnq = fminf(mnq, mm4[1][w]); mxy = fmaxf(mxy, mm4[2][w]); mny = fminf(mny, mm4[3][w]);
+            }
+            const float cnt = (float)a.batch * (float)a.history;
+            a.stats[0] = se / cnt;          // TD error (MSE loss)
+            a.stats[1] = norm;              // pre-clip gradient norm
+            a.stats[2] = mxq; a.stats[3] = sq / cnt; a.stats[4] = mnq;
+            a.stats[5] = mxy; a.stats[6] = sy / cnt; a.stats[7] = mny;
+            a.stats[8] = fminf(1.0f, a.clip / (norm + 1e-6f));
+            a.stats[9] = (float)k;
+            a.stats[10] = sync_target ? 1.f : 0.f;
+            a.stats[11] = finite ? 0.f : 1.f;
+            if (finite) a.step_counter[1] = k;
+        }
+    }
+}
+
+struct CopyArgs {
+    const float* src;
+    float* dst;
+    int n;
+};
+__global__ __launch_bounds__(kOptThreads) void dtqn_copy_kernel(CopyArgs a) {
+    const int p0 = ((int)blockIdx.x * kOptThreads + (int)threadIdx.x) * kOptVec;
+    if (p0 < a.n) st4(a.dst + p0, ld4(a.src + p0));
+}
+
+}  // namespace dtqn
+
+using namespace dtqn;
+
+static int opt_blocks(int n) { return (n + kOptBlockElems - 1) / kOptBlockElems; }
+
+extern "C" int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream) {
+    if (!net || !td) return DTQN_ERR_ARG;
+    if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
+    ReduceArgs a;
+    a.net = *net;
+    a.gsplit = td->gsplit; a.small = td->small; a.grd = td->grd; a.grad = td->grad;
+    a.norm_partial = td->norm_partial; a.step_counter = td->step_counter;
+    a.batch = td->batch; a.n_split = td->n_split;
+    hipLaunchKernelGGL(dtqn_reduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stream) {
+    if (!net || !td) return DTQN_ERR_ARG;
+    if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
+    NormArgs a;
+    a.grad = td->grad; a.norm_partial = td->norm_partial; a.n = net->n_trainable;
+    hipLaunchKernelGGL(dtqn_gradnorm_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream) {
+    if (!net || !td) return DTQN_ERR_ARG;
+    if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
+    AdamArgs a;
+    a.theta = td->theta_pol; a.theta_tgt = td->theta_tgt; a.grad = td->grad; a.m = td->adam_m; a.v = td->adam_v;
+    a.norm_partial = td->norm_partial; a.stats_partial = td->stats_partial; a.stats = td->stats;
+    a.step_counter = td->step_counter;
+    a.n = net->n_trainable; a.n_norm_blocks = td->n_norm_blocks; a.batch = td->batch; a.history = td->history;
+    a.tuf = td->target_update_frequency;
+    a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;
+    a.grad_scale = td->grad_scale;
+    hipLaunchKernelGGL(dtqn_clip_adam_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream) {
+    if (!net || !theta_pol || !theta_tgt) return DTQN_ERR_ARG;
+    CopyArgs a;
+    a.src = theta_pol; a.dst = theta_tgt; a.n = net->n_theta;
+    hipLaunchKernelGGL(dtqn_copy_kernel, dim3(opt_blocks(net->n_theta)), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}

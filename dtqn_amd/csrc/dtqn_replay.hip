@@ -1,0 +1,114 @@
+// Device-resident replay buffer maintenance (gfx950).  Pure HBM byte work: coalesced fills and
+// row writes, no arithmetic worth a matrix core.
+//
+// Replaces ReplayBuffer.store / store_obs / cleanse_episode (dtqn/buffers/replay_buffer.py:71-135)
+// and the index draw of ReplayBuffer.sample (:141-158).  The window gather itself (:160-167) is
+// fused into the forward / backward kernels, which read their (episode, start) rows in place.
+#include "dtqn_device.hpp"
+
+namespace dtqn {
+
+struct ApplyArgs {
+    DtqnReplay rp;
+    const DtqnReplayRecord* recs;
+    const float* obs_rows;
+    int n;
+};
+
+// One workgroup walks the records IN ORDER (a store_obs cleanses the slot its later stores write).
+__global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyArgs a) {
+    const int tid = (int)threadIdx.x;
+    const int T = a.rp.max_steps, O = a.rp.obs_dim;
+    for (int i = 0; i < a.n; ++i) {
+        const DtqnReplayRecord r = a.recs[i];
+        const int ep = r.ep;
+        float* obs = a.rp.obs + (size_t)ep * (T + 1) * O;
+        uint8_t* act = a.rp.actions + (size_t)ep * (T + 1);
+        float* rew = a.rp.rewards + (size_t)ep * T;
+        uint8_t* don = a.rp.dones + (size_t)ep * T;
+        const float* src = a.obs_rows + (size_t)r.obs_index * O;
+        if (r.kind == 0) {
+            // cleanse_episode (:100-135): obs <- mask, actions <- 0, rewards <- 0, dones <- True, length <- 0
+            for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? src[k] : a.rp.obs_mask;
+            for (int k = tid; k < T + 1; k += DTQN_THREADS) act[k] = 0;
+            for (int k = tid; k < T; k += DTQN_THREADS) { rew[k] = 0.f; don[k] = 1; }
+            if (tid == 0) a.rp.ep_len[ep] = 0;
+        } else {
+            // store (:71-86): obs at row t+1, action / reward / done at row t, episode length
+            const int t = r.t;
+            for (int k = tid; k < O; k += DTQN_THREADS) obs[(size_t)(t + 1) * O + k] = src[k];
+            if (tid == 0) {
+                act[t] = (uint8_t)r.action;
+                rew[t] = r.reward;
+                don[t] = r.done ? 1 : 0;
+                a.rp.ep_len[ep] = t + 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// splitmix64-style counter hash -> 32 random bits per (seed, step, element, draw)
+__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t step, uint32_t elem, uint32_t draw) {
+    unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^
+                           ((unsigned long long)elem << 20) ^ draw;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+struct SampleArgs {
+    const int32_t* ep_len;
+    int n_valid, exclude, ctx_len, batch;
+    uint32_t seed;
+    const int32_t* step_counter;
+    int32_t* ep_idx;
+    int32_t* start;
+};
+
+__global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_sample_kernel(SampleArgs a) {
+    const int b = (int)blockIdx.x * DTQN_THREADS + (int)threadIdx.x;
+    if (b >= a.batch) return;
+    const uint32_t step = a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : 0u;
+    const bool skip = a.exclude >= 0 && a.exclude < a.n_valid;
+    const uint32_t choices = (uint32_t)(a.n_valid - (skip ? 1 : 0));
+    // valid_episodes = [0, n_valid) \ {exclude}; random.choice -> uniform (replay_buffer.py:141-148)
+    uint32_t e = (uint32_t)(((unsigned long long)hash_u32(a.seed, step, (uint32_t)b, 0) * choices) >> 32);
+    if (skip && (int)e >= a.exclude) e += 1;
+    // start uniform on {0 .. max(0, len - L)} inclusive (:149-155)
+    const int len = a.ep_len[e];
+    const uint32_t span = (uint32_t)(len - a.ctx_len > 0 ? len - a.ctx_len : 0) + 1u;
+    const uint32_t s = (uint32_t)(((unsigned long long)hash_u32(a.seed, step, (uint32_t)b, 1) * span) >> 32);
+    a.ep_idx[b] = (int32_t)e;
+    a.start[b] = (int32_t)s;
+}
+
+}  // namespace dtqn
+
+using namespace dtqn;
+
+extern "C" int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* recs_dev, const float* obs_rows_dev,
+                                 int n, void* stream) {
+    if (!rp || n < 0) return DTQN_ERR_ARG;
+    if (n == 0) return DTQN_OK;
+    if (!recs_dev || !obs_rows_dev) return DTQN_ERR_ARG;
+    ApplyArgs a;
+    a.rp = *rp; a.recs = recs_dev; a.obs_rows = obs_rows_dev; a.n = n;
+    hipLaunchKernelGGL(dtqn_replay_apply_kernel, dim3(1), dim3(DTQN_THREADS), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed,
+                                  const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream) {
+    if (!rp || batch < 1 || !ep_idx_dev || !start_dev) return DTQN_ERR_ARG;
+    const bool skip = exclude >= 0 && exclude < n_valid;
+    if (n_valid - (skip ? 1 : 0) < 1) return DTQN_ERR_ARG;
+    SampleArgs a;
+    a.ep_len = rp->ep_len; a.n_valid = n_valid; a.exclude = exclude; a.ctx_len = ctx_len; a.batch = batch;
+    a.seed = seed; a.step_counter = step_counter_dev; a.ep_idx = ep_idx_dev; a.start = start_dev;
+    hipLaunchKernelGGL(dtqn_replay_sample_kernel, dim3((batch + DTQN_THREADS - 1) / DTQN_THREADS), dim3(DTQN_THREADS), 0,
+                       (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}

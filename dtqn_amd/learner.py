@@ -1,0 +1,178 @@
+"""Device-side state of one DTQN learner and the launch sequence of a TD update.
+
+`TdEngine` owns the flat parameter / optimizer buffers, the replay views and the workspaces the
+kernels need, as torch tensors (torch is the allocator and stream provider here, nothing more),
+and drives libdtqn_hip.so through the C ABI of include/dtqn_hip.h.  It is the body of
+DtqnAgent.train() (dtqn/agents/dtqn.py:162-269 in the reference) minus the host bookkeeping.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _binding as B
+from . import engine
+
+STAT_NAMES = ("td_error", "grad_norm", "qvalue_max", "qvalue_mean", "qvalue_min",
+              "target_max", "target_mean", "target_min", "clip_coef", "step", "target_synced", "nonfinite")
+OPT_BLOCK_ELEMS = 1024        # dtqn_optim.hip: 256 threads x float4
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class DeviceReplay:
+    """Episode-major replay arrays resident in HBM (layout: include/dtqn_hip.h, DtqnReplay)."""
+
+    def __init__(self, num_episodes: int, max_steps: int, obs_dim: int, obs_mask: float, device):
+        E, T, O = int(num_episodes), int(max_steps), int(obs_dim)
+        self.E, self.T, self.O, self.obs_mask = E, T, O, float(obs_mask)
+        self.device = device
+        # initial fill = the reference constructor's (replay_buffer.py:36-69)
+        self.obs = torch.full((E, T + 1, O), float(obs_mask), dtype=torch.float32, device=device)
+        self.actions = torch.zeros((E, T + 1), dtype=torch.uint8, device=device)
+        self.rewards = torch.zeros((E, T), dtype=torch.float32, device=device)
+        self.dones = torch.ones((E, T), dtype=torch.uint8, device=device)
+        self.ep_len = torch.zeros((E,), dtype=torch.int32, device=device)
+        self.view = B.DtqnReplay()
+        self.view.obs, self.view.actions = self.obs.data_ptr(), self.actions.data_ptr()
+        self.view.rewards, self.view.dones = self.rewards.data_ptr(), self.dones.data_ptr()
+        self.view.ep_len = self.ep_len.data_ptr()
+        self.view.num_episodes, self.view.max_steps, self.view.obs_dim = E, T, O
+        self.view.obs_mask = float(obs_mask)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.obs, self.actions, self.rewards, self.dones, self.ep_len))
+
+
+class TdEngine:
+    def __init__(self, net: B.DtqnNet, batch: int, *, lr=3e-4, gamma=0.99, history=None, tuf=10_000,
+                 grad_norm_clip=1.0, betas=(0.9, 0.999), eps=1e-8, n_split: Optional[int] = None,
+                 device=None, _test_lib=None):
+        # `_test_lib` exists for the CPU kernel-emulation tests only (tests/emu); the product path
+        # always resolves to the hipcc-built engine on a ROCm device and raises otherwise.
+        if _test_lib is None:
+            self.lib = engine.get_lib()
+            self.device = engine.require_gpu() if device is None else torch.device(device)
+            if self.device.type != "cuda":
+                raise engine.EngineUnavailable("TdEngine needs a ROCm device; there is no CPU path")
+        else:
+            self.lib = _test_lib
+            self.device = torch.device("cpu")
+        self.net = net
+        self.batch = int(batch)
+        dev = self.device
+        nt, nth = net.n_trainable, net.n_theta
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.theta_pol = torch.zeros(nth, **f32)
+        self.theta_tgt = torch.zeros(nth, **f32)
+        frozen = np.zeros(nth, dtype=np.float32)
+        self.lib.dtqn_net_fill_frozen(ctypes.byref(net), frozen.ctypes.data_as(ctypes.c_void_p))
+        self.theta_pol.copy_(torch.from_numpy(frozen))
+        self.theta_tgt.copy_(torch.from_numpy(frozen))
+        self.grad = torch.zeros(nt, **f32)
+        self.adam_m = torch.zeros(nt, **f32)
+        self.adam_v = torch.zeros(nt, **f32)
+        Bn = self.batch
+        if n_split is None:   # enough workgroups to fill 256 CUs, at least 2 sequences per wave-split
+            n_split = max(1, min(Bn // 4 if Bn >= 8 else 1, max(1, 1024 // max(1, net.n_wtiles)), 32))
+        self.n_split = int(n_split)
+        self.n_norm_blocks = (nt + OPT_BLOCK_ELEMS - 1) // OPT_BLOCK_ELEMS
+        self.act = torch.zeros(Bn * net.act_stride, **f32)
+        self.grd = torch.zeros(Bn * net.grd_stride, **f32)
+        self.small = torch.zeros(Bn * net.sp_stride, **f32)
+        self.q3 = torch.zeros(3 * Bn * net.lp * net.ap, **f32)
+        self.gsplit = torch.zeros(self.n_split * nt, **f32)
+        self.norm_partial = torch.zeros(self.n_norm_blocks, **f32)
+        self.stats_partial = torch.zeros(Bn * 8, **f32)
+        self.stats = torch.zeros(len(STAT_NAMES), **f32)
+        self.step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.ep_idx = torch.zeros(Bn, dtype=torch.int32, device=dev)
+        self.start = torch.zeros(Bn, dtype=torch.int32, device=dev)
+        jobs = (B.DtqnWJob * net.n_wjobs)()
+        rc = self.lib.dtqn_net_wjobs(ctypes.byref(net), jobs)
+        if rc != 0:
+            raise RuntimeError(f"dtqn_net_wjobs rc={rc}")
+        jb = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+        self.wjobs = torch.from_numpy(jb).to(dev)
+        td = B.DtqnTd()
+        td.theta_pol, td.theta_tgt = self.theta_pol.data_ptr(), self.theta_tgt.data_ptr()
+        td.grad, td.adam_m, td.adam_v = self.grad.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr()
+        td.ep_idx, td.start = self.ep_idx.data_ptr(), self.start.data_ptr()
+        td.act, td.grd, td.small, td.q3 = self.act.data_ptr(), self.grd.data_ptr(), self.small.data_ptr(), self.q3.data_ptr()
+        td.gsplit, td.norm_partial = self.gsplit.data_ptr(), self.norm_partial.data_ptr()
+        td.stats_partial, td.stats = self.stats_partial.data_ptr(), self.stats.data_ptr()
+        td.step_counter, td.wjobs = self.step_counter.data_ptr(), self.wjobs.data_ptr()
+        td.batch = Bn
+        td.history = int(net.ctx_len if history is None else history)
+        td.n_split, td.n_norm_blocks = self.n_split, self.n_norm_blocks
+        td.target_update_frequency = int(tuf)
+        td.gamma, td.lr, td.beta1, td.beta2, td.eps = float(gamma), float(lr), float(betas[0]), float(betas[1]), float(eps)
+        td.grad_norm_clip, td.grad_scale = float(grad_norm_clip), 1.0
+        self.td = td
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _stream(self):
+        if self.device.type == "cuda":
+            return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with DTQN status {rc}")
+
+    def workspace_bytes(self) -> int:
+        ts = (self.act, self.grd, self.small, self.q3, self.gsplit, self.norm_partial, self.stats_partial)
+        return sum(t.numel() * t.element_size() for t in ts)
+
+    def set_indices(self, ep_idx, start):
+        """Host-drawn (episode, start) pairs (reference RNG stream) -> device."""
+        self.ep_idx.copy_(torch.as_tensor(np.asarray(ep_idx, dtype=np.int32)), non_blocking=True)
+        self.start.copy_(torch.as_tensor(np.asarray(start, dtype=np.int32)), non_blocking=True)
+
+    def sample_on_device(self, replay: DeviceReplay, n_valid: int, exclude: int, seed: int):
+        self._check(self.lib.dtqn_replay_sample(ctypes.byref(replay.view), int(n_valid), int(exclude), self.net.ctx_len,
+                                                self.batch, ctypes.c_uint32(seed & 0xFFFFFFFF), _p(self.step_counter),
+                                                _p(self.ep_idx), _p(self.start), self._stream()), "dtqn_replay_sample")
+
+    # -- the update, whole or in stages (stages are what the data-parallel wrapper interleaves) --
+    def update(self, replay: DeviceReplay):
+        self._check(self.lib.dtqn_td_update(ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td),
+                                            self._stream()), "dtqn_td_update")
+
+    def forward_backward(self, replay: DeviceReplay):
+        s, n, r, t = self._stream(), ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td)
+        self._check(self.lib.dtqn_td_forward(n, r, t, s), "dtqn_td_forward")
+        self._check(self.lib.dtqn_td_backward(n, r, t, s), "dtqn_td_backward")
+        self._check(self.lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad")
+        self._check(self.lib.dtqn_td_reduce(n, t, s), "dtqn_td_reduce")
+
+    def recompute_gradnorm(self):
+        self._check(self.lib.dtqn_td_gradnorm(ctypes.byref(self.net), ctypes.byref(self.td), self._stream()), "dtqn_td_gradnorm")
+
+    def clip_adam(self):
+        self._check(self.lib.dtqn_td_clip_adam(ctypes.byref(self.net), ctypes.byref(self.td), self._stream()), "dtqn_td_clip_adam")
+
+    def target_sync(self):
+        self._check(self.lib.dtqn_target_sync(ctypes.byref(self.net), _p(self.theta_pol), _p(self.theta_tgt), self._stream()),
+                    "dtqn_target_sync")
+
+    def forward(self, obs: torch.Tensor, actions: Optional[torch.Tensor], target: bool = False) -> torch.Tensor:
+        """DTQN.forward on [B, n, O] float32 observations (inference; no autograd graph)."""
+        Bn, n = int(obs.shape[0]), int(obs.shape[1])
+        q = torch.empty((Bn, n, self.net.num_actions), dtype=torch.float32, device=self.device)
+        theta = self.theta_tgt if target else self.theta_pol
+        rc = self.lib.dtqn_forward(ctypes.byref(self.net), _p(theta), _p(obs), _p(actions), Bn, n, _p(q), self._stream())
+        if rc == B.DEFINES["DTQN_ERR_ARG"]:
+            raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
+        self._check(rc, "dtqn_forward")
+        return q
+
+    def read_stats(self) -> dict:
+        """Blocking read-back of the statistics of the last update."""
+        vals = self.stats.detach().cpu().numpy()
+        return dict(zip(STAT_NAMES, (float(v) for v in vals)))

@@ -101,7 +101,7 @@ typedef struct DtqnNet {
     int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */
     /* ---- derived: weight-gradient job table ---- */
     int32_t n_wjobs;
-    int32_t n_wtiles;         /* total 32x32 output tile groups over all jobs */
+    int32_t n_wtiles;         /* total 64x64 output blocks over all jobs */
 } DtqnNet;
 
 /* One weight-gradient GEMM:  dW[N][K] (+)= sum over tokens dY[t][N]^T X[t][K],  db[N] = sum_t dY[t][N].
@@ -112,7 +112,7 @@ typedef struct DtqnWJob {
     int32_t dy_off, ldy, N;
     int32_t w_off;           /* offset of dW in the flat gradient */
     int32_t b_off;           /* offset of db, or -1 */
-    int32_t tile0;           /* first global tile-group index of this job */
+    int32_t tile0;           /* first global 64x64 block index of this job */
     int32_t tiles_n, tiles_k;
 } DtqnWJob;
 

@@ -167,6 +167,7 @@ static inline float hipemu_frcp(float x) { return 1.0f / x; }
 #define __frcp_rn hipemu_frcp
 using std::fmaxf;
 using std::fminf;
+using std::isfinite;
 
 // ---- atomics ----------------------------------------------------------------
 static inline float atomicAdd(float* p, float v) { hipemu::atomic_add_f32(p, v); return 0.f; }

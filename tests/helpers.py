@@ -40,3 +40,138 @@ def ptr(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data_as(ctypes.c_void_p)
     return ctypes.c_void_p(a.data_ptr())
+
+
+# --------------------------------------------------------------------------- #
+# TD-update harness shared by the CPU-emulation tests and the -m gpu tests
+# --------------------------------------------------------------------------- #
+def fill_device_replay(dev_replay, host_buf):
+    """Copy an oracle ReplayOracle's arrays into a dtqn_amd DeviceReplay (test set-up only)."""
+    dev_replay.obs.copy_(torch.from_numpy(host_buf.obss))
+    dev_replay.actions.copy_(torch.from_numpy(host_buf.actions[:, :, 0]))
+    dev_replay.rewards.copy_(torch.from_numpy(host_buf.rewards[:, :, 0]))
+    dev_replay.dones.copy_(torch.from_numpy(host_buf.dones[:, :, 0].astype(np.uint8)))
+    dev_replay.ep_len.copy_(torch.from_numpy(host_buf.episode_lengths.astype(np.int32)))
+
+
+def oracle_batch(host_buf, eps, starts, discrete):
+    o, a, r, no, na, d, _ = host_buf.gather(eps, starts)
+    ot = torch.long if discrete else torch.float32
+    return O.Batch(obss=torch.as_tensor(o, dtype=ot), actions=torch.as_tensor(a, dtype=torch.long),
+                   rewards=torch.as_tensor(r, dtype=torch.float32), next_obss=torch.as_tensor(no, dtype=ot),
+                   next_actions=torch.as_tensor(na, dtype=torch.long), dones=torch.as_tensor(d, dtype=torch.long))
+
+
+def flat_from_params(net, params, keys):
+    """Concatenate oracle tensors into the engine's flat layout (trainable region only)."""
+    tab = B.param_table(net)
+    flat = np.zeros(net.n_trainable, dtype=np.float32)
+    for k in keys:
+        off, shape = tab[k]
+        v = params[k].detach().numpy().reshape(-1)
+        flat[off:off + v.size] = v
+    return flat
+
+
+def make_td_case(lib, cfg, *, seed, batch, T, n_eps, mask, history=None, tuf=10_000, lr=3e-4, device="cpu", test_lib=True):
+    """Oracle learner + dtqn_amd TdEngine on identical parameters and an identical synthetic replay."""
+    import random as pyrandom
+    from dtqn_amd.learner import DeviceReplay, TdEngine
+    from oracle.replay_oracle import ReplayOracle, synth_fill
+    net = net_from_cfg(lib, cfg)
+    pol = O.init_params(cfg, seed=seed, perturb=True)
+    tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+    hist = cfg.history_len if history is None else history
+    oracle = O.OracleLearner(cfg, pol, lr=lr, gamma=0.99, history=hist, tuf=tuf, target=tgt)
+    host = ReplayOracle((n_eps + 2) * T, cfg.obs_dim, mask, T, cfg.history_len)
+    synth_fill(host, np.random.Generator(np.random.PCG64(seed + 1000)), n_eps, cfg.discrete, cfg.vocab_sizes, cfg.num_actions)
+    eng = TdEngine(net, batch, lr=lr, gamma=0.99, history=hist, tuf=tuf, _test_lib=lib if test_lib else None,
+                   device=None if test_lib else device)
+    eng.theta_pol.copy_(torch.from_numpy(pack_theta(net, pol)))
+    eng.theta_tgt.copy_(torch.from_numpy(pack_theta(net, tgt)))
+    rep = DeviceReplay(host.max_size, T, cfg.obs_dim, mask, eng.device)
+    fill_device_replay(rep, host)
+    pyrandom.seed(seed)
+    return net, oracle, host, eng, rep
+
+
+def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4):
+    """Run n_updates on both sides from identical (episode, start) draws and compare every stage:
+    the three Q tensors, pre-clip gradients, statistics, parameters after the step."""
+    keys = O.trainable_keys(cfg)
+    Bn, L, A = eng.batch, cfg.history_len, cfg.num_actions
+    for it in range(n_updates):
+        eps, starts = host.sample_indices(Bn)
+        batch = oracle_batch(host, eps, starts, cfg.discrete)
+        eng.set_indices(eps, starts)
+        eng.forward_backward(rep)
+        # --- Q-values of the three forwards
+        # The gradient is discontinuous at every ReLU kink and at ties of the double-DQN argmax; two
+        # correct fp32 implementations can sit on different sides of a kink whose pre-activation is
+        # ~1e-7 (observed), which moves dW by percents.  So gradients are compared CONDITIONAL on the
+        # engine's own activation pattern (read from its saved activations) and argmax choices, and
+        # the number / size of the disagreements is bounded separately.
+        q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :A].copy()
+        act = eng.act.cpu().numpy().reshape(Bn, net.act_stride)
+        D = cfg.inner_embed_size
+        fld = lambda off, w: torch.from_numpy(act[:, off:off + net.lp * w].reshape(Bn, net.lp, w)[:, :L].copy() > 0)
+        masks = []
+        for l in range(cfg.num_layers):
+            base = net.ao_layer0 + l * net.act_layer_stride
+            masks += [fld(base + net.al_y1, D), fld(base + net.al_h, 4 * D), fld(base + net.al_y2, D)]
+        masks.append(fld(net.ao_hh, D))
+        probe = {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
+        grads, out = O.td_gradients(oracle.pol, oracle.tgt, cfg, batch, oracle.gamma, oracle.history, probe)
+        assert not probe["masks"], "oracle consumed fewer ReLU masks than the engine saved"
+        n_relu = sum(int(np.prod(m.shape)) for m in masks) if False else Bn * L * (6 * D * cfg.num_layers + D)
+        assert probe.get("relu_flips", 0) <= max(2, n_relu // 20000), probe
+        assert probe.get("max_flip_preact", 0.0) <= 2e-5 * max(1.0, float(out[4].detach().abs().max())), probe
+        assert probe.get("argmax_flips", 0) <= max(1, Bn * L // 500), probe
+        assert probe.get("max_flip_qgap", 0.0) <= 2e-4 * max(1.0, float(out[4].detach().abs().max())), probe
+        scale = max(1.0, float(out[4].detach().abs().max()))
+        for w, ref in enumerate((out[4], out[5], out[6])):
+            err = np.abs(q3[w] - ref.detach().numpy()).max()
+            assert err <= q_tol * scale, (it, w, err)
+        # --- gradients (flat, engine layout), relative to the largest entry as in the oracle's own golden check
+        ref_flat = flat_from_params(net, grads, keys)
+        got = eng.grad.cpu().numpy().copy()
+        gerr = np.abs(got - ref_flat).max()
+        assert gerr <= grad_rtol * np.abs(ref_flat).max(), (it, gerr, np.abs(ref_flat).max(), probe)
+        # --- optimizer step + statistics
+        pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+        eng.clip_adam()
+        st = eng.read_stats()
+        # teacher-force the oracle from the engine's pre-step parameters?  No: both sides started
+        # identical and took identical steps so far; compare the step itself on solid elements.
+        ref_stats = oracle.update(batch, grads_and_out=(grads, out))
+        assert st["nonfinite"] == 0.0
+        assert st["step"] == it + 1
+        for k in ("td_error", "grad_norm", "qvalue_max", "qvalue_mean", "qvalue_min", "target_max", "target_mean", "target_min"):
+            assert st[k] == ref_stats[k] or abs(st[k] - ref_stats[k]) <= 2e-4 * max(1.0, abs(ref_stats[k])), (it, k, st[k], ref_stats[k])
+        post = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+        ref_post = flat_from_params(net, oracle.pol, keys)
+        d = np.abs(post - ref_post)
+        solid = np.abs(ref_flat) >= 1e-3 * np.abs(ref_flat).max()
+        if it == 0:
+            assert d[solid].max() <= 2e-6, (it, d[solid].max())
+        # |Adam step| <= lr at k = 1 and <= lr*(1-b1)/sqrt(1-b2) = 3.17 lr in general
+        assert np.abs(post - pre).max() <= (1.001 if it == 0 else 3.2) * oracle.lr
+        assert d.max() <= 2.002 * oracle.lr * (it + 1)
+        # keep the two sides in lock-step for the next iteration (removes chaotic drift from the comparison)
+        eng.theta_pol[:net.n_trainable].copy_(torch.from_numpy(ref_post))
+        tab = B.param_table(net)
+        for k in keys:
+            off, shape = tab[k]
+            n = int(np.prod(shape))
+            eng.adam_m[off:off + n].copy_(oracle.opt.m[k].reshape(-1))
+            eng.adam_v[off:off + n].copy_(oracle.opt.v[k].reshape(-1))
+        # target sync parity
+        tgt_ref = pack_theta(net, oracle.tgt)[:net.n_trainable]
+        tgt_got = eng.theta_tgt.cpu().numpy()[:net.n_trainable].copy()
+        if (it + 1) % oracle.tuf == 0:
+            assert st["target_synced"] == 1.0
+            assert np.abs(tgt_got - post).max() == 0.0
+            eng.theta_tgt[:net.n_trainable].copy_(torch.from_numpy(tgt_ref))
+        else:
+            assert st["target_synced"] == 0.0
+            assert np.abs(tgt_got - tgt_ref).max() == 0.0

@@ -1,0 +1,39 @@
+"""Kernel-logic tests on the CPU for the full TD update (forward x3, loss, backward, weight
+gradients, reduce, clip + Adam) on the test-only HIP emulation, against the oracle."""
+import numpy as np
+import pytest
+
+from dtqn_amd import _binding as B
+from oracle import dtqn_oracle as O
+
+from helpers import make_td_case, check_td_updates
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import emu_build
+    return B.load_library(emu_build.build())
+
+
+CASES = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8), dict(batch=4, T=12, mask=-5)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, action_dim=4), dict(batch=3, T=30, mask=-5, history=7, tuf=2)),
+    (dict(obs_dim=10, num_actions=5, inner_embed_size=32, num_heads=2, history_len=12, discrete=True, vocab_sizes=9), dict(batch=5, T=20, mask=8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, identity=True, pos="sin"), dict(batch=4, T=12, mask=-5, tuf=3)),
+    (dict(obs_dim=1, num_actions=5, inner_embed_size=32, num_heads=4, history_len=30, discrete=True, vocab_sizes=22, action_dim=8, pos="none", identity=True),
+     dict(batch=2, T=40, mask=21)),
+]
+
+
+@pytest.mark.parametrize("kw,run", CASES)
+def test_td_update_small_variants(emu, kw, run):
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=9, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
+
+
+def test_td_update_cfg1_size(emu):
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=4, T=200, n_eps=8, mask=-5)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
