@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the DTQN TD-update hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one DtqnAgent.train() = one TD update (sample windows -> 3 forwards -> double-DQN loss
+-> backward -> clip -> Adam) on a device-resident synthetic replay of the shape SURVEY.md section 8d
+prescribes.  Workload at every N: BASELINE.json's metric configuration, DiscreteCarFlag-v0 shapes,
+context 50, d_model 64, 8 heads, 2 layers, batch 32 PER GPU (weak scaling: each rank owns its
+replay shard and batch; the only exchange is the flat-gradient all-reduce over RCCL).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dtqn_amd import dist as ddp                                  # noqa: E402
+from dtqn_amd.utils.agent_utils import get_agent                  # noqa: E402
+from dtqn_amd import envs as dt_envs                              # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: dense f32-input MFMA peak
+
+
+def cfg1_shapes():
+    return dict(O=3, A=3, T=200, L=50, D=64, H=8, NL=2)
+
+
+def f_tok(c):
+    """Algorithmic forward FLOPs per token: embed + NL*(in-proj, out-proj, FFN,
+    dense attention) + Q head."""
+    D, L = c["D"], c["L"]
+    return 2 * c["O"] * D + c["NL"] * (6 * D * D + 2 * D * D + 16 * D * D + 4 * L * D) + 2 * D * D + 2 * D * c["A"]
+
+
+def fill_synthetic_replay(agent, seed: int, c) -> None:
+    """SURVEY.md section 8d synthetic replay: every slot a finished episode, lengths U{5..T}, obs U(-1,1)^3,
+    actions U{0..A-1}, rewards from {0,0,0,+1,-1}, done on the last step, reference padding elsewhere."""
+    rb = agent.replay_buffer
+    E, T, O = rb.max_size, c["T"], c["O"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = rng.integers(5, T + 1, size=E)
+    obs = rng.uniform(-1, 1, size=(E, T + 1, O)).astype(np.float32)
+    act = rng.integers(0, c["A"], size=(E, T + 1)).astype(np.uint8)
+    rew = rng.choice(np.array([0, 0, 0, 1, -1], dtype=np.float32), size=(E, T))
+    done = np.ones((E, T), dtype=np.uint8)
+    t_idx = np.arange(T)[None, :]
+    live = t_idx < lens[:, None]
+    done[live] = 0
+    done[np.arange(E), lens - 1] = 1
+    rew[~live] = 0.0
+    act[:, :T][~live] = 0
+    act[np.arange(E), T] = 0
+    pad_obs = np.arange(T + 1)[None, :] > lens[:, None]
+    obs[pad_obs] = rb.obs_mask
+    rb.import_arrays(dict(obss=obs, actions=act, rewards=rew, dones=done, eplens=lens.astype(np.int32)))
+    rb.pos = [E + 1, 0]            # all slots finished (slot (E+1) % E is "in progress" and excluded, like the reference)
+
+
+def time_kernels(agent, iters: int = 50) -> dict:
+    """Average duration of each of the five launches, HIP events on the launch stream."""
+    eng, rep = agent.engine, agent.replay_buffer.dev
+    lib = eng.lib
+    n, r, t = ctypes.byref(eng.net), ctypes.byref(rep.view), ctypes.byref(eng.td)
+    stream = torch.cuda.current_stream()
+    s = ctypes.c_void_p(stream.cuda_stream)
+    stages = {"dtqn_forward_kernel": lambda: lib.dtqn_td_forward(n, r, t, s),
+              "dtqn_backward_kernel": lambda: lib.dtqn_td_backward(n, r, t, s),
+              "dtqn_wgrad_kernel": lambda: lib.dtqn_td_wgrad(n, t, s),
+              "dtqn_reduce_kernel": lambda: lib.dtqn_td_reduce(n, t, s),
+              "dtqn_clip_adam_kernel": lambda: lib.dtqn_td_clip_adam(n, t, s)}
+    out = {}
+    for name, fn in stages.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        out[name] = e0.elapsed_time(e1) * 1e3 / iters          # us
+    return out
+
+
+def cpu_baseline(c, batch: int, budget_s: float = 15.0) -> dict:
+    """The oracle (un-fused PyTorch-CPU eager port of the reference's path, parity-locked to the
+    reference by tests/test_oracle_golden.py) timed on this host's cores, same shapes."""
+    from oracle import dtqn_oracle as O
+    from oracle.replay_oracle import ReplayOracle, synth_fill
+    cfg = O.NetCfg(obs_dim=c["O"], num_actions=c["A"], inner_embed_size=c["D"], num_heads=c["H"], num_layers=c["NL"], history_len=c["L"])
+    learner = O.OracleLearner(cfg, O.init_params(cfg, seed=1))
+    buf = ReplayOracle(60 * c["T"], c["O"], -5, c["T"], c["L"])
+    synth_fill(buf, np.random.Generator(np.random.PCG64(1)), 58, False, 0, c["A"], min_len=5)
+
+    def one():
+        o, a, r, no, na, d, _ = buf.sample(batch)
+        learner.update(O.Batch(torch.as_tensor(o), torch.as_tensor(a, dtype=torch.long), torch.as_tensor(r), torch.as_tensor(no),
+                               torch.as_tensor(na, dtype=torch.long), torch.as_tensor(d, dtype=torch.long)))
+    for _ in range(3):
+        one()
+    # tiny-op workloads do not scale to every host core: sweep a few thread counts inside the budget
+    # and report the best one with the thread count that produced it
+    trials = {}
+    avail = os.cpu_count() or 1
+    for threads in sorted({1, min(8, avail), min(32, avail)}):
+        torch.set_num_threads(threads)
+        one()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 3:
+            one()
+            n += 1
+        trials[threads] = n / (time.perf_counter() - t0)
+    best = max(trials, key=trials.get)
+    torch.set_num_threads(min(avail, 8))
+    return {"value": trials[best], "unit": "TD-updates/s", "cores": best, "kind": "port",
+            "sample": f"~{budget_s:.0f} s of TD updates of the same workload (B={batch}, L={c['L']}, D={c['D']}) on the oracle; "
+                      f"updates/s by torch thread count: {json.dumps({str(k): round(v, 2) for k, v in trials.items()})} "
+                      f"on a {avail}-core host"}
+
+
+def env_step_rate(agent, seconds: float = 3.0) -> dict:
+    """Live actor loop on the host cores: epsilon-greedy get_action (GPU forward of the rolling
+    context) + CarFlag step + observe, and the reference's coupled 1 env step : 1 update loop."""
+    import run as runpy
+    from dtqn_amd.utils.epsilon_anneal import Constant
+    from dtqn_amd.utils.random import set_global_seed
+    env = dt_envs.make("DiscreteCarFlag-v0")
+    set_global_seed(1, env)
+    eps = Constant(0.1)
+    out = {}
+    for mode in ("actor_only", "coupled_1to1"):
+        agent.context_reset(env.reset())
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            if runpy.step(agent, env, eps):
+                agent.replay_buffer.flush()
+                agent.context_reset(env.reset())
+            if mode == "coupled_1to1":
+                agent.train()
+            n += 1
+        torch.cuda.synchronize()
+        out[mode] = n / (time.perf_counter() - t0)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json metric: 32)")
+    ap.add_argument("--sampler", default="device", choices=["device", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = ddp.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    c = cfg1_shapes()
+    env = dt_envs.make("DiscreteCarFlag-v0")
+    from dtqn_amd.utils.random import set_global_seed
+    set_global_seed(1 + rank, env)
+    agent = get_agent("DTQN", [env], 8, 0, c["D"], 500_000, device, 3e-4, args.batch, c["L"], -1, c["L"], 10_000, 0.99,
+                      c["H"], c["NL"], 0.0, False, "res", "learned", 0, sampler=args.sampler, sample_seed=1 + rank)
+    fill_synthetic_replay(agent, seed=1 + rank, c=c)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent.train()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.train()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    agent._drain_stats(block=True)
+
+    if rank == 0:
+        ms = elapsed * 1e3 / args.steps
+        ups = world * args.steps / elapsed                     # whole-job TD updates / s (each rank does one per step)
+        ft = f_tok(c)
+        tokens = args.batch * c["L"]
+        kern = time_kernels(agent)
+        dom = max(("dtqn_forward_kernel", "dtqn_backward_kernel"), key=lambda k: kern[k])
+        # algorithmic FLOPs per launch: forward kernel = 3 forwards; backward kernel = data-gradient half
+        # of the backward (~ 1x forward; the weight-gradient half runs in dtqn_wgrad_kernel)
+        flops = {"dtqn_forward_kernel": 3 * tokens * ft, "dtqn_backward_kernel": 1 * tokens * ft}[dom]
+        ach = flops / (kern[dom] * 1e-6) / 1e12
+        p_t = agent.engine.net.n_trainable
+        p_all = agent.engine.net.n_theta
+        gather_bytes = args.batch * ((c["L"] + 1) * 4 * c["O"] + (c["L"] + 1) + c["L"] * 4 + c["L"])
+        alg_bytes = gather_bytes + 4 * 2 * p_all + 4 * p_t + 28 * p_t
+        line = {
+            "metric": "env-steps/sec + TD-updates/sec, DiscreteCarFlag-v0 ctx=50 b=32, 1/2/4/8 GPU",
+            "value": ups, "unit": "TD-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic replay (SURVEY.md section 8d shapes), random-init weights",
+            "config": {"workload": "DiscreteCarFlag-v0 shapes: ctx=50, d_model=64, 8 heads, 2 layers, obs 3 f32, 3 actions, "
+                                   f"batch {args.batch} per GPU, history 50, device-resident replay 2500 episodes x 200 steps",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": flops, "launch_us": kern[dom]},
+            "hbm_view": {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
+                         "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernels_us": kern,
+            "algorithmic_gflop_per_update": 5 * tokens * ft / 1e9,
+        }
+        if world == 1:
+            rates = env_step_rate(agent)
+            line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
+                                         "note": "single host env, batch-1 actor forward on the GPU per step; "
+                                                 "in the coupled loop env-steps/s == TD-updates/s as in the reference"}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(c, args.batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,269 @@
+"""DTQN agent (actor + learner) with the reference's surface (dtqn/agents/dtqn.py:15-269 and its
+base class dtqn/agents/dqn.py:24-327), running on the gfx950 engine.
+
+What changed underneath:
+  * `train()` launches the fused HIP TD update (five kernels, dtqn_amd.learner.TdEngine) on the
+    device-resident replay; nothing of the batch ever exists on the host.
+  * the seven logged statistics come back through a pinned ring, asynchronously; the reference's
+    nine blocking `.item()` calls per update are gone.  RunningAverage.mean() drains the ring.
+  * `get_action()` stages the rolling context through pinned memory, one H2D + one D2H per env step.
+  * with torch.distributed initialised (one process per GPU, RCCL) the flat gradient is all-reduced
+    between the gradient and the optimizer kernels (dtqn_amd.dist).
+"""
+from __future__ import annotations
+
+import ctypes
+import random
+from enum import Enum
+from typing import Callable, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import dist as ddp
+from ..buffers.replay_buffer import ReplayBuffer
+from ..learner import STAT_NAMES, TdEngine
+from ..utils.context import Context
+from ..utils.logging_utils import DeferredRunningAverage, RunningAverage
+from ..utils.random import RNG
+
+
+class TrainMode(Enum):
+    TRAIN = 1
+    EVAL = 2
+
+
+class _AdamHandle:
+    """Stand-in for `agent.optimizer` (dqn.py:64): the Adam state lives in the engine's flat m / v
+    buffers; this exposes it for checkpoints in plain-array form."""
+
+    def __init__(self, eng: TdEngine):
+        self._eng = eng
+
+    def state_dict(self) -> dict:
+        e = self._eng
+        return {"step": int(e.step_counter[1].item()), "exp_avg": e.adam_m.cpu().numpy(), "exp_avg_sq": e.adam_v.cpu().numpy(),
+                "lr": e.td.lr, "betas": (e.td.beta1, e.td.beta2), "eps": e.td.eps}
+
+    def load_state_dict(self, sd: dict) -> None:
+        e = self._eng
+        e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
+        e.step_counter.fill_(int(sd["step"]))
+
+
+class DtqnAgent:
+    STATS_RING = 64
+
+    def __init__(self, network_factory: Callable[[], torch.nn.Module], buffer_size: int, device: torch.device,
+                 env_obs_length: int, max_env_steps: int, obs_mask: Union[int, float], num_actions: int,
+                 is_discrete_env: bool, learning_rate: float = 0.0003, batch_size: int = 32, context_len: int = 50,
+                 gamma: float = 0.99, grad_norm_clip: float = 1.0, target_update_frequency: int = 10_000,
+                 history: int = 50, bag_size: int = 0, sampler: str = "reference", ref_quirks: bool = False,
+                 sample_seed: int = 0, **kwargs):
+        if bag_size > 0:
+            raise NotImplementedError("the persistent-memory bag is outside dtqn_amd's scope")
+        self.context_len, self.env_obs_length = context_len, env_obs_length
+        self.device = torch.device(device)
+        self.policy_network = network_factory()
+        self.target_network = network_factory()
+        lib = self.policy_network._lib
+        self._test_mode = self.device.type != "cuda"          # CPU kernel-emulation tests only
+        self.num_actions, self.obs_mask, self.history = num_actions, obs_mask, history
+        self.batch_size, self.gamma = batch_size, gamma
+        self.grad_norm_clip, self.target_update_frequency = grad_norm_clip, target_update_frequency
+        self.is_discrete_env = is_discrete_env
+        self.obs_context_type = np.int_ if is_discrete_env else np.float32
+        self.obs_tensor_type = torch.long if is_discrete_env else torch.float32
+        self.sampler, self.sample_seed = sampler, int(sample_seed)
+        if sampler not in ("reference", "device"):
+            raise ValueError("sampler must be 'reference' (Python `random` stream) or 'device'")
+        self.engine = TdEngine(self.policy_network.net, batch_size, lr=learning_rate, gamma=gamma, history=history,
+                               tuf=target_update_frequency, grad_norm_clip=grad_norm_clip,
+                               device=None if self._test_mode else self.device,
+                               _test_lib=lib if self._test_mode else None,
+                               theta_pol=self.policy_network.flat, theta_tgt=self.target_network.flat)
+        self.target_update()
+        self.target_network.eval()
+        self.optimizer = _AdamHandle(self.engine)
+        self.replay_buffer = ReplayBuffer(buffer_size, env_obs_length=env_obs_length, obs_mask=obs_mask,
+                                          max_episode_steps=max_env_steps, context_len=context_len, device=self.device, lib=lib)
+        self.dp = ddp.DataParallel(self.engine) if ddp.is_distributed() else None
+        if self.dp is not None:
+            self.dp.broadcast_parameters()
+        # logging (dqn.py:80-89), fed asynchronously
+        self.num_train_steps = 0
+        drain = lambda: self._drain_stats(block=True)
+        self.td_errors, self.grad_norms = DeferredRunningAverage(100, drain), DeferredRunningAverage(100, drain)
+        self.qvalue_max, self.target_max = DeferredRunningAverage(100, drain), DeferredRunningAverage(100, drain)
+        self.qvalue_mean, self.target_mean = DeferredRunningAverage(100, drain), DeferredRunningAverage(100, drain)
+        self.qvalue_min, self.target_min = DeferredRunningAverage(100, drain), DeferredRunningAverage(100, drain)
+        self._stat_sinks = {"td_error": self.td_errors, "grad_norm": self.grad_norms, "qvalue_max": self.qvalue_max,
+                            "qvalue_mean": self.qvalue_mean, "qvalue_min": self.qvalue_min, "target_max": self.target_max,
+                            "target_mean": self.target_mean, "target_min": self.target_min}
+        cuda = self.device.type == "cuda"
+        self._stats_host = [torch.zeros(len(STAT_NAMES)).pin_memory() if cuda else torch.zeros(len(STAT_NAMES))
+                            for _ in range(self.STATS_RING)]
+        self._stats_events = [torch.cuda.Event() if cuda else None for _ in range(self.STATS_RING)]
+        self._stats_head = self._stats_tail = 0
+        self.train_mode = TrainMode.TRAIN
+        mk = lambda: Context(context_len, obs_mask, num_actions, env_obs_length, discrete=is_discrete_env, ref_quirks=ref_quirks)
+        self.train_context, self.eval_context = mk(), mk()
+        # actor staging: rolling context -> pinned -> device, Q row -> pinned
+        L, O, A = context_len, env_obs_length, num_actions
+        pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        self._ctx_obs_h, self._ctx_act_h = pin(torch.zeros(L, O)), pin(torch.zeros(L, dtype=torch.uint8))
+        self._ctx_obs_d = torch.zeros(L, O, device=self.device)
+        self._ctx_act_d = torch.zeros(L, dtype=torch.uint8, device=self.device)
+        self._q_d = torch.zeros(L, A, device=self.device)
+        self._q_h = pin(torch.zeros(A))
+
+    # ---- mode / context (dqn.py:102-115) -------------------------------------------------------
+    @property
+    def context(self) -> Context:
+        return self.train_context if self.train_mode == TrainMode.TRAIN else self.eval_context
+
+    def eval_on(self) -> None:
+        self.train_mode = TrainMode.EVAL
+        self.policy_network.eval()
+
+    def eval_off(self) -> None:
+        self.train_mode = TrainMode.TRAIN
+        self.policy_network.train()
+
+    # ---- actor (dtqn.py:76-160) -----------------------------------------------------------------
+    @torch.no_grad()
+    def get_action(self, epsilon: float = 0.0) -> int:
+        if RNG.rng.random() < epsilon:
+            return RNG.rng.integers(self.num_actions)
+        ctx = self.context
+        n = min(ctx.max_length, ctx.timestep + 1)                       # unpadded prefix of the window
+        self._ctx_obs_h[:n] = torch.from_numpy(np.asarray(ctx.obs[:n], dtype=np.float32))
+        self._ctx_act_h[:n] = torch.from_numpy(np.asarray(ctx.action[:n, 0], dtype=np.uint8))
+        self._ctx_obs_d[:n].copy_(self._ctx_obs_h[:n], non_blocking=True)
+        self._ctx_act_d[:n].copy_(self._ctx_act_h[:n], non_blocking=True)
+        eng = self.engine
+        rc = eng.lib.dtqn_forward(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
+                                  ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
+                                  1, n, ctypes.c_void_p(self._q_d.data_ptr()), eng._stream())
+        if rc != 0:
+            raise RuntimeError(f"dtqn_forward failed with DTQN status {rc}")
+        self._q_h.copy_(self._q_d[n - 1], non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return int(np.argmax(self._q_h.numpy()))                         # Q of the LAST timestep, first max
+
+    def context_reset(self, obs: np.ndarray) -> None:
+        self.context.reset(obs)
+        if self.train_mode == TrainMode.TRAIN:
+            self.replay_buffer.store_obs(obs)
+
+    def observe(self, obs: np.ndarray, action: int, reward: float, done: bool) -> None:
+        self.context.add_transition(obs, action, reward, done)
+        if self.train_mode == TrainMode.TRAIN:
+            self.replay_buffer.store(obs, action, reward, done, self.context.timestep)
+
+    # ---- learner (dtqn.py:162-269) --------------------------------------------------------------
+    def train(self) -> None:
+        rb = self.replay_buffer
+        if not rb.can_sample(self.batch_size):
+            return
+        self.eval_off()
+        rb.commit()
+        eng = self.engine
+        if self.sampler == "reference":
+            eng.set_indices(*rb.sample_indices(self.batch_size))
+        else:
+            n_valid, exclude = rb.valid_range()
+            eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed)
+        if self.dp is None:
+            eng.update(rb.dev)
+        else:
+            self.dp.update(rb.dev)
+        self._enqueue_stats()
+        self.num_train_steps += 1
+        # hard target sync happens on the device every target_update_frequency optimizer steps
+
+    def target_update(self) -> None:
+        """Hard update: target <- policy (dqn.py:208-210)."""
+        self.engine.target_sync()
+
+    # ---- asynchronous statistics ---------------------------------------------------------------
+    def _enqueue_stats(self) -> None:
+        if (self._stats_head + 1) % self.STATS_RING == self._stats_tail:
+            self._drain_stats(block=True)
+        slot = self._stats_head
+        self._stats_host[slot].copy_(self.engine.stats, non_blocking=True)
+        if self._stats_events[slot] is not None:
+            self._stats_events[slot].record()
+        self._stats_head = (slot + 1) % self.STATS_RING
+        self._drain_stats(block=False)
+
+    def _drain_stats(self, block: bool) -> None:
+        while self._stats_tail != self._stats_head:
+            slot = self._stats_tail
+            ev = self._stats_events[slot]
+            if ev is not None:
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            vals = self._stats_host[slot].numpy()
+            self._stats_tail = (slot + 1) % self.STATS_RING
+            if vals[STAT_NAMES.index("nonfinite")] != 0.0:
+                # clip_grad_norm_(error_if_nonfinite=True) raises here in the reference (dtqn.py:257-261)
+                raise RuntimeError("The total norm for gradients from `parameters` is non-finite, so it cannot be clipped.")
+            for name, sink in self._stat_sinks.items():
+                RunningAverage.add(sink, float(vals[STAT_NAMES.index(name)]))
+
+    # ---- checkpoints (dqn.py:212-327), plain arrays instead of pickled objects -------------------
+    def save_mini_checkpoint(self, checkpoint_dir: str, wandb_id: Optional[str]) -> None:
+        torch.save({"step": self.num_train_steps, "wandb_id": wandb_id}, checkpoint_dir + "_mini_checkpoint.pt")
+
+    @staticmethod
+    def load_mini_checkpoint(checkpoint_dir: str) -> dict:
+        return torch.load(checkpoint_dir + "_mini_checkpoint.pt")
+
+    def save_checkpoint(self, checkpoint_dir: str, wandb_id, episode_successes: RunningAverage,
+                        episode_rewards: RunningAverage, episode_lengths: RunningAverage, eps) -> None:
+        self._drain_stats(block=True)
+        self.save_mini_checkpoint(checkpoint_dir=checkpoint_dir, wandb_id=wandb_id)
+        ra = lambda r: {"size": r.size, "q": list(r.q), "sum": r.sum}
+        torch.save({
+            "step": self.num_train_steps, "wandb_id": wandb_id, "replay_buffer_pos": [self.replay_buffer.pos[0], 0],
+            "policy_net_state_dict": self.policy_network.state_dict(), "target_net_state_dict": self.target_network.state_dict(),
+            "optimizer_state_dict": self.optimizer.state_dict(), "epsilon": eps.val,
+            "episode_successes": ra(episode_successes), "episode_rewards": ra(episode_rewards), "episode_lengths": ra(episode_lengths),
+            **{k: ra(v) for k, v in (("td_errors", self.td_errors), ("grad_norms", self.grad_norms),
+                                     ("qvalue_max", self.qvalue_max), ("qvalue_mean", self.qvalue_mean),
+                                     ("qvalue_min", self.qvalue_min), ("target_max", self.target_max),
+                                     ("target_mean", self.target_mean), ("target_min", self.target_min))},
+            "random_rng_state": random.getstate(), "rng_bit_generator_state": RNG.rng.bit_generator.state,
+            "numpy_rng_state": np.random.get_state(), "torch_rng_state": torch.get_rng_state(),
+        }, checkpoint_dir + "_checkpoint.pt")
+        np.savez(checkpoint_dir + "buffer.npz", **self.replay_buffer.export_arrays())
+
+    def load_checkpoint(self, checkpoint_dir: str) -> Tuple[str, RunningAverage, RunningAverage, RunningAverage, float]:
+        ck = torch.load(checkpoint_dir + "_checkpoint.pt", weights_only=False)
+        self.num_train_steps = ck["step"]
+        self.replay_buffer.pos = ck["replay_buffer_pos"]
+        self.replay_buffer.import_arrays(dict(np.load(checkpoint_dir + "buffer.npz")))
+        self.policy_network.load_state_dict(ck["policy_net_state_dict"])
+        self.target_network.load_state_dict(ck["target_net_state_dict"])
+        self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+
+        def restore(dst: RunningAverage, src: dict) -> RunningAverage:
+            dst.size, dst.sum = src["size"], src["sum"]
+            dst.q.clear(); dst.q.extend(src["q"])
+            return dst
+        for k in ("td_errors", "grad_norms", "qvalue_max", "qvalue_mean", "qvalue_min", "target_max", "target_mean", "target_min"):
+            restore(getattr(self, k), ck[k])
+        random.setstate(ck["random_rng_state"])
+        RNG.rng.bit_generator.state = ck["rng_bit_generator_state"]
+        np.random.set_state(ck["numpy_rng_state"])
+        torch.set_rng_state(ck["torch_rng_state"])
+        out = [restore(RunningAverage(10), ck[k]) for k in ("episode_successes", "episode_rewards", "episode_lengths")]
+        return ck["wandb_id"], out[0], out[1], out[2], ck["epsilon"]
+
+
+# north_star spells the symbol this way; the reference's own name is DtqnAgent (dtqn/agents/dtqn.py:15)
+DTQNAgent = DtqnAgent

@@ -1,0 +1,154 @@
+"""Episode-major replay buffer with the reference's producer API (dtqn/buffers/replay_buffer.py),
+resident in HBM.
+
+Layout and semantics follow the reference (slot `pos[0] % max_size` is the episode in progress;
+row t+1 holds the observation after step t; unwritten tail = (mask, 0, 0.0, done)), but the arrays
+live on the GPU (dtqn_amd.learner.DeviceReplay).  The actor's writes are queued on the host as
+small records, staged through pinned memory, copied with one async H2D per flush and scattered by
+one kernel (dtqn_replay_apply), instead of five tiny host->device copies per env step.  Sampling
+never gathers on the host: the TD kernels read their windows in place from (episode, start) pairs.
+"""
+from __future__ import annotations
+
+import ctypes
+import random
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _binding as B
+from ..learner import DeviceReplay
+
+RECORD_DTYPE = np.dtype([("kind", "<i4"), ("ep", "<i4"), ("t", "<i4"), ("action", "<i4"), ("reward", "<f4"),
+                         ("done", "<i4"), ("obs_index", "<i4"), ("ep_len", "<i4")])
+assert RECORD_DTYPE.itemsize == ctypes.sizeof(B.DtqnReplayRecord)
+
+
+class ReplayBuffer:
+    STAGE_CAPACITY = 256     # records per staging buffer
+    STAGE_RING = 4
+
+    def __init__(self, buffer_size: int, env_obs_length: int, obs_mask, max_episode_steps: int,
+                 context_len: Optional[int] = 1, device=None, lib=None):
+        if isinstance(env_obs_length, tuple):
+            raise NotImplementedError("image observations are outside dtqn_amd's scope")
+        self.max_size = buffer_size // max_episode_steps
+        self.context_len = context_len
+        self.env_obs_length = env_obs_length
+        self.max_episode_steps = max_episode_steps
+        self.obs_mask = obs_mask
+        self.pos = [0, 0]
+        self.device = torch.device(device)
+        self._lib = lib
+        self.dev = DeviceReplay(self.max_size, max_episode_steps, env_obs_length, float(obs_mask), self.device)
+        # int32, not the reference's uint8 (which wraps at 256 and, under numpy >= 2, underflows in
+        # `episode_lengths[idx] - context_len`)
+        self.episode_lengths = np.zeros([self.max_size], dtype=np.int32)
+        cuda = self.device.type == "cuda"
+        C, O = self.STAGE_CAPACITY, env_obs_length
+        self._stage = []
+        for _ in range(self.STAGE_RING if cuda else 1):
+            rec_h = torch.zeros(C * RECORD_DTYPE.itemsize, dtype=torch.uint8)
+            obs_h = torch.zeros(C * O, dtype=torch.float32)
+            if cuda:
+                rec_h, obs_h = rec_h.pin_memory(), obs_h.pin_memory()
+            self._stage.append(dict(
+                rec_h=rec_h, obs_h=obs_h, rec_np=rec_h.numpy().view(RECORD_DTYPE), obs_np=obs_h.numpy().reshape(C, O),
+                rec_d=torch.zeros_like(rec_h, device=self.device), obs_d=torch.zeros_like(obs_h, device=self.device),
+                event=torch.cuda.Event() if cuda else None, busy=False))
+        self._cur, self._n = 0, 0
+
+    # ---- producer side (replay_buffer.py:71-98) ----------------------------------------------
+    def _push(self, kind: int, ep: int, t: int, action: int, reward: float, done: bool, obs, ep_len: int = 0) -> None:
+        if self._n == self.STAGE_CAPACITY:
+            self.commit()
+        st = self._stage[self._cur]
+        if self._n == 0 and st["busy"]:
+            st["event"].synchronize()          # the copy that last used this pinned buffer has completed
+            st["busy"] = False
+        i = self._n
+        st["obs_np"][i] = obs
+        st["rec_np"][i] = (kind, ep, t, action, reward, int(bool(done)), i, ep_len)
+        self._n += 1
+
+    def store_obs(self, obs: np.ndarray) -> None:
+        """First observation of an episode: cleanses the slot, then writes row 0."""
+        ep = self.pos[0] % self.max_size
+        self.episode_lengths[ep] = 0
+        self._push(0, ep, 0, 0, 0.0, True, obs)
+
+    def store(self, obs: np.ndarray, action, reward, done, episode_length: Optional[int] = 0) -> None:
+        ep, t = self.pos[0] % self.max_size, self.pos[1]
+        self.episode_lengths[ep] = episode_length
+        self._push(1, ep, t, int(action), float(reward), done, obs, int(episode_length))
+        self.pos = [self.pos[0], self.pos[1] + 1]
+
+    def can_sample(self, batch_size: int) -> bool:
+        return batch_size < self.pos[0]
+
+    def flush(self) -> None:
+        self.pos = [self.pos[0] + 1, 0]
+
+    def commit(self) -> None:
+        """Ship the queued records to the GPU: one H2D copy pair + one scatter kernel."""
+        if self._n == 0:
+            return
+        st, n = self._stage[self._cur], self._n
+        nb, no = n * RECORD_DTYPE.itemsize, n * self.env_obs_length
+        st["rec_d"][:nb].copy_(st["rec_h"][:nb], non_blocking=True)
+        st["obs_d"][:no].copy_(st["obs_h"][:no], non_blocking=True)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
+        rc = self._lib.dtqn_replay_apply(ctypes.byref(self.dev.view), ctypes.c_void_p(st["rec_d"].data_ptr()),
+                                         ctypes.c_void_p(st["obs_d"].data_ptr()), n, stream)
+        if rc != 0:
+            raise RuntimeError(f"dtqn_replay_apply failed with DTQN status {rc}")
+        if st["event"] is not None:
+            st["event"].record()
+            st["busy"] = True
+        self._cur = (self._cur + 1) % len(self._stage)
+        self._n = 0
+
+    # ---- consumer side -----------------------------------------------------------------------
+    def valid_range(self) -> Tuple[int, int]:
+        """(n_valid, exclude): finished slots are [0, n_valid) minus the one in progress (:141-145)."""
+        return min(self.pos[0], self.max_size), self.pos[0] % self.max_size
+
+    def sample_indices(self, batch_size: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(episode, start) draws with the reference's distribution AND its use of Python's `random`
+        stream (replay_buffer.py:141-158), so a seeded run visits the same windows."""
+        n_valid, exclude = self.valid_range()
+        valid = [i for i in range(n_valid) if i != exclude]
+        eps = np.fromiter((random.choice(valid) for _ in range(batch_size)), dtype=np.int32, count=batch_size)
+        L = self.context_len
+        starts = np.fromiter((random.randint(0, max(0, int(self.episode_lengths[e]) - L)) for e in eps),
+                             dtype=np.int32, count=batch_size)
+        return eps, starts
+
+    def sample(self, batch_size: int):
+        """Reference-shaped sample() -> numpy arrays (compatibility / debugging path: it gathers on
+        the device and copies back; the TD update does not use it)."""
+        self.commit()
+        eps, starts = self.sample_indices(batch_size)
+        e = torch.as_tensor(eps, dtype=torch.long, device=self.device).unsqueeze(1)
+        tr = torch.as_tensor(starts, dtype=torch.long, device=self.device).unsqueeze(1) + \
+            torch.arange(self.context_len, device=self.device).unsqueeze(0)
+        d = self.dev
+        out = (d.obs[e, tr], d.actions[e, tr].unsqueeze(-1), d.rewards[e, tr].unsqueeze(-1), d.obs[e, tr + 1],
+               d.actions[e, tr + 1].unsqueeze(-1), d.dones[e, tr].unsqueeze(-1).bool())
+        lens = np.clip(self.episode_lengths[eps.reshape(-1, 1)], 0, self.context_len)
+        return tuple(x.cpu().numpy() for x in out) + (lens,)
+
+    # ---- whole-array access (checkpointing) ---------------------------------------------------
+    def export_arrays(self) -> dict:
+        self.commit()
+        d = self.dev
+        return dict(obss=d.obs.cpu().numpy(), actions=d.actions.cpu().numpy(), rewards=d.rewards.cpu().numpy(),
+                    dones=d.dones.cpu().numpy(), eplens=self.episode_lengths.copy())
+
+    def import_arrays(self, arrays: dict) -> None:
+        d = self.dev
+        d.obs.copy_(torch.from_numpy(arrays["obss"])); d.actions.copy_(torch.from_numpy(arrays["actions"]))
+        d.rewards.copy_(torch.from_numpy(arrays["rewards"])); d.dones.copy_(torch.from_numpy(arrays["dones"]))
+        self.episode_lengths[:] = arrays["eplens"]
+        d.ep_len.copy_(torch.from_numpy(self.episode_lengths))

@@ -517,6 +517,7 @@ static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD>), dim3(a.batch), dim3(DTQN_THREADS), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }

@@ -244,6 +244,7 @@ static int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD>), dim3(nblocks), dim3(DTQN_THREADS), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }

@@ -212,6 +212,7 @@ extern "C" int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream
     a.gsplit = td->gsplit; a.small = td->small; a.grd = td->grd; a.grad = td->grad;
     a.norm_partial = td->norm_partial; a.step_counter = td->step_counter;
     a.batch = td->batch; a.n_split = td->n_split;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_reduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
@@ -221,6 +222,7 @@ extern "C" int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stre
     if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
     NormArgs a;
     a.grad = td->grad; a.norm_partial = td->norm_partial; a.n = net->n_trainable;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_gradnorm_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
@@ -236,6 +238,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.tuf = td->target_update_frequency;
     a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;
     a.grad_scale = td->grad_scale;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_clip_adam_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
@@ -244,6 +247,7 @@ extern "C" int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, floa
     if (!net || !theta_pol || !theta_tgt) return DTQN_ERR_ARG;
     CopyArgs a;
     a.src = theta_pol; a.dst = theta_tgt; a.n = net->n_theta;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_copy_kernel, dim3(opt_blocks(net->n_theta)), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }

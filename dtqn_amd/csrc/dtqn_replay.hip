@@ -41,7 +41,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 act[t] = (uint8_t)r.action;
                 rew[t] = r.reward;
                 don[t] = r.done ? 1 : 0;
-                a.rp.ep_len[ep] = t + 1;
+                a.rp.ep_len[ep] = r.ep_len;
             }
         }
         __syncthreads();
@@ -96,6 +96,7 @@ extern "C" int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* r
     if (!recs_dev || !obs_rows_dev) return DTQN_ERR_ARG;
     ApplyArgs a;
     a.rp = *rp; a.recs = recs_dev; a.obs_rows = obs_rows_dev; a.n = n;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_replay_apply_kernel, dim3(1), dim3(DTQN_THREADS), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
@@ -108,6 +109,7 @@ extern "C" int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude
     SampleArgs a;
     a.ep_len = rp->ep_len; a.n_valid = n_valid; a.exclude = exclude; a.ctx_len = ctx_len; a.batch = batch;
     a.seed = seed; a.step_counter = step_counter_dev; a.ep_idx = ep_idx_dev; a.start = start_dev;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_replay_sample_kernel, dim3((batch + DTQN_THREADS - 1) / DTQN_THREADS), dim3(DTQN_THREADS), 0,
                        (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;

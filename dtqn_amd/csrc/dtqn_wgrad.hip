@@ -132,6 +132,7 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     a.batch = td->batch; a.n_split = td->n_split; a.n_jobs = net->n_wjobs;
     const size_t lds = (size_t)3 * 64 * 68 * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(net->n_wtiles, td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }

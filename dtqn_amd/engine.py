@@ -4,6 +4,11 @@ from __future__ import annotations
 
 import os
 
+# torch must be imported BEFORE libdtqn_hip.so is dlopen'ed: the torch wheel bundles its own
+# libamdhip64, and the engine has to bind to that same runtime instance (its streams are torch's).
+# Loading the engine first would pull in /opt/rocm's copy and every launch on a torch stream fails.
+import torch  # noqa: F401
+
 from . import _binding
 
 _LIB = None

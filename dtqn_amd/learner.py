@@ -52,7 +52,8 @@ class DeviceReplay:
 class TdEngine:
     def __init__(self, net: B.DtqnNet, batch: int, *, lr=3e-4, gamma=0.99, history=None, tuf=10_000,
                  grad_norm_clip=1.0, betas=(0.9, 0.999), eps=1e-8, n_split: Optional[int] = None,
-                 device=None, _test_lib=None):
+                 device=None, _test_lib=None, theta_pol: Optional[torch.Tensor] = None,
+                 theta_tgt: Optional[torch.Tensor] = None):
         # `_test_lib` exists for the CPU kernel-emulation tests only (tests/emu); the product path
         # always resolves to the hipcc-built engine on a ROCm device and raises otherwise.
         if _test_lib is None:
@@ -68,12 +69,18 @@ class TdEngine:
         dev = self.device
         nt, nth = net.n_trainable, net.n_theta
         f32 = dict(dtype=torch.float32, device=dev)
-        self.theta_pol = torch.zeros(nth, **f32)
-        self.theta_tgt = torch.zeros(nth, **f32)
-        frozen = np.zeros(nth, dtype=np.float32)
-        self.lib.dtqn_net_fill_frozen(ctypes.byref(net), frozen.ctypes.data_as(ctypes.c_void_p))
-        self.theta_pol.copy_(torch.from_numpy(frozen))
-        self.theta_tgt.copy_(torch.from_numpy(frozen))
+        if theta_pol is None:
+            frozen = np.zeros(nth, dtype=np.float32)
+            self.lib.dtqn_net_fill_frozen(ctypes.byref(net), frozen.ctypes.data_as(ctypes.c_void_p))
+            self.theta_pol = torch.from_numpy(frozen).to(dev)
+            self.theta_tgt = torch.from_numpy(frozen.copy()).to(dev)
+        else:
+            # bind to the flat buffers of the caller's DTQN modules (dtqn_amd.networks.dtqn.DTQN.flat)
+            same_dev = lambda a, b: a.type == b.type and (a.type != "cuda" or (a.index if a.index is not None else torch.cuda.current_device()) == (b.index if b.index is not None else torch.cuda.current_device()))
+            for th in (theta_pol, theta_tgt):
+                if not same_dev(th.device, dev) or th.dtype != torch.float32 or th.numel() != nth or not th.is_contiguous():
+                    raise ValueError("theta buffers must be contiguous float32 tensors of n_theta elements on the engine device")
+            self.theta_pol, self.theta_tgt = theta_pol, theta_tgt
         self.grad = torch.zeros(nt, **f32)
         self.adam_m = torch.zeros(nt, **f32)
         self.adam_v = torch.zeros(nt, **f32)

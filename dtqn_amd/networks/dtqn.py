@@ -1,0 +1,138 @@
+"""DTQN network object with the reference's constructor, forward signature and state_dict layout
+(dtqn/networks/dtqn.py:16-218), backed by ONE flat fp32 device buffer that the gfx950 kernels
+read directly.
+
+The module is a parameter CONTAINER plus an inference `forward`: every nn.Parameter is a view
+into `self.flat` (layout: include/dtqn_hip.h, DtqnNet), so `state_dict()` / `load_state_dict()` /
+`parameters()` behave like the reference's and checkpoints are interchangeable, while the engine
+sees a single contiguous theta.  Training does not go through autograd: DtqnAgent.train() runs the
+fused HIP update on these same buffers.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _binding as B
+from .. import engine
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted state_dict keys."""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, _Node())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], param)
+
+
+class DTQN(nn.Module):
+    """Deep Transformer Q-Network.  Arguments as in the reference (dtqn.py:19-59); `pos` defaults
+    to "learned" (the reference's default value 1 is rejected by its own PosEnum)."""
+
+    def __init__(self, obs_dim: int, num_actions: int, embed_per_obs_dim: int, action_dim: int,
+                 inner_embed_size: int, num_heads: int, num_layers: int, history_len: int, dropout: float = 0.0,
+                 gate: str = "res", identity: bool = False, pos: Union[str, int] = "learned", discrete: bool = False,
+                 vocab_sizes: Optional[Union[np.ndarray, int]] = None, bag_size: int = 0, _test_lib=None, **kwargs):
+        super().__init__()
+        if isinstance(obs_dim, tuple):
+            raise NotImplementedError("image observations (conv embedding) are outside dtqn_amd's scope")
+        if bag_size > 0:
+            raise NotImplementedError("the persistent-memory bag is outside dtqn_amd's scope")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented in the fused kernels (reference default 0.0)")
+        if pos not in B.POS:
+            raise ValueError(f"{pos!r} is not a valid PosEnum")        # PosEnum(pos) in the reference (dtqn.py:101)
+        self._lib = _test_lib if _test_lib is not None else engine.get_lib()
+        self.obs_dim, self.discrete, self.history_len, self.bag_size = obs_dim, discrete, history_len, bag_size
+        self.num_actions = num_actions
+        self.net = B.make_net(self._lib, obs_dim=obs_dim, num_actions=num_actions, embed_per_obs_dim=embed_per_obs_dim,
+                              action_dim=action_dim, inner_embed_size=inner_embed_size, num_heads=num_heads,
+                              num_layers=num_layers, history_len=history_len, gate=gate, identity=identity, pos=pos,
+                              discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0)
+        if gate != "res":
+            raise NotImplementedError("gate='gru' is not yet covered by the gfx950 kernels (DESIGN.md coverage)")
+        net = self.net
+        flat = np.zeros(net.n_theta, dtype=np.float32)
+        self._lib.dtqn_net_fill_frozen(ctypes.byref(net), flat.ctypes.data_as(ctypes.c_void_p))
+        self.flat = torch.from_numpy(flat)
+        self._table = B.param_table(net)
+        self._views = {}
+        seen = {}
+        for key, (off, shape) in self._table.items():
+            trainable = off < net.n_trainable
+            if off in seen:                    # shared GRU gate: one Parameter under every layer prefix
+                p = seen[off]
+            else:
+                p = nn.Parameter(self.flat[off:off + int(np.prod(shape))].view(shape), requires_grad=trainable)
+                seen[off] = p
+                self._views[key] = (p, off, shape)
+            _attach(self, key, p)
+        # the reference keeps the causal mask as a frozen Parameter per layer (transformer.py:49-53);
+        # the kernels never read it, it exists for state_dict compatibility
+        mask = torch.triu(torch.ones(history_len, history_len), diagonal=1)
+        mask[mask.bool()] = -float("inf")
+        for l in range(num_layers):
+            _attach(self, f"transformer_layers.{l}.attn_mask", nn.Parameter(mask.clone(), requires_grad=False))
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """utils/torch_utils.py:4-15 as applied by DTQN.__init__ (dtqn.py:156): N(0, 0.02) weights of
+        Linear / Embedding / MultiheadAttention, zero biases, LayerNorm (1, 0); the learned position
+        table is a bare Parameter and stays 0 (position_encodings.py:41-43)."""
+        for key, (p, off, shape) in self._views.items():
+            if key == "position_embedding.position_encoding":
+                continue
+            if "layernorm" in key:
+                p.fill_(1.0 if key.endswith("weight") else 0.0)
+            elif key.endswith("bias"):
+                p.zero_()
+            else:
+                p.normal_(mean=0.0, std=0.02)
+
+    def _apply(self, fn, recurse=True):
+        """Module.to()/cuda()/float(): move the flat buffer once and re-point every view at it."""
+        super()._apply(fn, recurse)
+        self.flat = fn(self.flat)
+        if not self.flat.is_contiguous():
+            self.flat = self.flat.contiguous()
+        for key, (p, off, shape) in self._views.items():
+            p.data = self.flat[off:off + int(np.prod(shape))].view(shape)
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, obss: torch.Tensor, actions: Optional[torch.Tensor] = None,
+                bag_obss: Optional[torch.Tensor] = None, bag_actions: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """obss [B, seq, obs_dim] (float, or integer tokens for discrete envs), actions [B, seq, 1]
+        -> Q [B, seq, num_actions].  Inference only (no autograd graph)."""
+        seq = obss.size(1)
+        assert seq <= self.history_len, "Cannot forward, history is longer than expected."
+        obs_dim = obss.size(2)
+        assert obs_dim == self.obs_dim, f"Obs dim is incorrect. Expected {self.obs_dim} got {obs_dim}"
+        dev = self.flat.device
+        if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
+            raise engine.EngineUnavailable("DTQN.forward runs on the gfx950 engine only: move the module to a ROCm device")
+        o = obss.to(device=dev, dtype=torch.float32).contiguous()
+        a = None
+        if self.net.action_dim > 0:
+            a = actions.to(device=dev).reshape(obss.size(0), seq).to(torch.uint8).contiguous()
+        q = torch.empty((obss.size(0), seq, self.num_actions), dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        rc = self._lib.dtqn_forward(ctypes.byref(self.net), ctypes.c_void_p(self.flat.data_ptr()),
+                                    ctypes.c_void_p(o.data_ptr()), None if a is None else ctypes.c_void_p(a.data_ptr()),
+                                    int(obss.size(0)), int(seq), ctypes.c_void_p(q.data_ptr()), stream)
+        if rc != 0:
+            raise RuntimeError(f"dtqn_forward failed with DTQN status {rc}")
+        return q

@@ -1,0 +1,70 @@
+"""Environment construction and introspection (reference: utils/env_processing.py).
+
+Space types are recognised by class NAME so that both dtqn_amd.envs.spaces and (when installed)
+gym.spaces objects work."""
+from typing import Union
+
+import numpy as np
+
+from .. import envs as _envs
+
+DISCRETE_KINDS = ("Discrete", "MultiDiscrete", "MultiBinary")
+
+
+def _kind(space) -> str:
+    return type(space).__name__
+
+
+def make_env(id_or_path: str):
+    """Registered id -> env.  (The reference falls back to a gridverse YAML factory here,
+    utils/env_processing.py:36-54; that simulator is not available, see dtqn_amd.envs.)"""
+    return _envs.make(id_or_path)
+
+
+def is_discrete_env(env) -> bool:
+    return _kind(env.observation_space) in DISCRETE_KINDS
+
+
+def is_image_env(env) -> bool:
+    space = env.observation_space
+    return (_kind(space) == "Box" and len(getattr(space, "shape", ())) == 3
+            and np.all(np.asarray(space.low) == 0) and np.all(np.asarray(space.high) == 255))
+
+
+def get_env_obs_length(env) -> int:
+    space = env.observation_space
+    if is_image_env(env):
+        raise NotImplementedError("image observations (MiniHack pixel crops) are outside dtqn_amd's scope")
+    kind = _kind(space)
+    if kind == "Discrete":
+        return 1
+    if kind in ("MultiDiscrete", "Box"):
+        if len(space.shape) != 1:
+            raise NotImplementedError("We do not yet support 2D observation spaces")
+        return int(space.shape[0])
+    if kind == "MultiBinary":
+        return int(space.n)
+    raise NotImplementedError(f"We do not yet support {space}")
+
+
+def get_env_obs_mask(env) -> Union[int, float]:
+    """Padding value for unseen observations: one past the largest token for discrete spaces,
+    -5 for continuous ones (below CarFlag's minimum of -1.1; utils/env_processing.py:100-120)."""
+    space = env.observation_space
+    kind = _kind(space)
+    if kind == "Discrete":
+        return int(space.n)
+    if kind == "MultiDiscrete":
+        return int(max(space.nvec)) + 1
+    if kind == "Box":
+        return -5
+    raise NotImplementedError(f"We do not yet support {space}")
+
+
+def get_env_max_steps(env):
+    for attr in ("_max_episode_steps", "max_episode_steps"):
+        try:
+            return getattr(env, attr)
+        except AttributeError:
+            continue
+    return None

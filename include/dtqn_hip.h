@@ -151,7 +151,7 @@ typedef struct DtqnReplay {
 
 /* One producer record: what DtqnAgent.context_reset / observe push per env step
  * (replay_buffer.py:71-92).  kind 0 = store_obs (cleanse slot `ep`, write obs at row 0),
- * kind 1 = store (obs at row t+1, action/reward/done at row t, ep_len = t+1). */
+ * kind 1 = store (obs at row t+1, action/reward/done at row t, episode length = ep_len). */
 typedef struct DtqnReplayRecord {
     int32_t kind;
     int32_t ep;
@@ -160,7 +160,7 @@ typedef struct DtqnReplayRecord {
     float reward;
     int32_t done;
     int32_t obs_index;        /* row of the packed observation array that travels with the records */
-    int32_t reserved;
+    int32_t ep_len;           /* episode_lengths[ep] after this store (the `episode_length` argument) */
 } DtqnReplayRecord;
 
 /* Applies n records (device memory; staged by the host through pinned memory + hipMemcpyAsync)

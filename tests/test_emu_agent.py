@@ -1,0 +1,208 @@
+"""Host logic of the agent / replay buffer / CLI on the CPU, with the kernels running on the
+test-only HIP emulation: producer records -> device arrays, index draws, asynchronous statistics,
+target sync cadence, checkpoint round trip, data-parallel equivalence (gloo, world_size 2)."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from dtqn_amd import _binding as B
+from oracle import replay_oracle as RO
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import emu_build
+    return B.load_library(emu_build.build())
+
+
+def make_agent(emu, env, batch=4, L=8, D=16, H=2, tuf=3, **kw):
+    from dtqn_amd.agents.dtqn import DtqnAgent
+    from dtqn_amd.networks.dtqn import DTQN
+    from dtqn_amd.utils import env_processing as ep
+    obs_len, mask = ep.get_env_obs_length(env), ep.get_env_obs_mask(env)
+    disc = ep.is_discrete_env(env)
+
+    def factory():
+        m = DTQN(obs_len, env.action_space.n, 8, 0, D, H, 2, L, discrete=disc, vocab_sizes=mask + 1 if disc else None, _test_lib=emu)
+        m._allow_cpu = True
+        return m
+    return DtqnAgent(factory, buffer_size=12 * ep.get_env_max_steps(env), device=torch.device("cpu"), env_obs_length=obs_len,
+                     max_env_steps=ep.get_env_max_steps(env), obs_mask=mask, num_actions=env.action_space.n,
+                     is_discrete_env=disc, batch_size=batch, context_len=L, history=L, target_update_frequency=tuf, **kw)
+
+
+@pytest.mark.parametrize("env_id", ["DiscreteCarFlag-v0", "Memory-5-v0"])
+def test_rollout_fills_device_replay_like_the_reference_buffer(emu, env_id):
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.random import set_global_seed, RNG
+    env = envs.make(env_id)
+    set_global_seed(3, env)
+    agent = make_agent(emu, env, D=32)
+    shadow = RO.ReplayOracle(agent.replay_buffer.max_size * env._max_episode_steps, agent.env_obs_length, agent.obs_mask,
+                             env._max_episode_steps, agent.context_len)
+    # mirror every producer call into the oracle buffer
+    rb = agent.replay_buffer
+    orig = (rb.store_obs, rb.store, rb.flush)
+    rb.store_obs = lambda o: (orig[0](o), shadow.store_obs(o))
+    rb.store = lambda o, a, r, d, n=0: (orig[1](o, a, r, d, n), shadow.store(o, a, r, d, n))
+    rb.flush = lambda: (orig[2](), shadow.flush())
+    runpy.prepopulate(agent, 900 if env_id.startswith("Disc") else 400, [env])      # > 12 episodes: the ring wraps
+    arrays = rb.export_arrays()
+    assert np.array_equal(arrays["obss"], shadow.obss)
+    assert np.array_equal(arrays["actions"], shadow.actions[:, :, 0])
+    assert np.array_equal(arrays["rewards"], shadow.rewards[:, :, 0])
+    assert np.array_equal(arrays["dones"].astype(bool), shadow.dones[:, :, 0])
+    assert np.array_equal(arrays["eplens"], shadow.episode_lengths)
+    assert np.array_equal(rb.dev.ep_len.numpy(), shadow.episode_lengths)
+    assert list(rb.pos) == list(shadow.pos)
+    # index draws consume Python's `random` exactly like the reference's sample()
+    random.seed(5)
+    e1, s1 = rb.sample_indices(6)
+    random.seed(5)
+    e2, s2 = shadow.sample_indices(6)
+    assert np.array_equal(e1, e2) and np.array_equal(s1, s2)
+    random.seed(9)
+    got = rb.sample(5)
+    random.seed(9)
+    ref = shadow.sample(5)
+    for g, r in zip(got, ref):
+        assert np.array_equal(np.asarray(g).squeeze(), np.asarray(r).squeeze())
+
+
+def test_train_loop_statistics_and_target_sync(emu):
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import LinearAnneal
+    from dtqn_amd.utils.random import set_global_seed
+    env = envs.make("DiscreteCarFlag-v0")
+    set_global_seed(1, env)
+    agent = make_agent(emu, env, tuf=3)
+    agent.train()                                   # nothing to sample yet: silently returns (dtqn.py:163-164)
+    assert agent.num_train_steps == 0
+    runpy.prepopulate(agent, 1200, [env])
+    assert agent.replay_buffer.can_sample(agent.batch_size)
+    eps = LinearAnneal(1.0, 0.1, 10)
+    theta0 = agent.policy_network.flat.clone()
+    assert torch.equal(agent.target_network.flat, theta0)        # DqnAgent.__init__ copies policy -> target
+    agent.context_reset(env.reset())
+    for i in range(7):
+        if runpy.step(agent, env, eps):
+            agent.replay_buffer.flush()
+            agent.context_reset(env.reset())
+        agent.train()
+        eps.anneal()
+        if agent.num_train_steps in (3, 6):
+            assert torch.equal(agent.target_network.flat, agent.policy_network.flat)
+        elif agent.num_train_steps > 0:
+            assert not torch.equal(agent.target_network.flat, agent.policy_network.flat)
+    assert agent.num_train_steps == 7 and int(agent.engine.step_counter[1]) == 7
+    assert not torch.equal(agent.policy_network.flat, theta0)
+    assert len(agent.td_errors.q) <= 7
+    m = agent.td_errors.mean()                      # drains the asynchronous ring
+    assert len(agent.td_errors.q) == 7 and np.isfinite(m) and m >= 0
+    assert agent.grad_norms.mean() > 0 and agent.qvalue_max.mean() >= agent.qvalue_min.mean()
+    sr, ret, length = runpy.evaluate(agent, envs.make("DiscreteCarFlag-v0") if False else env, 2)
+    assert 0 <= sr <= 1 and length > 0
+    # the state_dict is the reference's layout and round-trips through load_state_dict
+    sd = agent.policy_network.state_dict()
+    assert "transformer_layers.1.attention.in_proj_weight" in sd and "transformer_layers.0.attn_mask" in sd
+    agent.target_network.load_state_dict(sd)
+    assert torch.equal(agent.target_network.flat, agent.policy_network.flat)
+
+
+def test_checkpoint_round_trip(emu, tmp_path):
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import LinearAnneal
+    from dtqn_amd.utils.logging_utils import RunningAverage
+    from dtqn_amd.utils.random import set_global_seed
+    env = envs.make("Memory-5-v0")
+    set_global_seed(2, env)
+    a = make_agent(emu, env, D=32)
+    runpy.prepopulate(a, 400, [env])
+    for _ in range(3):
+        a.train()
+    eps = LinearAnneal(1.0, 0.1, 10)
+    eps.anneal()
+    ras = [RunningAverage(10) for _ in range(3)]
+    ras[0].add(0.5)
+    path = str(tmp_path / "ck")
+    a.save_checkpoint(path, "wid", ras[0], ras[1], ras[2], eps)
+    b = make_agent(emu, env, D=32)
+    wid, s, r, l, ev = b.load_checkpoint(path)
+    assert wid == "wid" and ev == eps.val and s.mean() == 0.5 and b.num_train_steps == 3
+    assert torch.equal(a.policy_network.flat, b.policy_network.flat) and torch.equal(a.engine.adam_v, b.engine.adam_v)
+    assert torch.equal(a.replay_buffer.dev.obs, b.replay_buffer.dev.obs)
+    assert b.load_mini_checkpoint(path)["step"] == 3
+    # both continue identically
+    st = random.getstate()
+    a.train()
+    random.setstate(st)          # `random` is process-global: give b the same draw
+    b.train()
+    assert torch.allclose(a.policy_network.flat, b.policy_network.flat, atol=0, rtol=0)
+
+
+def test_cli_surface():
+    import run as runpy
+    a = runpy.get_args([])
+    assert a.envs == ["DiscreteCarFlag-v0"] and a.model == "DTQN" and a.num_steps == 2_000_000 and a.tuf == 10_000
+    assert (a.lr, a.batch, a.buf_size, a.context, a.in_embed, a.heads, a.layers) == (3e-4, 32, 500_000, 50, 128, 8, 2)
+    assert (a.gate, a.pos, a.history, a.discount, a.obs_embed, a.a_embed, a.bag_size) == ("res", "learned", 50, 0.99, 8, 0, 0)
+    b = runpy.get_args("--envs Memory-5-v0 --in-embed 64 --identity --pos sin --disable-wandb --sampler device".split())
+    assert b.envs == ["Memory-5-v0"] and b.identity and b.pos == "sin" and b.sampler == "device"
+
+
+DP_SCRIPT = r'''
+import os, sys, random
+sys.path.insert(0, "@REPO@"); sys.path.insert(0, "@REPO@/tests")
+import numpy as np, torch, torch.distributed as td
+from dtqn_amd import _binding as B, dist as ddp
+from oracle import dtqn_oracle as O
+from helpers import make_td_case
+from emu import emu_build
+rank, world, _ = ddp.init_from_env("cpu")
+emu = B.load_library(emu_build.build())
+cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8)
+# every rank builds the same replay; rank r trains on its own half of a 2*4 batch
+net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=4, T=12, n_eps=9, mask=-5)
+random.seed(77)
+eps, starts = host.sample_indices(8)
+dp = ddp.DataParallel(eng)
+dp.broadcast_parameters()
+eng.set_indices(eps[rank * 4:(rank + 1) * 4], starts[rank * 4:(rank + 1) * 4])
+dp.update(rep)
+np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.numpy())
+if rank == 0:
+    # single learner on the union batch
+    net1, _, host1, eng1, rep1 = make_td_case(emu, cfg, seed=21, batch=8, T=12, n_eps=9, mask=-5)
+    eng1.set_indices(eps, starts)
+    eng1.update(rep1)
+    np.save(os.environ["OUT"] + ".single.npy", eng1.theta_pol.numpy())
+    np.save(os.environ["OUT"] + ".stats.npy", np.array([eng.read_stats()["grad_norm"], eng1.read_stats()["grad_norm"]]))
+td.barrier()
+'''
+
+
+def test_data_parallel_equals_single_learner_gloo(emu, tmp_path):
+    """world_size 2 on CPU (gloo): all-reduced half-batches == one learner on the union batch."""
+    script = tmp_path / "dp.py"
+    script.write_text(DP_SCRIPT.replace("@REPO@", REPO))
+    out = str(tmp_path / "out")
+    env = dict(os.environ, OUT=out, HIPEMU_THREADS="2", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    r0, r1, single = (np.load(out + s) for s in (".rank0.npy", ".rank1.npy", ".single.npy"))
+    assert np.array_equal(r0, r1)                               # replicas stay bit-identical
+    norms = np.load(out + ".stats.npy")
+    assert abs(norms[0] - norms[1]) <= 1e-5 * norms[1]
+    assert np.abs(r0 - single).max() <= 2e-6                    # one Adam step, same gradient up to summation order
