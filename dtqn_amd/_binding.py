@@ -101,6 +101,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_clip_adam": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
+        "dtqn_debug_set_profile_buffer": [vp],
         "dtqn_abi_version": [],
         "dtqn_build_info": [],
     }

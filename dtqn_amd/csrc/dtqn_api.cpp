@@ -9,6 +9,13 @@ extern "C" const char* dtqn_build_info(void) {
 #endif
 }
 
+static void* g_profile_buffer = nullptr;
+extern "C" int dtqn_debug_set_profile_buffer(void* dev_buffer) {
+    g_profile_buffer = dev_buffer;
+    return DTQN_OK;
+}
+extern "C" void* dtqn_debug_profile_buffer(void) { return g_profile_buffer; }
+
 // DtqnAgent.train() after sampling (dtqn/agents/dtqn.py:215-269) on one GPU: five launches.
 extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     int rc;

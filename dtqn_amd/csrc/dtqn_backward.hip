@@ -27,6 +27,7 @@ struct BwdArgs {
     const int32_t* start;
     int batch, history;
     float gamma;
+    long long* prof;             // debug stage clock
 };
 
 // LayerNorm backward over the rows of a [LP][ld] tile.
@@ -36,12 +37,13 @@ struct BwdArgs {
 //   dst  : receives rstd*(g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy; assigned or accumulated
 //   dgb  : per-sequence partial of d gamma ([D]) followed (at +D) by d beta ([D])   (global)
 // Contains two __syncthreads(); caller must sync before (inputs ready) and after (dst ready).
-template <int D>
+template <int D, int NW>
 __device__ __forceinline__ void layernorm_backward(const float* dy, const float* xin, float* dst, bool accumulate,
                                                    int ld, int LP, const float* __restrict__ st,
                                                    const float* __restrict__ gamma, float* __restrict__ dgb,
                                                    float* red, const Thr& t) {
-    constexpr int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    constexpr int NT = NW * 64;
+    constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
     // pass A: column sums  d gamma[d] = sum_r dy*xhat,  d beta[d] = sum_r dy
     {
         const int d = t.tid % D, part = t.tid / D;
@@ -58,17 +60,18 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
         }
     }
     __syncthreads();
-    for (int idx = t.tid; idx < 2 * D; idx += DTQN_THREADS) {
+    for (int idx = t.tid; idx < 2 * D; idx += NT) {
         const int which = idx / D, d = idx - which * D;
         float s = 0.f;
         for (int p = 0; p < PARTS; ++p) s += red[(p * 2 + which) * D + d];
         dgb[which * D + d] = s;
     }
-    // pass B: rows (4 lanes per row)
-    constexpr int NV = D / 16;
+    // pass B: rows (LPR lanes per row)
+    constexpr int LPR = (NT / DTQN_MAX_LP) < (D / 4) ? (NT / DTQN_MAX_LP) : (D / 4);
+    constexpr int NV = D / (4 * LPR);
     float4 o[NV];
-    int row = t.tid >> 2;
-    const int part = t.tid & 3;
+    int row = t.tid / LPR;
+    const int part = t.tid % LPR;
     const bool valid = row < LP;
     row = valid ? row : 0;
     {
@@ -79,14 +82,14 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const float4 y = ld4(yp + 16 * j), x = ld4(xp + 16 * j), gm = ld4(gamma + part * 4 + 16 * j);
+            const float4 y = ld4(yp + 4 * LPR * j), x = ld4(xp + 4 * LPR * j), gm = ld4(gamma + part * 4 + 4 * LPR * j);
             gq[j] = make_float4(y.x * gm.x, y.y * gm.y, y.z * gm.z, y.w * gm.w);
             xh[j] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
             c1 += (gq[j].x + gq[j].y) + (gq[j].z + gq[j].w);
             c2 += (gq[j].x * xh[j].x + gq[j].y * xh[j].y) + (gq[j].z * xh[j].z + gq[j].w * xh[j].w);
         }
-        c1 += __shfl_xor(c1, 1); c1 += __shfl_xor(c1, 2);
-        c2 += __shfl_xor(c2, 1); c2 += __shfl_xor(c2, 2);
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
         c1 *= (1.0f / D);
         c2 *= (1.0f / D);
 #pragma unroll
@@ -103,10 +106,10 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             if (accumulate) {
-                const float4 p = ld4(dp + 16 * j);
-                st4(dp + 16 * j, make_float4(p.x + o[j].x, p.y + o[j].y, p.z + o[j].z, p.w + o[j].w));
+                const float4 p = ld4(dp + 4 * LPR * j);
+                st4(dp + 4 * LPR * j, make_float4(p.x + o[j].x, p.y + o[j].y, p.z + o[j].z, p.w + o[j].w));
             } else {
-                st4(dp + 16 * j, o[j]);
+                st4(dp + 4 * LPR * j, o[j]);
             }
         }
     }
@@ -115,14 +118,14 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 // Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each).
 //   pass 1 (item = query row t, head): delta = do . o ; dS = P*(dP - delta); dq = scale * dS k
 //   pass 2 (item = key row s, head):   dk = scale * dS^T q ; dv = P^T do      (in place over k, v)
-template <int HD>
+template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n, int h0,
                                                          const float* __restrict__ lse_g,   // [H][LP] global
                                                          const float* __restrict__ o_g,     // [LP][D] global
                                                          int D, float* delta_s, float* lse_s, const Thr& t) {
     const int HG = GW / HD;
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int item = t.tid; item < LP * HG; item += DTQN_THREADS) {
+    for (int item = t.tid; item < LP * HG; item += NW * 64) {
         const int row = item / HG, hl = item - row * HG;
         float* dqp = W5 + row * ld + 4 * GW + hl * HD;
         float dq[HD];
@@ -156,7 +159,7 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
                     sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
                     dp = fmaf(dO[c], v.x, dp); dp = fmaf(dO[c + 1], v.y, dp); dp = fmaf(dO[c + 2], v.z, dp); dp = fmaf(dO[c + 3], v.w, dp);
                 }
-                const float ds = expf(sc - lse) * (dp - delta);
+                const float ds = __expf(sc - lse) * (dp - delta);
 #pragma unroll
                 for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kk[c], dq[c]);
             }
@@ -168,7 +171,7 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
         lse_s[hl * LP + row] = lse;
     }
     __syncthreads();
-    for (int item = t.tid; item < LP * HG; item += DTQN_THREADS) {
+    for (int item = t.tid; item < LP * HG; item += NW * 64) {
         const int srow = item / HG, hl = item - srow * HG;
         float* kp = W5 + srow * ld + GW + hl * HD;
         float* vp = kp + GW;
@@ -196,7 +199,7 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
                 }
 #pragma unroll
                 for (int c = 0; c < HD; ++c) { sc = fmaf(qq[c], k[c], sc); dp = fmaf(dd[c], v[c], dp); }
-                const float p = expf(sc - lse_s[hl * LP + row]);
+                const float p = __expf(sc - lse_s[hl * LP + row]);
                 const float ds = p * (dp - delta_s[hl * LP + row]);
 #pragma unroll
                 for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(p, dd[c], dv[c]); }
@@ -211,8 +214,9 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
     }
 }
 
-template <int D, int MT, int HD>
-__global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) {
+template <int D, int MT, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
+    constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;
     constexpr int LDX = D + 4;
     constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
     constexpr int NC = 2 * D;                     // FFN hidden columns per pass
     constexpr int W5C = (5 * GW > NC ? 5 * GW : NC);
     constexpr int LD5 = W5C + 4;
-    constexpr int NTW = (D / 16 + DTQN_WAVES - 1) / DTQN_WAVES;
+    constexpr int MGX = pick_mg(D / 16, MT, NW);
+    using Own = Owned<D, MT, MGX, NW>;          // fixed ownership of a [LP][D] register-accumulated output
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
     const int b = (int)blockIdx.x;
@@ -238,10 +243,12 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
     float* delta_s = dq_s + LP * AP;                   // attention row terms           [GW/HD][LP]
     float* lse_s = delta_s + (GW / HD) * LP;
     float* red = lse_s + (GW / HD) * LP;               // LN column-sum scratch         [PARTS][2][D]
-    constexpr int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
     float* DU = red + PARTS * 2 * D;                   // identity only: branch grad    [LP][LDX]
 
     const int ep = a.ep_idx[b], st0 = a.start[b];
+    int ps = 0;
+    DTQN_PROF(a.prof, ps++);
 
     // ---------------- B0: double-DQN target, loss, dL/dQ, statistics (dtqn.py:219-253) ----------------
     {
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
         const float* q1 = a.q3 + ((size_t)1 * a.batch + b) * LP * AP;
         const float* q2 = a.q3 + ((size_t)2 * a.batch + b) * LP * AP;
         const float inv_count = 1.0f / ((float)a.batch * (float)a.history);
-        for (int idx = t.tid; idx < LP * AP; idx += DTQN_THREADS) dq_s[idx] = 0.f;
+        for (int idx = t.tid; idx < LP * AP; idx += NT) dq_s[idx] = 0.f;
         __syncthreads();
         if (t.wave == 0) {
             float sq = 0.f, mnq = INFINITY, mxq = -INFINITY, sy = 0.f, mny = INFINITY, mxy = -INFINITY, se = 0.f;
@@ -284,14 +291,19 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
             }
         }
         __syncthreads();
-        for (int idx = t.tid; idx < LP * AP; idx += DTQN_THREADS) grec[net.go_dq + idx] = dq_s[idx];
+        for (int idx = t.tid; idx < LP * AP; idx += NT) grec[net.go_dq + idx] = dq_s[idx];
     }
 
+    DTQN_PROF(a.prof, ps++);   // loss done
     // ---------------- B1: Q head backward ----------------
+    // (every GEMM stage fetches the weight fragment of its first work item before the barrier that
+    //  publishes its input; see StageDyW)
+    StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_h1;
+    g_h1.prefetch(theta + net.off_head1_w, D, t);
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* hh = rec + net.ao_hh;
-        for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
             const int r = idx / D, k = idx - r * D;
             float g = 0.f;
             if (hh[idx] > 0.f)
@@ -301,8 +313,9 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
         }
     }
     __syncthreads();
-    gemm_dyw<D, MT>(T2, LDX, theta + net.off_head1_w, D, D, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
+    g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
     __syncthreads();
+    DTQN_PROF(a.prof, ps++);   // head done
 
     // ---------------- layers, last to first ----------------
     for (int l = net.num_layers - 1; l >= 0; --l) {
@@ -310,17 +323,22 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
         const float* lrec = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
         float* lgrd = grec + net.go_layer0 + (size_t)l * net.grd_layer_stride;
         float* lsm = srec + net.so_ln + l * 4 * D;
+        const float* __restrict__ W1 = th + net.lo_f1_w;
+        const float* __restrict__ W2 = th + net.lo_f2_w;
+        StageDyW<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_dh;      // dh = df W2[:, chunk]
+        g_dh.prefetch(W2, 4 * D, t);
 
         if (!ident) {   // x_out = LN2(s2): dL/ds2
-            tile_load(T2, LDX, lrec + net.al_s2, LP, D, t);
+            tile_load<NW>(T2, LDX, lrec + net.al_s2, LP, D, t);
             __syncthreads();
-            layernorm_backward<D>(DX, T2, DX, false, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
             __syncthreads();
         }
+        DTQN_PROF(a.prof, ps++);   // LN2 bwd done
         // mlp gate (res): s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0]; the skip path keeps DX
         {
             const float* y2 = lrec + net.al_y2;
-            for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+            for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float g = y2[idx] > 0.f ? DX[r * LDX + c] : 0.f;
                 T2[r * LDX + c] = g;
@@ -330,118 +348,136 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
         __syncthreads();
         // FFN backward: dh = df W2 (masked by h > 0), du2 = dh W1, in hidden-column passes
         {
-            f32x4 xacc[NTW][MT];
+            f32x4 xacc[Own::PER_WAVE][MGX];
 #pragma unroll
-            for (int q = 0; q < NTW; ++q)
+            for (int q = 0; q < Own::PER_WAVE; ++q)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xacc[q][m] = zero4();
-            const float* __restrict__ W1 = th + net.lo_f1_w;
-            const float* __restrict__ W2 = th + net.lo_f2_w;
+                for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
+            float w1f[2][NC / 4];
             const float* hrec = lrec + net.al_h;
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
-                gemm_dyw<D, MT>(T2, LDX, W2 + c0, 4 * D, NC, t, [&](int r, int c, float v) {
+                g_dh.run(T2, LDX, t, [&](int r, int c, float v) {
                     const float g = hrec[(size_t)r * 4 * D + c0 + c] > 0.f ? v : 0.f;
                     W5[r * LD5 + c] = g;
                     lgrd[net.gl_dhp + (size_t)r * 4 * D + c0 + c] = g;
                 });
+                if (Own::valid(t.wave, 0))
+                    frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
 #pragma unroll
-                for (int q = 0; q < NTW; ++q) {
-                    const int nt = t.wave + q * DTQN_WAVES;
-                    if (nt * 16 < D) mma_dyw_tile<NC, MT>(W5, LD5, W1 + (size_t)c0 * D + nt * 16 + t.i, D, t, xacc[q]);
+                for (int q = 0; q < Own::PER_WAVE; ++q) {
+                    if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
+                        frag_dyw_fetch<NC>(w1f[(q + 1) & 1], W1 + (size_t)c0 * D + Own::nt(t.wave, q + 1) * 16 + t.i, D, t);
+                    if (Own::valid(t.wave, q))
+                        frag_dyw_mma<NC, MGX>(W5 + Own::mg(t.wave, q) * MGX * 16 * LD5, LD5, w1f[q & 1], t, xacc[q]);
                 }
+                if (c0 + NC < 4 * D) g_dh.prefetch(W2 + c0 + NC, 4 * D, t);
                 __syncthreads();
             }
             float* dst = ident ? DU : DX;
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-                const int nt = t.wave + q * DTQN_WAVES;
-                if (nt * 16 < D) {
-                    const int c = nt * 16 + t.i;
+            for (int q = 0; q < Own::PER_WAVE; ++q) {
+                if (Own::valid(t.wave, q)) {
+                    const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MGX; ++m)
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
-                            const int r = m * 16 + t.kq * 4 + r4;
+                            const int r = (Own::mg(t.wave, q) * MGX + m) * 16 + t.kq * 4 + r4;
                             if (ident) dst[r * LDX + c] = xacc[q][m][r4];
                             else dst[r * LDX + c] += xacc[q][m][r4];
                         }
                 }
             }
         }
+        // LayerNorm in front of / behind the FFN  (T2 is free again: nobody reads df any more)
+        tile_load<NW>(T2, LDX, lrec + net.al_s1, LP, D, t);
         __syncthreads();
-        // LayerNorm in front of / behind the FFN
-        tile_load(T2, LDX, lrec + net.al_s1, LP, D, t);
-        __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
-            layernorm_backward<D>(DX, T2, DX, false, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
         else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
-            layernorm_backward<D>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // LN1 bwd done
+        const float* __restrict__ Wo = th + net.lo_out_w;
+        const float* __restrict__ Win = th + net.lo_in_w;
+        StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
+        g_do.prefetch(Wo, D, t);
         // attention gate (res): s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]
         {
             const float* y1 = lrec + net.al_y1;
-            for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+            for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float g = y1[idx] > 0.f ? DX[r * LDX + c] : 0.f;
                 T2[r * LDX + c] = g;
                 lgrd[net.gl_da + idx] = g;
             }
         }
-        __syncthreads();
         // attention backward, one head group (GW columns) at a time; du1 = dqkv W_in accumulates in registers
         {
-            f32x4 xacc[NTW][MT];
+            f32x4 xacc[Own::PER_WAVE][MGX];
 #pragma unroll
-            for (int q = 0; q < NTW; ++q)
+            for (int q = 0; q < Own::PER_WAVE; ++q)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xacc[q][m] = zero4();
-            const float* __restrict__ Wo = th + net.lo_out_w;
-            const float* __restrict__ Win = th + net.lo_in_w;
+                for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
+            float winf[2][GW / 4];
             const float* qkv = lrec + net.al_qkv;
             for (int g = 0; g < NG; ++g) {
-                // q, k, v of this head group -> W5[:, 0:3GW]
-                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += DTQN_THREADS) {
+                // q, k, v of this head group -> W5[:, 0:3GW]   (W5 is free: the FFN / previous group are behind a barrier)
+                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
                     const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
                     st4(W5 + r * LD5 + which * GW + c, ld4(qkv + (size_t)r * 3 * D + which * D + g * GW + c));
                 }
+                __syncthreads();                   // da (T2) visible
                 // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW]
-                gemm_dyw<D, MT>(T2, LDX, Wo + g * GW, D, GW, t, [&](int r, int c, float v) { W5[r * LD5 + 3 * GW + c] = v; });
+                g_do.run(T2, LDX, t, [&](int r, int c, float v) { W5[r * LD5 + 3 * GW + c] = v; });
                 __syncthreads();
-                attention_backward_group<HD>(W5, LD5, GW, LP, L, g * (GW / HD), lrec + net.al_lse, lrec + net.al_o, D,
-                                             delta_s, lse_s, t);
+                DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
+                // first W_in fragment of this wave in flight during the attention passes
+                if (Own::valid(t.wave, 0))
+                    frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
+                attention_backward_group<HD, NW>(W5, LD5, GW, LP, L, g * (GW / HD), lrec + net.al_lse, lrec + net.al_o, D,
+                                                 delta_s, lse_s, t);
                 __syncthreads();
+                DTQN_PROF(a.prof, ps++);   // attention bwd done
                 // dq | dk | dv of the group -> grd record (columns of the packed [LP][3D] layout)
-                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += DTQN_THREADS) {
+                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
                     const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
                     const float* sp = W5 + r * LD5 + (which == 0 ? 4 * GW : which * GW) + c;
                     st4(lgrd + net.gl_dqkv + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
                 }
+                // du1 += dq W_in[q rows] + dk W_in[k rows] + dv W_in[v rows]: 3 fragments per owned item, double-buffered
 #pragma unroll
-                for (int q = 0; q < NTW; ++q) {
-                    const int nt = t.wave + q * DTQN_WAVES;
-                    if (nt * 16 < D) {
-                        const float* wc = Win + nt * 16 + t.i;
-                        mma_dyw_tile<GW, MT>(W5 + 4 * GW, LD5, wc + (size_t)(0 * D + g * GW) * D, D, t, xacc[q]);
-                        mma_dyw_tile<GW, MT>(W5 + 1 * GW, LD5, wc + (size_t)(1 * D + g * GW) * D, D, t, xacc[q]);
-                        mma_dyw_tile<GW, MT>(W5 + 2 * GW, LD5, wc + (size_t)(2 * D + g * GW) * D, D, t, xacc[q]);
+                for (int q = 0; q < Own::PER_WAVE; ++q) {
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+                        const int step = q * 3 + part;
+                        // next fragment: (q, part + 1) or (q + 1, 0)
+                        const int nq = part < 2 ? q : q + 1, np = part < 2 ? part + 1 : 0;
+                        if (nq < Own::PER_WAVE && Own::valid(t.wave, nq))
+                            frag_dyw_fetch<GW>(winf[(step + 1) & 1], Win + (size_t)(np * D + g * GW) * D + Own::nt(t.wave, nq) * 16 + t.i, D, t);
+                        if (Own::valid(t.wave, q)) {
+                            const float* rows = W5 + Own::mg(t.wave, q) * MGX * 16 * LD5 + (part == 0 ? 4 * GW : part * GW);
+                            frag_dyw_mma<GW, MGX>(rows, LD5, winf[step & 1], t, xacc[q]);
+                        }
                     }
                 }
+                if (g + 1 < NG) g_do.prefetch(Wo + (g + 1) * GW, D, t);
                 __syncthreads();
             }
             float* dst = ident ? DU : DX;
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-                const int nt = t.wave + q * DTQN_WAVES;
-                if (nt * 16 < D) {
-                    const int c = nt * 16 + t.i;
+            for (int q = 0; q < Own::PER_WAVE; ++q) {
+                if (Own::valid(t.wave, q)) {
+                    const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MGX; ++m)
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
-                            const int r = m * 16 + t.kq * 4 + r4;
+                            const int r = (Own::mg(t.wave, q) * MGX + m) * 16 + t.kq * 4 + r4;
                             if (ident) dst[r * LDX + c] = xacc[q][m][r4];
                             else dst[r * LDX + c] += xacc[q][m][r4];
                         }
@@ -449,24 +485,26 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
             }
         }
         __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // dqkv W_in done
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
             const float* xin = l == 0 ? rec + net.ao_x0 : rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2;
-            tile_load(T2, LDX, xin, LP, D, t);
+            tile_load<NW>(T2, LDX, xin, LP, D, t);
             __syncthreads();
-            layernorm_backward<D>(DU, T2, DX, true, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
             __syncthreads();
         }
     }
 
     // ---------------- embedding: dL/dx0 -> record; table / action-embedding partials ----------------
-    tile_store(DX, LDX, grec + net.go_dx0, LP, D, t);
+    DTQN_PROF(a.prof, ps++);
+    tile_store<NW>(DX, LDX, grec + net.go_dx0, LP, D, t);
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
     if (net.discrete) {
         const int KE = net.ke, KEP = net.kep, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim;
         const float* __restrict__ We = theta + net.off_obs_w;
         float* dein = W5;    // [LP][KEP]: dL/d(gathered table rows) = dx0[:, a:] W_e
-        for (int idx = t.tid; idx < LP * KEP; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < LP * KEP; idx += NT) {
             const int r = idx / KEP, k = idx - r * KEP;
             float g = 0.f;
             if (r < L && k < KE)
@@ -474,7 +512,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
             dein[idx] = g;
         }
         __syncthreads();
-        for (int idx = t.tid; idx < V * e; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < V * e; idx += NT) {
             const int v = idx / e, c = idx - v * e;
             float g = 0.f;
             for (int r = 0; r < L; ++r)
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_backward_kernel(BwdArgs a) 
         }
     }
     if (adim > 0) {
-        for (int idx = t.tid; idx < A * adim; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < A * adim; idx += NT) {
             const int v = idx / adim, c = idx - v * adim;
             float g = 0.f;
             if (L == 1) {
@@ -505,20 +543,21 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     const int LP = net->lp, D = net->d_model, HD = net->head_dim;
     const int GW = D >= 64 ? 64 : D, NC = 2 * D;
     const int W5C = 5 * GW > NC ? 5 * GW : NC;
-    const int PARTS = DTQN_THREADS / D >= 1 ? DTQN_THREADS / D : 1;
+    const int NT = waves_for(*net) * 64;
+    const int PARTS = NT / D >= 1 ? NT / D : 1;
     size_t fl = 2 * (size_t)LP * (D + 4) + (size_t)LP * (W5C + 4) + (size_t)LP * net->ap + 2 * (size_t)(GW / HD) * LP +
                 (size_t)PARTS * 2 * D;
     if (net->identity) fl += (size_t)LP * (D + 4);
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD>
+template <int D, int MT, int HD, int NW>
 static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD>), dim3(a.batch), dim3(DTQN_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW>), dim3(a.batch), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 
@@ -547,16 +586,21 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.rew_ep_stride = rp->max_steps;
     a.ep_idx = td->ep_idx; a.start = td->start;
     a.batch = td->batch; a.history = td->history; a.gamma = td->gamma;
-    const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim;
+    a.prof = dtqn_debug_profile_buffer() ? static_cast<long long*>(dtqn_debug_profile_buffer()) + 64 : nullptr;
+    const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
-#define DTQN_BWD_CASE(d, mt, hd) \
-    if (D == d && MT == mt && HD == hd) return launch_bwd<d, mt, hd>(a, s);
-    DTQN_BWD_CASE(64, 4, 8)
-    DTQN_BWD_CASE(128, 4, 16)
-    DTQN_BWD_CASE(64, 4, 16)
-    DTQN_BWD_CASE(16, 1, 8)
-    DTQN_BWD_CASE(32, 2, 8)
-    DTQN_BWD_CASE(32, 1, 16)
+#define DTQN_BWD_CASE(d, mt, hd, nw) \
+    if (D == d && MT == mt && HD == hd && NW == nw) return launch_bwd<d, mt, hd, nw>(a, s);
+    DTQN_BWD_CASE(64, 4, 8, 4)
+    DTQN_BWD_CASE(64, 4, 8, 8)
+    DTQN_BWD_CASE(64, 4, 8, 16)
+    DTQN_BWD_CASE(128, 4, 16, 4)
+    DTQN_BWD_CASE(128, 4, 16, 8)
+    DTQN_BWD_CASE(64, 4, 16, 8)
+    DTQN_BWD_CASE(16, 1, 8, 4)
+    DTQN_BWD_CASE(16, 1, 8, 8)
+    DTQN_BWD_CASE(32, 2, 8, 4)
+    DTQN_BWD_CASE(32, 1, 16, 4)
 #undef DTQN_BWD_CASE
     return DTQN_ERR_CONFIG;
 }

@@ -1,6 +1,6 @@
 // Device building blocks shared by the DTQN forward / backward kernels (gfx950, wave64).
 //
-// One workgroup = DTQN_THREADS (4 waves) owns ONE sequence: its [LP x D] context tile lives in LDS
+// One workgroup = NW waves (template parameter: 4, 8 or 16) owns ONE sequence: its [LP x D] context tile lives in LDS
 // for the whole pass.  Dense projections run on the exact-f32 matrix core
 // (v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r is
 // D[(l>>4)*4+r][l&15]).  The contraction index is permuted so that each lane's k-slices are
@@ -10,12 +10,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dtqn_hip.h"
 #include "dtqn_limits.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
+
+extern "C" void* dtqn_debug_profile_buffer(void);
+
+// stage timestamp (debug): workgroup 0, thread 0 only; PROF costs one uniform branch when disabled
+#define DTQN_PROF(buf, slot) \
+    do { if ((buf) != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (buf)[slot] = (long long)wall_clock64(); } while (0)
 
 namespace dtqn {
 
@@ -75,22 +83,134 @@ __device__ __forceinline__ void mma_xwT_tile(const float* Xs, int lda, const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split-phase fragments: the weight fragment of a work item is FETCHED (global loads issued) well
+// before it is consumed, so the L2 round trip overlaps the barrier / the previous item's MFMAs.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void frag_xwT_fetch(float4 (&bf)[K / 16], const float* __restrict__ Wrow, const Thr& t) {
+    const float4* wp = reinterpret_cast<const float4*>(Wrow + t.kq * (K / 4));
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) bf[s] = wp[s];
+}
+// MFMA order matters: v_mfma_f32_16x16x4_f32 issues every 32 cycles per SIMD but a DEPENDENT
+// accumulate needs 40, and a ds_read_b128 -> use is ~64+ cycles.  So the A fragments of step s+1 are
+// read while step s multiplies, and consecutive MFMAs always hit different accumulators (across the
+// MG row tiles; for MG == 1 the k-steps alternate between two accumulators that are summed at the end).
+template <int K, int MG>
+__device__ __forceinline__ void frag_xwT_mma(const float* Xs, int lda, const float4 (&bf)[K / 16], const Thr& t, f32x4 (&acc)[MG]) {
+    constexpr int KS = K / 16;
+    const float* xp = Xs + t.i * lda + t.kq * (K / 4);
+    float4 af[2][MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) af[0][m] = ld4(xp + m * 16 * lda);
+    f32x4 alt = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(xp + m * 16 * lda + 4 * (s + 1));
+        }
+        const float b4[4] = {bf[s].x, bf[s].y, bf[s].z, bf[s].w};
+        if (MG == 1) {
+            const float a4[4] = {af[s & 1][0].x, af[s & 1][0].y, af[s & 1][0].z, af[s & 1][0].w};
+            acc[0] = mfma16(a4[0], b4[0], acc[0]);
+            alt = mfma16(a4[1], b4[1], alt);
+            acc[0] = mfma16(a4[2], b4[2], acc[0]);
+            alt = mfma16(a4[3], b4[3], alt);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int m = 0; m < MG; ++m) {
+                    const float4 a = af[s & 1][m];
+                    const float av = c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w));
+                    acc[m] = mfma16(av, b4[c], acc[m]);
+                }
+            }
+        }
+    }
+    if (MG == 1) {
+        acc[0][0] += alt[0]; acc[0][1] += alt[1]; acc[0][2] += alt[2]; acc[0][3] += alt[3];
+    }
+}
+template <int NN>
+__device__ __forceinline__ void frag_dyw_fetch(float (&bf)[NN / 4], const float* __restrict__ Wcol, int ldw, const Thr& t) {
+    const float* wp = Wcol + (size_t)(t.kq * (NN / 4)) * ldw;
+#pragma unroll
+    for (int q = 0; q < NN / 4; ++q) bf[q] = wp[(size_t)q * ldw];
+}
+template <int NN, int MG>
+__device__ __forceinline__ void frag_dyw_mma(const float* dYs, int lda, const float (&bf)[NN / 4], const Thr& t, f32x4 (&acc)[MG]) {
+    constexpr int KS = NN / 16;
+    const float* yp = dYs + t.i * lda + t.kq * (NN / 4);
+    float4 af[2][MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) af[0][m] = ld4(yp + m * 16 * lda);
+    f32x4 alt = zero4();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(yp + m * 16 * lda + 4 * (s + 1));
+        }
+        if (MG == 1) {
+            const float4 a = af[s & 1][0];
+            acc[0] = mfma16(a.x, bf[4 * s + 0], acc[0]);
+            alt = mfma16(a.y, bf[4 * s + 1], alt);
+            acc[0] = mfma16(a.z, bf[4 * s + 2], acc[0]);
+            alt = mfma16(a.w, bf[4 * s + 3], alt);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int m = 0; m < MG; ++m) {
+                    const float4 a = af[s & 1][m];
+                    const float av = c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w));
+                    acc[m] = mfma16(av, bf[4 * s + c], acc[m]);
+                }
+            }
+        }
+    }
+    if (MG == 1) {
+        acc[0][0] += alt[0]; acc[0][1] += alt[1]; acc[0][2] += alt[2]; acc[0][3] += alt[3];
+    }
+}
+
+// How many of the MT row tiles one work item keeps (sharing one weight fragment): the largest
+// power-of-two divisor of MT that still leaves at least NW items, so every wave has work.
+constexpr int pick_mg(int ntiles, int MT, int NW) {
+    // minimise the MFMA work of the busiest wave, ceil(items / NW) * MG; prefer the larger MG on ties
+    // (more reuse of the weight fragment)
+    int best = 1, best_cost = 1 << 30;
+    for (int mg = 1; mg <= MT; mg <<= 1) {
+        if (MT % mg != 0) continue;
+        const int items = ntiles * (MT / mg);
+        const int cost = ((items + NW - 1) / NW) * mg;
+        if (cost <= best_cost) { best = mg; best_cost = cost; }
+    }
+    return best;
+}
+
 // Y[rows][N] = X * W^T, W global [N][ldw]; epi(row, col, value) is called for every element the lane owns.
-template <int K, int MT, typename Epi>
+// Work item = (16-column n-tile, group of MG row tiles), dealt round-robin to the NW waves.
+template <int K, int MT, int MG, int NW, typename Epi>
 __device__ __forceinline__ void gemm_xwT(const float* Xs, int lda, const float* __restrict__ W, int ldw, int N,
                                          const Thr& t, Epi epi) {
+    constexpr int MGROUPS = MT / MG;
     const int ntiles = (N + 15) >> 4;
-    for (int nt = t.wave; nt < ntiles; nt += DTQN_WAVES) {
+    for (int item = t.wave; item < ntiles * MGROUPS; item += NW) {
+        const int nt = item / MGROUPS, mg = item - nt * MGROUPS;
         const int col = nt * 16 + t.i;
-        f32x4 acc[MT];
+        f32x4 acc[MG];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = zero4();
-        mma_xwT_tile<K, MT>(Xs, lda, col < N ? W + (size_t)col * ldw : nullptr, t, acc);
+        for (int m = 0; m < MG; ++m) acc[m] = zero4();
+        mma_xwT_tile<K, MG>(Xs + mg * MG * 16 * lda, lda, col < N ? W + (size_t)col * ldw : nullptr, t, acc);
         if (col < N) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) epi(m * 16 + t.kq * 4 + r, col, acc[m][r]);
+                for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, col, acc[m][r]);
         }
     }
 }
@@ -127,49 +247,148 @@ __device__ __forceinline__ void mma_dyw_tile(const float* dYs, int lda, const fl
     }
 }
 
-// dX[rows][Kout] = dY * W, W global [NN][ldw]; epi(row, col, value).
-template <int NN, int MT, typename Epi>
+// dX[rows][Kout] = dY * W, W global [NN][ldw]; epi(row, col, value).  Same item scheme as gemm_xwT.
+template <int NN, int MT, int MG, int NW, typename Epi>
 __device__ __forceinline__ void gemm_dyw(const float* dYs, int lda, const float* __restrict__ W, int ldw, int Kout,
                                          const Thr& t, Epi epi) {
+    constexpr int MGROUPS = MT / MG;
     const int ktiles = (Kout + 15) >> 4;
-    for (int kt = t.wave; kt < ktiles; kt += DTQN_WAVES) {
+    for (int item = t.wave; item < ktiles * MGROUPS; item += NW) {
+        const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
         const int col = kt * 16 + t.i;
-        f32x4 acc[MT];
+        f32x4 acc[MG];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = zero4();
-        mma_dyw_tile<NN, MT>(dYs, lda, col < Kout ? W + col : nullptr, ldw, t, acc);
+        for (int m = 0; m < MG; ++m) acc[m] = zero4();
+        mma_dyw_tile<NN, MG>(dYs + mg * MG * 16 * lda, lda, col < Kout ? W + col : nullptr, ldw, t, acc);
         if (col < Kout) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) epi(m * 16 + t.kq * 4 + r, col, acc[m][r]);
+                for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, col, acc[m][r]);
         }
     }
 }
+
+// Register-resident accumulation across several partial GEMMs with a FIXED output ownership:
+// the D/16 x (MT/MG) output items of a [LP][D] tile are dealt to the NW waves once; item q of this
+// wave is (nt, mg) = owned_item<..>(wave, q).
+template <int D, int MT, int MG, int NW>
+struct Owned {
+    static constexpr int MGROUPS = MT / MG;
+    static constexpr int ITEMS = (D / 16) * MGROUPS;
+    static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
+    __device__ static __forceinline__ bool valid(int wave, int q) { return wave + q * NW < ITEMS; }
+    __device__ static __forceinline__ int nt(int wave, int q) { return (wave + q * NW) / MGROUPS; }
+    __device__ static __forceinline__ int mg(int wave, int q) { return (wave + q * NW) % MGROUPS; }
+};
+
+// Pipelined GEMM stage  Y[LP][NTILES*16] = X W^T  (W global, [N][ldw]).  Usage:
+//     StageXwT<...> g;  g.prefetch(W, ldw, t);  __syncthreads();  g.run(Xs, lda, t, epi);
+// prefetch() issues the weight loads of this wave's first item BEFORE the barrier that publishes X;
+// run() double-buffers the following items.
+template <int K, int MT, int MG, int NW, int NTILES>
+struct StageXwT {
+    static constexpr int MGROUPS = MT / MG;
+    static constexpr int ITEMS = NTILES * MGROUPS;
+    static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
+    float4 bf[2][K / 16];
+    const float* W;
+    int ldw;
+    __device__ __forceinline__ void fetch(int q, const Thr& t) {
+        const int item = t.wave + q * NW;
+        if (item < ITEMS) frag_xwT_fetch<K>(bf[q & 1], W + (size_t)((item / MGROUPS) * 16 + t.i) * ldw, t);
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t) {
+        W = W_;
+        ldw = ldw_;
+        fetch(0, t);
+    }
+    template <typename Epi>
+    __device__ __forceinline__ void run(const float* Xs, int lda, const Thr& t, Epi epi) {
+#pragma unroll
+        for (int q = 0; q < PER_WAVE; ++q) {
+            if (q + 1 < PER_WAVE) fetch(q + 1, t);
+            const int item = t.wave + q * NW;
+            if (item < ITEMS) {
+                const int nt = item / MGROUPS, mg = item - nt * MGROUPS;
+                f32x4 acc[MG];
+#pragma unroll
+                for (int m = 0; m < MG; ++m) acc[m] = zero4();
+                frag_xwT_mma<K, MG>(Xs + mg * MG * 16 * lda, lda, bf[q & 1], t, acc);
+#pragma unroll
+                for (int m = 0; m < MG; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, nt * 16 + t.i, acc[m][r]);
+            }
+        }
+    }
+};
+
+// Same for  dX[LP][KTILES*16] = dY W  (contraction over the NN rows of W).
+template <int NN, int MT, int MG, int NW, int KTILES>
+struct StageDyW {
+    static constexpr int MGROUPS = MT / MG;
+    static constexpr int ITEMS = KTILES * MGROUPS;
+    static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
+    float bf[2][NN / 4];
+    const float* W;
+    int ldw;
+    __device__ __forceinline__ void fetch(int q, const Thr& t) {
+        const int item = t.wave + q * NW;
+        if (item < ITEMS) frag_dyw_fetch<NN>(bf[q & 1], W + (item / MGROUPS) * 16 + t.i, ldw, t);
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t) {
+        W = W_;
+        ldw = ldw_;
+        fetch(0, t);
+    }
+    template <typename Epi>
+    __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Epi epi) {
+#pragma unroll
+        for (int q = 0; q < PER_WAVE; ++q) {
+            if (q + 1 < PER_WAVE) fetch(q + 1, t);
+            const int item = t.wave + q * NW;
+            if (item < ITEMS) {
+                const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
+                f32x4 acc[MG];
+#pragma unroll
+                for (int m = 0; m < MG; ++m) acc[m] = zero4();
+                frag_dyw_mma<NN, MG>(dYs + mg * MG * 16 * lda, lda, bf[q & 1], t, acc);
+#pragma unroll
+                for (int m = 0; m < MG; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, kt * 16 + t.i, acc[m][r]);
+            }
+        }
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm over D of every row of a [LP][ld] LDS tile (eps 1e-5, biased variance;
 // torch.nn.LayerNorm as used at dtqn/networks/transformer.py:28-29).  4 lanes per row.
 // Optionally records (mean, rstd) per row to st_out[row*2..] (global).
 // ------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int NW>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t) {
-    constexpr int NV = D / 16;  // float4 chunks per lane
-    for (int base = 0; base < LP; base += DTQN_THREADS / 4) {
-        const int row = base + (t.tid >> 2), part = t.tid & 3;
+    constexpr int THREADS = NW * 64;
+    constexpr int LPR = (THREADS / DTQN_MAX_LP) < (D / 4) ? (THREADS / DTQN_MAX_LP) : (D / 4);   // lanes per row (4, 8 or 16)
+    constexpr int NV = D / (4 * LPR);                                                           // float4 chunks per lane
+    constexpr int ROWS = THREADS / LPR;
+    for (int base = 0; base < LP; base += ROWS) {
+        const int row = base + t.tid / LPR, part = t.tid % LPR;
         const bool valid = row < LP;
         const float* sp = src + (valid ? row : 0) * ld + part * 4;
         float4 v[NV];
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            v[j] = ld4(sp + 16 * j);
+            v[j] = ld4(sp + 4 * LPR * j);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
         const float mean = sum * (1.0f / D);
         float sq = 0.f;
 #pragma unroll
@@ -177,20 +396,20 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
             const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
             sq += (a * a + b * b) + (c * c + d * d);
         }
-        sq += __shfl_xor(sq, 1);
-        sq += __shfl_xor(sq, 2);
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
         if (valid) {
             float* dp = dst + row * ld + part * 4;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                const float4 g = ld4(gamma + part * 4 + 16 * j), b = ld4(beta + part * 4 + 16 * j);
+                const float4 g = ld4(gamma + part * 4 + 4 * LPR * j), b = ld4(beta + part * 4 + 4 * LPR * j);
                 float4 o;
                 o.x = (v[j].x - mean) * rstd * g.x + b.x;
                 o.y = (v[j].y - mean) * rstd * g.y + b.y;
                 o.z = (v[j].z - mean) * rstd * g.z + b.z;
                 o.w = (v[j].w - mean) * rstd * g.w + b.w;
-                st4(dp + 16 * j, o);
+                st4(dp + 4 * LPR * j, o);
             }
             if (st_out != nullptr && part == 0) {
                 st_out[row * 2 + 0] = mean;
@@ -209,11 +428,11 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
 //   torch.nn.MultiheadAttention as called at transformer.py:64-70: q scaled by hd^-0.5, float
 //   additive mask = strictly-upper-triangular -inf  => keys s <= t only.
 // ------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int NW>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t) {
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int item = t.tid; item < LP * H; item += DTQN_THREADS) {
+    for (int item = t.tid; item < LP * H; item += NW * 64) {
         const int row = item / H, h = item - row * H;
         float* qp = Ws + row * ld + h * HD;
         if (row >= n) {
@@ -241,8 +460,8 @@ __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int 
                 sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
             }
             const float mn = fmaxf(m, sc);
-            const float corr = expf(m - mn);
-            const float p = expf(sc - mn);
+            const float corr = __expf(m - mn);
+            const float p = __expf(sc - mn);
             l = l * corr + p;
 #pragma unroll
             for (int c = 0; c < HD; c += 4) {
@@ -255,24 +474,40 @@ __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int 
         const float inv = 1.0f / l;
 #pragma unroll
         for (int c = 0; c < HD; c += 4) st4(qp + c, make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv));
-        if (lse_out != nullptr) lse_out[h * LP + row] = m + logf(l);
+        if (lse_out != nullptr) lse_out[h * LP + row] = m + __logf(l);
     }
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.
+template <int NW>
 __device__ __forceinline__ void tile_store(const float* s, int ld, float* __restrict__ g, int rows, int cols, const Thr& t) {
     const int c4 = cols >> 2;
-    for (int idx = t.tid; idx < rows * c4; idx += DTQN_THREADS) {
+    for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
         const int r = idx / c4, c = (idx - r * c4) * 4;
         st4(g + (size_t)r * cols + c, ld4(s + r * ld + c));
     }
 }
+template <int NW>
 __device__ __forceinline__ void tile_load(float* s, int ld, const float* __restrict__ g, int rows, int cols, const Thr& t) {
     const int c4 = cols >> 2;
-    for (int idx = t.tid; idx < rows * c4; idx += DTQN_THREADS) {
+    for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
         const int r = idx / c4, c = (idx - r * c4) * 4;
         st4(s + r * ld + c, ld4(g + (size_t)r * cols + c));
     }
+}
+
+// Waves per workgroup for a given network.  More waves = more matrix-core issue slots per CU for the one
+// sequence a workgroup owns (the small-batch regime is latency-bound), fewer = more registers per wave.
+// DTQN_WAVES in the environment overrides the default (tuning / tests).
+static inline int waves_for(const DtqnNet& net) {
+    int nw = net.d_model <= 64 ? (net.lp >= 64 ? 8 : 4) : (net.lp >= 64 ? 8 : 4);
+    if (net.d_model == 32 || net.d_model == 16) nw = 4;
+    const char* e = getenv("DTQN_WAVES");
+    if (e != nullptr) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) nw = v;
+    }
+    return nw;
 }
 
 __device__ __forceinline__ const float* layer_theta(const DtqnNet& net, const float* theta, int l) {

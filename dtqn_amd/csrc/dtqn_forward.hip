@@ -26,13 +26,15 @@ struct FwdArgs {
     long long q_which_stride, q_seq_stride;
     int q_row_stride;
     float* act;                 // nullptr: inference; else activation records for which == 0
+    long long* prof;            // debug stage clock (see dtqn_debug_set_profile_buffer)
 };
 
 __device__ __forceinline__ int lds_ldx(int D) { return D + 4; }
 __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 
-template <int D, int MT, int HD>
-__global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
+template <int D, int MT, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+    constexpr int NT = NW * 64;                    // threads per workgroup
     constexpr int LP = MT * 16;
     constexpr int LDX = D + 4, LDW = 3 * D + 4;
     constexpr int NC = 2 * D;                      // FFN hidden columns per pass
@@ -49,14 +51,16 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
     float* Ws = Xs + LP * LDX;                         // q|k|v, FFN hidden, staging [LP][LDW]
     float* Us = Ws + LP * LDW;                         // identity only: LN output   [LP][LDX]
 
+    int ps = 0;
+    DTQN_PROF(a.prof, ps++);
     // ---------------- window gather + embedding ----------------
     const int ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
     const int row0 = (a.start != nullptr ? a.start[b] : 0) + (which > 0 ? 1 : 0);
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
     const int KE = net.ke, KEP = net.kep;
-    float* ein = Ws;                                   // [LP][KEP] embedding-linear input
-    for (int idx = t.tid; idx < LP * KEP; idx += DTQN_THREADS) {
+    float* ein = Ws;                                   // [LP][KEP] embedding-linear input (wavefront-level gather)
+    for (int idx = t.tid; idx < LP * KEP; idx += NT) {
         const int r = idx / KEP, k = idx - r * KEP;
         float v = 0.f;
         if (r < n && k < KE) {
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
         const float* __restrict__ We = theta + net.off_obs_w;
         const float* __restrict__ be = theta + net.off_obs_b;
         const float* __restrict__ pos = theta + net.off_pos;
-        for (int idx = t.tid; idx < LP * D; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
             const int r = idx / D, d = idx - r * D;
             float v = 0.f;
             if (r < n) {
@@ -98,94 +102,113 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
             if (rec != nullptr) rec[net.ao_x0 + idx] = v;
         }
     }
-    __syncthreads();
+    DTQN_PROF(a.prof, ps++);   // embed done; Xs is published by the barrier that opens layer 0
 
     // ---------------- transformer layers ----------------
+    // Every GEMM stage fetches the weight fragment of its first work item BEFORE the barrier that
+    // publishes its input, so the L2 round trip overlaps the tail of the previous stage.
+    constexpr int MG2 = pick_mg(D / 16, MT, NW);
+    using Own = Owned<D, MT, MG2, NW>;                 // fixed ownership of the FFN-2 output tile
     for (int l = 0; l < net.num_layers; ++l) {
         const float* __restrict__ th = layer_theta(net, theta, l);
         float* lrec = rec != nullptr ? rec + net.ao_layer0 + (size_t)l * net.act_layer_stride : nullptr;
         const float* src = Xs;
+        StageXwT<D, MT, pick_mg(3 * D / 16, MT, NW), NW, 3 * D / 16> g_qkv;
+        g_qkv.prefetch(th + net.lo_in_w, D, t);
+        __syncthreads();                               // residual stream of the previous stage visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
             __syncthreads();
             src = Us;
         }
-        if (lrec != nullptr) tile_store(src, LDX, lrec + net.al_u1, LP, D, t);
+        if (lrec != nullptr) tile_store<NW>(src, LDX, lrec + net.al_u1, LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
             const float* __restrict__ bin = th + net.lo_in_b;
             float* qkv_g = lrec ? lrec + net.al_qkv : nullptr;
-            gemm_xwT<D, MT>(src, LDX, th + net.lo_in_w, D, 3 * D, t, [&](int r, int c, float v) {
+            g_qkv.run(src, LDX, t, [&](int r, int c, float v) {
                 v += bin[c];
                 Ws[r * LDW + c] = v;
                 if (qkv_g != nullptr) qkv_g[r * 3 * D + c] = v;
             });
         }
         __syncthreads();
-        attention_forward<HD>(Ws, LDW, D, H, LP, n, lrec ? lrec + net.al_lse : nullptr, t);
+        DTQN_PROF(a.prof, ps++);   // qkv done
+        StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_out;
+        g_out.prefetch(th + net.lo_out_w, D, t);       // in flight during attention
+        attention_forward<HD, NW>(Ws, LDW, D, H, LP, n, lrec ? lrec + net.al_lse : nullptr, t);
         __syncthreads();
-        if (lrec != nullptr) tile_store(Ws, LDW, lrec + net.al_o, LP, D, t);
+        DTQN_PROF(a.prof, ps++);   // attention done
+        if (lrec != nullptr) tile_store<NW>(Ws, LDW, lrec + net.al_o, LP, D, t);
         // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
         {
             const float* __restrict__ bo = th + net.lo_out_b;
             float* y_g = lrec ? lrec + net.al_y1 : nullptr;
             float* s_g = lrec ? lrec + net.al_s1 : nullptr;
-            gemm_xwT<D, MT>(Ws, LDW, th + net.lo_out_w, D, D, t, [&](int r, int c, float v) {
+            g_out.run(Ws, LDW, t, [&](int r, int c, float v) {
                 const float y = fmaxf(v + bo[c], 0.f);
                 const float s = Xs[r * LDX + c] + y;
                 Xs[r * LDX + c] = s;
                 if (y_g != nullptr) { y_g[r * D + c] = y; s_g[r * D + c] = s; }
             });
         }
+        const float* __restrict__ W1 = th + net.lo_f1_w;
+        const float* __restrict__ b1 = th + net.lo_f1_b;
+        const float* __restrict__ W2 = th + net.lo_f2_w;
+        StageXwT<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_f1;
+        g_f1.prefetch(W1, D, t);                       // in flight during LN1
         __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // out-proj done
         if (!ident) {  // x = LN1(x)
-            layernorm_rows<D>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
             src = Us;
         }
         __syncthreads();
-        if (lrec != nullptr) tile_store(src, LDX, lrec + net.al_u2, LP, D, t);
+        DTQN_PROF(a.prof, ps++);   // LN1 done
+        if (lrec != nullptr) tile_store<NW>(src, LDX, lrec + net.al_u2, LP, D, t);
         // FFN D -> 4D -> D in hidden-column passes of NC; the second GEMM accumulates in registers
         {
-            constexpr int NTW = (D / 16 + DTQN_WAVES - 1) / DTQN_WAVES;   // output n-tiles per wave
-            f32x4 facc[NTW][MT];
+            f32x4 facc[Own::PER_WAVE][MG2];
 #pragma unroll
-            for (int q = 0; q < NTW; ++q)
+            for (int q = 0; q < Own::PER_WAVE; ++q)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) facc[q][m] = zero4();
-            const float* __restrict__ W1 = th + net.lo_f1_w;
-            const float* __restrict__ b1 = th + net.lo_f1_b;
-            const float* __restrict__ W2 = th + net.lo_f2_w;
+                for (int m = 0; m < MG2; ++m) facc[q][m] = zero4();
+            float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
             float* h_g = lrec ? lrec + net.al_h : nullptr;
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
-                gemm_xwT<D, MT>(src, LDX, W1 + (size_t)c0 * D, D, NC, t, [&](int r, int c, float v) {
+                g_f1.run(src, LDX, t, [&](int r, int c, float v) {
                     const float hv = fmaxf(v + b1[c0 + c], 0.f);
                     Ws[r * LDW + c] = hv;
                     if (h_g != nullptr) h_g[r * 4 * D + c0 + c] = hv;
                 });
-                __syncthreads();
+                if (Own::valid(t.wave, 0))
+                    frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
+                __syncthreads();                       // hidden chunk visible
 #pragma unroll
-                for (int q = 0; q < NTW; ++q) {
-                    const int nt = t.wave + q * DTQN_WAVES;
-                    if (nt * 16 < D) mma_xwT_tile<NC, MT>(Ws, LDW, W2 + (size_t)(nt * 16 + t.i) * 4 * D + c0, t, facc[q]);
+                for (int q = 0; q < Own::PER_WAVE; ++q) {
+                    if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
+                        frag_xwT_fetch<NC>(w2f[(q + 1) & 1], W2 + (size_t)(Own::nt(t.wave, q + 1) * 16 + t.i) * 4 * D + c0, t);
+                    if (Own::valid(t.wave, q))
+                        frag_xwT_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW, w2f[q & 1], t, facc[q]);
                 }
-                __syncthreads();
+                if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t);
+                __syncthreads();                       // everyone is done reading this chunk of the hidden
             }
             const float* __restrict__ b2 = th + net.lo_f2_b;
             float* y_g = lrec ? lrec + net.al_y2 : nullptr;
             float* s_g = lrec ? lrec + net.al_s2 : nullptr;
 #pragma unroll
-            for (int q = 0; q < NTW; ++q) {
-                const int nt = t.wave + q * DTQN_WAVES;
-                if (nt * 16 < D) {
-                    const int c = nt * 16 + t.i;
+            for (int q = 0; q < Own::PER_WAVE; ++q) {
+                if (Own::valid(t.wave, q)) {
+                    const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MG2; ++m)
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
-                            const int r = m * 16 + t.kq * 4 + r4;
+                            const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
                             const float y = fmaxf(facc[q][m][r4] + b2[c], 0.f);
                             const float s = Xs[r * LDX + c] + y;
                             Xs[r * LDX + c] = s;
@@ -194,19 +217,24 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // FFN done
         if (!ident) {  // x = LN2(x)
-            layernorm_rows<D>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
             __syncthreads();
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
         }
+        // the residual stream is published by the barrier that opens the next layer / the head
     }
 
     // ---------------- Q head: Linear(D,D) -> ReLU -> Linear(D,A)  (dtqn.py:149-153,216) ----------------
-    if (rec != nullptr) tile_store(Xs, LDX, rec + net.ao_xf, LP, D, t);
+    StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_head;
+    g_head.prefetch(theta + net.off_head1_w, D, t);
+    __syncthreads();
+    DTQN_PROF(a.prof, ps++);       // layers done
+    if (rec != nullptr) tile_store<NW>(Xs, LDX, rec + net.ao_xf, LP, D, t);
     {
         const float* __restrict__ bh = theta + net.off_head1_b;
         float* hh_g = rec ? rec + net.ao_hh : nullptr;
-        gemm_xwT<D, MT>(Xs, LDX, theta + net.off_head1_w, D, D, t, [&](int r, int c, float v) {
+        g_head.run(Xs, LDX, t, [&](int r, int c, float v) {
             const float hv = fmaxf(v + bh[c], 0.f);
             Ws[r * LDW + c] = hv;
             if (hh_g != nullptr) hh_g[r * D + c] = hv;
@@ -217,7 +245,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* __restrict__ b2 = theta + net.off_head2_b;
         float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride;
-        for (int idx = t.tid; idx < n * A; idx += DTQN_THREADS) {
+        for (int idx = t.tid; idx < n * A; idx += NT) {
             const int r = idx / A, ac = idx - r * A;
             const float* hrow = Ws + r * LDW;
             const float* w = W2 + (size_t)ac * D;
@@ -230,6 +258,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_forward_kernel(FwdArgs a) {
             q[r * a.q_row_stride + ac] = acc;
         }
     }
+    DTQN_PROF(a.prof, ps++);       // end
 }
 
 static size_t fwd_lds_bytes(const DtqnNet* net) {
@@ -239,26 +268,30 @@ static size_t fwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD>
+template <int D, int MT, int HD, int NW>
 static int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD>), dim3(nblocks), dim3(DTQN_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 
 static int dispatch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
-    const int D = a.net.d_model, MT = a.net.lp / 16, HD = a.net.head_dim;
-#define DTQN_FWD_CASE(d, mt, hd) \
-    if (D == d && MT == mt && HD == hd) return launch_fwd<d, mt, hd>(a, nblocks, stream);
-    DTQN_FWD_CASE(64, 4, 8)
-    DTQN_FWD_CASE(128, 4, 16)
-    DTQN_FWD_CASE(64, 4, 16)
-    DTQN_FWD_CASE(16, 1, 8)
-    DTQN_FWD_CASE(32, 2, 8)
-    DTQN_FWD_CASE(32, 1, 16)
+    const int D = a.net.d_model, MT = a.net.lp / 16, HD = a.net.head_dim, NW = waves_for(a.net);
+#define DTQN_FWD_CASE(d, mt, hd, nw) \
+    if (D == d && MT == mt && HD == hd && NW == nw) return launch_fwd<d, mt, hd, nw>(a, nblocks, stream);
+    DTQN_FWD_CASE(64, 4, 8, 4)
+    DTQN_FWD_CASE(64, 4, 8, 8)
+    DTQN_FWD_CASE(64, 4, 8, 16)
+    DTQN_FWD_CASE(128, 4, 16, 4)
+    DTQN_FWD_CASE(128, 4, 16, 8)
+    DTQN_FWD_CASE(64, 4, 16, 8)
+    DTQN_FWD_CASE(16, 1, 8, 4)
+    DTQN_FWD_CASE(16, 1, 8, 8)
+    DTQN_FWD_CASE(32, 2, 8, 4)
+    DTQN_FWD_CASE(32, 1, 16, 4)
 #undef DTQN_FWD_CASE
     return DTQN_ERR_CONFIG;
 }
@@ -292,6 +325,7 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
     a.q_seq_stride = (long long)n * net->num_actions;
     a.q_row_stride = net->num_actions;
     a.act = nullptr;
+    a.prof = nullptr;
     return dispatch_fwd(a, batch, (hipStream_t)stream);
 }
 
@@ -312,5 +346,6 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.q_seq_stride = (long long)net->lp * net->ap;
     a.q_row_stride = net->ap;
     a.act = td->act;
+    a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
     return dispatch_fwd(a, 3 * td->batch, (hipStream_t)stream);
 }

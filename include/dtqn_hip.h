@@ -243,6 +243,11 @@ int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, v
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
 int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
 
+/* Debug aid: when a device buffer of >= 2*64 int64 is registered, workgroup 0 of the forward (slots
+ * 0..63) and backward (slots 64..127) TD kernels records the 100 MHz wall clock at its stage
+ * boundaries into it.  NULL disables (default). */
+int dtqn_debug_set_profile_buffer(void* dev_buffer);
+
 /* Library self-description. */
 int dtqn_abi_version(void);
 const char* dtqn_build_info(void);

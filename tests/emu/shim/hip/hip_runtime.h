@@ -169,6 +169,9 @@ using std::fmaxf;
 using std::fminf;
 using std::isfinite;
 
+static inline long long wall_clock64() { return 0; }
+static inline long long clock64() { return 0; }
+
 // ---- atomics ----------------------------------------------------------------
 static inline float atomicAdd(float* p, float v) { hipemu::atomic_add_f32(p, v); return 0.f; }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

@@ -1,0 +1,33 @@
+"""Per-stage wall-clock breakdown of workgroup 0 of the TD forward / backward kernels (debug aid)."""
+import ctypes, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from oracle import dtqn_oracle as O
+from helpers import make_td_case
+from dtqn_amd import engine
+lib = engine.get_lib(); engine.require_gpu()
+Bn = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=1, batch=Bn, T=200, n_eps=300, mask=-5, device="cuda", test_lib=False)
+eps, starts = host.sample_indices(Bn); eng.set_indices(eps, starts)
+prof = torch.zeros(128, dtype=torch.int64, device="cuda")
+lib.dtqn_debug_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
+for _ in range(5): eng.forward_backward(rep)
+torch.cuda.synchronize()
+acc = np.zeros(128)
+N = 20
+for _ in range(N):
+    prof.zero_(); eng.forward_backward(rep); torch.cuda.synchronize()
+    p = prof.cpu().numpy().astype(np.float64)
+    for base in (0, 64):
+        seg = p[base:base + 64]; n = int((seg > 0).sum())
+        acc[base + 1:base + n] += np.diff(seg[:n]) / 100.0     # 100 MHz -> us
+        acc[base] += (seg[n - 1] - seg[0]) / 100.0
+fw = ["total", "embed"] + [f"L{l}:{s}" for l in range(2) for s in ("qkv", "attn", "outproj", "LN1", "FFN", "LN2")] + ["head+Q"]
+bw = ["total", "loss", "head"] + [f"L{l}:{s}" for l in (1, 0) for s in ("LN2b", "FFNb", "LN1b", "dO", "attnb", "dqkvWin")] + ["tail"]
+for name, base, labels in (("forward", 0, fw), ("backward", 64, bw)):
+    print(f"== {name} (B={Bn}, workgroup 0, mean of {N})")
+    for i, lab in enumerate(labels):
+        print(f"  {lab:12s} {acc[base + i] / N:8.2f} us")
+lib.dtqn_debug_set_profile_buffer(None)
