@@ -337,10 +337,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
         // mlp gate (res): s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0]; the skip path keeps DX
         {
-            const float* y2 = lrec + net.al_y2;
+            const float* m2 = lrec + net.al_m2;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                const float g = y2[idx] > 0.f ? DX[r * LDX + c] : 0.f;
+                const float g = mask_bit(m2, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
                 T2[r * LDX + c] = g;
                 lgrd[net.gl_df + idx] = g;
             }
@@ -354,10 +354,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float w1f[2][NC / 4];
-            const float* hrec = lrec + net.al_h;
+            const float* mh = lrec + net.al_mh;
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
                 g_dh.run(T2, LDX, t, [&](int r, int c, float v) {
-                    const float g = hrec[(size_t)r * 4 * D + c0 + c] > 0.f ? v : 0.f;
+                    const float g = mask_bit(mh, 4 * D / 16, r, c0 + c) ? v : 0.f;
                     W5[r * LD5 + c] = g;
                     lgrd[net.gl_dhp + (size_t)r * 4 * D + c0 + c] = g;
                 });
@@ -406,10 +406,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         g_do.prefetch(Wo, D, t);
         // attention gate (res): s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]
         {
-            const float* y1 = lrec + net.al_y1;
+            const float* m1 = lrec + net.al_m1;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                const float g = y1[idx] > 0.f ? DX[r * LDX + c] : 0.f;
+                const float g = mask_bit(m1, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
                 T2[r * LDX + c] = g;
                 lgrd[net.gl_da + idx] = g;
             }

@@ -25,6 +25,12 @@ extern "C" void* dtqn_debug_profile_buffer(void);
 #define DTQN_PROF(buf, slot) \
     do { if ((buf) != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (buf)[slot] = (long long)wall_clock64(); } while (0)
 
+// Keep-alive for prefetched registers: forces the compiler to place its s_waitcnt for the loads that
+// produced `x` HERE (the test-only host build defines it away).
+#ifndef DTQN_ASM_KEEP
+#define DTQN_ASM_KEEP(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace dtqn {
 
 struct Thr {
@@ -46,6 +52,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;
+}
+__device__ __forceinline__ void retire4(float4& v) {
+    DTQN_ASM_KEEP(v.x); DTQN_ASM_KEEP(v.y); DTQN_ASM_KEEP(v.z); DTQN_ASM_KEEP(v.w);
+}
+// ReLU pattern of one accumulator register across the wave -> one 64-bit word of the mask record
+// (index: (row tile, column tile, r)); must be called by every lane of the wave.
+__device__ __forceinline__ void ballot_store(float* mask_rec, int ctiles, int row, int col, bool on, int lane) {
+    const unsigned long long bits = __ballot(on ? 1 : 0);
+    if (lane == 0) reinterpret_cast<unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)] = bits;
+}
+__device__ __forceinline__ bool mask_bit(const float* mask_rec, int ctiles, int row, int col) {
+    const unsigned long long w = reinterpret_cast<const unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)];
+    return (w >> ((((row >> 2) & 3) << 4) + (col & 15))) & 1ull;
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -303,6 +322,12 @@ struct StageXwT {
         ldw = ldw_;
         fetch(0, t);
     }
+    // wait for the prefetched first fragment NOW (call before issuing stores: CDNA4's vmcnt also counts
+    // stores, so a later wait for this fragment would sit behind their acknowledgements)
+    __device__ __forceinline__ void retire() {
+#pragma unroll
+        for (int s = 0; s < K / 16; ++s) retire4(bf[0][s]);
+    }
     template <typename Epi>
     __device__ __forceinline__ void run(const float* Xs, int lda, const Thr& t, Epi epi) {
 #pragma unroll
@@ -342,6 +367,10 @@ struct StageDyW {
         ldw = ldw_;
         fetch(0, t);
     }
+    __device__ __forceinline__ void retire() {
+#pragma unroll
+        for (int q = 0; q < NN / 4; ++q) DTQN_ASM_KEEP(bf[0][q]);
+    }
     template <typename Epi>
     __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Epi epi) {
 #pragma unroll
@@ -371,7 +400,8 @@ struct StageDyW {
 template <int D, int NW>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                               float* __restrict__ st_out, const Thr& t) {
+                                               float* __restrict__ st_out, const Thr& t,
+                                               float* __restrict__ save_in = nullptr, float* __restrict__ save_out = nullptr) {
     constexpr int THREADS = NW * 64;
     constexpr int LPR = (THREADS / DTQN_MAX_LP) < (D / 4) ? (THREADS / DTQN_MAX_LP) : (D / 4);   // lanes per row (4, 8 or 16)
     constexpr int NV = D / (4 * LPR);                                                           // float4 chunks per lane
@@ -386,6 +416,10 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
         for (int j = 0; j < NV; ++j) {
             v[j] = ld4(sp + 4 * LPR * j);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        if (save_in != nullptr && valid) {   // dense [LP][D] record of the LN input
+#pragma unroll
+            for (int j = 0; j < NV; ++j) st4(save_in + (size_t)row * D + part * 4 + 4 * LPR * j, v[j]);
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
@@ -410,6 +444,7 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
                 o.z = (v[j].z - mean) * rstd * g.z + b.z;
                 o.w = (v[j].w - mean) * rstd * g.w + b.w;
                 st4(dp + 4 * LPR * j, o);
+                if (save_out != nullptr) st4(save_out + (size_t)row * D + part * 4 + 4 * LPR * j, o);
             }
             if (st_out != nullptr && part == 0) {
                 st_out[row * 2 + 0] = mean;
@@ -480,11 +515,12 @@ __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int 
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.
 template <int NW>
-__device__ __forceinline__ void tile_store(const float* s, int ld, float* __restrict__ g, int rows, int cols, const Thr& t) {
+__device__ __forceinline__ void tile_store(const float* s, int ld, float* __restrict__ g, int rows, int cols, const Thr& t, int gld = 0) {
     const int c4 = cols >> 2;
+    if (gld == 0) gld = cols;
     for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
         const int r = idx / c4, c = (idx - r * c4) * 4;
-        st4(g + (size_t)r * cols + c, ld4(s + r * ld + c));
+        st4(g + (size_t)r * gld + c, ld4(s + r * ld + c));
     }
 }
 template <int NW>

@@ -105,8 +105,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     DTQN_PROF(a.prof, ps++);   // embed done; Xs is published by the barrier that opens layer 0
 
     // ---------------- transformer layers ----------------
-    // Every GEMM stage fetches the weight fragment of its first work item BEFORE the barrier that
-    // publishes its input, so the L2 round trip overlaps the tail of the previous stage.
+    // Stage discipline (training pass):
+    //  * every GEMM stage fetches the weight fragment of its first work item BEFORE the barrier that
+    //    publishes its input and RETIRES it right after the barrier, before any store is issued;
+    //  * epilogues write LDS only; what the backward needs is copied LDS -> global as coalesced 16 B/lane
+    //    stores at the START of the next stage (or straight from the LayerNorm registers), so store
+    //    acknowledgements overlap that stage's MFMAs instead of sitting in front of its first wait;
+    //  * ReLU patterns are saved as wave ballots (64 bits per accumulator register), not as tensors.
     constexpr int MG2 = pick_mg(D / 16, MT, NW);
     using Own = Owned<D, MT, MG2, NW>;                 // fixed ownership of the FFN-2 output tile
     for (int l = 0; l < net.num_layers; ++l) {
@@ -117,39 +122,39 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         g_qkv.prefetch(th + net.lo_in_w, D, t);
         __syncthreads();                               // residual stream of the previous stage visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t,
+                                  nullptr, lrec ? lrec + net.al_u1 : nullptr);
             __syncthreads();
             src = Us;
         }
-        if (lrec != nullptr) tile_store<NW>(src, LDX, lrec + net.al_u1, LP, D, t);
+        g_qkv.retire();
+        if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, lrec + net.al_u1, LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
             const float* __restrict__ bin = th + net.lo_in_b;
-            float* qkv_g = lrec ? lrec + net.al_qkv : nullptr;
-            g_qkv.run(src, LDX, t, [&](int r, int c, float v) {
-                v += bin[c];
-                Ws[r * LDW + c] = v;
-                if (qkv_g != nullptr) qkv_g[r * 3 * D + c] = v;
-            });
+            g_qkv.run(src, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = v + bin[c]; });
         }
-        __syncthreads();
-        DTQN_PROF(a.prof, ps++);   // qkv done
         StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_out;
         g_out.prefetch(th + net.lo_out_w, D, t);       // in flight during attention
+        __syncthreads();
+        DTQN_PROF(a.prof, ps++);   // qkv done
+        if (lrec != nullptr) {                         // q|k|v -> record before attention overwrites q
+            tile_store<NW>(Ws, LDW, lrec + net.al_qkv, LP, 3 * D, t);
+            __syncthreads();
+        }
         attention_forward<HD, NW>(Ws, LDW, D, H, LP, n, lrec ? lrec + net.al_lse : nullptr, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
+        g_out.retire();
         if (lrec != nullptr) tile_store<NW>(Ws, LDW, lrec + net.al_o, LP, D, t);
         // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
         {
             const float* __restrict__ bo = th + net.lo_out_b;
-            float* y_g = lrec ? lrec + net.al_y1 : nullptr;
-            float* s_g = lrec ? lrec + net.al_s1 : nullptr;
+            float* m_g = lrec ? lrec + net.al_m1 : nullptr;
             g_out.run(Ws, LDW, t, [&](int r, int c, float v) {
                 const float y = fmaxf(v + bo[c], 0.f);
-                const float s = Xs[r * LDX + c] + y;
-                Xs[r * LDX + c] = s;
-                if (y_g != nullptr) { y_g[r * D + c] = y; s_g[r * D + c] = s; }
+                if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                Xs[r * LDX + c] += y;
             });
         }
         const float* __restrict__ W1 = th + net.lo_f1_w;
@@ -159,16 +164,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         g_f1.prefetch(W1, D, t);                       // in flight during LN1
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // out-proj done
-        if (!ident) {  // x = LN1(x)
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t);
+        if (!ident) {  // x = LN1(x); s1 (input) and u2 (output) go to the record from the LN registers
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t,
+                                  lrec ? lrec + net.al_s1 : nullptr, lrec ? lrec + net.al_u2 : nullptr);
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t,
+                                  lrec ? lrec + net.al_s1 : nullptr, lrec ? lrec + net.al_u2 : nullptr);
             src = Us;
         }
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 done
-        if (lrec != nullptr) tile_store<NW>(src, LDX, lrec + net.al_u2, LP, D, t);
         // FFN D -> 4D -> D in hidden-column passes of NC; the second GEMM accumulates in registers
         {
             f32x4 facc[Own::PER_WAVE][MG2];
@@ -177,16 +183,22 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MG2; ++m) facc[q][m] = zero4();
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
-            float* h_g = lrec ? lrec + net.al_h : nullptr;
+            float* mh_g = lrec ? lrec + net.al_mh : nullptr;
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+                g_f1.retire();
                 g_f1.run(src, LDX, t, [&](int r, int c, float v) {
                     const float hv = fmaxf(v + b1[c0 + c], 0.f);
+                    if (mh_g != nullptr) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
                     Ws[r * LDW + c] = hv;
-                    if (h_g != nullptr) h_g[r * 4 * D + c0 + c] = hv;
                 });
                 if (Own::valid(t.wave, 0))
                     frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
                 __syncthreads();                       // hidden chunk visible
+                if (Own::valid(t.wave, 0)) {
+#pragma unroll
+                    for (int s = 0; s < NC / 16; ++s) retire4(w2f[0][s]);
+                }
+                if (lrec != nullptr) tile_store<NW>(Ws, LDW, lrec + net.al_h + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
                     if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
@@ -198,8 +210,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 __syncthreads();                       // everyone is done reading this chunk of the hidden
             }
             const float* __restrict__ b2 = th + net.lo_f2_b;
-            float* y_g = lrec ? lrec + net.al_y2 : nullptr;
-            float* s_g = lrec ? lrec + net.al_s2 : nullptr;
+            float* m_g = lrec ? lrec + net.al_m2 : nullptr;
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
                 if (Own::valid(t.wave, q)) {
@@ -210,17 +221,19 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
                             const float y = fmaxf(facc[q][m][r4] + b2[c], 0.f);
-                            const float s = Xs[r * LDX + c] + y;
-                            Xs[r * LDX + c] = s;
-                            if (y_g != nullptr) { y_g[r * D + c] = y; s_g[r * D + c] = s; }
+                            if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                            Xs[r * LDX + c] += y;
                         }
                 }
             }
         }
         DTQN_PROF(a.prof, ps++);   // FFN done
-        if (!ident) {  // x = LN2(x)
-            __syncthreads();
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t);
+        __syncthreads();
+        if (!ident) {  // x = LN2(x); s2 from the LN registers
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t,
+                                  lrec ? lrec + net.al_s2 : nullptr, nullptr);
+        } else if (lrec != nullptr) {
+            tile_store<NW>(Xs, LDX, lrec + net.al_s2, LP, D, t);
         }
         // the residual stream is published by the barrier that opens the next layer / the head
     }
@@ -230,17 +243,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     g_head.prefetch(theta + net.off_head1_w, D, t);
     __syncthreads();
     DTQN_PROF(a.prof, ps++);       // layers done
+    g_head.retire();
     if (rec != nullptr) tile_store<NW>(Xs, LDX, rec + net.ao_xf, LP, D, t);
     {
         const float* __restrict__ bh = theta + net.off_head1_b;
-        float* hh_g = rec ? rec + net.ao_hh : nullptr;
-        g_head.run(Xs, LDX, t, [&](int r, int c, float v) {
-            const float hv = fmaxf(v + bh[c], 0.f);
-            Ws[r * LDW + c] = hv;
-            if (hh_g != nullptr) hh_g[r * D + c] = hv;
-        });
+        g_head.run(Xs, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v + bh[c], 0.f); });
     }
     __syncthreads();
+    if (rec != nullptr) tile_store<NW>(Ws, LDW, rec + net.ao_hh, LP, D, t);
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* __restrict__ b2 = theta + net.off_head2_b;

@@ -103,12 +103,13 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         net->al_qkv = lc.take(LP * 3 * D);
         net->al_lse = lc.take(H * LP);
         net->al_o = lc.take(LP * D);
-        net->al_y1 = lc.take(LP * D);
+        net->al_m1 = lc.take((LP / 16) * (D / 16) * 4 * 2);
         net->al_s1 = lc.take(LP * D);
         net->al_st1 = lc.take(LP * 2);
         net->al_u2 = lc.take(LP * D);
         net->al_h = lc.take(LP * 4 * D);
-        net->al_y2 = lc.take(LP * D);
+        net->al_mh = lc.take((LP / 16) * (4 * D / 16) * 4 * 2);
+        net->al_m2 = lc.take((LP / 16) * (D / 16) * 4 * 2);
         net->al_s2 = lc.take(LP * D);
         net->al_st2 = lc.take(LP * 2);
         net->al_gate1 = gru ? lc.take(4 * LP * D) : -1;
@@ -205,7 +206,7 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
                 const int ga = ab + (g == 0 ? net->al_gate1 : net->al_gate2);   // z, r, h~, r*x
                 const int gg = gb + (g == 0 ? net->gl_gate1 : net->gl_gate2);   // dz_pre, dr_pre, dh_pre
                 // y = relu(sub-layer out), x = stream before the gate
-                const int y_off = ab + (g == 0 ? net->al_y1 : net->al_y2);
+                const int y_off = ab + (g == 0 ? net->al_m1 : net->al_m2);   // TODO(gru): needs the y values, not the masks
                 // stream before the attention gate: post-LN -> u1 (layer input); identity -> layer input stream.
                 // stream before the mlp gate: post-LN -> u2 (= LN1 output); identity -> s1.
                 int x_off;

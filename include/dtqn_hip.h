@@ -89,7 +89,9 @@ typedef struct DtqnNet {
     /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
     int32_t act_stride;       /* floats per sequence */
     int32_t ao_ein, ao_x0, ao_layer0, act_layer_stride, ao_xf, ao_hh;
-    int32_t al_u1, al_qkv, al_lse, al_o, al_y1, al_s1, al_st1, al_u2, al_h, al_y2, al_s2, al_st2;
+    int32_t al_u1, al_qkv, al_lse, al_o, al_m1, al_s1, al_st1, al_u2, al_h, al_mh, al_m2, al_s2, al_st2;
+    /* al_m1 / al_mh / al_m2: ReLU activation patterns as wave ballots, one 64-bit word per
+     * (16-row tile, 16-column tile, r): bit (kq*16 + i) <-> row tile*16 + kq*4 + r, column ctile*16 + i */
     int32_t al_gate1, al_gate2;   /* GRU: z, r, h~, r*x, each [LP][D] */
     /* ---- derived: per-sequence gradient record written by the backward-data kernel ---- */
     int32_t grd_stride;

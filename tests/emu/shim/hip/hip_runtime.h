@@ -18,6 +18,7 @@
 #include <functional>
 
 #define DTQN_HIPEMU 1
+#define DTQN_ASM_KEEP(x) ((void)(x))   /* device-only register keep-alive (dtqn_device.hpp) */
 
 // ---- qualifiers -------------------------------------------------------------
 #define __global__

@@ -115,10 +115,22 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         act = eng.act.cpu().numpy().reshape(Bn, net.act_stride)
         D = cfg.inner_embed_size
         fld = lambda off, w: torch.from_numpy(act[:, off:off + net.lp * w].reshape(Bn, net.lp, w)[:, :L].copy() > 0)
+
+        def ballots(off, w):
+            """Decode the engine's ReLU ballot words (include/dtqn_hip.h, al_m1/al_mh/al_m2) into [B, L, w] booleans."""
+            ct = w // 16
+            nwords = (net.lp // 16) * ct * 4
+            words = np.ascontiguousarray(act[:, off:off + 2 * nwords]).view(np.uint64).reshape(Bn, nwords)
+            rows, cols = np.meshgrid(np.arange(L), np.arange(w), indexing="ij")
+            widx = ((rows >> 4) * ct + (cols >> 4)) * 4 + (rows & 3)
+            bit = (((rows >> 2) & 3) << 4) + (cols & 15)
+            return torch.from_numpy(((words[:, widx] >> bit.astype(np.uint64)) & np.uint64(1)).astype(bool))
         masks = []
         for l in range(cfg.num_layers):
             base = net.ao_layer0 + l * net.act_layer_stride
-            masks += [fld(base + net.al_y1, D), fld(base + net.al_h, 4 * D), fld(base + net.al_y2, D)]
+            m_h = ballots(base + net.al_mh, 4 * D)
+            assert torch.equal(m_h, fld(base + net.al_h, 4 * D)), "hidden ballot disagrees with the saved hidden"
+            masks += [ballots(base + net.al_m1, D), m_h, ballots(base + net.al_m2, D)]
         masks.append(fld(net.ao_hh, D))
         probe = {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
         grads, out = O.td_gradients(oracle.pol, oracle.tgt, cfg, batch, oracle.gamma, oracle.history, probe)
