@@ -116,13 +116,12 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 }
 
 // Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each).
-//   pass 1 (item = query row t, head): delta = do . o ; dS = P*(dP - delta); dq = scale * dS k
+//   delta_s[h][t] = dO . o was produced by the dO GEMM's epilogue; lse_s[h][t] is staged by the caller.
+//   pass 1 (item = query row t, head): dS = P*(dP - delta); dq = scale * dS k
 //   pass 2 (item = key row s, head):   dk = scale * dS^T q ; dv = P^T do      (in place over k, v)
 template <int HD, int NW>
-__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n, int h0,
-                                                         const float* __restrict__ lse_g,   // [H][LP] global
-                                                         const float* __restrict__ o_g,     // [LP][D] global
-                                                         int D, float* delta_s, float* lse_s, const Thr& t) {
+__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
+                                                         const float* delta_s, const float* lse_s, const Thr& t) {
     const int HG = GW / HD;
     const float scale = 1.0f / sqrtf((float)HD);
     for (int item = t.tid; item < LP * HG; item += NW * 64) {
@@ -131,21 +130,17 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
         float dq[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) dq[c] = 0.f;
-        float delta = 0.f, lse = 0.f;
         if (row < n) {
             const float* qp = W5 + row * ld + hl * HD;
             const float* dop = W5 + row * ld + 3 * GW + hl * HD;
-            const float* op = o_g + (size_t)row * D + (h0 + hl) * HD;
             float q[HD], dO[HD];
 #pragma unroll
             for (int c = 0; c < HD; c += 4) {
-                const float4 x = ld4(qp + c), g = ld4(dop + c), ov = ld4(op + c);
+                const float4 x = ld4(qp + c), g = ld4(dop + c);
                 q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
                 dO[c] = g.x; dO[c + 1] = g.y; dO[c + 2] = g.z; dO[c + 3] = g.w;
-                delta = fmaf(g.x, ov.x, delta); delta = fmaf(g.y, ov.y, delta);
-                delta = fmaf(g.z, ov.z, delta); delta = fmaf(g.w, ov.w, delta);
             }
-            lse = lse_g[(h0 + hl) * LP + row];
+            const float delta = delta_s[hl * LP + row], lse = lse_s[hl * LP + row];
             const float* kbase = W5 + GW + hl * HD;
             for (int s = 0; s <= row; ++s) {
                 const float* kp = kbase + s * ld;
@@ -167,8 +162,6 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
 #pragma unroll
         for (int c = 0; c < HD; c += 4)
             st4(dqp + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
-        delta_s[hl * LP + row] = delta;
-        lse_s[hl * LP + row] = lse;
     }
     __syncthreads();
     for (int item = t.tid; item < LP * HG; item += NW * 64) {
@@ -296,10 +289,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 
     DTQN_PROF(a.prof, ps++);   // loss done
     // ---------------- B1: Q head backward ----------------
-    // (every GEMM stage fetches the weight fragment of its first work item before the barrier that
-    //  publishes its input; see StageDyW)
+    // Memory discipline of this kernel: every global LOAD (weight fragments, saved activations) is
+    // issued one stage before its use; every global STORE of a gradient tensor is a coalesced copy of
+    // the LDS tile, issued at the start of the NEXT stage after the prefetched fragment has been
+    // retired, so that no s_waitcnt ever sits behind a freshly issued store.
+    static_assert(HD <= 16, "delta-in-epilogue needs a head inside one 16-column tile");
     StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_h1;
-    g_h1.prefetch(theta + net.off_head1_w, D, t);
+    TileRegs<NW, LP, D> tr;                                // saved-activation tile in flight
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* hh = rec + net.ao_hh;
@@ -309,10 +305,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             if (hh[idx] > 0.f)
                 for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + k], g);
             T2[r * LDX + k] = g;
-            grec[net.go_dhh + idx] = g;
         }
     }
+    g_h1.prefetch(theta + net.off_head1_w, D, t);
+    if (!ident) tr.load(rec + net.ao_layer0 + (size_t)(net.num_layers - 1) * net.act_layer_stride + net.al_s2, D, t);
     __syncthreads();
+    g_h1.retire();
+    tile_store<NW>(T2, LDX, grec + net.go_dhh, LP, D, t);
     g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
     __syncthreads();
     DTQN_PROF(a.prof, ps++);   // head done
@@ -328,21 +327,20 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         StageDyW<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_dh;      // dh = df W2[:, chunk]
         g_dh.prefetch(W2, 4 * D, t);
 
-        if (!ident) {   // x_out = LN2(s2): dL/ds2
-            tile_load<NW>(T2, LDX, lrec + net.al_s2, LP, D, t);
+        if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
+            tr.to_lds(T2, LDX, t);
             __syncthreads();
             layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
             __syncthreads();
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
+        tr.load(lrec + net.al_s1, D, t);               // needed after the FFN: in flight during it
         // mlp gate (res): s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0]; the skip path keeps DX
         {
             const float* m2 = lrec + net.al_m2;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                const float g = mask_bit(m2, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
-                T2[r * LDX + c] = g;
-                lgrd[net.gl_df + idx] = g;
+                T2[r * LDX + c] = mask_bit(m2, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
             }
         }
         __syncthreads();
@@ -354,16 +352,32 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float w1f[2][NC / 4];
-            const float* mh = lrec + net.al_mh;
+            const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(lrec + net.al_mh);
+            constexpr int MGH = pick_mg(NC / 16, MT, NW);
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
-                g_dh.run(T2, LDX, t, [&](int r, int c, float v) {
-                    const float g = mask_bit(mh, 4 * D / 16, r, c0 + c) ? v : 0.f;
-                    W5[r * LD5 + c] = g;
-                    lgrd[net.gl_dhp + (size_t)r * 4 * D + c0 + c] = g;
-                });
+                g_dh.retire();
+                if (c0 == 0) tile_store<NW>(T2, LDX, lgrd + net.gl_df, LP, D, t);
+                unsigned long long mw[MGH][4];         // ReLU ballots of the item's accumulator registers
+                g_dh.run(T2, LDX, t,
+                         [&](int kt, int mg) {
+#pragma unroll
+                             for (int m = 0; m < MGH; ++m)
+#pragma unroll
+                                 for (int r = 0; r < 4; ++r)
+                                     mw[m][r] = mh[((mg * MGH + m) * (4 * D / 16) + (c0 >> 4) + kt) * 4 + r];
+                         },
+                         [&](int r, int c, float v) {
+                             const unsigned long long w = mw[(r >> 4) % MGH][r & 3];
+                             W5[r * LD5 + c] = ((w >> t.lane) & 1ull) ? v : 0.f;
+                         });
                 if (Own::valid(t.wave, 0))
                     frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
+                if (Own::valid(t.wave, 0)) {
+#pragma unroll
+                    for (int q = 0; q < NC / 4; ++q) DTQN_ASM_KEEP(w1f[0][q]);
+                }
+                tile_store<NW>(W5, LD5, lgrd + net.gl_dhp + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
                     if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
@@ -391,7 +405,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             }
         }
         // LayerNorm in front of / behind the FFN  (T2 is free again: nobody reads df any more)
-        tile_load<NW>(T2, LDX, lrec + net.al_s1, LP, D, t);
+        tr.to_lds(T2, LDX, t);                         // s1
+        const float* __restrict__ Wo = th + net.lo_out_w;
+        const float* __restrict__ Win = th + net.lo_in_w;
+        StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
+        g_do.prefetch(Wo, D, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
@@ -400,18 +418,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
-        const float* __restrict__ Wo = th + net.lo_out_w;
-        const float* __restrict__ Win = th + net.lo_in_w;
-        StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
-        g_do.prefetch(Wo, D, t);
         // attention gate (res): s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]
         {
             const float* m1 = lrec + net.al_m1;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                const float g = mask_bit(m1, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
-                T2[r * LDX + c] = g;
-                lgrd[net.gl_da + idx] = g;
+                T2[r * LDX + c] = mask_bit(m1, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
             }
         }
         // attention backward, one head group (GW columns) at a time; du1 = dqkv W_in accumulates in registers
@@ -423,6 +435,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float winf[2][GW / 4];
             const float* qkv = lrec + net.al_qkv;
+            const float* o_g = lrec + net.al_o;
+            constexpr int MGO = pick_mg(GW / 16, MT, NW);
             for (int g = 0; g < NG; ++g) {
                 // q, k, v of this head group -> W5[:, 0:3GW]   (W5 is free: the FFN / previous group are behind a barrier)
                 for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
@@ -430,18 +444,40 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
                     st4(W5 + r * LD5 + which * GW + c, ld4(qkv + (size_t)r * 3 * D + which * D + g * GW + c));
                 }
+                // log-sum-exp of this group's heads -> LDS
+                for (int idx = t.tid; idx < (GW / HD) * LP; idx += NT) lse_s[idx] = lrec[net.al_lse + g * (GW / HD) * LP + idx];
                 __syncthreads();                   // da (T2) visible
-                // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW]
-                g_do.run(T2, LDX, t, [&](int r, int c, float v) { W5[r * LD5 + 3 * GW + c] = v; });
-                __syncthreads();
-                DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
+                g_do.retire();
+                if (g == 0) tile_store<NW>(T2, LDX, lgrd + net.gl_da, LP, D, t);
+                // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW];  delta = do . o per (row, head)
+                float ov[MGO][4];
+                g_do.run(T2, LDX, t,
+                         [&](int kt, int mg) {
+#pragma unroll
+                             for (int m = 0; m < MGO; ++m)
+#pragma unroll
+                                 for (int r = 0; r < 4; ++r)
+                                     ov[m][r] = o_g[(size_t)((mg * MGO + m) * 16 + t.kq * 4 + r) * D + g * GW + kt * 16 + t.i];
+                         },
+                         [&](int r, int c, float v) {
+                             W5[r * LD5 + 3 * GW + c] = v;
+                             float p = v * ov[(r >> 4) % MGO][r & 3];
+#pragma unroll
+                             for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
+                             if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LP + r] = p;
+                         });
                 // first W_in fragment of this wave in flight during the attention passes
                 if (Own::valid(t.wave, 0))
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
-                attention_backward_group<HD, NW>(W5, LD5, GW, LP, L, g * (GW / HD), lrec + net.al_lse, lrec + net.al_o, D,
-                                                 delta_s, lse_s, t);
+                __syncthreads();
+                DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
+                attention_backward_group<HD, NW>(W5, LD5, GW, LP, L, delta_s, lse_s, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
+                if (Own::valid(t.wave, 0)) {
+#pragma unroll
+                    for (int q = 0; q < GW / 4; ++q) DTQN_ASM_KEEP(winf[0][q]);
+                }
                 // dq | dk | dv of the group -> grd record (columns of the packed [LP][3D] layout)
                 for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
@@ -455,7 +491,6 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                     for (int part = 0; part < 3; ++part) {
                         const int step = q * 3 + part;
-                        // next fragment: (q, part + 1) or (q + 1, 0)
                         const int nq = part < 2 ? q : q + 1, np = part < 2 ? part + 1 : 0;
                         if (nq < Own::PER_WAVE && Own::valid(t.wave, nq))
                             frag_dyw_fetch<GW>(winf[(step + 1) & 1], Win + (size_t)(np * D + g * GW) * D + Own::nt(t.wave, nq) * 16 + t.i, D, t);
@@ -467,6 +502,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 }
                 if (g + 1 < NG) g_do.prefetch(Wo + (g + 1) * GW, D, t);
                 __syncthreads();
+            }
+            // next stage's saved activation goes in flight now: s2 of the layer below (post-LN), or the
+            // LN1 input of this layer (identity)
+            if (!ident) {
+                if (l > 0) tr.load(rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2, D, t);
+            } else {
+                tr.load(l == 0 ? rec + net.ao_x0 : rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2, D, t);
             }
             float* dst = ident ? DU : DX;
 #pragma unroll
@@ -487,8 +529,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // dqkv W_in done
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
-            const float* xin = l == 0 ? rec + net.ao_x0 : rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2;
-            tile_load<NW>(T2, LDX, xin, LP, D, t);
+            tr.to_lds(T2, LDX, t);
             __syncthreads();
             layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
             __syncthreads();

@@ -373,12 +373,18 @@ struct StageDyW {
     }
     template <typename Epi>
     __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Epi epi) {
+        run(dYs, lda, t, [](int, int) {}, epi);
+    }
+    // pre(kt, mg) runs before the MFMAs of each item: the place to issue the loads its epilogue needs
+    template <typename Pre, typename Epi>
+    __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Pre pre, Epi epi) {
 #pragma unroll
         for (int q = 0; q < PER_WAVE; ++q) {
             if (q + 1 < PER_WAVE) fetch(q + 1, t);
             const int item = t.wave + q * NW;
             if (item < ITEMS) {
                 const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
+                pre(kt, mg);
                 f32x4 acc[MG];
 #pragma unroll
                 for (int m = 0; m < MG; ++m) acc[m] = zero4();
@@ -545,6 +551,35 @@ static inline int waves_for(const DtqnNet& net) {
     }
     return nw;
 }
+
+// A dense [ROWS][COLS] global tile parked in registers: load() issues the (coalesced, 16 B/lane) global
+// loads one or more stages before the data is needed; to_lds() drops it into an LDS tile later.
+template <int NW, int ROWS, int COLS>
+struct TileRegs {
+    static constexpr int C4 = COLS / 4;
+    static constexpr int N = (ROWS * C4 + NW * 64 - 1) / (NW * 64);
+    float4 v[N];
+    __device__ __forceinline__ void load(const float* __restrict__ g, int gld, const Thr& t) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int idx = t.tid + k * NW * 64;
+            if (idx < ROWS * C4) {
+                const int r = idx / C4, c = (idx - r * C4) * 4;
+                v[k] = ld4(g + (size_t)r * gld + c);
+            }
+        }
+    }
+    __device__ __forceinline__ void to_lds(float* s, int ld, const Thr& t) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int idx = t.tid + k * NW * 64;
+            if (idx < ROWS * C4) {
+                const int r = idx / C4, c = (idx - r * C4) * 4;
+                st4(s + r * ld + c, v[k]);
+            }
+        }
+    }
+};
 
 __device__ __forceinline__ const float* layer_theta(const DtqnNet& net, const float* theta, int l) {
     return theta + net.off_layer0 + (size_t)l * net.layer_stride;
