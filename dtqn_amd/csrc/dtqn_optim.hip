@@ -32,8 +32,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     return s;
 }
 
-// grad[p] = sum of the weight-gradient splits, or (for LayerNorm affine / embedding tables / learned
-// position table) the sum over sequences of the backward kernel's per-sequence partials.
+// grad[p] = sum over the batch splits of gsplit[s][p].
 __global__ __launch_bounds__(kOptThreads) void dtqn_reduce_kernel(ReduceArgs a) {
     __shared__ float red[kOptThreads / 64];
     const DtqnNet& net = a.net;
@@ -42,40 +41,11 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_reduce_kernel(ReduceArgs a) 
     if (blockIdx.x == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];   // publish the step count of the previous update
     float v[kOptVec] = {0.f, 0.f, 0.f, 0.f};
     if (p0 < net.n_trainable) {
-        const int D = net.d_model, L = net.ctx_len, LP = net.lp;
-        // which source? (all segment boundaries are multiples of 4, so a float4 never straddles two)
-        int kind = 0, src = 0;
-        const int lrel = p0 - net.off_layer0;
-        if (lrel >= 0 && lrel < net.layer_stride * net.num_layers && (lrel % net.layer_stride) < 4 * D) {
-            kind = 1; src = net.so_ln + (lrel / net.layer_stride) * 4 * D + (lrel % net.layer_stride);
-        } else if (net.discrete && p0 >= net.off_obs_tab && p0 < net.off_obs_tab + net.vocab * net.embed_per_obs) {
-            kind = 1; src = net.so_tab + (p0 - net.off_obs_tab);
-        } else if (net.action_dim > 0 && p0 >= net.off_act_emb && p0 < net.off_act_emb + net.num_actions * net.action_dim) {
-            kind = 1; src = net.so_act + (p0 - net.off_act_emb);
-        } else if (net.pos == DTQN_POS_LEARNED && p0 >= net.off_pos && p0 < net.off_pos + L * D) {
-            kind = 2; src = net.go_dx0 + (p0 - net.off_pos);
-        }
-        if (kind == 0) {
-            for (int s = 0; s < a.n_split; ++s) {
-                const float4 x = ld4(a.gsplit + (size_t)s * net.n_trainable + p0);
-                v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-            }
-        } else {
-            const float* base = kind == 1 ? a.small : a.grd;
-            const size_t stride = kind == 1 ? (size_t)net.sp_stride : (size_t)net.grd_stride;
-            // tables may end off a float4 boundary inside their padded slot: the padding of the
-            // per-sequence record is never written, so guard the tail element-wise
-            int valid = 4;
-            if (kind == 1 && net.discrete && p0 >= net.off_obs_tab && p0 < net.off_obs_tab + net.vocab * net.embed_per_obs)
-                valid = net.off_obs_tab + net.vocab * net.embed_per_obs - p0;
-            if (kind == 1 && net.action_dim > 0 && p0 >= net.off_act_emb && p0 < net.off_act_emb + net.num_actions * net.action_dim)
-                valid = net.off_act_emb + net.num_actions * net.action_dim - p0;
-            (void)LP;
-            for (int b = 0; b < a.batch; ++b) {
-                const float* sp = base + (size_t)b * stride + src;
-                for (int c = 0; c < 4; ++c)
-                    if (c < valid) v[c] += sp[c];
-            }
+        // every gradient element (weight / bias GEMM blocks and the per-sequence partials folded in by the
+        // extra blocks of dtqn_wgrad_kernel) is a sum over the batch splits; never-written padding is zero
+        for (int s = 0; s < a.n_split; ++s) {
+            const float4 x = ld4(a.gsplit + (size_t)s * net.n_trainable + p0);
+            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
         }
         st4(a.grad + p0, make_float4(v[0], v[1], v[2], v[3]));
     }

@@ -12,24 +12,70 @@
 
 namespace dtqn {
 
+constexpr int kMaxWJobs = 64;          // (1 + 4*NL + 24*NL(gru) + 2) <= 64 for the covered nets; kernarg stays < 4 KB
 struct WgradArgs {
     DtqnNet net;
-    const DtqnWJob* jobs;
+    DtqnWJob jobs[kMaxWJobs];           // by value: the job lookup is a scalar-cache walk, not L2 round trips
     const float* act;
     const float* grd;
     float* gsplit;          // [n_split][n_trainable]
+    const float* small;     // [B][sp_stride] per-sequence partials of the backward kernel
     int batch, n_split, n_jobs;
+    int n_small;            // elements of the small-partials index space (LN affine, tables, learned pos table)
 };
 
-__global__ __launch_bounds__(DTQN_THREADS) void dtqn_wgrad_kernel(WgradArgs a) {
+// Extra blocks of the same launch: sum the backward kernel's per-sequence partials (LayerNorm gamma/beta,
+// embedding tables, learned position table = dL/dx0 summed over sequences) over this split's sequences and
+// drop them into gsplit at their parameter offsets, so that dtqn_td_reduce is one uniform sum over splits.
+__device__ __forceinline__ void small_partials_block(const WgradArgs& a, int sb, int split) {
+    const DtqnNet& net = a.net;
+    const int D = net.d_model;
+    const int n_ln = net.num_layers * 4 * D;
+    const int n_tab = net.discrete ? net.vocab * net.embed_per_obs : 0;
+    const int n_act = net.action_dim > 0 ? net.num_actions * net.action_dim : 0;
+    const int b_lo = (int)((long long)a.batch * split / a.n_split);
+    const int b_hi = (int)((long long)a.batch * (split + 1) / a.n_split);
+    float* out = a.gsplit + (size_t)split * net.n_trainable;
+    for (int e = sb * 1024 + (int)threadIdx.x; e < min(a.n_small, (sb + 1) * 1024); e += DTQN_THREADS) {
+        int dst, src;
+        const float* base = a.small;
+        size_t stride = (size_t)net.sp_stride;
+        if (e < n_ln) {
+            const int l = e / (4 * D);
+            dst = net.off_layer0 + l * net.layer_stride + (e - l * 4 * D);
+            src = net.so_ln + e;
+        } else if (e < n_ln + n_tab) {
+            dst = net.off_obs_tab + (e - n_ln);
+            src = net.so_tab + (e - n_ln);
+        } else if (e < n_ln + n_tab + n_act) {
+            dst = net.off_act_emb + (e - n_ln - n_tab);
+            src = net.so_act + (e - n_ln - n_tab);
+        } else {
+            dst = net.off_pos + (e - n_ln - n_tab - n_act);
+            src = net.go_dx0 + (e - n_ln - n_tab - n_act);
+            base = a.grd;
+            stride = (size_t)net.grd_stride;
+        }
+        float v = 0.f;
+        for (int b = b_lo; b < b_hi; ++b) v += base[(size_t)b * stride + src];
+        out[dst] = v;
+    }
+}
+
+__global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a) {
     const Thr t = make_thr();
     const DtqnNet& net = a.net;
     const int LP = net.lp;
+    if ((int)blockIdx.x >= net.n_wtiles) {
+        small_partials_block(a, (int)blockIdx.x - net.n_wtiles, (int)blockIdx.y);
+        return;
+    }
     // locate the job of this block
     const int tile = (int)blockIdx.x, split = (int)blockIdx.y;
     int j = 0;
-    while (j + 1 < a.n_jobs && a.jobs[j + 1].tile0 <= tile) ++j;
-    const DtqnWJob job = a.jobs[j];
+    for (int k = 1; k < a.n_jobs; ++k)
+        if (a.jobs[k].tile0 <= tile) j = k;
+    const DtqnWJob& job = a.jobs[j];
     const int local = tile - job.tile0;
     const int bn = local / job.tiles_k, bk = local - bn * job.tiles_k;
     const int nbase = bn * 64, kbase = bk * 64;
@@ -50,13 +96,24 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_wgrad_kernel(WgradArgs a) {
 
     const int b_lo = (int)((long long)a.batch * split / a.n_split);
     const int b_hi = (int)((long long)a.batch * (split + 1) / a.n_split);
-    for (int b = b_lo + t.wave; b < b_hi; b += DTQN_WAVES) {
+    // work unit = (sequence of this split, quarter of its LP/4 token steps); units are dealt to the 4 waves,
+    // so even a one-sequence split keeps every wave busy
+    constexpr int NSUB = 4;
+    const int steps_per_sub = (LP / 4 + NSUB - 1) / NSUB;
+    const int units = (b_hi - b_lo) * NSUB;
+    for (int u = t.wave; u < units; u += DTQN_WAVES) {
+        const int b = b_lo + u / NSUB, sub = u - (u / NSUB) * NSUB;
+        const int s_lo = sub * steps_per_sub, s_hi = min(LP / 4, s_lo + steps_per_sub);
         const float* yp = ybase + (size_t)b * ystride + (size_t)t.kq * job.ldy + ycol;
         const float* xp = xbase + (size_t)b * xstride + (size_t)t.kq * job.ldx + xcol;
-#pragma unroll 4
-        for (int s = 0; s < LP / 4; ++s) {
-            const float4 av = yok ? ld4(yp + (size_t)4 * s * job.ldy) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 bv = xok ? ld4(xp + (size_t)4 * s * job.ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // explicit 2-deep pipeline: the operands of step s+1 are in flight while step s multiplies
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 av = (yok && s_lo < s_hi) ? ld4(yp + (size_t)4 * s_lo * job.ldy) : z4;
+        float4 bv = (xok && s_lo < s_hi) ? ld4(xp + (size_t)4 * s_lo * job.ldx) : z4;
+#pragma unroll 2
+        for (int s = s_lo; s < s_hi; ++s) {
+            const float4 an = (yok && s + 1 < s_hi) ? ld4(yp + (size_t)4 * (s + 1) * job.ldy) : z4;
+            const float4 bn = (xok && s + 1 < s_hi) ? ld4(xp + (size_t)4 * (s + 1) * job.ldx) : z4;
             bsum.x += av.x; bsum.y += av.y; bsum.z += av.z; bsum.w += av.w;
             const float aa[4] = {av.x, av.y, av.z, av.w};
             const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -64,57 +121,56 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_wgrad_kernel(WgradArgs a) {
             for (int cn = 0; cn < 4; ++cn)
 #pragma unroll
                 for (int ck = 0; ck < 4; ++ck) acc[cn][ck] = mfma16(aa[cn], bb[ck], acc[cn][ck]);
+            av = an;
+            bv = bn;
         }
     }
-    // bias: sum over the 4 token phases (kq) of this lane's columns
+    // bias: sum over the 4 token phases (kq) of this lane's columns (dY column n = nbase + 4*i + c)
     bsum.x += __shfl_xor(bsum.x, 16); bsum.y += __shfl_xor(bsum.y, 16); bsum.z += __shfl_xor(bsum.z, 16); bsum.w += __shfl_xor(bsum.w, 16);
     bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32); bsum.z += __shfl_xor(bsum.z, 32); bsum.w += __shfl_xor(bsum.w, 32);
 
-    // cross-wave sum through LDS: waves 1..3 publish, wave 0 accumulates and stores
-    float* red = reinterpret_cast<float*>(dtqn_smem);          // [3][64 lanes][68]
-    if (t.wave > 0) {
-        float* rp = red + ((size_t)(t.wave - 1) * 64 + t.lane) * 68;
+    // cross-wave sum through LDS: every wave publishes its 64x64 slab (+ a bias row) in output layout, then all
+    // 256 threads add the four slabs in a fixed order and store coalesced rows (deterministic, few registers)
+    constexpr int SLD = 68;                                    // slab leading dimension (floats)
+    float* slab = reinterpret_cast<float*>(dtqn_smem) + (size_t)t.wave * 65 * SLD;
+    // acc[cn][ck][r]: n = 4*(kq*4 + r) + cn,  k = 4*i + ck
 #pragma unroll
-        for (int cn = 0; cn < 4; ++cn)
+    for (int cn = 0; cn < 4; ++cn)
 #pragma unroll
-            for (int ck = 0; ck < 4; ++ck)
-                st4(rp + (cn * 4 + ck) * 4, make_float4(acc[cn][ck][0], acc[cn][ck][1], acc[cn][ck][2], acc[cn][ck][3]));
-        st4(rp + 64, bsum);
-    }
+        for (int r = 0; r < 4; ++r)
+            st4(slab + (4 * (t.kq * 4 + r) + cn) * SLD + 4 * t.i,
+                make_float4(acc[cn][0][r], acc[cn][1][r], acc[cn][2][r], acc[cn][3][r]));
+    if (t.kq == 0) st4(slab + 64 * SLD + 4 * t.i, bsum);
     __syncthreads();
-    if (t.wave == 0) {
-        for (int w = 0; w < DTQN_WAVES - 1; ++w) {
-            const float* rp = red + ((size_t)w * 64 + t.lane) * 68;
+    const float* s0 = reinterpret_cast<const float*>(dtqn_smem);
+    float* out = a.gsplit + (size_t)split * net.n_trainable;
+    for (int idx = t.tid; idx < 64 * 16; idx += DTQN_THREADS) {
+        const int nl = idx >> 4, k4 = (idx & 15) * 4;
+        const int n = nbase + nl, k = kbase + k4;
+        if (n < job.N && k < job.K) {
+            float4 v = ld4(s0 + nl * SLD + k4);
 #pragma unroll
-            for (int cn = 0; cn < 4; ++cn)
-#pragma unroll
-                for (int ck = 0; ck < 4; ++ck) {
-                    const float4 v = ld4(rp + (cn * 4 + ck) * 4);
-                    acc[cn][ck][0] += v.x; acc[cn][ck][1] += v.y; acc[cn][ck][2] += v.z; acc[cn][ck][3] += v.w;
-                }
-            const float4 bvv = ld4(rp + 64);
-            bsum.x += bvv.x; bsum.y += bvv.y; bsum.z += bvv.z; bsum.w += bvv.w;
-        }
-        float* out = a.gsplit + (size_t)split * net.n_trainable;
-        // acc[cn][ck][r]: n = nbase + 4*(kq*4 + r) + cn,  k = kbase + 4*i + ck
-#pragma unroll
-        for (int cn = 0; cn < 4; ++cn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = nbase + 4 * (t.kq * 4 + r) + cn;
-                if (n < job.N) {
-#pragma unroll
-                    for (int ck = 0; ck < 4; ++ck) {
-                        const int k = kbase + 4 * t.i + ck;
-                        if (k < job.K) out[job.w_off + (size_t)n * job.K + k] = acc[cn][ck][r];
-                    }
-                }
+            for (int wv = 1; wv < DTQN_WAVES; ++wv) {
+                const float4 x = ld4(s0 + (size_t)wv * 65 * SLD + nl * SLD + k4);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
-        if (job.b_off >= 0 && bk == 0 && t.kq == 0) {
-            const float bb[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+            float* op = out + job.w_off + (size_t)n * job.K + k;
+            if (k + 3 < job.K && (job.K & 3) == 0) {
+                st4(op, v);
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int c = 0; c < 4; ++c)
+                    if (k + c < job.K) op[c] = vv[c];
+            }
+        }
+    }
+    if (job.b_off >= 0 && bk == 0 && t.tid < 64) {
+        const int n = nbase + t.tid;
+        if (n < job.N) {
+            float v = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (ycol + c < job.N) out[job.b_off + ycol + c] = bb[c];
+            for (int wv = 0; wv < DTQN_WAVES; ++wv) v += s0[(size_t)wv * 65 * SLD + 64 * SLD + t.tid];
+            out[job.b_off + n] = v;
         }
     }
 }
@@ -124,15 +180,20 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_wgrad_kernel(WgradArgs a) {
 using namespace dtqn;
 
 extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream) {
-    if (!net || !td || td->batch < 1 || td->n_split < 1 || !td->wjobs) return DTQN_ERR_ARG;
+    if (!net || !td || td->batch < 1 || td->n_split < 1) return DTQN_ERR_ARG;
+    if (net->n_wjobs > kMaxWJobs) return DTQN_ERR_CONFIG;
     WgradArgs a;
     a.net = *net;
-    a.jobs = td->wjobs;
-    a.act = td->act; a.grd = td->grd; a.gsplit = td->gsplit;
+    if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
+    a.act = td->act; a.grd = td->grd; a.gsplit = td->gsplit; a.small = td->small;
     a.batch = td->batch; a.n_split = td->n_split; a.n_jobs = net->n_wjobs;
-    const size_t lds = (size_t)3 * 64 * 68 * sizeof(float);
+    a.n_small = net->num_layers * 4 * net->d_model + (net->discrete ? net->vocab * net->embed_per_obs : 0) +
+                (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
+                (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);
+    const int small_blocks = (a.n_small + 1023) / 1024;
+    const size_t lds = (size_t)DTQN_WAVES * 65 * 68 * sizeof(float);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(net->n_wtiles, td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(net->n_wtiles + small_blocks, td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }

@@ -85,8 +85,8 @@ class TdEngine:
         self.adam_m = torch.zeros(nt, **f32)
         self.adam_v = torch.zeros(nt, **f32)
         Bn = self.batch
-        if n_split is None:   # enough workgroups to fill 256 CUs, at least 2 sequences per wave-split
-            n_split = max(1, min(Bn // 4 if Bn >= 8 else 1, max(1, 1024 // max(1, net.n_wtiles)), 32))
+        if n_split is None:   # enough workgroups to fill 256 CUs; the 4 waves of a block split sequences x token quarters
+            n_split = max(1, min(Bn, 16))
         self.n_split = int(n_split)
         self.n_norm_blocks = (nt + OPT_BLOCK_ELEMS - 1) // OPT_BLOCK_ELEMS
         self.act = torch.zeros(Bn * net.act_stride, **f32)

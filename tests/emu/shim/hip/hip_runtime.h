@@ -168,6 +168,8 @@ static inline float hipemu_frcp(float x) { return 1.0f / x; }
 #define __frcp_rn hipemu_frcp
 using std::fmaxf;
 using std::fminf;
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 using std::isfinite;
 
 static inline long long wall_clock64() { return 0; }
