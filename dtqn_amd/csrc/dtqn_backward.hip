@@ -7,6 +7,7 @@
 // per-sequence `grd` record; dtqn_wgrad.hip contracts those against the saved activations over all
 // B*L tokens, so no per-sequence weight-gradient partials exist.
 #include "dtqn_device.hpp"
+#include "dtqn_gru.hpp"
 
 namespace dtqn {
 
@@ -207,7 +208,7 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
     }
 }
 
-template <int D, int MT, int HD, int NW>
+template <int D, int MT, int HD, int NW, bool GRU>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     const int b = (int)blockIdx.x;
     const int L = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
     const bool ident = net.identity != 0;
+    constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     const float* __restrict__ theta = a.theta;
     const float* rec = a.act + (size_t)b * net.act_stride;
     float* grec = a.grd + (size_t)b * net.grd_stride;
@@ -335,12 +337,18 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
         tr.load(lrec + net.al_s1, D, t);               // needed after the FFN: in flight during it
-        // mlp gate (res): s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0]; the skip path keeps DX
+        // mlp gate.  res: s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0], the skip path keeps DX.
+        // gru: DX <- dL/dx (skip path), T2 <- dL/dy, then the same ReLU mask.
+        if (gru) {
+            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_mlp, net, lrec + net.al_gate2, lgrd + net.gl_gate2, t);
+            __syncthreads();
+        }
         {
             const float* m2 = lrec + net.al_m2;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                T2[r * LDX + c] = mask_bit(m2, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
+                const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
+                T2[r * LDX + c] = mask_bit(m2, D / 16, r, c) ? dy : 0.f;
             }
         }
         __syncthreads();
@@ -418,12 +426,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
-        // attention gate (res): s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]
+        // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
+        if (gru) {
+            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_attn, net, lrec + net.al_gate1, lgrd + net.gl_gate1, t);
+            __syncthreads();
+        }
         {
             const float* m1 = lrec + net.al_m1;
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
-                T2[r * LDX + c] = mask_bit(m1, D / 16, r, c) ? DX[r * LDX + c] : 0.f;
+                const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
+                T2[r * LDX + c] = mask_bit(m1, D / 16, r, c) ? dy : 0.f;
             }
         }
         // attention backward, one head group (GW columns) at a time; du1 = dqkv W_in accumulates in registers
@@ -592,14 +605,22 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW>
-static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
+template <int D, int MT, int HD, int NW, bool GRU>
+static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW>), dim3(a.batch), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU>), dim3(a.batch), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+template <int D, int MT, int HD, int NW>
+static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
+    if (a.net.gate == DTQN_GATE_GRU) {
+        if constexpr (D <= 64) return launch_bwd2<D, MT, HD, NW, true>(a, stream);
+        else return DTQN_ERR_CONFIG;
+    }
+    return launch_bwd2<D, MT, HD, NW, false>(a, stream);
 }
 
 }  // namespace dtqn
@@ -615,7 +636,6 @@ extern "C" int dtqn_lds_bytes_backward(const DtqnNet* net) {
 extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (td->history < 1 || td->history > net->ctx_len) return DTQN_ERR_ARG;
-    if (net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
     if (bwd_lds_bytes(net) > 160 * 1024) return DTQN_ERR_CONFIG;
     BwdArgs a;
     a.net = *net;

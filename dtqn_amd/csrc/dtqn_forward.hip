@@ -7,6 +7,7 @@
 // ReplayBuffer.sample (replay_buffer.py:160-167): the workgroup reads its (episode, start) window
 // straight out of the device-resident replay arrays.
 #include "dtqn_device.hpp"
+#include "dtqn_gru.hpp"
 
 namespace dtqn {
 
@@ -32,7 +33,7 @@ struct FwdArgs {
 __device__ __forceinline__ int lds_ldx(int D) { return D + 4; }
 __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 
-template <int D, int MT, int HD, int NW>
+template <int D, int MT, int HD, int NW, bool GRU>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     constexpr int NT = NW * 64;                    // threads per workgroup
     constexpr int LP = MT * 16;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int n = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const bool ident = net.identity != 0;
+    constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     float* rec = (a.act != nullptr && which == 0) ? a.act + (size_t)b * net.act_stride : nullptr;
 
     float* Xs = reinterpret_cast<float*>(dtqn_smem);   // residual stream            [LP][LDX]
@@ -154,8 +156,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             g_out.run(Ws, LDW, t, [&](int r, int c, float v) {
                 const float y = fmaxf(v + bo[c], 0.f);
                 if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
-                Xs[r * LDX + c] += y;
+                if (gru) Ws[r * LDW + D + c] = y;          // y tile for the GRU gate (k columns are free now)
+                else Xs[r * LDX + c] += y;                 // ResGate: x + y  (gates.py:40-41)
             });
+        }
+        if (gru) {                                         // x <- GRUGate(x, y)  (gates.py:26-31)
+            __syncthreads();
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_attn, net, lrec ? lrec + net.al_gate1 : nullptr, t);
         }
         const float* __restrict__ W1 = th + net.lo_f1_w;
         const float* __restrict__ b1 = th + net.lo_f1_b;
@@ -222,10 +229,15 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
                             const float y = fmaxf(facc[q][m][r4] + b2[c], 0.f);
                             if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
-                            Xs[r * LDX + c] += y;
+                            if (gru) Ws[r * LDW + D + c] = y;
+                            else Xs[r * LDX + c] += y;
                         }
                 }
             }
+        }
+        if (gru) {
+            __syncthreads();
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_mlp, net, lrec ? lrec + net.al_gate2 : nullptr, t);
         }
         DTQN_PROF(a.prof, ps++);   // FFN done
         __syncthreads();
@@ -278,14 +290,22 @@ static size_t fwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW>
-static int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
+template <int D, int MT, int HD, int NW, bool GRU>
+static int launch_fwd2(const FwdArgs& a, int nblocks, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+template <int D, int MT, int HD, int NW>
+static int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
+    if (a.net.gate == DTQN_GATE_GRU) {
+        if constexpr (D <= 64) return launch_fwd2<D, MT, HD, NW, true>(a, nblocks, stream);
+        else return DTQN_ERR_CONFIG;
+    }
+    return launch_fwd2<D, MT, HD, NW, false>(a, nblocks, stream);
 }
 
 static int dispatch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
@@ -321,7 +341,6 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
-    if (net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
     FwdArgs a;
     a.net = *net;
     a.theta_a = theta; a.theta_b = theta;
@@ -342,7 +361,6 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (rp->obs_dim != net->obs_dim || rp->max_steps < net->ctx_len) return DTQN_ERR_ARG;
-    if (net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
     FwdArgs a;
     a.net = *net;
     a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;

@@ -112,8 +112,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         net->al_m2 = lc.take((LP / 16) * (D / 16) * 4 * 2);
         net->al_s2 = lc.take(LP * D);
         net->al_st2 = lc.take(LP * 2);
-        net->al_gate1 = gru ? lc.take(4 * LP * D) : -1;
-        net->al_gate2 = gru ? lc.take(4 * LP * D) : -1;
+        net->al_gate1 = gru ? lc.take(6 * LP * D) : -1;
+        net->al_gate2 = gru ? lc.take(6 * LP * D) : -1;
         net->act_layer_stride = lc.pos;
     }
     net->ao_layer0 = ac.take(net->act_layer_stride * NL);
@@ -160,8 +160,9 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         count(D, 4 * D);
     }
     if (gru) {
-        // shared gate weights see the tokens of every layer: one job per (layer, gate, matrix)
-        for (int l = 0; l < NL; ++l) for (int g = 0; g < 2; ++g) for (int m = 0; m < 6; ++m) count(D, D);
+        // shared gate weights see the tokens of every layer: one job per (gate, matrix), looping over layers
+        for (int g = 0; g < 2; ++g) for (int m = 0; m < 6; ++m) count(D, D);
+        if (D > 64) return DTQN_ERR_CONFIG;      // the GRU backward keeps five [LP][D] tiles in LDS (DESIGN.md coverage)
     }
     count(D, D);
     count(A, D);
@@ -183,6 +184,8 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
         w.tile0 = tile;
         w.tiles_n = (N + 63) / 64;
         w.tiles_k = (K + 63) / 64;
+        w.n_layers = 1;
+        w.x_lstride = w.dy_lstride = 0;
         tile += w.tiles_n * w.tiles_k;
     };
     // embedding linear: dY = dx0[:, a:], X = e_in
@@ -197,27 +200,24 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
         add(1, ab + net->al_h, 4 * D, 4 * D, gb + net->gl_df, D, D, tb + net->lo_f2_w, tb + net->lo_f2_b);
     }
     if (net->gate == DTQN_GATE_GRU) {
+        // gate record: z, r, h~, r*x, x, y ; gradient record: dz_pre, dr_pre, dh_pre  (each [LP][D])
         const int LPD = net->lp * D;
-        for (int l = 0; l < NL; ++l) {
-            const int ab = net->ao_layer0 + l * net->act_layer_stride;
-            const int gb = net->go_layer0 + l * net->grd_layer_stride;
-            for (int g = 0; g < 2; ++g) {
-                const int gate_w = g == 0 ? net->off_gate_attn : net->off_gate_mlp;
-                const int ga = ab + (g == 0 ? net->al_gate1 : net->al_gate2);   // z, r, h~, r*x
-                const int gg = gb + (g == 0 ? net->gl_gate1 : net->gl_gate2);   // dz_pre, dr_pre, dh_pre
-                // y = relu(sub-layer out), x = stream before the gate
-                const int y_off = ab + (g == 0 ? net->al_m1 : net->al_m2);   // TODO(gru): needs the y values, not the masks
-                // stream before the attention gate: post-LN -> u1 (layer input); identity -> layer input stream.
-                // stream before the mlp gate: post-LN -> u2 (= LN1 output); identity -> s1.
-                int x_off;
-                if (g == 0) x_off = net->identity ? (l == 0 ? net->ao_x0 : net->ao_layer0 + (l - 1) * net->act_layer_stride + net->al_s2) : ab + net->al_u1;
-                else x_off = net->identity ? ab + net->al_s1 : ab + net->al_u2;
-                add(1, y_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_w_r, -1);
-                add(1, x_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_u_r, -1);
-                add(1, y_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_w_z, gate_w + net->go_b_z);
-                add(1, x_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_u_z, -1);
-                add(1, y_off, D, D, gg + 2 * LPD, D, D, gate_w + net->go_w_g, -1);
-                add(1, ga + 3 * LPD, D, D, gg + 2 * LPD, D, D, gate_w + net->go_u_g, -1);
+        for (int g = 0; g < 2; ++g) {
+            const int gate_w = g == 0 ? net->off_gate_attn : net->off_gate_mlp;
+            const int ga = net->ao_layer0 + (g == 0 ? net->al_gate1 : net->al_gate2);
+            const int gg = net->go_layer0 + (g == 0 ? net->gl_gate1 : net->gl_gate2);
+            const int x_off = ga + 4 * LPD, y_off = ga + 5 * LPD, rx_off = ga + 3 * LPD;
+            const int first = j;
+            add(1, y_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_w_r, -1);
+            add(1, x_off, D, D, gg + 1 * LPD, D, D, gate_w + net->go_u_r, -1);
+            add(1, y_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_w_z, gate_w + net->go_b_z);
+            add(1, x_off, D, D, gg + 0 * LPD, D, D, gate_w + net->go_u_z, -1);
+            add(1, y_off, D, D, gg + 2 * LPD, D, D, gate_w + net->go_w_g, -1);
+            add(1, rx_off, D, D, gg + 2 * LPD, D, D, gate_w + net->go_u_g, -1);
+            for (int q = first; q < j; ++q) {
+                jobs[q].n_layers = NL;
+                jobs[q].x_lstride = net->act_layer_stride;
+                jobs[q].dy_lstride = net->grd_layer_stride;
             }
         }
     }

@@ -12,7 +12,7 @@
 
 namespace dtqn {
 
-constexpr int kMaxWJobs = 64;          // (1 + 4*NL + 24*NL(gru) + 2) <= 64 for the covered nets; kernarg stays < 4 KB
+constexpr int kMaxWJobs = 48;          // 1 + 4*NL + 12 (gru) + 2 <= 47 for NL <= 8; the kernarg block stays under 4 KB
 struct WgradArgs {
     DtqnNet net;
     DtqnWJob jobs[kMaxWJobs];           // by value: the job lookup is a scalar-cache walk, not L2 round trips
@@ -100,12 +100,13 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     // so even a one-sequence split keeps every wave busy
     constexpr int NSUB = 4;
     const int steps_per_sub = (LP / 4 + NSUB - 1) / NSUB;
-    const int units = (b_hi - b_lo) * NSUB;
+    const int units = (b_hi - b_lo) * NSUB * job.n_layers;
     for (int u = t.wave; u < units; u += DTQN_WAVES) {
-        const int b = b_lo + u / NSUB, sub = u - (u / NSUB) * NSUB;
+        const int lyr = u / ((b_hi - b_lo) * NSUB), ul = u - lyr * (b_hi - b_lo) * NSUB;
+        const int b = b_lo + ul / NSUB, sub = ul - (ul / NSUB) * NSUB;
         const int s_lo = sub * steps_per_sub, s_hi = min(LP / 4, s_lo + steps_per_sub);
-        const float* yp = ybase + (size_t)b * ystride + (size_t)t.kq * job.ldy + ycol;
-        const float* xp = xbase + (size_t)b * xstride + (size_t)t.kq * job.ldx + xcol;
+        const float* yp = ybase + (size_t)b * ystride + (size_t)lyr * job.dy_lstride + (size_t)t.kq * job.ldy + ycol;
+        const float* xp = xbase + (size_t)b * xstride + (size_t)lyr * job.x_lstride + (size_t)t.kq * job.ldx + xcol;
         // explicit 2-deep pipeline: the operands of step s+1 are in flight while step s multiplies
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 av = (yok && s_lo < s_hi) ? ld4(yp + (size_t)4 * s_lo * job.ldy) : z4;

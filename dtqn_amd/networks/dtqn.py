@@ -59,8 +59,6 @@ class DTQN(nn.Module):
                               action_dim=action_dim, inner_embed_size=inner_embed_size, num_heads=num_heads,
                               num_layers=num_layers, history_len=history_len, gate=gate, identity=identity, pos=pos,
                               discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0)
-        if gate != "res":
-            raise NotImplementedError("gate='gru' is not yet covered by the gfx950 kernels (DESIGN.md coverage)")
         net = self.net
         flat = np.zeros(net.n_theta, dtype=np.float32)
         self._lib.dtqn_net_fill_frozen(ctypes.byref(net), flat.ctypes.data_as(ctypes.c_void_p))

@@ -92,7 +92,7 @@ typedef struct DtqnNet {
     int32_t al_u1, al_qkv, al_lse, al_o, al_m1, al_s1, al_st1, al_u2, al_h, al_mh, al_m2, al_s2, al_st2;
     /* al_m1 / al_mh / al_m2: ReLU activation patterns as wave ballots, one 64-bit word per
      * (16-row tile, 16-column tile, r): bit (kq*16 + i) <-> row tile*16 + kq*4 + r, column ctile*16 + i */
-    int32_t al_gate1, al_gate2;   /* GRU: z, r, h~, r*x, each [LP][D] */
+    int32_t al_gate1, al_gate2;   /* GRU gate records (attention / mlp gate): z, r, h~, r*x, x, y, each [LP][D] */
     /* ---- derived: per-sequence gradient record written by the backward-data kernel ---- */
     int32_t grd_stride;
     int32_t go_dx0, go_layer0, grd_layer_stride, go_dhh, go_dq;
@@ -116,6 +116,9 @@ typedef struct DtqnWJob {
     int32_t b_off;           /* offset of db, or -1 */
     int32_t tile0;           /* first global 64x64 block index of this job */
     int32_t tiles_n, tiles_k;
+    int32_t n_layers;        /* > 1: the weights are shared by every layer (GRU gates); operands of layer l are  */
+    int32_t x_lstride;       /*      at x_off + l * x_lstride / dy_off + l * dy_lstride and the products are      */
+    int32_t dy_lstride;      /*      summed over l                                                               */
 } DtqnWJob;
 
 /* Fills every derived field of `net` from its inputs.  Returns DTQN_ERR_CONFIG when the variant

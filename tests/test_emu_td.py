@@ -22,6 +22,9 @@ CASES = [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, identity=True, pos="sin"), dict(batch=4, T=12, mask=-5, tuf=3)),
     (dict(obs_dim=1, num_actions=5, inner_embed_size=32, num_heads=4, history_len=30, discrete=True, vocab_sizes=22, action_dim=8, pos="none", identity=True),
      dict(batch=2, T=40, mask=21)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, gate="gru"), dict(batch=4, T=12, mask=-5, tuf=2)),
+    (dict(obs_dim=10, num_actions=5, inner_embed_size=32, num_heads=4, history_len=20, discrete=True, vocab_sizes=9, gate="gru", identity=True, action_dim=4, pos="sin"),
+     dict(batch=3, T=30, mask=8)),
 ]
 
 

@@ -42,13 +42,13 @@ def hip_forward(lib, cfg, params, obs, act):
 
 def test_golden_G4_actor_variable_length(lib):
     z = np.load(os.path.join(GOLDEN, "G4_actor_varlen.npz"))
-    tag = "res"
-    cfg = O.NetCfg(**json.loads(str(z[f"{tag}/cfg"])))
-    params = O.init_params(cfg, seed=41, perturb=True)
-    for n in (1, 2, 17, 50):
-        got = hip_forward(lib, cfg, params, z[f"{tag}/n{n}_obs"], z[f"{tag}/n{n}_act"])
-        ref = z[f"{tag}/n{n}_q"]
-        assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), n
+    for tag in ("res", "gru_a8_sin"):          # residual gate; GRU gate + action embedding + sinusoidal encodings
+        cfg = O.NetCfg(**json.loads(str(z[f"{tag}/cfg"])))
+        params = O.init_params(cfg, seed=41, perturb=True)
+        for n in (1, 2, 17, 50):
+            got = hip_forward(lib, cfg, params, z[f"{tag}/n{n}_obs"], z[f"{tag}/n{n}_act"])
+            ref = z[f"{tag}/n{n}_q"]
+            assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), (tag, n)
 
 
 def test_golden_G1_q_values(lib):
@@ -73,6 +73,7 @@ VARIANTS = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, identity=True, pos="sin"),
     dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=4, history_len=64, discrete=True, vocab_sizes=22,
          action_dim=8, pos="none"),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, gate="gru", action_dim=8, pos="sin"),
 ]
 
 

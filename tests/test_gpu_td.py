@@ -29,6 +29,10 @@ CASES = [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, identity=True, pos="sin", action_dim=8), dict(batch=16, T=200, mask=-5, n_eps=30, tuf=2)),
     (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9), dict(batch=8, T=50, mask=8, n_eps=20)),
     (dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=4, history_len=64, discrete=True, vocab_sizes=22, pos="none"), dict(batch=6, T=70, mask=21, n_eps=12)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, gate="gru"), dict(batch=16, T=200, mask=-5, n_eps=30, tuf=2)),
+    (dict(obs_dim=10, num_actions=10, inner_embed_size=64, num_heads=8, history_len=50, discrete=True, vocab_sizes=9, gate="gru", identity=True, action_dim=8, pos="sin"),
+     dict(batch=8, T=50, mask=8, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, gate="gru"), dict(batch=4, T=12, mask=-5)),
 ]
 
 
