@@ -140,11 +140,15 @@ def env_step_rate(agent, seconds: float = 3.0) -> dict:
     set_global_seed(1, env)
     eps = Constant(0.1)
     out = {}
-    for mode in ("actor_only", "coupled_1to1"):
+    for mode in ("actor_only", "coupled_1to1", "coupled_1to1_overlapped"):
         agent.context_reset(env.reset())
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            if runpy.step(agent, env, eps):
+            if mode == "coupled_1to1_overlapped":
+                done = runpy.step_overlapped(agent, env, eps)      # actor forward || TD update on two streams
+            else:
+                done = runpy.step(agent, env, eps)
+            if done:
                 agent.replay_buffer.flush()
                 agent.context_reset(env.reset())
             if mode == "coupled_1to1":
@@ -232,8 +236,11 @@ def main():
         if world == 1:
             rates = env_step_rate(agent)
             line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
-                                         "note": "single host env, batch-1 actor forward on the GPU per step; "
-                                                 "in the coupled loop env-steps/s == TD-updates/s as in the reference"}
+                                         "coupled_overlapped_two_streams": rates["coupled_1to1_overlapped"],
+                                         "note": "single host env (CarFlag on the host cores), batch-1 actor forward on the GPU per "
+                                                 "step; in the coupled loops env-steps/s == TD-updates/s as in the reference "
+                                                 "(1 update per env step); 'overlapped' runs the actor forward of step t+1 "
+                                                 "concurrently with update t+1 (run.py --overlap)"}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(c, args.batch)
         print(json.dumps(line), flush=True)

@@ -116,6 +116,13 @@ class DtqnAgent:
         self._ctx_act_d = torch.zeros(L, dtype=torch.uint8, device=self.device)
         self._q_d = torch.zeros(L, A, device=self.device)
         self._q_h = pin(torch.zeros(A))
+        # pipelined mode (begin_action / train / finish_action): the actor forward of step t+1 runs on its own
+        # stream CONCURRENTLY with TD update t+1; it reads the weights produced by update t, and update t+1's
+        # optimizer kernel waits for it (write-after-read on theta)
+        self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
+        self._ev_update_done = torch.cuda.Event() if cuda else None
+        self._ev_actor_done = torch.cuda.Event() if cuda else None
+        self._actor_inflight = False
 
     # ---- mode / context (dqn.py:102-115) -------------------------------------------------------
     @property
@@ -131,12 +138,10 @@ class DtqnAgent:
         self.policy_network.train()
 
     # ---- actor (dtqn.py:76-160) -----------------------------------------------------------------
-    @torch.no_grad()
-    def get_action(self, epsilon: float = 0.0) -> int:
-        if RNG.rng.random() < epsilon:
-            return RNG.rng.integers(self.num_actions)
+    def _launch_actor_forward(self, stream_ptr) -> int:
+        """Stage the unpadded prefix of the rolling context and launch the batch-1 forward; returns n."""
         ctx = self.context
-        n = min(ctx.max_length, ctx.timestep + 1)                       # unpadded prefix of the window
+        n = min(ctx.max_length, ctx.timestep + 1)
         self._ctx_obs_h[:n] = torch.from_numpy(np.asarray(ctx.obs[:n], dtype=np.float32))
         self._ctx_act_h[:n] = torch.from_numpy(np.asarray(ctx.action[:n, 0], dtype=np.uint8))
         self._ctx_obs_d[:n].copy_(self._ctx_obs_h[:n], non_blocking=True)
@@ -144,13 +149,46 @@ class DtqnAgent:
         eng = self.engine
         rc = eng.lib.dtqn_forward(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
                                   ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
-                                  1, n, ctypes.c_void_p(self._q_d.data_ptr()), eng._stream())
+                                  1, n, ctypes.c_void_p(self._q_d.data_ptr()), stream_ptr)
         if rc != 0:
             raise RuntimeError(f"dtqn_forward failed with DTQN status {rc}")
-        self._q_h.copy_(self._q_d[n - 1], non_blocking=True)
+        self._q_h.copy_(self._q_d[n - 1], non_blocking=True)         # Q of the LAST timestep
+        return n
+
+    @torch.no_grad()
+    def get_action(self, epsilon: float = 0.0) -> int:
+        if RNG.rng.random() < epsilon:
+            return RNG.rng.integers(self.num_actions)
+        self._launch_actor_forward(self.engine._stream())
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
-        return int(np.argmax(self._q_h.numpy()))                         # Q of the LAST timestep, first max
+        return int(np.argmax(self._q_h.numpy()))                         # first max, like torch.argmax
+
+    # ---- pipelined actor (same action semantics: the policy after the previous update) ----------------
+    @torch.no_grad()
+    def begin_action(self, epsilon: float = 0.0):
+        """Start choosing the action for the current context without blocking.  The forward is queued on the
+        actor stream behind the last TD update; call train() next (it overlaps), then finish_action()."""
+        if RNG.rng.random() < epsilon:
+            return int(RNG.rng.integers(self.num_actions))
+        if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
+            return self._sync_forward_action()
+        self._actor_stream.wait_event(self._ev_update_done)
+        with torch.cuda.stream(self._actor_stream):
+            self._launch_actor_forward(ctypes.c_void_p(self._actor_stream.cuda_stream))
+            self._ev_actor_done.record(self._actor_stream)
+        self._actor_inflight = True
+        return None
+
+    def _sync_forward_action(self) -> int:
+        self._launch_actor_forward(self.engine._stream())
+        return int(np.argmax(self._q_h.numpy()))
+
+    def finish_action(self, pending) -> int:
+        if pending is not None:
+            return pending
+        self._actor_stream.synchronize()
+        return int(np.argmax(self._q_h.numpy()))
 
     def context_reset(self, obs: np.ndarray) -> None:
         self.context.reset(obs)
@@ -175,10 +213,22 @@ class DtqnAgent:
         else:
             n_valid, exclude = rb.valid_range()
             eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed)
-        if self.dp is None:
+        if self._actor_inflight:
+            # the gradient kernels overlap the actor forward; only the optimizer kernel (which overwrites theta)
+            # has to wait for it
+            eng.forward_backward(rb.dev)
+            if self.dp is not None:
+                self.dp.allreduce_gradient()
+                eng.recompute_gradnorm()
+            torch.cuda.current_stream(self.device).wait_event(self._ev_actor_done)
+            eng.clip_adam()
+            self._actor_inflight = False
+        elif self.dp is None:
             eng.update(rb.dev)
         else:
             self.dp.update(rb.dev)
+        if self._ev_update_done is not None:
+            self._ev_update_done.record(torch.cuda.current_stream(self.device))
         self._enqueue_stats()
         self.num_train_steps += 1
         # hard target sync happens on the device every target_update_frequency optimizer steps

@@ -67,6 +67,9 @@ def get_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("--sampler", default="reference", choices=["reference", "device"])
     p.add_argument("--ref-quirks", action="store_true", help="reproduce the reference's int-truncated actor context")
     p.add_argument("--prepopulate", type=int, default=50_000, help="random steps before training (reference: 50 000)")
+    p.add_argument("--overlap", action="store_true",
+                   help="pipeline the actor forward of step t+1 with TD update t+1 on two HIP streams (same policy-vs-action "
+                        "semantics; an episode that ends at step t becomes sampleable one update later)")
     return p.parse_args(argv)
 
 
@@ -100,6 +103,16 @@ def step(agent, env, eps) -> bool:
     return done
 
 
+def step_overlapped(agent, env, eps) -> bool:
+    """step() + train() with the actor forward and the TD update running concurrently on the GPU."""
+    pending = agent.begin_action(epsilon=eps.val)      # actor stream, behind the previous update
+    agent.train()                                      # learner stream; its optimizer kernel waits for the actor
+    action = agent.finish_action(pending)
+    obs, reward, done, info = env.step(action)
+    agent.observe(obs, action, reward, False if info.get("TimeLimit.truncated", False) else done)
+    return done
+
+
 def prepopulate(agent, prepop_steps: int, envs) -> None:
     """Fill the replay buffer with uniformly random behaviour (run.py:380-405)."""
     t = 0
@@ -116,18 +129,25 @@ def prepopulate(agent, prepop_steps: int, envs) -> None:
 
 
 def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, eval_episodes, policy_path, save_policy,
-          logger, mean_success_rate, mean_episode_length, mean_reward, time_remaining, verbose=False, is_main=True):
+          logger, mean_success_rate, mean_episode_length, mean_reward, time_remaining, verbose=False, is_main=True,
+          overlap=False):
     """Main loop: one env step, one TD update (run.py:246-353)."""
     start = time()
     agent.eval_off()
     env = RNG.rng.choice(envs)
     agent.context_reset(env.reset())
     for timestep in range(agent.num_train_steps, total_steps):
-        if step(agent, env, eps):
-            agent.replay_buffer.flush()
-            env = RNG.rng.choice(envs)
-            agent.context_reset(env.reset())
-        agent.train()
+        if overlap:
+            if step_overlapped(agent, env, eps):       # includes this step's train()
+                agent.replay_buffer.flush()
+                env = RNG.rng.choice(envs)
+                agent.context_reset(env.reset())
+        else:
+            if step(agent, env, eps):
+                agent.replay_buffer.flush()
+                env = RNG.rng.choice(envs)
+                agent.context_reset(env.reset())
+            agent.train()
         eps.anneal()
         if timestep % eval_frequency == 0 and is_main:
             hours = (time() - start) / 3600
@@ -194,7 +214,8 @@ def run_experiment(args):
     logger = get_logger(policy_path, args, wandb_kwargs) if is_main else None
     time_remaining = args.time_limit * 3600 - (time() - start) if args.time_limit else None
     train(agent, envs, eval_envs, args.envs, args.num_steps, eps, args.eval_frequency, args.eval_episodes, policy_path,
-          args.save_policy, logger, mean_success_rate, mean_reward, mean_episode_length, time_remaining, args.verbose, is_main)
+          args.save_policy, logger, mean_success_rate, mean_reward, mean_episode_length, time_remaining, args.verbose, is_main,
+          overlap=args.overlap)
     if is_main:
         agent.save_mini_checkpoint(checkpoint_dir=policy_path, wandb_id=None)
     return agent
