@@ -125,7 +125,17 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
                                                          const float* delta_s, const float* lse_s, const Thr& t) {
     const int HG = GW / HD;
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int item = t.tid; item < LP * HG; item += NW * 64) {
+    const int nblocks = (LP * HG + 63) / 64;
+    const bool one_round = nblocks <= NW && (64 % HG) == 0;
+    const int nlive = (n * HG + 63) / 64;
+    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
+        int item = it0;
+        if (one_round) {
+            const int blk = balanced_block<NW>(t.wave, nblocks, nlive, false);
+            if (blk < 0) continue;
+            item = blk * 64 + t.lane;
+            if (item >= LP * HG) continue;
+        }
         const int row = item / HG, hl = item - row * HG;
         float* dqp = W5 + row * ld + 4 * GW + hl * HD;
         float dq[HD];
@@ -165,7 +175,14 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
             st4(dqp + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
     }
     __syncthreads();
-    for (int item = t.tid; item < LP * HG; item += NW * 64) {
+    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
+        int item = it0;
+        if (one_round) {
+            const int blk = balanced_block<NW>(t.wave, nblocks, nlive, true);
+            if (blk < 0) continue;
+            item = blk * 64 + t.lane;
+            if (item >= LP * HG) continue;
+        }
         const int srow = item / HG, hl = item - srow * HG;
         float* kp = W5 + srow * ld + GW + hl * HD;
         float* vp = kp + GW;
@@ -216,7 +233,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
     constexpr int NG = D / GW;
     constexpr int NC = 2 * D;                     // FFN hidden columns per pass
-    constexpr int W5C = (5 * GW > NC ? 5 * GW : NC);
+    constexpr bool OST = D <= 64;                 // stage the attention output o in LDS too (sixth W5 tile) when it fits
+    constexpr int W5C = ((OST ? 6 : 5) * GW > NC ? (OST ? 6 : 5) * GW : NC);
     constexpr int LD5 = W5C + 4;
     constexpr int MGX = pick_mg(D / 16, MT, NW);
     using Own = Owned<D, MT, MGX, NW>;          // fixed ownership of a [LP][D] register-accumulated output
@@ -239,11 +257,20 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     float* lse_s = delta_s + (GW / HD) * LP;
     float* red = lse_s + (GW / HD) * LP;               // LN column-sum scratch         [PARTS][2][D]
     constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
-    float* DU = red + PARTS * 2 * D;                   // identity only: branch grad    [LP][LDX]
+    float* st_s = red + PARTS * 2 * D;                 // LayerNorm (mean, rstd) of this layer [2][LP][2]
+    float* DU = st_s + 4 * LP;                         // identity only: branch grad    [LP][LDX]
 
     const int ep = a.ep_idx[b], st0 = a.start[b];
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
+    // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
+    static_assert(HD <= 16, "delta-in-epilogue needs a head inside one 16-column tile");
+    StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_h1;
+    g_h1.prefetch(theta + net.off_head1_w, D, t);
+    TileRegs<NW, LP, D> tr;                                // saved-activation tile in flight
+    TileRegs<NW, LP, D> trh;
+    trh.load(rec + net.ao_hh, D, t);
+    if (!ident) tr.load(rec + net.ao_layer0 + (size_t)(net.num_layers - 1) * net.act_layer_stride + net.al_s2, D, t);
 
     // ---------------- B0: double-DQN target, loss, dL/dQ, statistics (dtqn.py:219-253) ----------------
     {
@@ -257,17 +284,19 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             float sq = 0.f, mnq = INFINITY, mxq = -INFINITY, sy = 0.f, mny = INFINITY, mxy = -INFINITY, se = 0.f;
             for (int r = t.lane; r < LP; r += 64) {
                 if (r < L && r >= L - a.history) {
+                    // one round trip: none of these addresses depends on a loaded value
                     const int at = (int)a.actions[(size_t)ep * a.act_ep_stride + st0 + r];
                     const float rew = a.rewards[(size_t)ep * a.rew_ep_stride + st0 + r];
                     const float dn = a.dones[(size_t)ep * a.rew_ep_stride + st0 + r] ? 1.f : 0.f;
-                    const float q = q0[r * AP + at];
+                    float q = 0.f, best = q1[r * AP], qt = q2[r * AP];
                     int am = 0;
-                    float best = q1[r * AP];
-                    for (int c = 1; c < A; ++c) {          // torch.argmax: first maximal index
-                        const float v = q1[r * AP + c];
-                        if (v > best) { best = v; am = c; }
+                    for (int c = 0; c < A; ++c) {          // torch.argmax: first maximal index
+                        const float v0 = q0[r * AP + c], v1 = q1[r * AP + c], v2 = q2[r * AP + c];
+                        if (c == at) q = v0;
+                        if (c > 0 && v1 > best) { best = v1; am = c; qt = v2; }
                     }
-                    const float y = rew + (1.f - dn) * (q2[r * AP + am] * a.gamma);
+                    (void)am;
+                    const float y = rew + (1.f - dn) * (qt * a.gamma);
                     const float diff = q - y;
                     dq_s[r * AP + at] = 2.f * diff * inv_count;
                     sq += q; mnq = fminf(mnq, q); mxq = fmaxf(mxq, q);
@@ -295,22 +324,27 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     // issued one stage before its use; every global STORE of a gradient tensor is a coalesced copy of
     // the LDS tile, issued at the start of the NEXT stage after the prefetched fragment has been
     // retired, so that no s_waitcnt ever sits behind a freshly issued store.
-    static_assert(HD <= 16, "delta-in-epilogue needs a head inside one 16-column tile");
-    StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_h1;
-    TileRegs<NW, LP, D> tr;                                // saved-activation tile in flight
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
-        const float* hh = rec + net.ao_hh;
-        for (int idx = t.tid; idx < LP * D; idx += NT) {
-            const int r = idx / D, k = idx - r * D;
-            float g = 0.f;
-            if (hh[idx] > 0.f)
-                for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + k], g);
-            T2[r * LDX + k] = g;
+        constexpr int C4 = D / 4;
+#pragma unroll
+        for (int k4 = 0; k4 < TileRegs<NW, LP, D>::N; ++k4) {
+            const int idx4 = t.tid + k4 * NT;
+            if (idx4 < LP * C4) {
+                const int r = idx4 / C4, c0 = (idx4 - r * C4) * 4;
+                const float hv[4] = {trh.v[k4].x, trh.v[k4].y, trh.v[k4].z, trh.v[k4].w};
+                float g4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = 0.f;
+                    if (hv[e] > 0.f)
+                        for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + c0 + e], g);
+                    g4[e] = g;
+                }
+                st4(T2 + r * LDX + c0, make_float4(g4[0], g4[1], g4[2], g4[3]));
+            }
         }
     }
-    g_h1.prefetch(theta + net.off_head1_w, D, t);
-    if (!ident) tr.load(rec + net.ao_layer0 + (size_t)(net.num_layers - 1) * net.act_layer_stride + net.al_s2, D, t);
     __syncthreads();
     g_h1.retire();
     tile_store<NW>(T2, LDX, grec + net.go_dhh, LP, D, t);
@@ -328,11 +362,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         const float* __restrict__ W2 = th + net.lo_f2_w;
         StageDyW<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_dh;      // dh = df W2[:, chunk]
         g_dh.prefetch(W2, 4 * D, t);
+        // (mean, rstd) of both LayerNorms of this layer -> LDS (published by the next barrier)
+        for (int idx = t.tid; idx < 4 * LP; idx += NT)
+            st_s[idx] = idx < 2 * LP ? lrec[net.al_st1 + idx] : lrec[net.al_st2 + idx - 2 * LP];
 
         if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
             __syncthreads();
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
@@ -414,6 +451,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         }
         // LayerNorm in front of / behind the FFN  (T2 is free again: nobody reads df any more)
         tr.to_lds(T2, LDX, t);                         // s1
+        // q | k | v (| o) of head group 0 go in flight now; they land in W5 after the LayerNorm backward
+        TileRegs<NW, LP, GW> tq, tk, tv, to;
+        {
+            const float* qkv0 = lrec + net.al_qkv;
+            tq.load(qkv0, 3 * D, t); tk.load(qkv0 + D, 3 * D, t); tv.load(qkv0 + 2 * D, 3 * D, t);
+            if (OST) to.load(lrec + net.al_o, D, t);
+        }
         const float* __restrict__ Wo = th + net.lo_out_w;
         const float* __restrict__ Win = th + net.lo_in_w;
         StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
@@ -421,9 +465,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
-            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
         else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
-            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st2, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
         // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
@@ -451,12 +495,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             const float* o_g = lrec + net.al_o;
             constexpr int MGO = pick_mg(GW / 16, MT, NW);
             for (int g = 0; g < NG; ++g) {
-                // q, k, v of this head group -> W5[:, 0:3GW]   (W5 is free: the FFN / previous group are behind a barrier)
-                for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
-                    const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
-                    const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
-                    st4(W5 + r * LD5 + which * GW + c, ld4(qkv + (size_t)r * 3 * D + which * D + g * GW + c));
-                }
+                // q, k, v (o) of this head group -> W5   (W5 is free: the FFN / previous group are behind a barrier)
+                tq.to_lds(W5, LD5, t); tk.to_lds(W5 + GW, LD5, t); tv.to_lds(W5 + 2 * GW, LD5, t);
+                if (OST) to.to_lds(W5 + 5 * GW, LD5, t);
                 // log-sum-exp of this group's heads -> LDS
                 for (int idx = t.tid; idx < (GW / HD) * LP; idx += NT) lse_s[idx] = lrec[net.al_lse + g * (GW / HD) * LP + idx];
                 __syncthreads();                   // da (T2) visible
@@ -466,15 +507,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 float ov[MGO][4];
                 g_do.run(T2, LDX, t,
                          [&](int kt, int mg) {
+                             if (!OST) {
 #pragma unroll
-                             for (int m = 0; m < MGO; ++m)
+                                 for (int m = 0; m < MGO; ++m)
 #pragma unroll
-                                 for (int r = 0; r < 4; ++r)
-                                     ov[m][r] = o_g[(size_t)((mg * MGO + m) * 16 + t.kq * 4 + r) * D + g * GW + kt * 16 + t.i];
+                                     for (int r = 0; r < 4; ++r)
+                                         ov[m][r] = o_g[(size_t)((mg * MGO + m) * 16 + t.kq * 4 + r) * D + g * GW + kt * 16 + t.i];
+                             }
                          },
                          [&](int r, int c, float v) {
                              W5[r * LD5 + 3 * GW + c] = v;
-                             float p = v * ov[(r >> 4) % MGO][r & 3];
+                             float p = v * (OST ? W5[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
 #pragma unroll
                              for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
                              if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LP + r] = p;
@@ -513,7 +556,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                         }
                     }
                 }
-                if (g + 1 < NG) g_do.prefetch(Wo + (g + 1) * GW, D, t);
+                if (g + 1 < NG) {
+                    g_do.prefetch(Wo + (g + 1) * GW, D, t);
+                    const float* qkvn = qkv + (g + 1) * GW;
+                    tq.load(qkvn, 3 * D, t); tk.load(qkvn + D, 3 * D, t); tv.load(qkvn + 2 * D, 3 * D, t);
+                    if (OST) to.load(o_g + (g + 1) * GW, D, t);
+                }
                 __syncthreads();
             }
             // next stage's saved activation goes in flight now: s2 of the layer below (post-LN), or the
@@ -544,7 +592,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, lrec + net.al_st1, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
             __syncthreads();
         }
     }
@@ -596,11 +644,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 static size_t bwd_lds_bytes(const DtqnNet* net) {
     const int LP = net->lp, D = net->d_model, HD = net->head_dim;
     const int GW = D >= 64 ? 64 : D, NC = 2 * D;
-    const int W5C = 5 * GW > NC ? 5 * GW : NC;
+    const int ntile = D <= 64 ? 6 : 5;
+    const int W5C = ntile * GW > NC ? ntile * GW : NC;
     const int NT = waves_for(*net) * 64;
     const int PARTS = NT / D >= 1 ? NT / D : 1;
     size_t fl = 2 * (size_t)LP * (D + 4) + (size_t)LP * (W5C + 4) + (size_t)LP * net->ap + 2 * (size_t)(GW / HD) * LP +
-                (size_t)PARTS * 2 * D;
+                (size_t)PARTS * 2 * D + 4 * (size_t)LP;
     if (net->identity) fl += (size_t)LP * (D + 4);
     return fl * sizeof(float);
 }

@@ -460,6 +460,23 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
     }
 }
 
+// Causal attention work is triangular: the 64-item block of query rows [8g, 8g+8) costs ~8(g+1) key steps
+// (the reverse for the key-row pass of the backward).  Waves w and w + NW/2 share a SIMD (waves are dealt to
+// SIMDs cyclically), so block b of the natural order is handed to the wave that pairs the most expensive
+// block with the cheapest one: wave w < NW/2 takes the w-th most expensive block, wave w + NW/2 the w-th
+// cheapest.  Only used when all items fit one round (blocks <= NW); returns the block this wave processes,
+// or -1 for none.  `descending` = cost falls with the block index (key-row pass).
+template <int NW>
+__device__ __forceinline__ int balanced_block(int wave, int nblocks, int nlive, bool descending) {
+    // live blocks 0..nlive-1 carry work (cost rising with index unless `descending`), blocks >= nlive are padding
+    int rank;                                   // 0 = most expensive
+    if (wave < NW / 2) rank = wave;
+    else rank = NW - 1 - (wave - NW / 2);
+    if (rank >= nblocks) return -1;
+    if (rank >= nlive) return rank;             // padding block (still has to zero its outputs)
+    return descending ? rank : nlive - 1 - rank;
+}
+
 // ------------------------------------------------------------------------------------------
 // Causal multi-head self-attention on a [LP][ld] LDS tile laid out [q | k | v] (3*D columns).
 // Work item = (query row t, head h), h fastest across lanes so a wave's 8 heads x 8 rows read
@@ -473,7 +490,17 @@ template <int HD, int NW>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t) {
     const float scale = 1.0f / sqrtf((float)HD);
-    for (int item = t.tid; item < LP * H; item += NW * 64) {
+    const int nblocks = (LP * H + 63) / 64;
+    const bool one_round = nblocks <= NW && (64 % H) == 0;
+    const int nlive = (n * H + 63) / 64;
+    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * H); it0 += NW * 64) {
+        int item = it0;
+        if (one_round) {
+            const int blk = balanced_block<NW>(t.wave, nblocks, nlive, false);
+            if (blk < 0) continue;
+            item = blk * 64 + t.lane;
+            if (item >= LP * H) continue;
+        }
         const int row = item / H, h = item - row * H;
         float* qp = Ws + row * ld + h * HD;
         if (row >= n) {
@@ -489,26 +516,46 @@ __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int 
             q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
             acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.f;
         }
+        // blocked online softmax: KB keys per step give KB independent dot products / exponentials (one
+        // serial chain per key would leave the two waves of a SIMD nothing to overlap) and one rescale per block
+        constexpr int KB = 4;
         float m = -INFINITY, l = 0.f;
         const float* kbase = Ws + D + h * HD;
-        for (int s = 0; s <= row; ++s) {
-            const float* kp = kbase + s * ld;
-            const float* vp = kp + D;
-            float sc = 0.f;
+        for (int s0 = 0; s0 <= row; s0 += KB) {
+            float sc[KB];
 #pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const float4 k = ld4(kp + c);
-                sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
+            for (int j = 0; j < KB; ++j) {
+                const int s = s0 + j <= row ? s0 + j : row;            // clamp: the duplicate is masked below
+                const float* kp = kbase + s * ld;
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < HD; c += 4) {
+                    const float4 k = ld4(kp + c);
+                    a = fmaf(q[c], k.x, a); a = fmaf(q[c + 1], k.y, a); a = fmaf(q[c + 2], k.z, a); a = fmaf(q[c + 3], k.w, a);
+                }
+                sc[j] = s0 + j <= row ? a : -INFINITY;
             }
-            const float mn = fmaxf(m, sc);
-            const float corr = __expf(m - mn);
-            const float p = __expf(sc - mn);
-            l = l * corr + p;
+            float mb = sc[0];
 #pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const float4 v = ld4(vp + c);
-                acc[c] = fmaf(p, v.x, acc[c] * corr); acc[c + 1] = fmaf(p, v.y, acc[c + 1] * corr);
-                acc[c + 2] = fmaf(p, v.z, acc[c + 2] * corr); acc[c + 3] = fmaf(p, v.w, acc[c + 3] * corr);
+            for (int j = 1; j < KB; ++j) mb = fmaxf(mb, sc[j]);
+            const float mn = fmaxf(m, mb);
+            const float corr = __expf(m - mn);
+            float p[KB], ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) { p[j] = __expf(sc[j] - mn); ps += p[j]; }
+            l = l * corr + ps;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc[c] *= corr;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const int s = s0 + j <= row ? s0 + j : row;
+                const float* vp = kbase + s * ld + D;
+#pragma unroll
+                for (int c = 0; c < HD; c += 4) {
+                    const float4 v = ld4(vp + c);
+                    acc[c] = fmaf(p[j], v.x, acc[c]); acc[c + 1] = fmaf(p[j], v.y, acc[c + 1]);
+                    acc[c + 2] = fmaf(p[j], v.z, acc[c + 2]); acc[c + 3] = fmaf(p[j], v.w, acc[c + 3]);
+                }
             }
             m = mn;
         }

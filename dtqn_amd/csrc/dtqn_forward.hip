@@ -61,28 +61,55 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
     const int KE = net.ke, KEP = net.kep;
-    float* ein = Ws;                                   // [LP][KEP] embedding-linear input (wavefront-level gather)
-    for (int idx = t.tid; idx < LP * KEP; idx += NT) {
-        const int r = idx / KEP, k = idx - r * KEP;
-        float v = 0.f;
-        if (r < n && k < KE) {
-            if (net.discrete) {
-                const int j = k / net.embed_per_obs, c = k - j * net.embed_per_obs;
-                int tok = (int)obs_rows[(size_t)r * O + j];
-                tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
-                v = theta[net.off_obs_tab + tok * net.embed_per_obs + c];
-            } else {
-                v = obs_rows[(size_t)r * O + k];
+    const float* __restrict__ We = theta + net.off_obs_w;
+    const float* __restrict__ be = theta + net.off_obs_b;
+    const float* __restrict__ pos = theta + net.off_pos;
+    if (!net.discrete && KE <= 8) {
+        // continuous observations: every token row is a handful of floats read straight from the replay
+        // window; a single pass, no LDS staging, no barrier
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
+            const int r = idx / D, d = idx - r * D;
+            float v = 0.f;
+            if (r < n) {
+                if (d < adim) {
+                    if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else {
+                    const float* w = We + (size_t)(d - adim) * KE;
+                    const float* e = obs_rows + (size_t)r * O;
+                    float acc = be[d - adim];
+                    for (int k = 0; k < KE; ++k) acc = fmaf(e[k], w[k], acc);
+                    v = acc;
+                }
+                v += pos[r * D + d];
             }
+            Xs[r * LDX + d] = v;
+            if (rec != nullptr) rec[net.ao_x0 + idx] = v;
         }
-        ein[idx] = v;
-        if (rec != nullptr) rec[net.ao_ein + idx] = v;
-    }
-    __syncthreads();
-    {
-        const float* __restrict__ We = theta + net.off_obs_w;
-        const float* __restrict__ be = theta + net.off_obs_b;
-        const float* __restrict__ pos = theta + net.off_pos;
+        if (rec != nullptr)
+            for (int idx = t.tid; idx < LP * KEP; idx += NT) {
+                const int r = idx / KEP, k = idx - r * KEP;
+                rec[net.ao_ein + idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
+            }
+    } else {
+        float* ein = Ws;                               // [LP][KEP] embedding-linear input (wavefront-level gather)
+        for (int idx = t.tid; idx < LP * KEP; idx += NT) {
+            const int r = idx / KEP, k = idx - r * KEP;
+            float v = 0.f;
+            if (r < n && k < KE) {
+                if (net.discrete) {
+                    const int j = k / net.embed_per_obs, c = k - j * net.embed_per_obs;
+                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
+                    v = theta[net.off_obs_tab + tok * net.embed_per_obs + c];
+                } else {
+                    v = obs_rows[(size_t)r * O + k];
+                }
+            }
+            ein[idx] = v;
+            if (rec != nullptr) rec[net.ao_ein + idx] = v;
+        }
+        __syncthreads();
         for (int idx = t.tid; idx < LP * D; idx += NT) {
             const int r = idx / D, d = idx - r * D;
             float v = 0.f;
