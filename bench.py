@@ -84,14 +84,33 @@ def time_kernels(agent, iters: int = 50) -> dict:
     for name, fn in stages.items():
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
+        stream.synchronize()
+        # one event pair per launch, drained in between: the same quantity rocprofv3 --kernel-trace reports
+        # per dispatch (back-to-back launches of a 32-workgroup kernel would overlap their ramp-up/drain)
+        ts = []
         for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
             fn()
-        e1.record(stream)
-        e1.synchronize()
-        out[name] = e0.elapsed_time(e1) * 1e3 / iters          # us
+            e1.record(stream)
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        out[name] = float(np.mean(ts))          # us
     return out
+
+
+def pmc_traffic(kernel: str, batch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic_B32.json;
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950's wide coalesced reads).  None when no profile matches this batch."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{batch}.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    for k, v in d.items():
+        if k.startswith(kernel):
+            return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+    return None
 
 
 def cpu_baseline(c, batch: int, budget_s: float = 15.0) -> dict:
@@ -167,6 +186,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json metric: 32)")
     ap.add_argument("--sampler", default="device", choices=["device", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env-rate", action="store_true", help="skip the live env-steps/s loops (cleaner rocprofv3 traces)")
     args = ap.parse_args()
 
     rank, world, local = ddp.init_from_env("cuda")
@@ -226,14 +246,14 @@ def main():
                                    f"batch {args.batch} per GPU, history 50, device-resident replay 2500 episodes x 200 steps",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch),
                          "algorithmic_flops_per_launch": flops, "launch_us": kern[dom]},
             "hbm_view": {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
                          "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "kernels_us": kern,
             "algorithmic_gflop_per_update": 5 * tokens * ft / 1e9,
         }
-        if world == 1:
+        if world == 1 and not args.no_env_rate:
             rates = env_step_rate(agent)
             line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
                                          "coupled_overlapped_two_streams": rates["coupled_1to1_overlapped"],
@@ -241,8 +261,8 @@ def main():
                                                  "step; in the coupled loops env-steps/s == TD-updates/s as in the reference "
                                                  "(1 update per env step); 'overlapped' runs the actor forward of step t+1 "
                                                  "concurrently with update t+1 (run.py --overlap)"}
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(c, args.batch)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(c, args.batch)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -49,10 +49,10 @@ class _AdamHandle:
         e = self._eng
         e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
         e.step_counter.fill_(int(sd["step"]))
+        e.step_counter[2] = 0          # statistics-ring call counter restarts with the loading agent's host counters
 
 
 class DtqnAgent:
-    STATS_RING = 64
 
     def __init__(self, network_factory: Callable[[], torch.nn.Module], buffer_size: int, device: torch.device,
                  env_obs_length: int, max_env_steps: int, obs_mask: Union[int, float], num_actions: int,
@@ -101,10 +101,8 @@ class DtqnAgent:
                             "qvalue_mean": self.qvalue_mean, "qvalue_min": self.qvalue_min, "target_max": self.target_max,
                             "target_mean": self.target_mean, "target_min": self.target_min}
         cuda = self.device.type == "cuda"
-        self._stats_host = [torch.zeros(len(STAT_NAMES)).pin_memory() if cuda else torch.zeros(len(STAT_NAMES))
-                            for _ in range(self.STATS_RING)]
-        self._stats_events = [torch.cuda.Event() if cuda else None for _ in range(self.STATS_RING)]
-        self._stats_head = self._stats_tail = 0
+        self._calls_issued = 0        # dtqn_td_clip_adam launches so far
+        self._calls_read = 0          # ... whose statistics have been consumed from the pinned ring
         self.train_mode = TrainMode.TRAIN
         mk = lambda: Context(context_len, obs_mask, num_actions, env_obs_length, discrete=is_discrete_env, ref_quirks=ref_quirks)
         self.train_context, self.eval_context = mk(), mk()
@@ -134,8 +132,9 @@ class DtqnAgent:
         self.policy_network.eval()
 
     def eval_off(self) -> None:
+        if self.train_mode != TrainMode.TRAIN or self.policy_network.training is False:
+            self.policy_network.train()          # walks the whole module tree: only when the mode really changes
         self.train_mode = TrainMode.TRAIN
-        self.policy_network.train()
 
     # ---- actor (dtqn.py:76-160) -----------------------------------------------------------------
     def _launch_actor_forward(self, stream_ptr) -> int:
@@ -173,6 +172,9 @@ class DtqnAgent:
             return int(RNG.rng.integers(self.num_actions))
         if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
             return self._sync_forward_action()
+        if not getattr(self, "_update_recorded", True):       # order the actor behind the last TD update (pipelined mode only)
+            self._ev_update_done.record(torch.cuda.current_stream(self.device))
+            self._update_recorded = True
         self._actor_stream.wait_event(self._ev_update_done)
         with torch.cuda.stream(self._actor_stream):
             self._launch_actor_forward(ctypes.c_void_p(self._actor_stream.cuda_stream))
@@ -208,11 +210,12 @@ class DtqnAgent:
         self.eval_off()
         rb.commit()
         eng = self.engine
+        sp = eng._stream()
         if self.sampler == "reference":
             eng.set_indices(*rb.sample_indices(self.batch_size))
         else:
             n_valid, exclude = rb.valid_range()
-            eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed)
+            eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed, sp)
         if self._actor_inflight:
             # the gradient kernels overlap the actor forward; only the optimizer kernel (which overwrites theta)
             # has to wait for it
@@ -224,11 +227,10 @@ class DtqnAgent:
             eng.clip_adam()
             self._actor_inflight = False
         elif self.dp is None:
-            eng.update(rb.dev)
+            eng.update(rb.dev, sp)
         else:
             self.dp.update(rb.dev)
-        if self._ev_update_done is not None:
-            self._ev_update_done.record(torch.cuda.current_stream(self.device))
+        self._update_recorded = False
         self._enqueue_stats()
         self.num_train_steps += 1
         # hard target sync happens on the device every target_update_frequency optimizer steps
@@ -238,32 +240,37 @@ class DtqnAgent:
         self.engine.target_sync()
 
     # ---- asynchronous statistics ---------------------------------------------------------------
+    # The optimizer kernel writes the statistics of call k to slot (k-1) % RING_SLOTS of a pinned host ring and
+    # tags the slot with k last; the host only polls memory: no copy, event or sync per update.
     def _enqueue_stats(self) -> None:
-        if (self._stats_head + 1) % self.STATS_RING == self._stats_tail:
+        self._calls_issued += 1
+        if self._calls_issued - self._calls_read >= self.engine.RING_SLOTS - 1:
             self._drain_stats(block=True)
-        slot = self._stats_head
-        self._stats_host[slot].copy_(self.engine.stats, non_blocking=True)
-        if self._stats_events[slot] is not None:
-            self._stats_events[slot].record()
-        self._stats_head = (slot + 1) % self.STATS_RING
-        self._drain_stats(block=False)
+        else:
+            self._drain_stats(block=False)
 
     def _drain_stats(self, block: bool) -> None:
-        while self._stats_tail != self._stats_head:
-            slot = self._stats_tail
-            ev = self._stats_events[slot]
-            if ev is not None:
-                if block:
-                    ev.synchronize()
-                elif not ev.query():
+        eng = self.engine
+        ring, slots = eng.stats_ring_np, eng.RING_SLOTS
+        i_nonfinite = STAT_NAMES.index("nonfinite")
+        idx = [(name, STAT_NAMES.index(name)) for name in self._stat_sinks]
+        while self._calls_read < self._calls_issued:
+            k = self._calls_read + 1
+            row = ring[(k - 1) % slots]
+            if row[9] != float(k):
+                if not block:
                     return
-            vals = self._stats_host[slot].numpy()
-            self._stats_tail = (slot + 1) % self.STATS_RING
-            if vals[STAT_NAMES.index("nonfinite")] != 0.0:
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()
+                if row[9] != float(k):
+                    raise RuntimeError(f"statistics of update call {k} never arrived (ring tag {row[9]})")
+            vals = row.copy()
+            self._calls_read = k
+            if vals[i_nonfinite] != 0.0:
                 # clip_grad_norm_(error_if_nonfinite=True) raises here in the reference (dtqn.py:257-261)
                 raise RuntimeError("The total norm for gradients from `parameters` is non-finite, so it cannot be clipped.")
-            for name, sink in self._stat_sinks.items():
-                RunningAverage.add(sink, float(vals[STAT_NAMES.index(name)]))
+            for name, i in idx:
+                RunningAverage.add(self._stat_sinks[name], float(vals[i]))
 
     # ---- checkpoints (dqn.py:212-327), plain arrays instead of pickled objects -------------------
     def save_mini_checkpoint(self, checkpoint_dir: str, wandb_id: Optional[str]) -> None:

@@ -80,8 +80,9 @@ struct AdamArgs {
     const float* norm_partial;
     const float* stats_partial;
     float* stats;
+    float* stats_ring;
     int32_t* step_counter;
-    int n, n_norm_blocks, batch, history, tuf;
+    int n, n_norm_blocks, batch, history, tuf, ring_slots;
     float lr, beta1, beta2, eps, clip, grad_scale;
 };
 
@@ -154,6 +155,16 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
             a.stats[10] = sync_target ? 1.f : 0.f;
             a.stats[11] = finite ? 0.f : 1.f;
             if (finite) a.step_counter[1] = k;
+            const int call = a.step_counter[2] + 1;       // every call counts, also a skipped (non-finite) one
+            a.step_counter[2] = call;
+            if (a.stats_ring != nullptr) {
+                // host-visible copy: payload first, fence, then the tag the host polls
+                float* slot = a.stats_ring + (size_t)((call - 1) % a.ring_slots) * 12;
+                for (int i = 0; i < 12; ++i)
+                    if (i != 9) slot[i] = a.stats[i];
+                __threadfence_system();
+                slot[9] = (float)call;
+            }
         }
     }
 }
@@ -204,6 +215,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.theta = td->theta_pol; a.theta_tgt = td->theta_tgt; a.grad = td->grad; a.m = td->adam_m; a.v = td->adam_v;
     a.norm_partial = td->norm_partial; a.stats_partial = td->stats_partial; a.stats = td->stats;
     a.step_counter = td->step_counter;
+    a.stats_ring = td->stats_ring; a.ring_slots = td->stats_ring_slots > 0 ? td->stats_ring_slots : 1;
     a.n = net->n_trainable; a.n_norm_blocks = td->n_norm_blocks; a.batch = td->batch; a.history = td->history;
     a.tuf = td->target_update_frequency;
     a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;

@@ -97,7 +97,11 @@ class TdEngine:
         self.norm_partial = torch.zeros(self.n_norm_blocks, **f32)
         self.stats_partial = torch.zeros(Bn * 8, **f32)
         self.stats = torch.zeros(len(STAT_NAMES), **f32)
-        self.step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.step_counter = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.RING_SLOTS = 256
+        ring = torch.zeros(self.RING_SLOTS, len(STAT_NAMES), dtype=torch.float32)
+        self.stats_ring = ring.pin_memory() if dev.type == "cuda" else ring      # written by the optimizer kernel, polled by the host
+        self.stats_ring_np = self.stats_ring.numpy()
         self.ep_idx = torch.zeros(Bn, dtype=torch.int32, device=dev)
         self.start = torch.zeros(Bn, dtype=torch.int32, device=dev)
         jobs = (B.DtqnWJob * net.n_wjobs)()
@@ -113,6 +117,7 @@ class TdEngine:
         td.act, td.grd, td.small, td.q3 = self.act.data_ptr(), self.grd.data_ptr(), self.small.data_ptr(), self.q3.data_ptr()
         td.gsplit, td.norm_partial = self.gsplit.data_ptr(), self.norm_partial.data_ptr()
         td.stats_partial, td.stats = self.stats_partial.data_ptr(), self.stats.data_ptr()
+        td.stats_ring, td.stats_ring_slots = self.stats_ring.data_ptr(), self.RING_SLOTS
         td.step_counter, td.wjobs = self.step_counter.data_ptr(), self.wjobs.data_ptr()
         td.batch = Bn
         td.history = int(net.ctx_len if history is None else history)
@@ -141,15 +146,16 @@ class TdEngine:
         self.ep_idx.copy_(torch.as_tensor(np.asarray(ep_idx, dtype=np.int32)), non_blocking=True)
         self.start.copy_(torch.as_tensor(np.asarray(start, dtype=np.int32)), non_blocking=True)
 
-    def sample_on_device(self, replay: DeviceReplay, n_valid: int, exclude: int, seed: int):
+    def sample_on_device(self, replay: DeviceReplay, n_valid: int, exclude: int, seed: int, stream=None):
         self._check(self.lib.dtqn_replay_sample(ctypes.byref(replay.view), int(n_valid), int(exclude), self.net.ctx_len,
                                                 self.batch, ctypes.c_uint32(seed & 0xFFFFFFFF), _p(self.step_counter),
-                                                _p(self.ep_idx), _p(self.start), self._stream()), "dtqn_replay_sample")
+                                                _p(self.ep_idx), _p(self.start), stream if stream is not None else self._stream()),
+                    "dtqn_replay_sample")
 
     # -- the update, whole or in stages (stages are what the data-parallel wrapper interleaves) --
-    def update(self, replay: DeviceReplay):
+    def update(self, replay: DeviceReplay, stream=None):
         self._check(self.lib.dtqn_td_update(ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td),
-                                            self._stream()), "dtqn_td_update")
+                                            stream if stream is not None else self._stream()), "dtqn_td_update")
 
     def forward_backward(self, replay: DeviceReplay):
         s, n, r, t = self._stream(), ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td)

@@ -208,14 +208,19 @@ typedef struct DtqnTd {
     float* gsplit;            /* [n_split][n_trainable] split-K partials of the weight gradients */
     float* norm_partial;      /* [n_norm_blocks] per-block sum of squares of grad */
     float* stats_partial;     /* [B][8] */
-    float* stats;             /* [8 + 4]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, nonfinite flag */
-    int32_t* step_counter;    /* [2]: number of optimizer steps taken; updates since last target sync */
+    float* stats;             /* [12]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, step, target-synced, non-finite flag */
+    float* stats_ring;        /* optional [stats_ring_slots][12] in PINNED HOST memory (device-visible): every call of
+                               * dtqn_td_clip_adam also writes its statistics to slot (call_index % slots), entry 9 (the
+                               * 1-based call index, written last) being the completion tag; the host polls it instead of
+                               * enqueueing a device->host copy and an event per update */
+    int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls */
     const DtqnWJob* wjobs;    /* device copy of the job table */
     /* hyper-parameters */
     int32_t batch;            /* B (local) */
     int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
     int32_t n_split;          /* token splits of the weight-gradient kernel */
     int32_t n_norm_blocks;
+    int32_t stats_ring_slots;
     int32_t target_update_frequency;
     float gamma;
     float lr;

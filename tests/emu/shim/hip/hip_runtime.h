@@ -186,6 +186,7 @@ static inline int atomicMax(int* p, int v) {
     return old;
 }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- runtime API subset -------------------------------------------------------
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
