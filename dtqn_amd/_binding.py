@@ -93,6 +93,8 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
+        "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
+        "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],
         "dtqn_td_forward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_backward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_wgrad": [P(DtqnNet), P(DtqnTd), vp],

@@ -367,6 +367,7 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
                             int batch, int n, float* q_out, void* stream) {
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
+    if (net->tiled) return DTQN_ERR_CONFIG;                             // use dtqn_forward_tiled
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
     FwdArgs a;
     a.net = *net;
@@ -388,6 +389,7 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (rp->obs_dim != net->obs_dim || rp->max_steps < net->ctx_len) return DTQN_ERR_ARG;
+    if (net->tiled) return DTQN_ERR_CONFIG;                             // training on the tiled path: not built yet
     FwdArgs a;
     a.net = *net;
     a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;

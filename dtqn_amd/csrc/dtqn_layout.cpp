@@ -1,6 +1,7 @@
 // Host-side layout of the flat parameter buffer, the per-sequence activation / gradient records
 // and the weight-gradient job table (see include/dtqn_hip.h, DtqnNet).  Pure C++ (no device code).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "dtqn_hip.h"
@@ -33,6 +34,12 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
+    net->tiled = 0;
+    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr) {
+        // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
+        net->tiled = 1;
+        net->lp = (L + 63) / 64 * 64;
+    }
     net->ke = net->discrete ? O * e : O;
     net->kep = up4(net->ke);
     net->ap = up4(A);
@@ -40,8 +47,13 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->ffn_chunk = 2 * D;
     const int LP = net->lp;
     // kernels cover what fits the per-sequence LDS tile (DESIGN.md "coverage")
-    if (LP > DTQN_MAX_LP || D > DTQN_MAX_D || net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
-    if (A > DTQN_MAX_ACTIONS || net->kep > 3 * D) return DTQN_ERR_CONFIG;
+    if (net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
+    if (net->tiled) {
+        // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
+        if (!(D == 64 || D == 128 || D == 256) || LP > 256 || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
+        if ((size_t)3 * LP * (net->head_dim + 4) * sizeof(float) > 150 * 1024) return DTQN_ERR_CONFIG;
+    }
+    if (A > DTQN_MAX_ACTIONS || (!net->tiled && net->kep > 3 * D)) return DTQN_ERR_CONFIG;
 
     // ---- theta: trainable region first ----
     Cursor c;

@@ -128,6 +128,18 @@ class DTQN(nn.Module):
             a = actions.to(device=dev).reshape(obss.size(0), seq).to(torch.uint8).contiguous()
         q = torch.empty((obss.size(0), seq, self.num_actions), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        if self.net.tiled:      # contexts / widths beyond one workgroup's LDS: row-block tiled kernels + a workspace
+            need = self._lib.dtqn_forward_workspace_floats(ctypes.byref(self.net), int(obss.size(0)))
+            ws = getattr(self, "_tiled_ws", None)
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._tiled_ws = torch.empty(need, dtype=torch.float32, device=dev)
+            rc = self._lib.dtqn_forward_tiled(ctypes.byref(self.net), ctypes.c_void_p(self.flat.data_ptr()),
+                                              ctypes.c_void_p(o.data_ptr()), None if a is None else ctypes.c_void_p(a.data_ptr()),
+                                              int(obss.size(0)), int(seq), ctypes.c_void_p(q.data_ptr()),
+                                              ctypes.c_void_p(ws.data_ptr()), stream)
+            if rc != 0:
+                raise RuntimeError(f"dtqn_forward_tiled failed with DTQN status {rc}")
+            return q
         rc = self._lib.dtqn_forward(ctypes.byref(self.net), ctypes.c_void_p(self.flat.data_ptr()),
                                     ctypes.c_void_p(o.data_ptr()), None if a is None else ctypes.c_void_p(a.data_ptr()),
                                     int(obss.size(0)), int(seq), ctypes.c_void_p(q.data_ptr()), stream)

@@ -69,6 +69,8 @@ typedef struct DtqnNet {
     int32_t ap;               /* A padded to 4 */
     int32_t head_dim;
     int32_t ffn_chunk;        /* columns of the 4D hidden processed per LDS pass */
+    int32_t tiled;            /* 0: one workgroup holds a whole sequence in LDS (L <= 64, D <= 128);
+                               * 1: row-block tiled kernels over global-memory tensors (L <= 256, D <= 256; forward only) */
     /* ---- derived: theta layout (floats) ---- */
     int32_t off_act_emb;      /* [A][a]            action_embedding.embedding.0.weight */
     int32_t off_obs_tab;      /* [V][e]            obs_embedding.observation_embedding.0.weight */
@@ -186,6 +188,13 @@ int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_l
  * ------------------------------------------------------------------------------------------ */
 int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                  int batch, int n, float* q_out, void* stream);
+
+/* The same for nets with `tiled == 1` (contexts / widths that do not fit one workgroup's LDS, BASELINE
+ * configs 4 and 5): row blocks of 64 tokens, GEMM stages on the matrix core over global-memory tensors,
+ * attention per (sequence, head).  `workspace` holds dtqn_forward_workspace_floats(net, batch) floats. */
+int dtqn_forward_workspace_floats(const DtqnNet* net, int batch);
+int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                       int batch, int n, float* q_out, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One TD update = DtqnAgent.train() (dtqn/agents/dtqn.py:162-269) after sampling.

@@ -73,3 +73,40 @@ def test_forward_cfg1_size(emu):
         ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act)).numpy()
     got = _fwd(emu, cfg, params, obs, act)
     assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+TILED = [
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50),
+    dict(obs_dim=6, num_actions=6, inner_embed_size=64, num_heads=4, history_len=70, discrete=True, vocab_sizes=12, identity=True, pos="sin"),
+    dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=2, history_len=130, discrete=True, vocab_sizes=22, action_dim=8),
+]
+
+
+@pytest.mark.parametrize("kw", TILED)
+def test_tiled_forward_path(emu, kw, monkeypatch):
+    """Row-block tiled kernels (the path of BASELINE configs 4 / 5), forced on small widths so the CPU emulation
+    finishes quickly: multi-block contexts (L > 64), variable length, identity / discrete / action variants."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    cfg = O.NetCfg(**kw)
+    net = net_from_cfg(emu, cfg)
+    assert net.tiled == 1 and net.lp % 64 == 0
+    params = O.init_params(cfg, seed=3, perturb=True)
+    theta = pack_theta(net, params)
+    rng = np.random.default_rng(5)
+    for n in sorted({1, cfg.history_len // 2 + 1, cfg.history_len}):
+        Bn = 2
+        obs = (rng.integers(0, cfg.vocab_sizes, size=(Bn, n, cfg.obs_dim)) if cfg.discrete
+               else rng.uniform(-1, 1, size=(Bn, n, cfg.obs_dim)).astype(np.float32))
+        act = rng.integers(0, cfg.num_actions, size=(Bn, n, 1))
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs, dtype=torch.long if cfg.discrete else torch.float32),
+                            torch.as_tensor(act, dtype=torch.long)).numpy()
+        q = np.full((Bn, n, cfg.num_actions), np.nan, dtype=np.float32)
+        ws = np.zeros(emu.dtqn_forward_workspace_floats(ctypes.byref(net), Bn), dtype=np.float32)
+        obs_f = np.ascontiguousarray(obs, dtype=np.float32)
+        act_u8 = np.ascontiguousarray(act.reshape(Bn, n), dtype=np.uint8)
+        rc = emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), ptr(ws), None)
+        assert rc == 0
+        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
+    # the whole-sequence kernels refuse a tiled net, and the training entry points are not built for it
+    assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), None) == B.DEFINES["DTQN_ERR_CONFIG"]

@@ -34,7 +34,11 @@ def hip_forward(lib, cfg, params, obs, act):
     obs_d = torch.as_tensor(np.ascontiguousarray(obs, dtype=np.float32)).to(dev)
     act_d = torch.as_tensor(np.ascontiguousarray(act.reshape(Bn, n), dtype=np.uint8)).to(dev)
     q = torch.full((Bn, n, cfg.num_actions), float("nan"), device=dev)
-    rc = lib.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_d), ptr(act_d), Bn, n, ptr(q), engine.stream_ptr())
+    if net.tiled:
+        ws = torch.empty(lib.dtqn_forward_workspace_floats(ctypes.byref(net), Bn), device=dev)
+        rc = lib.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs_d), ptr(act_d), Bn, n, ptr(q), ptr(ws), engine.stream_ptr())
+    else:
+        rc = lib.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_d), ptr(act_d), Bn, n, ptr(q), engine.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
     return q.cpu().numpy()
@@ -66,6 +70,25 @@ def test_golden_G1_q_values(lib):
     assert np.abs(got - z["q_next_tgt"]).max() <= Q_TOL * scale
 
 
+def test_golden_G3_cfg345_q_values(lib):
+    """BASELINE configs 3, 4, 5 at their full network sizes (D=128/L=50, D=128/L=128, D=256/L=256) against the
+    Q-values the reference produced; cfg 3 runs on the whole-sequence kernels, cfg 4 and 5 on the tiled path."""
+    z = np.load(os.path.join(GOLDEN, "G3_cfg345_td.npz"))
+    for name in json.loads(str(z["names"])):
+        p = name + "/"
+        cfg = O.NetCfg(**json.loads(str(z[p + "cfg"])))
+        seed = int(z[p + "seed"])
+        pol = O.init_params(cfg, seed=seed, perturb=True)
+        tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+        scale = max(1.0, np.abs(z[p + "q_all"]).max())
+        for params, obs_k, act_k, q_k in ((pol, "batch0_obss", "batch0_actions", "q_all"),
+                                          (pol, "batch0_next_obss", "batch0_next_actions", "q_next_pol"),
+                                          (tgt, "batch0_next_obss", "batch0_next_actions", "q_next_tgt")):
+            got = hip_forward(lib, cfg, params, z[p + obs_k], z[p + act_k])
+            err = np.abs(got - z[p + q_k]).max()
+            assert err <= Q_TOL * scale, (name, q_k, err, scale)
+
+
 VARIANTS = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8),
     dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, action_dim=4),
@@ -74,6 +97,10 @@ VARIANTS = [
     dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=4, history_len=64, discrete=True, vocab_sizes=22,
          action_dim=8, pos="none"),
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, gate="gru", action_dim=8, pos="sin"),
+    # tiled path (L > 64 or D > 128)
+    dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, history_len=128, discrete=True, vocab_sizes=12),
+    dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=256, discrete=True, vocab_sizes=22, identity=True, pos="sin"),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=256, num_heads=8, history_len=100, action_dim=8),
 ]
 
 
