@@ -7,6 +7,7 @@
 // per-sequence `grd` record; dtqn_wgrad.hip contracts those against the saved activations over all
 // B*L tokens, so no per-sequence weight-gradient partials exist.
 #include "dtqn_device.hpp"
+#include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
 
 namespace dtqn {
@@ -30,200 +31,6 @@ struct BwdArgs {
     float gamma;
     long long* prof;             // debug stage clock
 };
-
-// LayerNorm backward over the rows of a [LP][ld] tile.
-//   dy   : gradient w.r.t. the LN output            (LDS, [LP][ld])
-//   xin  : the LN input                             (LDS, [LP][ld])
-//   st   : (mean, rstd) per row                     (global, [LP][2])
-//   dst  : receives rstd*(g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy; assigned or accumulated
-//   dgb  : per-sequence partial of d gamma ([D]) followed (at +D) by d beta ([D])   (global)
-// Contains two __syncthreads(); caller must sync before (inputs ready) and after (dst ready).
-template <int D, int NW>
-__device__ __forceinline__ void layernorm_backward(const float* dy, const float* xin, float* dst, bool accumulate,
-                                                   int ld, int LP, const float* __restrict__ st,
-                                                   const float* __restrict__ gamma, float* __restrict__ dgb,
-                                                   float* red, const Thr& t) {
-    constexpr int NT = NW * 64;
-    constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
-    // pass A: column sums  d gamma[d] = sum_r dy*xhat,  d beta[d] = sum_r dy
-    {
-        const int d = t.tid % D, part = t.tid / D;
-        if (part < PARTS) {
-            float sg = 0.f, sb = 0.f;
-            for (int r = part; r < LP; r += PARTS) {
-                const float mean = st[r * 2], rstd = st[r * 2 + 1];
-                const float g = dy[r * ld + d];
-                sg = fmaf(g, (xin[r * ld + d] - mean) * rstd, sg);
-                sb += g;
-            }
-            red[(part * 2 + 0) * D + d] = sg;
-            red[(part * 2 + 1) * D + d] = sb;
-        }
-    }
-    __syncthreads();
-    for (int idx = t.tid; idx < 2 * D; idx += NT) {
-        const int which = idx / D, d = idx - which * D;
-        float s = 0.f;
-        for (int p = 0; p < PARTS; ++p) s += red[(p * 2 + which) * D + d];
-        dgb[which * D + d] = s;
-    }
-    // pass B: rows (LPR lanes per row)
-    constexpr int LPR = (NT / DTQN_MAX_LP) < (D / 4) ? (NT / DTQN_MAX_LP) : (D / 4);
-    constexpr int NV = D / (4 * LPR);
-    float4 o[NV];
-    int row = t.tid / LPR;
-    const int part = t.tid % LPR;
-    const bool valid = row < LP;
-    row = valid ? row : 0;
-    {
-        const float mean = st[row * 2], rstd = st[row * 2 + 1];
-        const float* yp = dy + row * ld + part * 4;
-        const float* xp = xin + row * ld + part * 4;
-        float4 gq[NV], xh[NV];
-        float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const float4 y = ld4(yp + 4 * LPR * j), x = ld4(xp + 4 * LPR * j), gm = ld4(gamma + part * 4 + 4 * LPR * j);
-            gq[j] = make_float4(y.x * gm.x, y.y * gm.y, y.z * gm.z, y.w * gm.w);
-            xh[j] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
-            c1 += (gq[j].x + gq[j].y) + (gq[j].z + gq[j].w);
-            c2 += (gq[j].x * xh[j].x + gq[j].y * xh[j].y) + (gq[j].z * xh[j].z + gq[j].w * xh[j].w);
-        }
-#pragma unroll
-        for (int m = 1; m < LPR; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
-        c1 *= (1.0f / D);
-        c2 *= (1.0f / D);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            o[j].x = rstd * (gq[j].x - c1 - xh[j].x * c2);
-            o[j].y = rstd * (gq[j].y - c1 - xh[j].y * c2);
-            o[j].z = rstd * (gq[j].z - c1 - xh[j].z * c2);
-            o[j].w = rstd * (gq[j].w - c1 - xh[j].w * c2);
-        }
-    }
-    __syncthreads();   // every lane has read dy / dst before anyone overwrites dst (dst may alias dy)
-    if (valid) {
-        float* dp = dst + row * ld + part * 4;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            if (accumulate) {
-                const float4 p = ld4(dp + 4 * LPR * j);
-                st4(dp + 4 * LPR * j, make_float4(p.x + o[j].x, p.y + o[j].y, p.z + o[j].z, p.w + o[j].w));
-            } else {
-                st4(dp + 4 * LPR * j, o[j]);
-            }
-        }
-    }
-}
-
-// Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each).
-//   delta_s[h][t] = dO . o was produced by the dO GEMM's epilogue; lse_s[h][t] is staged by the caller.
-//   pass 1 (item = query row t, head): dS = P*(dP - delta); dq = scale * dS k
-//   pass 2 (item = key row s, head):   dk = scale * dS^T q ; dv = P^T do      (in place over k, v)
-template <int HD, int NW>
-__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
-                                                         const float* delta_s, const float* lse_s, const Thr& t) {
-    const int HG = GW / HD;
-    const float scale = 1.0f / sqrtf((float)HD);
-    const int nblocks = (LP * HG + 63) / 64;
-    const bool one_round = nblocks <= NW && (64 % HG) == 0;
-    const int nlive = (n * HG + 63) / 64;
-    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
-        int item = it0;
-        if (one_round) {
-            const int blk = balanced_block<NW>(t.wave, nblocks, nlive, false);
-            if (blk < 0) continue;
-            item = blk * 64 + t.lane;
-            if (item >= LP * HG) continue;
-        }
-        const int row = item / HG, hl = item - row * HG;
-        float* dqp = W5 + row * ld + 4 * GW + hl * HD;
-        float dq[HD];
-#pragma unroll
-        for (int c = 0; c < HD; ++c) dq[c] = 0.f;
-        if (row < n) {
-            const float* qp = W5 + row * ld + hl * HD;
-            const float* dop = W5 + row * ld + 3 * GW + hl * HD;
-            float q[HD], dO[HD];
-#pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const float4 x = ld4(qp + c), g = ld4(dop + c);
-                q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
-                dO[c] = g.x; dO[c + 1] = g.y; dO[c + 2] = g.z; dO[c + 3] = g.w;
-            }
-            const float delta = delta_s[hl * LP + row], lse = lse_s[hl * LP + row];
-            const float* kbase = W5 + GW + hl * HD;
-            for (int s = 0; s <= row; ++s) {
-                const float* kp = kbase + s * ld;
-                const float* vp = kp + GW;
-                float sc = 0.f, dp = 0.f;
-                float kk[HD];
-#pragma unroll
-                for (int c = 0; c < HD; c += 4) {
-                    const float4 k = ld4(kp + c), v = ld4(vp + c);
-                    kk[c] = k.x; kk[c + 1] = k.y; kk[c + 2] = k.z; kk[c + 3] = k.w;
-                    sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
-                    dp = fmaf(dO[c], v.x, dp); dp = fmaf(dO[c + 1], v.y, dp); dp = fmaf(dO[c + 2], v.z, dp); dp = fmaf(dO[c + 3], v.w, dp);
-                }
-                const float ds = __expf(sc - lse) * (dp - delta);
-#pragma unroll
-                for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kk[c], dq[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < HD; c += 4)
-            st4(dqp + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
-    }
-    __syncthreads();
-    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
-        int item = it0;
-        if (one_round) {
-            const int blk = balanced_block<NW>(t.wave, nblocks, nlive, true);
-            if (blk < 0) continue;
-            item = blk * 64 + t.lane;
-            if (item >= LP * HG) continue;
-        }
-        const int srow = item / HG, hl = item - srow * HG;
-        float* kp = W5 + srow * ld + GW + hl * HD;
-        float* vp = kp + GW;
-        float dk[HD], dv[HD];
-#pragma unroll
-        for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
-        if (srow < n) {
-            float k[HD], v[HD];
-#pragma unroll
-            for (int c = 0; c < HD; c += 4) {
-                const float4 x = ld4(kp + c), y = ld4(vp + c);
-                k[c] = x.x; k[c + 1] = x.y; k[c + 2] = x.z; k[c + 3] = x.w;
-                v[c] = y.x; v[c + 1] = y.y; v[c + 2] = y.z; v[c + 3] = y.w;
-            }
-            for (int row = n - 1; row >= srow; --row) {
-                const float* qp = W5 + row * ld + hl * HD;
-                const float* dop = qp + 3 * GW;
-                float sc = 0.f, dp = 0.f;
-                float qq[HD], dd[HD];
-#pragma unroll
-                for (int c = 0; c < HD; c += 4) {
-                    const float4 x = ld4(qp + c), g = ld4(dop + c);
-                    qq[c] = x.x * scale; qq[c + 1] = x.y * scale; qq[c + 2] = x.z * scale; qq[c + 3] = x.w * scale;
-                    dd[c] = g.x; dd[c + 1] = g.y; dd[c + 2] = g.z; dd[c + 3] = g.w;
-                }
-#pragma unroll
-                for (int c = 0; c < HD; ++c) { sc = fmaf(qq[c], k[c], sc); dp = fmaf(dd[c], v[c], dp); }
-                const float p = __expf(sc - lse_s[hl * LP + row]);
-                const float ds = p * (dp - delta_s[hl * LP + row]);
-#pragma unroll
-                for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(p, dd[c], dv[c]); }
-            }
-        }
-        // NOTE: other items of this pass read only q / do / lse / delta, never k or v of another row
-#pragma unroll
-        for (int c = 0; c < HD; c += 4) {
-            st4(kp + c, make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]));
-            st4(vp + c, make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]));
-        }
-    }
-}
 
 template <int D, int MT, int HD, int NW, bool GRU>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
@@ -280,40 +87,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         const float inv_count = 1.0f / ((float)a.batch * (float)a.history);
         for (int idx = t.tid; idx < LP * AP; idx += NT) dq_s[idx] = 0.f;
         __syncthreads();
-        if (t.wave == 0) {
-            float sq = 0.f, mnq = INFINITY, mxq = -INFINITY, sy = 0.f, mny = INFINITY, mxy = -INFINITY, se = 0.f;
-            for (int r = t.lane; r < LP; r += 64) {
-                if (r < L && r >= L - a.history) {
-                    // one round trip: none of these addresses depends on a loaded value
-                    const int at = (int)a.actions[(size_t)ep * a.act_ep_stride + st0 + r];
-                    const float rew = a.rewards[(size_t)ep * a.rew_ep_stride + st0 + r];
-                    const float dn = a.dones[(size_t)ep * a.rew_ep_stride + st0 + r] ? 1.f : 0.f;
-                    float q = 0.f, best = q1[r * AP], qt = q2[r * AP];
-                    int am = 0;
-                    for (int c = 0; c < A; ++c) {          // torch.argmax: first maximal index
-                        const float v0 = q0[r * AP + c], v1 = q1[r * AP + c], v2 = q2[r * AP + c];
-                        if (c == at) q = v0;
-                        if (c > 0 && v1 > best) { best = v1; am = c; qt = v2; }
-                    }
-                    (void)am;
-                    const float y = rew + (1.f - dn) * (qt * a.gamma);
-                    const float diff = q - y;
-                    dq_s[r * AP + at] = 2.f * diff * inv_count;
-                    sq += q; mnq = fminf(mnq, q); mxq = fmaxf(mxq, q);
-                    sy += y; mny = fminf(mny, y); mxy = fmaxf(mxy, y);
-                    se = fmaf(diff, diff, se);
-                }
-            }
-            for (int m = 32; m >= 1; m >>= 1) {
-                sq += __shfl_xor(sq, m); sy += __shfl_xor(sy, m); se += __shfl_xor(se, m);
-                mnq = fminf(mnq, __shfl_xor(mnq, m)); mxq = fmaxf(mxq, __shfl_xor(mxq, m));
-                mny = fminf(mny, __shfl_xor(mny, m)); mxy = fmaxf(mxy, __shfl_xor(mxy, m));
-            }
-            if (t.lane == 0) {
-                float* sp = a.stats_partial + (size_t)b * 8;
-                sp[0] = se; sp[1] = sq; sp[2] = mxq; sp[3] = mnq; sp[4] = sy; sp[5] = mxy; sp[6] = mny; sp[7] = 0.f;
-            }
-        }
+        if (t.wave == 0)
+            td_loss_wave(q0, q1, q2, AP, A, L, LP, a.history, a.gamma, inv_count,
+                         a.actions + (size_t)ep * a.act_ep_stride + st0, a.rewards + (size_t)ep * a.rew_ep_stride + st0,
+                         a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + (size_t)b * 8, t.lane);
         __syncthreads();
         for (int idx = t.tid; idx < LP * AP; idx += NT) grec[net.go_dq + idx] = dq_s[idx];
     }

@@ -149,6 +149,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->go_layer0 = gc.take(net->grd_layer_stride * NL);
     net->go_dhh = gc.take(LP * D);
     net->go_dq = gc.take(LP * net->ap);
+    net->go_gstream = net->tiled ? gc.take(LP * D) : -1;
+    net->go_do = net->tiled ? gc.take(LP * D) : -1;
     net->grd_stride = gc.pos;
 
     // ---- small partials ----

@@ -100,6 +100,7 @@ typedef struct DtqnNet {
     int32_t go_dx0, go_layer0, grd_layer_stride, go_dhh, go_dq;
     int32_t gl_dqkv, gl_da, gl_dhp, gl_df;
     int32_t gl_gate1, gl_gate2;   /* GRU: d z_pre, d r_pre, d h_pre, each [LP][D] */
+    int32_t go_gstream, go_do;    /* tiled path only: dL/d(stream) and dL/d(attention output) scratch, each [LP][D] */
     /* ---- derived: per-sequence small partials (LayerNorm affine, embedding tables) ---- */
     int32_t sp_stride;
     int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */
@@ -191,7 +192,8 @@ int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const
 
 /* The same for nets with `tiled == 1` (contexts / widths that do not fit one workgroup's LDS, BASELINE
  * configs 4 and 5): row blocks of 64 tokens, GEMM stages on the matrix core over global-memory tensors,
- * attention per (sequence, head).  `workspace` holds dtqn_forward_workspace_floats(net, batch) floats. */
+ * attention per (sequence, head).  `workspace` holds dtqn_forward_workspace_floats(net, batch) floats
+ * (= batch activation records). */
 int dtqn_forward_workspace_floats(const DtqnNet* net, int batch);
 int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                        int batch, int n, float* q_out, float* workspace, void* stream);
