@@ -462,7 +462,7 @@ extern "C" int dtqn_lds_bytes_backward(const DtqnNet* net) {
 extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (td->history < 1 || td->history > net->ctx_len) return DTQN_ERR_ARG;
-    if (net->tiled) return DTQN_ERR_CONFIG;
+    if (net->tiled) return tiled_td_backward(net, rp, td, (hipStream_t)stream);
     if (bwd_lds_bytes(net) > 160 * 1024) return DTQN_ERR_CONFIG;
     BwdArgs a;
     a.net = *net;

@@ -21,6 +21,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
 
 extern "C" void* dtqn_debug_profile_buffer(void);
 
+namespace dtqn {
+// row-block tiled TD passes (dtqn_tiled.hip), dispatched to by dtqn_td_forward / dtqn_td_backward when net->tiled
+int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
+int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
+}  // namespace dtqn
+
 // stage timestamp (debug): workgroup 0, thread 0 only; PROF costs one uniform branch when disabled
 #define DTQN_PROF(buf, slot) \
     do { if ((buf) != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (buf)[slot] = (long long)wall_clock64(); } while (0)

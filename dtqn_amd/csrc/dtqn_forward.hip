@@ -389,7 +389,7 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (rp->obs_dim != net->obs_dim || rp->max_steps < net->ctx_len) return DTQN_ERR_ARG;
-    if (net->tiled) return DTQN_ERR_CONFIG;                             // training on the tiled path: not built yet
+    if (net->tiled) return tiled_td_forward(net, rp, td, (hipStream_t)stream);
     FwdArgs a;
     a.net = *net;
     a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;

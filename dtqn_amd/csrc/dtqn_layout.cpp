@@ -51,7 +51,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
         if (!(D == 64 || D == 128 || D == 256) || LP > 256 || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
-        if ((size_t)3 * LP * (net->head_dim + 4) * sizeof(float) > 150 * 1024) return DTQN_ERR_CONFIG;
+        if (((size_t)LP * (4 * net->head_dim + 4) + 2 * (size_t)LP) * sizeof(float) > 160 * 1024) return DTQN_ERR_CONFIG;
     }
     if (A > DTQN_MAX_ACTIONS || (!net->tiled && net->kep > 3 * D)) return DTQN_ERR_CONFIG;
 
@@ -149,7 +149,6 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->go_layer0 = gc.take(net->grd_layer_stride * NL);
     net->go_dhh = gc.take(LP * D);
     net->go_dq = gc.take(LP * net->ap);
-    net->go_gstream = net->tiled ? gc.take(LP * D) : -1;
     net->go_do = net->tiled ? gc.take(LP * D) : -1;
     net->grd_stride = gc.pos;
 

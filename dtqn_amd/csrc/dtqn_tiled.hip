@@ -1,43 +1,66 @@
-// Row-block tiled DTQN forward for contexts / widths that do not fit one workgroup's LDS
-// (BASELINE configs 4 and 5: L = 128 / 256, D = 128 / 256).  Same arithmetic as dtqn_forward.hip
-// (DTQN.forward, dtqn/networks/dtqn.py:158-218), different decomposition:
-//   * tensors live in a global workspace, token-major [S][LPB][cols], LPB = L rounded up to 64;
-//   * every projection is a matrix-core GEMM over 64-row blocks (the block's input tile staged in LDS,
-//     128 output columns per workgroup, K walked in chunks of D with register accumulation);
-//   * attention runs per (sequence, head) with that head's q | k | v held in LDS;
-//   * LayerNorm is a row-wise kernel.
-// Forward only (inference / actor / parity of Q-values); the training path of these configs is not built.
+// Row-block tiled DTQN path for contexts / widths that do not fit one workgroup's LDS
+// (BASELINE configs 4 and 5: L = 128 / 256, D = 128 / 256): inference forward AND the TD training pass.
+// Same arithmetic as dtqn_forward.hip / dtqn_backward.hip (DTQN.forward, dtqn/networks/dtqn.py:158-218;
+// DtqnAgent.train, dtqn/agents/dtqn.py:199-256), different decomposition:
+//   * every tensor lives in the per-sequence activation / gradient RECORDS of include/dtqn_hip.h (the same
+//     fields the whole-sequence kernels save), token-major [LPB][cols], LPB = L rounded up to 64;
+//   * every projection (forward X W^T, backward dY W) is a matrix-core GEMM over 64-row blocks: the block's
+//     operand tile staged in LDS, 128 output columns per workgroup, the contraction walked in chunks with
+//     register accumulation; residual adds, ReLU, the ReLU ballots and the gradient masks are GEMM epilogues;
+//   * attention (forward and backward) runs per (sequence, head) with that head's tiles held in LDS;
+//   * LayerNorm (forward and backward) are row-wise kernels.
+// The weight gradients, the reduction and Adam are the SAME kernels as on the whole-sequence path
+// (dtqn_wgrad.hip, dtqn_optim.hip): they only see the records.
+// Training coverage: post-LN (identity = False), residual gate.  Inference also covers identity = True.
 #include "dtqn_device.hpp"
+#include "dtqn_bwd_device.hpp"
 
 namespace dtqn {
 
-constexpr int TNW = 8;                 // waves per workgroup of the tiled kernels
+constexpr int TNW = 8;                 // waves per workgroup of the GEMM / row-wise kernels
 constexpr int TNT = TNW * 64;
 constexpr int TROWS = 64;              // rows per block
 
-struct TlCommon {
-    DtqnNet net;
-    int S;                             // sequences
-    int n;                             // real rows per sequence
-    int lpb;                           // padded rows per sequence
+// One tensor inside the per-sequence records: element (s, row, col) = base[s * stride + row * ld + col]
+struct Fld {
+    float* base;
+    long long stride;
+    int ld;
 };
+static inline Fld fld(float* rec, long long stride, int off, int ld) { return Fld{rec + off, stride, ld}; }
+static inline Fld nofld() { return Fld{nullptr, 0, 0}; }
+__device__ __forceinline__ float* frow(const Fld& f, int s, int row) { return f.base + (size_t)s * f.stride + (size_t)row * f.ld; }
 
-// ---- embedding + position ---------------------------------------------------------------------
+// ---- embedding + position ---------------------------------------------------------------------------
 struct TlEmbedArgs {
-    TlCommon c;
-    const float* theta;
-    const float* obs;                  // [S][n][O]
-    const uint8_t* actions;            // [S][n] or nullptr
-    float* X;                          // [S][lpb][D]
+    DtqnNet net;
+    const float* theta_a;              // sequences [0, split)
+    const float* theta_b;              // sequences [split, S)
+    int split;
+    const float* obs;
+    const uint8_t* actions;
+    long long obs_ep_stride, act_ep_stride;
+    const int32_t* ep_idx;             // replay mode (TD): sequence s = which * batch + b reads episode ep_idx[b]
+    const int32_t* start;              //   from row start[b] + (which > 0); nullptr: sequence s reads "episode" s from row 0
+    int batch;
+    int n, rpb;
+    Fld x;                             // [LPB][D] embedded tokens + positions
+    Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
 };
 __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
-    const DtqnNet& net = a.c.net;
-    const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, n = a.c.n;
-    const int s = (int)blockIdx.x / (a.c.lpb / TROWS), rb = (int)blockIdx.x % (a.c.lpb / TROWS);
-    const float* __restrict__ theta = a.theta;
-    const float* obs_rows = a.obs + (size_t)s * n * O;
-    const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)s * n : nullptr;
-    float* xo = a.X + ((size_t)s * a.c.lpb + rb * TROWS) * D;
+    const DtqnNet& net = a.net;
+    const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n;
+    const int s = (int)blockIdx.x / a.rpb, rb = (int)blockIdx.x % a.rpb;
+    const float* __restrict__ theta = s >= a.split ? a.theta_b : a.theta_a;
+    int ep = s, row_first = 0;
+    if (a.ep_idx != nullptr) {
+        const int which = s / a.batch, b = s - which * a.batch;
+        ep = a.ep_idx[b];
+        row_first = a.start[b] + (which > 0 ? 1 : 0);
+    }
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row_first * O;
+    const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
+    float* xo = frow(a.x, s, rb * TROWS);
     for (int idx = (int)threadIdx.x; idx < TROWS * D; idx += TNT) {
         const int rl = idx / D, d = idx - rl * D, r = rb * TROWS + rl;
         float v = 0.f;
@@ -62,40 +85,61 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
             }
             v += theta[net.off_pos + r * D + d];
         }
-        xo[idx] = v;
+        xo[(size_t)rl * a.x.ld + d] = v;
+    }
+    if (a.ein.base != nullptr) {
+        float* eo = frow(a.ein, s, rb * TROWS);
+        for (int idx = (int)threadIdx.x; idx < TROWS * KEP; idx += TNT) {
+            const int rl = idx / KEP, k = idx - rl * KEP, r = rb * TROWS + rl;
+            float v = 0.f;
+            if (r < n && k < KE) {
+                if (net.discrete) {
+                    const int j = k / net.embed_per_obs, cdim = k - j * net.embed_per_obs;
+                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
+                    v = theta[net.off_obs_tab + tok * net.embed_per_obs + cdim];
+                } else {
+                    v = obs_rows[(size_t)r * O + k];
+                }
+            }
+            eo[idx] = v;
+        }
     }
 }
 
-// ---- linear: OUT[rows][N] (op)= IN[rows][K] * W[N][K]^T + b ------------------------------------------
-//   mode 0: OUT = acc + b      mode 1: OUT = relu(acc + b)      mode 2: OUT += relu(acc + b)   (residual gate)
+// ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T + b) ------------------------------------------------
+//   mode 0: OUT = y      mode 1: OUT = relu(y)      mode 2: OUT = RES + relu(y)   (residual gate)
+//   modes 1 / 2 optionally save the ReLU pattern as wave ballots (same word layout as the whole-sequence kernels)
 struct TlLinearArgs {
-    const float* in;   int ldi;        // input tensor, row stride (floats); rows are global row indices
-    const float* W;    int K, N;       // W [N][K]
-    const float* bias;
-    float* out;        int ldo;
-    int mode;
+    Fld in, out, res, mask;            // mask.base == nullptr: no ballots
+    const float *Wa, *Wb, *ba, *bb;    // sequences >= split use Wb / bb
+    int split;
+    int K, N, rpb, mode;
 };
 template <int D>
 __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
     constexpr int LDT = D + 4;
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDT] input tile of the current K chunk
     const Thr t = make_thr();
-    const size_t row0 = (size_t)blockIdx.x * TROWS;
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
     const int ntile = (int)blockIdx.y * TNW + t.wave;                 // this wave's 16-column output tile
     const int col = ntile * 16 + t.i;
-    const bool live = col < a.N;
+    const bool live = col < a.N;                                      // N is a multiple of 16: wave-uniform
+    const float* __restrict__ W = s >= a.split ? a.Wb : a.Wa;
+    const float* __restrict__ bias = s >= a.split ? a.bb : a.ba;
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = zero4();
     float4 bf[2][D / 16];
-    const float* wrow = a.W + (size_t)(live ? col : 0) * a.K;
+    const float* wrow = W + (size_t)(live ? col : 0) * a.K;
     frag_xwT_fetch<D>(bf[0], wrow, t);
+    const float* in0 = frow(a.in, s, row0);
     const int nchunks = a.K / D;
     for (int kc = 0; kc < nchunks; ++kc) {
         __syncthreads();                                              // previous chunk's tile fully consumed
         for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
-            st4(Xt + r * LDT + c, ld4(a.in + (row0 + r) * a.ldi + (size_t)kc * D + c));
+            st4(Xt + r * LDT + c, ld4(in0 + (size_t)r * a.in.ld + (size_t)kc * D + c));
         }
         if (kc + 1 < nchunks) frag_xwT_fetch<D>(bf[(kc + 1) & 1], wrow + (size_t)(kc + 1) * D, t);
         __syncthreads();
@@ -103,24 +147,87 @@ __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
         else frag_xwT_mma<D, 4>(Xt, LDT, bf[0], t, acc);
     }
     if (live) {
-        const float b = a.bias != nullptr ? a.bias[col] : 0.f;
+        const float b = bias[col];
+        float* mrec = a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                float* op = a.out + (row0 + m * 16 + t.kq * 4 + r4) * a.ldo + col;
+                const int row = row0 + m * 16 + t.kq * 4 + r4;
+                float* op = frow(a.out, s, row) + col;
                 const float v = acc[m][r4] + b;
-                if (a.mode == 0) *op = v;
-                else if (a.mode == 1) *op = fmaxf(v, 0.f);
-                else *op += fmaxf(v, 0.f);
+                if (a.mode == 0) {
+                    *op = v;
+                } else {
+                    if (mrec != nullptr) ballot_store(mrec, a.N / 16, row, col, v > 0.f, t.lane);
+                    const float y = fmaxf(v, 0.f);
+                    *op = a.mode == 1 ? y : frow(a.res, s, row)[col] + y;
+                }
             }
     }
 }
 
-// ---- attention per (sequence, head) -------------------------------------------------------------------
+// ---- backward linear: dX[rows][KOUT] (op)= dY[rows][N] * W[N][KOUT] --------------------------------------------
+//   mode 0: OUT = v      mode 1: OUT = v where the saved ReLU ballot of OUT's forward twin is set, else 0
+//   mode 2: OUT += v
+struct TlDxArgs {
+    Fld dy, out, mask;
+    const float* W;
+    int N, KOUT, rpb, mode;
+};
+template <int KC>
+__global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
+    constexpr int LDT = KC + 4;
+    float* Yt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDT] dY tile of the current chunk
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int ntile = (int)blockIdx.y * TNW + t.wave;
+    const int col = ntile * 16 + t.i;
+    const bool live = col < a.KOUT;
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = zero4();
+    float bf[2][KC / 4];
+    const float* wcol = a.W + (live ? col : 0);
+    frag_dyw_fetch<KC>(bf[0], wcol, a.KOUT, t);
+    const float* dy0 = frow(a.dy, s, row0);
+    const int nchunks = a.N / KC;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();
+        for (int idx = t.tid; idx < TROWS * (KC / 4); idx += TNT) {
+            const int r = idx / (KC / 4), c = (idx - r * (KC / 4)) * 4;
+            st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * a.dy.ld + (size_t)kc * KC + c));
+        }
+        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf[(kc + 1) & 1], wcol + (size_t)(kc + 1) * KC * a.KOUT, a.KOUT, t);
+        __syncthreads();
+        if (kc & 1) frag_dyw_mma<KC, 4>(Yt, LDT, bf[1], t, acc);
+        else frag_dyw_mma<KC, 4>(Yt, LDT, bf[0], t, acc);
+    }
+    if (live) {
+        const unsigned long long* mrec =
+            a.mode == 1 ? reinterpret_cast<const unsigned long long*>(a.mask.base + (size_t)s * a.mask.stride) : nullptr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = row0 + m * 16 + t.kq * 4 + r4;
+                float* op = frow(a.out, s, row) + col;
+                const float v = acc[m][r4];
+                if (a.mode == 0) *op = v;
+                else if (a.mode == 2) *op += v;
+                else {
+                    const unsigned long long w = mrec[((row >> 4) * (a.KOUT / 16) + (col >> 4)) * 4 + r4];
+                    *op = ((w >> t.lane) & 1ull) ? v : 0.f;
+                }
+            }
+    }
+}
+
+// ---- attention per (sequence, head) -----------------------------------------------------------------------------
 struct TlAttnArgs {
-    const float* qkv;                  // [S][lpb][3D]
-    float* o;                          // [S][lpb][D]
+    Fld qkv;                           // [LPB][3D]
+    Fld o;                             // [LPB][D]
+    Fld lse;                           // [H][LPB] (base may be null)
     int D, lpb, n;
 };
 template <int HD>
@@ -129,147 +236,542 @@ __global__ __launch_bounds__(256) void tl_attn_kernel(TlAttnArgs a) {
     float* T = reinterpret_cast<float*>(dtqn_smem);                    // [lpb][q | k | v] of this head
     const Thr t = make_thr();
     const int s = (int)blockIdx.x, h = (int)blockIdx.y;
-    const float* src = a.qkv + (size_t)s * a.lpb * 3 * a.D;
+    const float* src = frow(a.qkv, s, 0);
     for (int idx = t.tid; idx < a.lpb * 3 * (HD / 4); idx += 256) {
         const int r = idx / (3 * (HD / 4)), rem = idx - r * (3 * (HD / 4));
         const int which = rem / (HD / 4), c = (rem - which * (HD / 4)) * 4;
-        st4(T + r * LDH + which * HD + c, ld4(src + (size_t)r * 3 * a.D + which * a.D + h * HD + c));
+        st4(T + r * LDH + which * HD + c, ld4(src + (size_t)r * a.qkv.ld + which * a.D + h * HD + c));
     }
     __syncthreads();
-    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, nullptr, t);   // one head: "D" = HD, H = 1
+    float* lse = a.lse.base != nullptr ? a.lse.base + (size_t)s * a.lse.stride + (size_t)h * a.lpb : nullptr;
+    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, lse, t);       // one head: "D" = HD, H = 1
     __syncthreads();
-    float* dst = a.o + (size_t)s * a.lpb * a.D + h * HD;
+    float* dst = frow(a.o, s, 0) + h * HD;
     for (int idx = t.tid; idx < a.lpb * (HD / 4); idx += 256) {
         const int r = idx / (HD / 4), c = (idx - r * (HD / 4)) * 4;
-        st4(dst + (size_t)r * a.D + c, ld4(T + r * LDH + c));
+        st4(dst + (size_t)r * a.o.ld + c, ld4(T + r * LDH + c));
     }
 }
 
-// ---- LayerNorm over 64-row blocks -----------------------------------------------------------------------
+// backward: LDS tile [q | k | v | dO] of one head; dq goes straight to the record, dk / dv replace k / v in LDS
+struct TlAttnBwdArgs {
+    Fld qkv, o, lse;                   // saved by the forward
+    Fld dO;                            // [LPB][D] dL/d(attention output)
+    Fld dqkv;                          // [LPB][3D] out
+    int D, lpb, n;
+};
+template <int HD>
+__global__ __launch_bounds__(256) void tl_attn_bwd_kernel(TlAttnBwdArgs a) {
+    constexpr int LDH = 4 * HD + 4;
+    float* T = reinterpret_cast<float*>(dtqn_smem);
+    float* delta_s = T + (size_t)a.lpb * LDH;
+    float* lse_s = delta_s + a.lpb;
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x, h = (int)blockIdx.y;
+    const float* src = frow(a.qkv, s, 0);
+    const float* dsrc = frow(a.dO, s, 0);
+    for (int idx = t.tid; idx < a.lpb * 4 * (HD / 4); idx += 256) {
+        const int r = idx / (4 * (HD / 4)), rem = idx - r * (4 * (HD / 4));
+        const int which = rem / (HD / 4), c = (rem - which * (HD / 4)) * 4;
+        const float* p = which < 3 ? src + (size_t)r * a.qkv.ld + which * a.D + h * HD + c : dsrc + (size_t)r * a.dO.ld + h * HD + c;
+        st4(T + r * LDH + which * HD + c, ld4(p));
+    }
+    __syncthreads();
+    {
+        const float* og = frow(a.o, s, 0) + h * HD;
+        const float* lg = a.lse.base + (size_t)s * a.lse.stride + (size_t)h * a.lpb;
+        for (int r = t.tid; r < a.lpb; r += 256) {
+            float p = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; c += 4) {
+                const float4 ov = ld4(og + (size_t)r * a.o.ld + c), dv = ld4(T + r * LDH + 3 * HD + c);
+                p = fmaf(ov.x, dv.x, p); p = fmaf(ov.y, dv.y, p); p = fmaf(ov.z, dv.z, p); p = fmaf(ov.w, dv.w, p);
+            }
+            delta_s[r] = p;
+            lse_s[r] = lg[r];
+        }
+    }
+    __syncthreads();
+    float* dq = frow(a.dqkv, s, 0) + h * HD;
+    attention_backward_group<HD, 4>(T, LDH, HD, a.lpb, a.n, delta_s, lse_s, t, dq, a.dqkv.ld);
+    __syncthreads();
+    for (int idx = t.tid; idx < a.lpb * 2 * (HD / 4); idx += 256) {
+        const int r = idx / (2 * (HD / 4)), rem = idx - r * (2 * (HD / 4));
+        const int which = 1 + rem / (HD / 4), c = (rem % (HD / 4)) * 4;
+        st4(dq + (size_t)r * a.dqkv.ld + which * a.D + c, ld4(T + r * LDH + which * HD + c));
+    }
+}
+
+// ---- LayerNorm over 64-row blocks -----------------------------------------------------------------------------------
 struct TlLnArgs {
-    const float* src;
-    float* dst;
-    const float* gamma;
-    const float* beta;
+    Fld src, dst, st;                  // st: (mean, rstd) per row, base may be null
+    const float *ga, *gb, *ba, *bb;    // gamma / beta, sequences >= split use the second set
+    int split, rpb;
 };
 template <int D>
 __global__ __launch_bounds__(TNT) void tl_layernorm_kernel(TlLnArgs a) {
     const Thr t = make_thr();
-    const size_t row0 = (size_t)blockIdx.x * TROWS;
-    layernorm_rows<D, TNW>(a.src + row0 * D, a.dst + row0 * D, D, TROWS, a.gamma, a.beta, nullptr, t);
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    float* st = a.st.base != nullptr ? a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2 : nullptr;
+    layernorm_rows<D, TNW>(frow(a.src, s, row0), frow(a.dst, s, row0), D, TROWS, s >= a.split ? a.gb : a.ga,
+                           s >= a.split ? a.bb : a.ba, st, t);
 }
 
-// ---- Q = HH W2^T + b2 -----------------------------------------------------------------------------------
+// backward, one workgroup per sequence walking its row blocks (the gamma / beta partial of the sequence is
+// accumulated across the blocks); dst may alias dy
+struct TlLnBwdArgs {
+    Fld dy, xin, st, dst;
+    const float* gamma;
+    float* small;                      // per-sequence partial record
+    long long small_stride;
+    int dgb_off;
+    int rpb;
+};
+template <int D>
+__global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
+    float* red = reinterpret_cast<float*>(dtqn_smem);
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x;
+    float* dgb = a.small + (size_t)s * a.small_stride + a.dgb_off;
+    for (int rb = 0; rb < a.rpb; ++rb) {
+        const int row0 = rb * TROWS;
+        layernorm_backward<D, TNW>(frow(a.dy, s, row0), frow(a.xin, s, row0), frow(a.dst, s, row0), false, D, TROWS,
+                                   a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2, a.gamma, dgb, red, t, rb > 0);
+        __syncthreads();
+    }
+}
+
+// ---- dst = src where the saved ReLU ballot is set, else 0 (gate backward) ---------------------------------------------
+struct TlMaskArgs {
+    Fld src, dst, mask;
+    int D, rpb;
+};
+__global__ __launch_bounds__(TNT) void tl_mask_kernel(TlMaskArgs a) {
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const float* mrec = a.mask.base + (size_t)s * a.mask.stride;
+    const int c4 = a.D / 4;
+    for (int idx = (int)threadIdx.x; idx < TROWS * c4; idx += TNT) {
+        const int r = row0 + idx / c4, c = (idx % c4) * 4;
+        const float4 v = ld4(frow(a.src, s, r) + c);
+        float4 o;
+        o.x = mask_bit(mrec, a.D / 16, r, c) ? v.x : 0.f;
+        o.y = mask_bit(mrec, a.D / 16, r, c + 1) ? v.y : 0.f;
+        o.z = mask_bit(mrec, a.D / 16, r, c + 2) ? v.z : 0.f;
+        o.w = mask_bit(mrec, a.D / 16, r, c + 3) ? v.w : 0.f;
+        st4(frow(a.dst, s, r) + c, o);
+    }
+}
+
+// ---- Q = HH W2^T + b2 ---------------------------------------------------------------------------------------------------
 struct TlQArgs {
-    const float* hh;                   // [S][lpb][D]
-    const float* W2;
-    const float* b2;
-    float* q;                          // [S][n][A]
-    int D, A, lpb, n, S;
+    Fld hh;
+    const float *W2a, *W2b, *b2a, *b2b;
+    int split;
+    float* q;
+    long long q_seq_stride;
+    int q_row_stride;
+    int D, A, n, S;
 };
 __global__ __launch_bounds__(256) void tl_qhead_kernel(TlQArgs a) {
     const int total = a.S * a.n * a.A;
     for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < total; idx += (int)gridDim.x * 256) {
         const int ac = idx % a.A, r = (idx / a.A) % a.n, s = idx / (a.A * a.n);
-        const float* hrow = a.hh + ((size_t)s * a.lpb + r) * a.D;
-        const float* w = a.W2 + (size_t)ac * a.D;
-        float acc = a.b2[ac];
+        const float* hrow = frow(a.hh, s, r);
+        const float* w = (s >= a.split ? a.W2b : a.W2a) + (size_t)ac * a.D;
+        float acc = (s >= a.split ? a.b2b : a.b2a)[ac];
         for (int k = 0; k < a.D; k += 4) {
             const float4 hv = ld4(hrow + k), wv = ld4(w + k);
             acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
         }
-        a.q[idx] = acc;
+        a.q[(size_t)s * a.q_seq_stride + (size_t)r * a.q_row_stride + ac] = acc;
     }
 }
 
-// ---- host orchestration -------------------------------------------------------------------------------------
-template <int D>
-static int launch_linear(const TlLinearArgs& a, int row_blocks, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * (D + 4) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tl_linear_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((tl_linear_kernel<D>), dim3(row_blocks, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+// ---- TD loss (one workgroup per sampled sequence) and the VALU half of the Q-head backward ----------------------
+struct TlLossArgs {
+    DtqnNet net;
+    const float* q3;
+    float* grd;
+    float* stats_partial;
+    const uint8_t* actions;
+    const float* rewards;
+    const uint8_t* dones;
+    long long act_ep_stride, rew_ep_stride;
+    const int32_t* ep_idx;
+    const int32_t* start;
+    int batch, history;
+    float gamma;
+};
+__global__ __launch_bounds__(256) void tl_loss_kernel(TlLossArgs a) {
+    const DtqnNet& net = a.net;
+    const int b = (int)blockIdx.x, LP = net.lp, AP = net.ap;
+    float* dq = a.grd + (size_t)b * net.grd_stride + net.go_dq;
+    for (int idx = (int)threadIdx.x; idx < LP * AP; idx += 256) dq[idx] = 0.f;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ep = a.ep_idx[b], st0 = a.start[b];
+        const size_t qs = (size_t)LP * AP;
+        td_loss_wave(a.q3 + ((size_t)0 * a.batch + b) * qs, a.q3 + ((size_t)1 * a.batch + b) * qs, a.q3 + ((size_t)2 * a.batch + b) * qs,
+                     AP, net.num_actions, net.ctx_len, LP, a.history, a.gamma, 1.0f / ((float)a.batch * (float)a.history),
+                     a.actions + (size_t)ep * a.act_ep_stride + st0, a.rewards + (size_t)ep * a.rew_ep_stride + st0,
+                     a.dones + (size_t)ep * a.rew_ep_stride + st0, dq, a.stats_partial + (size_t)b * 8, (int)threadIdx.x);
+    }
 }
-template <int D>
-static int launch_ln(const TlLnArgs& a, int row_blocks, hipStream_t stream) {
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((tl_layernorm_kernel<D>), dim3(row_blocks), dim3(TNT), 0, stream, a);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
-}
-template <int HD>
-static int launch_attn(const TlAttnArgs& a, int S, int H, hipStream_t stream) {
-    const size_t lds = (size_t)a.lpb * (3 * HD + 4) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tl_attn_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((tl_attn_kernel<HD>), dim3(S, H), dim3(256), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+// dhh = (dq W2) * [hh > 0]
+struct TlHeadBwdArgs {
+    Fld hh, dq, dhh;
+    const float* W2;
+    int D, A, rpb;
+};
+__global__ __launch_bounds__(TNT) void tl_head_bwd_kernel(TlHeadBwdArgs a) {
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int c4 = a.D / 4;
+    for (int idx = (int)threadIdx.x; idx < TROWS * c4; idx += TNT) {
+        const int r = row0 + idx / c4, c0 = (idx % c4) * 4;
+        const float4 hv4 = ld4(frow(a.hh, s, r) + c0);
+        const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+        const float* dqr = frow(a.dq, s, r);
+        float g4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float g = 0.f;
+            if (hv[e] > 0.f)
+                for (int c = 0; c < a.A; ++c) g = fmaf(dqr[c], a.W2[(size_t)c * a.D + c0 + e], g);
+            g4[e] = g;
+        }
+        st4(frow(a.dhh, s, r) + c0, make_float4(g4[0], g4[1], g4[2], g4[3]));
+    }
 }
 
+// ---- embedding backward: table / action-embedding partials of one sequence ------------------------------------------
+struct TlEmbedBwdArgs {
+    DtqnNet net;
+    const float* theta;
+    const float* grd;
+    float* small;
+    const float* obs;
+    const uint8_t* actions;
+    long long obs_ep_stride, act_ep_stride;
+    const int32_t* ep_idx;
+    const int32_t* start;
+};
+__global__ __launch_bounds__(256) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
+    const DtqnNet& net = a.net;
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int D = net.d_model, L = net.ctx_len, A = net.num_actions, adim = net.action_dim, LP = net.lp;
+    const float* DX = a.grd + (size_t)b * net.grd_stride + net.go_dx0;
+    float* srec = a.small + (size_t)b * net.sp_stride;
+    const int ep = a.ep_idx[b], st0 = a.start[b];
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
+    const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
+    if (net.discrete) {
+        const int KE = net.ke, KEP = net.kep, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim;
+        const float* __restrict__ We = a.theta + net.off_obs_w;
+        float* dein = reinterpret_cast<float*>(dtqn_smem);   // [LP][KEP]: dL/d(gathered table rows) = dx0[:, a:] W_e
+        for (int idx = tid; idx < LP * KEP; idx += 256) {
+            const int r = idx / KEP, k = idx - r * KEP;
+            float g = 0.f;
+            if (r < L && k < KE)
+                for (int d = 0; d < D - adim; ++d) g = fmaf(DX[(size_t)r * D + adim + d], We[(size_t)d * KE + k], g);
+            dein[idx] = g;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < V * e; idx += 256) {
+            const int v = idx / e, c = idx - v * e;
+            float g = 0.f;
+            for (int r = 0; r < L; ++r)
+                for (int j = 0; j < O; ++j) {
+                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+                    if (tok == v) g += dein[r * KEP + j * e + c];
+                }
+            srec[net.so_tab + idx] = g;
+        }
+    }
+    if (adim > 0) {
+        for (int idx = tid; idx < A * adim; idx += 256) {
+            const int v = idx / adim, c = idx - v * adim;
+            float g = 0.f;
+            if (L == 1) {
+                if ((int)act_rows[0] == v) g = DX[c];
+            } else {
+                for (int r = 1; r < L; ++r)
+                    if ((int)act_rows[r - 1] == v) g += DX[(size_t)r * D + c];
+            }
+            srec[net.so_act + idx] = g;
+        }
+    }
+}
+
+// ---- launch helpers --------------------------------------------------------------------------------------------------------
+#define TL_LAUNCH(kernel, grid, block, lds, stream, args)                                                            \
+    do {                                                                                                             \
+        if ((lds) > 0)                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
+        (void)hipGetLastError();                                                                                     \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args);                                                  \
+        if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;                                                 \
+    } while (0)
+
 template <int D>
-static int forward_tiled(const DtqnNet& net, const float* theta, const float* obs, const uint8_t* actions, int S, int n,
-                         float* q_out, float* ws, hipStream_t stream) {
-    const int lpb = net.lp, H = net.num_heads, HD = net.head_dim;
-    const size_t R = (size_t)S * lpb;
-    const int RB = (int)(R / TROWS);
-    float* X = ws;
-    float* U = X + R * D;
-    float* QKV = U + R * D;
-    float* O = QKV + R * 3 * D;
-    float* HID = O + R * D;
+static int launch_linear(const TlLinearArgs& a, int S, hipStream_t stream) {
+    const size_t lds = (size_t)TROWS * (D + 4) * sizeof(float);
+    TL_LAUNCH((tl_linear_kernel<D>), dim3(S * a.rpb, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
+template <int KC>
+static int launch_dx(const TlDxArgs& a, int S, hipStream_t stream) {
+    const size_t lds = (size_t)TROWS * (KC + 4) * sizeof(float);
+    TL_LAUNCH((tl_dx_kernel<KC>), dim3(S * a.rpb, (a.KOUT + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
+template <int D>
+static int launch_ln(const TlLnArgs& a, int S, hipStream_t stream) {
+    TL_LAUNCH((tl_layernorm_kernel<D>), dim3(S * a.rpb), dim3(TNT), 0, stream, a);
+    return DTQN_OK;
+}
+template <int D>
+static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
+    constexpr int PARTS = TNT / D >= 1 ? TNT / D : 1;
+    const size_t lds = (size_t)PARTS * 2 * D * sizeof(float);
+    TL_LAUNCH((tl_layernorm_bwd_kernel<D>), dim3(S), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
+static int launch_attn(const TlAttnArgs& a, int S, int H, int HD, hipStream_t stream) {
+    const size_t lds = (size_t)a.lpb * (3 * HD + 4) * sizeof(float);
+    if (HD == 8) TL_LAUNCH((tl_attn_kernel<8>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32>), dim3(S, H), dim3(256), lds, stream, a);
+    else return DTQN_ERR_CONFIG;
+    return DTQN_OK;
+}
+static int launch_attn_bwd(const TlAttnBwdArgs& a, int S, int H, int HD, hipStream_t stream) {
+    const size_t lds = ((size_t)a.lpb * (4 * HD + 4) + 2 * (size_t)a.lpb) * sizeof(float);
+    if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32>), dim3(S, H), dim3(256), lds, stream, a);
+    else return DTQN_ERR_CONFIG;
+    return DTQN_OK;
+}
+
+// Where the forward keeps its tensors.  Training: the DtqnNet activation record (every layer saved).
+// Inference: the same per-layer fields but ONE layer region reused by every layer, followed by xf | hh.
+struct RecMap {
+    long long stride;
+    int layer_stride;
+    int xf, hh;
+};
+static RecMap rec_map(const DtqnNet& net, bool training) {
+    RecMap m;
+    if (training) {
+        m.stride = net.act_stride; m.layer_stride = net.act_layer_stride; m.xf = net.ao_xf; m.hh = net.ao_hh;
+    } else {
+        m.layer_stride = 0;
+        m.xf = net.ao_layer0 + net.act_layer_stride;
+        m.hh = m.xf + net.lp * net.d_model;
+        m.stride = m.hh + net.lp * net.d_model;
+    }
+    return m;
+}
+
+struct EmbedSrc {
+    const float* obs;
+    const uint8_t* actions;
+    long long obs_ep_stride, act_ep_stride;
+    const int32_t* ep_idx;
+    const int32_t* start;
+    int batch;
+};
+
+// All S sequences through the network.  theta_a serves sequences [0, split), theta_b the rest.
+template <int D>
+static int forward_records(const DtqnNet& net, const float* theta_a, const float* theta_b, int split, const EmbedSrc& src,
+                           int S, int n, float* rec, bool training, float* q_out, long long q_seq_stride, int q_row_stride,
+                           hipStream_t stream) {
+    const int lpb = net.lp, H = net.num_heads, HD = net.head_dim, rpb = lpb / TROWS;
+    const RecMap rm = rec_map(net, training);
+    const bool ident = net.identity != 0;
     int rc;
+    auto F = [&](int off, int ld) { return fld(rec, rm.stride, off, ld); };
+    auto L0 = [&](int l) { return net.ao_layer0 + l * rm.layer_stride; };
     {
         TlEmbedArgs e;
-        e.c.net = net; e.c.S = S; e.c.n = n; e.c.lpb = lpb;
-        e.theta = theta; e.obs = obs; e.actions = actions; e.X = X;
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(tl_embed_kernel, dim3(RB), dim3(TNT), 0, stream, e);
-        if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;
+        e.net = net; e.theta_a = theta_a; e.theta_b = theta_b; e.split = split;
+        e.obs = src.obs; e.actions = src.actions; e.obs_ep_stride = src.obs_ep_stride; e.act_ep_stride = src.act_ep_stride;
+        e.ep_idx = src.ep_idx; e.start = src.start; e.batch = src.batch;
+        e.n = n; e.rpb = rpb;
+        e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
+        e.ein = training ? F(net.ao_ein, net.kep) : nofld();
+        TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), 0, stream, e);
     }
-    const bool ident = net.identity != 0;
+    auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
+        TlLinearArgs a;
+        a.in = in; a.out = out; a.res = res; a.mask = mask;
+        a.Wa = theta_a + w_off; a.Wb = theta_b + w_off; a.ba = theta_a + b_off; a.bb = theta_b + b_off;
+        a.split = split; a.K = K; a.N = N; a.rpb = rpb; a.mode = mode;
+        return launch_linear<D>(a, S, stream);
+    };
+    auto lnorm = [&](Fld s_, Fld d_, Fld st, int w_off, int b_off) {
+        TlLnArgs a;
+        a.src = s_; a.dst = d_; a.st = st;
+        a.ga = theta_a + w_off; a.gb = theta_b + w_off; a.ba = theta_a + b_off; a.bb = theta_b + b_off;
+        a.split = split; a.rpb = rpb;
+        return launch_ln<D>(a, S, stream);
+    };
     for (int l = 0; l < net.num_layers; ++l) {
-        const float* th = theta + net.off_layer0 + (size_t)l * net.layer_stride;
-        const float* src = X;
-        if (ident) {
-            TlLnArgs ln{X, U, th + net.lo_ln1_w, th + net.lo_ln1_b};
-            if ((rc = launch_ln<D>(ln, RB, stream)) != DTQN_OK) return rc;
-            src = U;
+        const int tb = net.off_layer0 + l * net.layer_stride, ab = L0(l);
+        const bool last = l + 1 == net.num_layers;
+        const Fld u1 = F(ab + net.al_u1, D), s1 = F(ab + net.al_s1, D), u2 = F(ab + net.al_u2, D), s2 = F(ab + net.al_s2, D);
+        const Fld st1 = training ? F(ab + net.al_st1, 2) : nofld(), st2 = training ? F(ab + net.al_st2, 2) : nofld();
+        // the residual stream entering the layer: post-LN keeps it in u1 itself; identity in x0 / the previous s2
+        const Fld stream_in = !ident ? u1 : (l == 0 ? F(net.ao_x0, D) : F(L0(l - 1) + net.al_s2, D));
+        if (ident && (rc = lnorm(stream_in, u1, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b)) != DTQN_OK) return rc;
+        if ((rc = linear(u1, D, 3 * D, tb + net.lo_in_w, tb + net.lo_in_b, F(ab + net.al_qkv, 3 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
+        {
+            TlAttnArgs at;
+            at.qkv = F(ab + net.al_qkv, 3 * D); at.o = F(ab + net.al_o, D);
+            at.lse = training ? F(ab + net.al_lse, lpb) : nofld();
+            at.D = D; at.lpb = lpb; at.n = n;
+            if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
-        TlLinearArgs qkv{src, D, th + net.lo_in_w, D, 3 * D, th + net.lo_in_b, QKV, 3 * D, 0};
-        if ((rc = launch_linear<D>(qkv, RB, stream)) != DTQN_OK) return rc;
-        TlAttnArgs at{QKV, O, D, lpb, n};
-        if (HD == 8) rc = launch_attn<8>(at, S, H, stream);
-        else if (HD == 16) rc = launch_attn<16>(at, S, H, stream);
-        else if (HD == 32) rc = launch_attn<32>(at, S, H, stream);
-        else rc = DTQN_ERR_CONFIG;
+        // s1 = stream + relu(o W_o^T + b)
+        if ((rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, s1, 2, stream_in,
+                         training ? F(ab + net.al_m1, 0) : nofld())) != DTQN_OK) return rc;
+        if (!ident) rc = lnorm(s1, u2, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b);
+        else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
         if (rc != DTQN_OK) return rc;
-        TlLinearArgs outp{O, D, th + net.lo_out_w, D, D, th + net.lo_out_b, X, D, 2};          // x += relu(o W_o^T + b)
-        if ((rc = launch_linear<D>(outp, RB, stream)) != DTQN_OK) return rc;
+        if ((rc = linear(u2, D, 4 * D, tb + net.lo_f1_w, tb + net.lo_f1_b, F(ab + net.al_h, 4 * D), 1, nofld(),
+                         training ? F(ab + net.al_mh, 0) : nofld())) != DTQN_OK) return rc;
+        // s2 = (post-LN: u2 | identity: s1) + relu(h W_2^T + b)
+        if ((rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, s2, 2, ident ? s1 : u2,
+                         training ? F(ab + net.al_m2, 0) : nofld())) != DTQN_OK) return rc;
         if (!ident) {
-            TlLnArgs ln{X, X, th + net.lo_ln1_w, th + net.lo_ln1_b};
-            if ((rc = launch_ln<D>(ln, RB, stream)) != DTQN_OK) return rc;
-            src = X;
-        } else {
-            TlLnArgs ln{X, U, th + net.lo_ln2_w, th + net.lo_ln2_b};
-            if ((rc = launch_ln<D>(ln, RB, stream)) != DTQN_OK) return rc;
-            src = U;
-        }
-        TlLinearArgs f1{src, D, th + net.lo_f1_w, D, 4 * D, th + net.lo_f1_b, HID, 4 * D, 1};
-        if ((rc = launch_linear<D>(f1, RB, stream)) != DTQN_OK) return rc;
-        TlLinearArgs f2{HID, 4 * D, th + net.lo_f2_w, 4 * D, D, th + net.lo_f2_b, X, D, 2};
-        if ((rc = launch_linear<D>(f2, RB, stream)) != DTQN_OK) return rc;
-        if (!ident) {
-            TlLnArgs ln{X, X, th + net.lo_ln2_w, th + net.lo_ln2_b};
-            if ((rc = launch_ln<D>(ln, RB, stream)) != DTQN_OK) return rc;
+            const Fld nxt = last ? F(rm.xf, D) : F(L0(l + 1) + net.al_u1, D);
+            if ((rc = lnorm(s2, nxt, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b)) != DTQN_OK) return rc;
         }
     }
-    TlLinearArgs h1{X, D, theta + net.off_head1_w, D, D, theta + net.off_head1_b, U, D, 1};
-    if ((rc = launch_linear<D>(h1, RB, stream)) != DTQN_OK) return rc;
-    TlQArgs qa{U, theta + net.off_head2_w, theta + net.off_head2_b, q_out, D, net.num_actions, lpb, n, S};
+    const Fld xf = ident ? F(L0(net.num_layers - 1) + net.al_s2, D) : F(rm.xf, D);
+    if ((rc = linear(xf, D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
+    TlQArgs qa;
+    qa.hh = F(rm.hh, D);
+    qa.W2a = theta_a + net.off_head2_w; qa.W2b = theta_b + net.off_head2_w;
+    qa.b2a = theta_a + net.off_head2_b; qa.b2b = theta_b + net.off_head2_b;
+    qa.split = split; qa.q = q_out; qa.q_seq_stride = q_seq_stride; qa.q_row_stride = q_row_stride;
+    qa.D = D; qa.A = net.num_actions; qa.n = n; qa.S = S;
     const int total = S * n * net.num_actions;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(tl_qhead_kernel, dim3((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), dim3(256), 0, stream, qa);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+    TL_LAUNCH(tl_qhead_kernel, dim3((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), dim3(256), 0, stream, qa);
+    return DTQN_OK;
+}
+
+// Data-gradient chain of the B TRAIN sequences (records [0, B) of td->act), post-LN / residual gate.
+// The gradient of the residual stream lives in grd.go_dx0 throughout (it IS dL/dx0 at the end).
+template <int D>
+static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const DtqnTd& td, hipStream_t stream) {
+    constexpr int KC = D < 128 ? D : 128;
+    const int lpb = net.lp, H = net.num_heads, HD = net.head_dim, rpb = lpb / TROWS, B = td.batch, L = net.ctx_len;
+    const float* theta = td.theta_pol;
+    float* act = td.act;
+    float* grd = td.grd;
+    int rc;
+    auto FA = [&](int off, int ld) { return fld(act, net.act_stride, off, ld); };
+    auto FG = [&](int off, int ld) { return fld(grd, net.grd_stride, off, ld); };
+    const long long obs_ep_stride = (long long)(rp.max_steps + 1) * rp.obs_dim, act_ep_stride = rp.max_steps + 1;
+    {
+        TlLossArgs a;
+        a.net = net; a.q3 = td.q3; a.grd = grd; a.stats_partial = td.stats_partial;
+        a.actions = rp.actions; a.rewards = rp.rewards; a.dones = rp.dones;
+        a.act_ep_stride = act_ep_stride; a.rew_ep_stride = rp.max_steps;
+        a.ep_idx = td.ep_idx; a.start = td.start; a.batch = B; a.history = td.history; a.gamma = td.gamma;
+        TL_LAUNCH(tl_loss_kernel, dim3(B), dim3(256), 0, stream, a);
+    }
+    {
+        TlHeadBwdArgs a;
+        a.hh = FA(net.ao_hh, D); a.dq = FG(net.go_dq, net.ap); a.dhh = FG(net.go_dhh, D);
+        a.W2 = theta + net.off_head2_w; a.D = D; a.A = net.num_actions; a.rpb = rpb;
+        TL_LAUNCH(tl_head_bwd_kernel, dim3(B * rpb), dim3(TNT), 0, stream, a);
+    }
+    const Fld G = FG(net.go_dx0, D);
+    auto dx = [&](Fld dy, int N, int w_off, int KOUT, Fld out, int mode, Fld mask) {
+        TlDxArgs a;
+        a.dy = dy; a.out = out; a.mask = mask; a.W = theta + w_off; a.N = N; a.KOUT = KOUT; a.rpb = rpb; a.mode = mode;
+        return launch_dx<KC>(a, B, stream);
+    };
+    auto ln_bwd = [&](Fld xin, Fld st, int gamma_off, int dgb_off) {
+        TlLnBwdArgs a;
+        a.dy = G; a.xin = xin; a.st = st; a.dst = G; a.gamma = theta + gamma_off;
+        a.small = td.small; a.small_stride = net.sp_stride; a.dgb_off = dgb_off; a.rpb = rpb;
+        return launch_ln_bwd<D>(a, B, stream);
+    };
+    auto mask = [&](Fld m, Fld dst) {
+        TlMaskArgs a;
+        a.src = G; a.dst = dst; a.mask = m; a.D = D; a.rpb = rpb;
+        TL_LAUNCH(tl_mask_kernel, dim3(B * rpb), dim3(TNT), 0, stream, a);
+        return DTQN_OK;
+    };
+    if ((rc = dx(FG(net.go_dhh, D), D, net.off_head1_w, D, G, 0, nofld())) != DTQN_OK) return rc;       // dL/dxf
+    for (int l = net.num_layers - 1; l >= 0; --l) {
+        const int tb = net.off_layer0 + l * net.layer_stride;
+        const int ab = net.ao_layer0 + l * net.act_layer_stride, gb = net.go_layer0 + l * net.grd_layer_stride;
+        const int sm = net.so_ln + l * 4 * D;
+        // x_out = LN2(s2)
+        if ((rc = ln_bwd(FA(ab + net.al_s2, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D)) != DTQN_OK) return rc;
+        // s2 = u2 + relu(f):  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  du2 = ds2 + dh' W1
+        if ((rc = mask(FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
+        if ((rc = dx(FG(gb + net.gl_df, D), D, tb + net.lo_f2_w, 4 * D, FG(gb + net.gl_dhp, 4 * D), 1, FA(ab + net.al_mh, 0))) != DTQN_OK) return rc;
+        if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+        // u2 = LN1(s1)
+        if ((rc = ln_bwd(FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm)) != DTQN_OK) return rc;
+        // s1 = x + relu(a):  da = ds1 * [a > 0];  dO = da W_o;  attention backward;  dx = ds1 + dqkv W_in
+        if ((rc = mask(FA(ab + net.al_m1, 0), FG(gb + net.gl_da, D))) != DTQN_OK) return rc;
+        if ((rc = dx(FG(gb + net.gl_da, D), D, tb + net.lo_out_w, D, FG(net.go_do, D), 0, nofld())) != DTQN_OK) return rc;
+        {
+            TlAttnBwdArgs a;
+            a.qkv = FA(ab + net.al_qkv, 3 * D); a.o = FA(ab + net.al_o, D); a.lse = FA(ab + net.al_lse, lpb);
+            a.dO = FG(net.go_do, D); a.dqkv = FG(gb + net.gl_dqkv, 3 * D);
+            a.D = D; a.lpb = lpb; a.n = L;
+            if ((rc = launch_attn_bwd(a, B, H, HD, stream)) != DTQN_OK) return rc;
+        }
+        if ((rc = dx(FG(gb + net.gl_dqkv, 3 * D), 3 * D, tb + net.lo_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+    }
+    if (net.discrete || net.action_dim > 0) {
+        TlEmbedBwdArgs a;
+        a.net = net; a.theta = theta; a.grd = grd; a.small = td.small;
+        a.obs = rp.obs; a.actions = rp.actions; a.obs_ep_stride = obs_ep_stride; a.act_ep_stride = act_ep_stride;
+        a.ep_idx = td.ep_idx; a.start = td.start;
+        const size_t lds = net.discrete ? (size_t)lpb * net.kep * sizeof(float) : 0;
+        if (lds > 150 * 1024) return DTQN_ERR_CONFIG;
+        TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(256), lds, stream, a);
+    }
+    return DTQN_OK;
+}
+
+int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream) {
+    if (net->identity || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;     // training coverage of the tiled path
+    EmbedSrc src;
+    src.obs = rp->obs; src.actions = rp->actions;
+    src.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim; src.act_ep_stride = rp->max_steps + 1;
+    src.ep_idx = td->ep_idx; src.start = td->start; src.batch = td->batch;
+    const int S = 3 * td->batch;
+    const long long qs = (long long)net->lp * net->ap;
+#define DTQN_TL_CASE(d) \
+    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, 2 * td->batch, src, S, net->ctx_len, td->act, true, td->q3, qs, net->ap, stream);
+    switch (net->d_model) {
+        DTQN_TL_CASE(64)
+        DTQN_TL_CASE(128)
+        DTQN_TL_CASE(256)
+        default: return DTQN_ERR_CONFIG;
+    }
+#undef DTQN_TL_CASE
+}
+
+int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream) {
+    if (net->identity || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
+    switch (net->d_model) {
+        case 64: return backward_records<64>(*net, *rp, *td, stream);
+        case 128: return backward_records<128>(*net, *rp, *td, stream);
+        case 256: return backward_records<256>(*net, *rp, *td, stream);
+        default: return DTQN_ERR_CONFIG;
+    }
 }
 
 }  // namespace dtqn
@@ -278,8 +780,7 @@ using namespace dtqn;
 
 extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
-    const long long R = (long long)batch * net->lp;
-    const long long fl = R * net->d_model * 10;       // X, U, QKV (3), O, HID (4)
+    const long long fl = (long long)batch * rec_map(*net, false).stride;
     return fl < 0x7fffffffLL ? (int)fl : 0;
 }
 
@@ -290,10 +791,15 @@ extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const 
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
     if (!net->tiled || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
     hipStream_t s = (hipStream_t)stream;
+    EmbedSrc src;
+    src.obs = obs; src.actions = actions;
+    src.obs_ep_stride = (long long)n * net->obs_dim; src.act_ep_stride = n;
+    src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
+    const long long qs = (long long)n * net->num_actions;
     switch (net->d_model) {
-        case 64: return forward_tiled<64>(*net, theta, obs, actions, batch, n, q_out, workspace, s);
-        case 128: return forward_tiled<128>(*net, theta, obs, actions, batch, n, q_out, workspace, s);
-        case 256: return forward_tiled<256>(*net, theta, obs, actions, batch, n, q_out, workspace, s);
+        case 64: return forward_records<64>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
+        case 128: return forward_records<128>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
+        case 256: return forward_records<256>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
         default: return DTQN_ERR_CONFIG;
     }
 }

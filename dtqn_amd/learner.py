@@ -89,7 +89,9 @@ class TdEngine:
             n_split = max(1, min(Bn, 16))
         self.n_split = int(n_split)
         self.n_norm_blocks = (nt + OPT_BLOCK_ELEMS - 1) // OPT_BLOCK_ELEMS
-        self.act = torch.zeros(Bn * net.act_stride, **f32)
+        # the tiled path keeps the records of all three forwards (policy(o), policy(o'), target(o')); the
+        # whole-sequence kernels only save the training forward's
+        self.act = torch.zeros((3 if net.tiled else 1) * Bn * net.act_stride, **f32)
         self.grd = torch.zeros(Bn * net.grd_stride, **f32)
         self.small = torch.zeros(Bn * net.sp_stride, **f32)
         self.q3 = torch.zeros(3 * Bn * net.lp * net.ap, **f32)

@@ -100,7 +100,7 @@ typedef struct DtqnNet {
     int32_t go_dx0, go_layer0, grd_layer_stride, go_dhh, go_dq;
     int32_t gl_dqkv, gl_da, gl_dhp, gl_df;
     int32_t gl_gate1, gl_gate2;   /* GRU: d z_pre, d r_pre, d h_pre, each [LP][D] */
-    int32_t go_gstream, go_do;    /* tiled path only: dL/d(stream) and dL/d(attention output) scratch, each [LP][D] */
+    int32_t go_do;                /* tiled path only: dL/d(attention output) scratch [LP][D] */
     /* ---- derived: per-sequence small partials (LayerNorm affine, embedding tables) ---- */
     int32_t sp_stride;
     int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */

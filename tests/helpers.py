@@ -112,7 +112,7 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         # engine's own activation pattern (read from its saved activations) and argmax choices, and
         # the number / size of the disagreements is bounded separately.
         q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :A].copy()
-        act = eng.act.cpu().numpy().reshape(Bn, net.act_stride)
+        act = eng.act.cpu().numpy()[:Bn * net.act_stride].reshape(Bn, net.act_stride)
         D = cfg.inner_embed_size
         fld = lambda off, w: torch.from_numpy(act[:, off:off + net.lp * w].reshape(Bn, net.lp, w)[:, :L].copy() > 0)
 

@@ -40,3 +40,24 @@ def test_td_update_cfg1_size(emu):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=4, T=200, n_eps=8, mask=-5)
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+TILED = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=70, action_dim=4, pos="sin"),
+     dict(batch=2, T=90, mask=-5, history=9, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=2, num_layers=1, history_len=12, discrete=True, vocab_sizes=9, action_dim=8),
+     dict(batch=3, T=20, mask=8)),
+]
+
+
+@pytest.mark.parametrize("kw,run", TILED)
+def test_td_update_tiled_path(emu, kw, run, monkeypatch):
+    """The row-block tiled training path (BASELINE configs 4 / 5) forced on small shapes: same checks as the
+    whole-sequence kernels (Q x3, conditional gradients, statistics, Adam step, target sync)."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=33, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    assert net.tiled == 1 and net.lp % 64 == 0
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
