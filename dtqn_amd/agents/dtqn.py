@@ -113,6 +113,7 @@ class DtqnAgent:
         self._ctx_obs_d = torch.zeros(L, O, device=self.device)
         self._ctx_act_d = torch.zeros(L, dtype=torch.uint8, device=self.device)
         self._q_d = torch.zeros(L, A, device=self.device)
+        self._actor_ws = None
         self._q_h = pin(torch.zeros(A))
         # pipelined mode (begin_action / train / finish_action): the actor forward of step t+1 runs on its own
         # stream CONCURRENTLY with TD update t+1; it reads the weights produced by update t, and update t+1's
@@ -146,9 +147,18 @@ class DtqnAgent:
         self._ctx_obs_d[:n].copy_(self._ctx_obs_h[:n], non_blocking=True)
         self._ctx_act_d[:n].copy_(self._ctx_act_h[:n], non_blocking=True)
         eng = self.engine
-        rc = eng.lib.dtqn_forward(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
-                                  ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
-                                  1, n, ctypes.c_void_p(self._q_d.data_ptr()), stream_ptr)
+        if eng.net.tiled:       # long contexts / wide models: row-block tiled kernels over a private workspace
+            if self._actor_ws is None:
+                need = eng.lib.dtqn_forward_workspace_floats(ctypes.byref(eng.net), 1)
+                self._actor_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            rc = eng.lib.dtqn_forward_tiled(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
+                                            ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
+                                            1, n, ctypes.c_void_p(self._q_d.data_ptr()), ctypes.c_void_p(self._actor_ws.data_ptr()),
+                                            stream_ptr)
+        else:
+            rc = eng.lib.dtqn_forward(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
+                                      ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
+                                      1, n, ctypes.c_void_p(self._q_d.data_ptr()), stream_ptr)
         if rc != 0:
             raise RuntimeError(f"dtqn_forward failed with DTQN status {rc}")
         self._q_h.copy_(self._q_d[n - 1], non_blocking=True)         # Q of the LAST timestep

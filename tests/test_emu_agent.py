@@ -118,6 +118,29 @@ def test_train_loop_statistics_and_target_sync(emu):
     assert torch.equal(agent.target_network.flat, agent.policy_network.flat)
 
 
+def test_agent_on_the_tiled_path(emu, monkeypatch):
+    """Acting and training through the row-block tiled kernels (forced on a small width) behind the agent surface."""
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import Constant
+    from dtqn_amd.utils.random import set_global_seed
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    env = envs.make("DiscreteCarFlag-v0")
+    set_global_seed(2, env)
+    agent = make_agent(emu, env, batch=2, L=8, D=64, H=8, tuf=2)
+    assert agent.policy_network.net.tiled == 1
+    runpy.prepopulate(agent, 600, [env])
+    theta0 = agent.policy_network.flat.clone()
+    agent.context_reset(env.reset())
+    for _ in range(3):
+        if runpy.step(agent, env, Constant(0.3)):
+            agent.replay_buffer.flush(); agent.context_reset(env.reset())
+        agent.train()
+    assert agent.num_train_steps == 3 and np.isfinite(agent.td_errors.mean())
+    assert not torch.equal(theta0, agent.policy_network.flat)
+    assert not torch.equal(agent.target_network.flat, theta0)          # tuf = 2: the target was synced after update 2
+
+
 def test_overlapped_step_matches_serial_step(emu):
     """begin_action / train / finish_action (two-stream pipeline on the GPU) chooses the same actions and
     reaches the same parameters as get_action + train when no episode boundary falls inside the window

@@ -90,3 +90,28 @@ def test_gru_agent_trains():
         agent.train()
     assert np.isfinite(agent.td_errors.mean()) and not torch.equal(theta0, agent.policy_network.flat)
     assert "transformer_layers.1.mlp_gate.u_g.weight" in agent.policy_network.state_dict()
+
+
+def test_long_context_agent_runs_on_the_tiled_path():
+    """context 128 / width 128 (BASELINE config-4 class): acting and training both go through the row-block tiled
+    kernels behind the same agent surface."""
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.agent_utils import get_agent
+    from dtqn_amd.utils.epsilon_anneal import Constant
+    from dtqn_amd.utils.random import set_global_seed
+    env = envs.make("DiscreteCarFlag-v0")           # 200-step episodes: windows of 128 fit
+    set_global_seed(6, env)
+    agent = get_agent("DTQN", [env], 8, 0, 128, 20_000, torch.device("cuda"), 3e-4, 8, 128, -1, 128, 1000, 0.99, 8, 2, 0.0,
+                      False, "res", "learned", 0)
+    assert agent.policy_network.net.tiled == 1
+    runpy.prepopulate(agent, 4000, [env])
+    theta0 = agent.policy_network.flat.clone()
+    agent.context_reset(env.reset())
+    for _ in range(6):
+        if runpy.step(agent, env, Constant(0.2)):
+            agent.replay_buffer.flush(); agent.context_reset(env.reset())
+        agent.train()
+    assert agent.num_train_steps == 6
+    assert np.isfinite(agent.td_errors.mean()) and np.isfinite(agent.grad_norms.mean())
+    assert not torch.equal(theta0, agent.policy_network.flat)
