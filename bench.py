@@ -33,15 +33,43 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: dense f32-input MFMA peak
 
 
+# BASELINE.json `configs` as shapes.  B = per-GPU batch.  Config 1 is the one the
+# metric is quoted on; 2-5 are reported as extra lines ("other_configs") and drive the parity tests.
+CONFIGS = {
+    1: dict(name="DiscreteCarFlag-v0", kind="box", O=3, A=3, T=200, L=50, D=64, H=8, NL=2, B=32),
+    2: dict(name="DiscreteCarFlag-v0", kind="box", O=3, A=3, T=200, L=50, D=64, H=8, NL=2, B=256),
+    3: dict(name="Memory-5-v0 shapes", kind="multidiscrete", nvec=7, O=10, A=10, T=50, L=50, D=128, H=8, NL=2, B=512),
+    4: dict(name="gv_memory.7x7 shapes", kind="multidiscrete", nvec=10, O=6, A=6, T=250, L=128, D=128, H=8, NL=2, B=128),
+    5: dict(name="POMDP-hallway shapes", kind="discrete", nvec=21, O=1, A=5, T=256, L=256, D=256, H=8, NL=2, B=32),
+}
+
+
 def cfg1_shapes():
-    return dict(O=3, A=3, T=200, L=50, D=64, H=8, NL=2)
+    return CONFIGS[1]
+
+
+class SyntheticEnv:
+    """Spaces + episode limit of a BASELINE config whose simulator is not available (gridverse, gym-pomdps): only
+    what get_agent() introspects.  Never stepped."""
+
+    def __init__(self, c):
+        from dtqn_amd.envs import spaces
+        if c["kind"] == "box":
+            self.observation_space = spaces.Box(low=-1.1, high=1.1, shape=(c["O"],), dtype=np.float32)
+        elif c["kind"] == "multidiscrete":
+            self.observation_space = spaces.MultiDiscrete([c["nvec"]] * c["O"])
+        else:
+            self.observation_space = spaces.Discrete(c["nvec"])
+        self.action_space = spaces.Discrete(c["A"])
+        self._max_episode_steps = c["T"]
 
 
 def f_tok(c):
     """Algorithmic forward FLOPs per token: embed + NL*(in-proj, out-proj, FFN,
     dense attention) + Q head."""
     D, L = c["D"], c["L"]
-    return 2 * c["O"] * D + c["NL"] * (6 * D * D + 2 * D * D + 16 * D * D + 4 * L * D) + 2 * D * D + 2 * D * c["A"]
+    e_in = c["O"] if c["kind"] == "box" else c["O"] * 8
+    return 2 * e_in * D + c["NL"] * (6 * D * D + 2 * D * D + 16 * D * D + 4 * L * D) + 2 * D * D + 2 * D * c["A"]
 
 
 def fill_synthetic_replay(agent, seed: int, c) -> None:
@@ -51,7 +79,10 @@ def fill_synthetic_replay(agent, seed: int, c) -> None:
     E, T, O = rb.max_size, c["T"], c["O"]
     rng = np.random.Generator(np.random.PCG64(seed))
     lens = rng.integers(5, T + 1, size=E)
-    obs = rng.uniform(-1, 1, size=(E, T + 1, O)).astype(np.float32)
+    if c["kind"] == "box":
+        obs = rng.uniform(-1, 1, size=(E, T + 1, O)).astype(np.float32)
+    else:
+        obs = rng.integers(0, c["nvec"], size=(E, T + 1, O)).astype(np.float32)      # tokens, stored as f32 on the device
     act = rng.integers(0, c["A"], size=(E, T + 1)).astype(np.uint8)
     rew = rng.choice(np.array([0, 0, 0, 1, -1], dtype=np.float32), size=(E, T))
     done = np.ones((E, T), dtype=np.uint8)
@@ -149,6 +180,44 @@ def cpu_baseline(c, batch: int, budget_s: float = 15.0) -> dict:
                       f"on a {avail}-core host"}
 
 
+def make_agent(c, batch, device, rank, sampler):
+    env = dt_envs.make("DiscreteCarFlag-v0") if c["kind"] == "box" else SyntheticEnv(c)
+    from dtqn_amd.utils.random import set_global_seed
+    if c["kind"] == "box":
+        set_global_seed(1 + rank, env)
+    agent = get_agent("DTQN", [env], 8, 0, c["D"], 500_000, device, 3e-4, batch, c["L"], c["T"], c["L"], 10_000, 0.99,
+                      c["H"], c["NL"], 0.0, False, "res", "learned", 0, sampler=sampler, sample_seed=1 + rank)
+    fill_synthetic_replay(agent, seed=1 + rank, c=c)
+    return agent
+
+
+def other_configs(device, steps: int = 60) -> dict:
+    """BASELINE configs 2-5 at their per-GPU batch on this GPU: TD-updates/s and the achieved algorithmic
+    FP32 FLOP rate of the whole update (5 * B * L * F_tok) against the MFMA peak."""
+    out = {}
+    for cid in (2, 3, 4, 5):
+        c = CONFIGS[cid]
+        agent = make_agent(c, c["B"], device, 0, "device")
+        for _ in range(10):
+            agent.train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            agent.train()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        agent._drain_stats(block=True)
+        gflop = 5 * c["B"] * c["L"] * f_tok(c) / 1e9
+        out[f"config{cid}"] = {"workload": f"{c['name']}: ctx={c['L']}, d_model={c['D']}, {c['H']} heads, {c['NL']} layers, batch {c['B']}",
+                               "td_updates_per_s": 1.0 / dt, "ms_per_update": dt * 1e3, "samples_per_s": c["B"] / dt,
+                               "algorithmic_gflop_per_update": gflop, "achieved_tflops": gflop / dt / 1e3,
+                               "frac_of_f32_mfma_peak": gflop / dt / 1e3 / MFMA_F32_PEAK_TFLOPS,
+                               "kernel_path": "row-block tiled" if agent.engine.net.tiled else "whole-sequence (LDS-resident)"}
+        del agent
+        torch.cuda.empty_cache()
+    return out
+
+
 def env_step_rate(agent, seconds: float = 3.0) -> dict:
     """Live actor loop on the host cores: epsilon-greedy get_action (GPU forward of the rolling
     context) + CarFlag step + observe, and the reference's coupled 1 env step : 1 update loop."""
@@ -183,7 +252,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE.json metric: 32)")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs index + 1 (metric: 1)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; BASELINE.json metric: 32)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 2-5")
     ap.add_argument("--sampler", default="device", choices=["device", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-rate", action="store_true", help="skip the live env-steps/s loops (cleaner rocprofv3 traces)")
@@ -194,13 +265,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    c = cfg1_shapes()
-    env = dt_envs.make("DiscreteCarFlag-v0")
-    from dtqn_amd.utils.random import set_global_seed
-    set_global_seed(1 + rank, env)
-    agent = get_agent("DTQN", [env], 8, 0, c["D"], 500_000, device, 3e-4, args.batch, c["L"], -1, c["L"], 10_000, 0.99,
-                      c["H"], c["NL"], 0.0, False, "res", "learned", 0, sampler=args.sampler, sample_seed=1 + rank)
-    fill_synthetic_replay(agent, seed=1 + rank, c=c)
+    c = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = c["B"]
+    agent = make_agent(c, args.batch, device, rank, args.sampler)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -227,6 +295,7 @@ def main():
         ups = world * args.steps / elapsed                     # whole-job TD updates / s (each rank does one per step)
         ft = f_tok(c)
         tokens = args.batch * c["L"]
+        tiled = bool(agent.engine.net.tiled)
         kern = time_kernels(agent)
         dom = max(("dtqn_forward_kernel", "dtqn_backward_kernel"), key=lambda k: kern[k])
         # algorithmic FLOPs per launch: forward kernel = 3 forwards; backward kernel = data-gradient half
@@ -242,8 +311,9 @@ def main():
             "value": ups, "unit": "TD-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic replay (SURVEY.md section 8d shapes), random-init weights",
-            "config": {"workload": "DiscreteCarFlag-v0 shapes: ctx=50, d_model=64, 8 heads, 2 layers, obs 3 f32, 3 actions, "
-                                   f"batch {args.batch} per GPU, history 50, device-resident replay 2500 episodes x 200 steps",
+            "config": {"workload": f"{c['name']} shapes (BASELINE config {args.config}): ctx={c['L']}, d_model={c['D']}, {c['H']} heads, "
+                                   f"{c['NL']} layers, obs {c['O']} {'f32' if c['kind'] == 'box' else 'tokens'}, {c['A']} actions, "
+                                   f"batch {args.batch} per GPU, history {c['L']}, device-resident replay {500_000 // c['T']} episodes x {c['T']} steps",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch),
@@ -253,7 +323,11 @@ def main():
             "kernels_us": kern,
             "algorithmic_gflop_per_update": 5 * tokens * ft / 1e9,
         }
-        if world == 1 and not args.no_env_rate:
+        if tiled:
+            line["roofline"]["kernel"] = dom.replace("_kernel", "") + " stage (row-block tiled: a sequence of tl_* kernels)"
+        if world == 1 and args.config == 1 and not args.no_other_configs:
+            line["other_configs"] = other_configs(device)
+        if world == 1 and c["kind"] == "box" and not args.no_env_rate:
             rates = env_step_rate(agent)
             line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
                                          "coupled_overlapped_two_streams": rates["coupled_1to1_overlapped"],
