@@ -91,12 +91,161 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
     }
 }
 
+// Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each), on the f32
+// matrix core.  Flash-style recomputation from the saved log-sum-exp: P = exp(S - lse), no reductions.
+//   delta_s[h][t] = dO . o was produced by the dO GEMM's epilogue; lse_s[h][t] is staged by the caller.
+//   pass 1, item = (head, 16-row QUERY tile ti), key tiles tj <= ti:
+//       S^T = K Q^T and dP^T = V dO^T come out of the MFMA with lane (i, kq) holding keys s = kq*4 + r of query
+//       t = i, so lse / delta are per-lane scalars and dS^T = P^T (dP^T - delta) is directly the B operand of
+//       dQ^T[c][t] += K^T[c][s] dS^T[s][t]
+//   pass 2, item = (head, 16-row KEY tile tj), query tiles ti >= tj:
+//       S = Q K^T and dP = dO V^T (rows t = kq*4 + r, column s = i); P and dS are the B operands of
+//       dV^T[c][s] += dO^T[c][t] P[t][s] and dK^T[c][s] += Q^T[c][t] dS[t][s]        (in place over k, v at the end)
+// Lane (i, kq) ends up with four consecutive columns c = kq*4.. of output row i: one 16-byte store.
+template <int HD, int NW>
+__device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld, int GW, int LP, int n,
+                                                              const float* delta_s, const float* lse_s, const Thr& t,
+                                                              float* dq_base = nullptr, int dq_ld = 0) {
+    // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
+    // caller cannot afford a fifth LDS tile
+    if (dq_base == nullptr) { dq_base = W5 + 4 * GW; dq_ld = ld; }
+    constexpr int KS = HD / 4, CT = (HD + 15) / 16;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int HG = GW / HD, MT = LP / 16, last_tile = (n - 1) / 16;
+    const float scale = 1.0f / sqrtf((float)HD), scale2 = scale * LOG2E;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int item = t.wave; item < HG * MT; item += NW) {
+        const int h = item % HG, ti = item / HG;
+        const int t0 = ti * 16, trow = t0 + t.i;
+        float* dqp = dq_base + (size_t)trow * dq_ld + h * HD;
+        if (ti > last_tile) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + t.kq * 4 < HD) st4(dqp + ct * 16 + t.kq * 4, z4);
+            continue;
+        }
+        float qf[KS], dof[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = W5[trow * ld + h * HD + t.kq * KS + s] * scale2;
+            dof[s] = W5[trow * ld + 3 * GW + h * HD + t.kq * KS + s];
+        }
+        const float lse2 = lse_s[h * LP + trow] * LOG2E, delta = delta_s[h * LP + trow];
+        f32x4 acc[CT][2];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = zero4(); acc[ct][1] = zero4(); }
+        for (int tj = 0; tj <= ti; ++tj) {
+            const int s0 = tj * 16;
+            const float* kp = W5 + (s0 + t.i) * ld + GW + h * HD + t.kq * KS;
+            const float* vp = kp + GW;
+            f32x4 st = zero4(), dp = zero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                st = mfma16(kp[s], qf[s], st);
+                dp = mfma16(vp[s], dof[s], dp);
+            }
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = DTQN_EXP2(st[r] - lse2);
+                if (s0 + t.kq * 4 + r > trow) p = 0.f;
+                ds[r] = p * (dp[r] - delta);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = W5 + (s0 + t.kq * 4 + r) * ld + GW + h * HD;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + t.i;
+                    acc[ct][r & 1] = mfma16(krow[c < HD ? c : 0], ds[r], acc[ct][r & 1]);
+                }
+            }
+        }
+        const float f = trow < n ? scale : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + t.kq * 4;
+            if (c < HD)
+                st4(dqp + c, make_float4((acc[ct][0][0] + acc[ct][1][0]) * f, (acc[ct][0][1] + acc[ct][1][1]) * f,
+                                         (acc[ct][0][2] + acc[ct][1][2]) * f, (acc[ct][0][3] + acc[ct][1][3]) * f));
+        }
+    }
+    __syncthreads();
+    for (int item = t.wave; item < HG * MT; item += NW) {
+        const int h = item % HG, tj = item / HG;
+        const int s0 = tj * 16, srow = s0 + t.i;
+        float* kout = W5 + srow * ld + GW + h * HD;
+        float* vout = kout + GW;
+        if (tj > last_tile) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + t.kq * 4 < HD) { st4(kout + ct * 16 + t.kq * 4, z4); st4(vout + ct * 16 + t.kq * 4, z4); }
+            continue;
+        }
+        float kf[KS], vf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = kout[t.kq * KS + s] * scale2;
+            vf[s] = vout[t.kq * KS + s];
+        }
+        f32x4 acck[CT][2], accv[CT][2];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acck[ct][0] = zero4(); acck[ct][1] = zero4(); accv[ct][0] = zero4(); accv[ct][1] = zero4(); }
+        for (int ti = tj; ti <= last_tile; ++ti) {
+            const int t0 = ti * 16;
+            const float* qp = W5 + (t0 + t.i) * ld + h * HD + t.kq * KS;
+            const float* dop = qp + 3 * GW;
+            f32x4 st = zero4(), dp = zero4();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                st = mfma16(qp[s], kf[s], st);
+                dp = mfma16(dop[s], vf[s], dp);
+            }
+            // st[r] = S[t0 + kq*4 + r][s0 + i]
+            const float4 l4 = ld4(lse_s + h * LP + t0 + t.kq * 4), d4 = ld4(delta_s + h * LP + t0 + t.kq * 4);
+            const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
+            float p[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tr = t0 + t.kq * 4 + r;
+                p[r] = DTQN_EXP2(st[r] - lse4[r] * LOG2E);
+                if (srow > tr || tr >= n) p[r] = 0.f;
+                ds[r] = p[r] * (dp[r] - del4[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* qrow = W5 + (t0 + t.kq * 4 + r) * ld + h * HD;
+                const float* dorow = qrow + 3 * GW;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + t.i;
+                    const int cc = c < HD ? c : 0;
+                    acck[ct][r & 1] = mfma16(qrow[cc], ds[r], acck[ct][r & 1]);
+                    accv[ct][r & 1] = mfma16(dorow[cc], p[r], accv[ct][r & 1]);
+                }
+            }
+        }
+        // NOTE: other items of this pass read only q / do / lse / delta, never k or v of another tile
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + t.kq * 4;
+            if (c < HD) {
+                st4(kout + c, make_float4((acck[ct][0][0] + acck[ct][1][0]) * scale, (acck[ct][0][1] + acck[ct][1][1]) * scale,
+                                          (acck[ct][0][2] + acck[ct][1][2]) * scale, (acck[ct][0][3] + acck[ct][1][3]) * scale));
+                st4(vout + c, make_float4(accv[ct][0][0] + accv[ct][1][0], accv[ct][0][1] + accv[ct][1][1],
+                                          accv[ct][0][2] + accv[ct][1][2], accv[ct][0][3] + accv[ct][1][3]));
+            }
+        }
+    }
+}
+
+// VALU version of the same two passes (narrow heads, see attention_forward_valu): one lane per (row, head) item.
 // Attention backward for one head group resident in W5 = [q | k | v | do | dq] (GW columns each).
 //   delta_s[h][t] = dO . o was produced by the dO GEMM's epilogue; lse_s[h][t] is staged by the caller.
 //   pass 1 (item = query row t, head): dS = P*(dP - delta); dq = scale * dS k
 //   pass 2 (item = key row s, head):   dk = scale * dS^T q ; dv = P^T do      (in place over k, v)
 template <int HD, int NW>
-__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
+__device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
                                                          float* dq_base = nullptr, int dq_ld = 0) {
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
@@ -202,6 +351,14 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
             st4(vp + c, make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]));
         }
     }
+}
+
+template <int HD, int NW>
+__device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
+                                                         const float* delta_s, const float* lse_s, const Thr& t,
+                                                         float* dq_base = nullptr, int dq_ld = 0) {
+    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld);
+    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld);
 }
 
 // Double-DQN target, MSE and dL/dQ of ONE sequence, executed by one wave (dtqn/agents/dtqn.py:219-253).

@@ -33,6 +33,31 @@ int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td
 
 // Keep-alive for prefetched registers: forces the compiler to place its s_waitcnt for the loads that
 // produced `x` HERE (the test-only host build defines it away).
+// gfx950 lane-swap instructions on two copies of one register: [0] / [1] = the value held by the lower / upper half
+// (v_permlane32_swap) or the even / odd 16-lane row of the pair (v_permlane16_swap).  VALU-rate cross-lane exchange:
+// no LDS round trip, unlike the ds_bpermute behind __shfl_xor.
+#ifndef DTQN_LANE_SWAP32
+struct LanePair {
+    float v[2];
+    __device__ __forceinline__ float operator[](int k) const { return v[k]; }
+};
+__device__ __forceinline__ LanePair dtqn_lane_swap32(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return LanePair{{__uint_as_float(r[0]), __uint_as_float(r[1])}};
+}
+__device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return LanePair{{__uint_as_float(r[0]), __uint_as_float(r[1])}};
+}
+#define DTQN_LANE_SWAP32(x) dtqn_lane_swap32(x)
+#define DTQN_LANE_SWAP16(x) dtqn_lane_swap16(x)
+#endif
+// 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range reduction code)
+#ifndef DTQN_EXP2
+#define DTQN_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 #ifndef DTQN_ASM_KEEP
 #define DTQN_ASM_KEEP(x) asm volatile("" : "+v"(x))
 #endif
@@ -64,6 +89,19 @@ __device__ __forceinline__ void retire4(float4& v) {
 }
 // ReLU pattern of one accumulator register across the wave -> one 64-bit word of the mask record
 // (index: (row tile, column tile, r)); must be called by every lane of the wave.
+// Reductions over the four lanes {i, i+16, i+32, i+48} that hold one column of an MFMA 16x16 output tile.
+__device__ __forceinline__ float kq_max(float v) {
+    const auto a = DTQN_LANE_SWAP32(v);
+    v = fmaxf(a[0], a[1]);
+    const auto b = DTQN_LANE_SWAP16(v);
+    return fmaxf(b[0], b[1]);
+}
+__device__ __forceinline__ float kq_sum(float v) {
+    const auto a = DTQN_LANE_SWAP32(v);
+    v = a[0] + a[1];
+    const auto b = DTQN_LANE_SWAP16(v);
+    return b[0] + b[1];
+}
 __device__ __forceinline__ void ballot_store(float* mask_rec, int ctiles, int row, int col, bool on, int lane) {
     const unsigned long long bits = __ballot(on ? 1 : 0);
     if (lane == 0) reinterpret_cast<unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)] = bits;
@@ -484,16 +522,144 @@ __device__ __forceinline__ int balanced_block(int wave, int nblocks, int nlive, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Causal multi-head self-attention on a [LP][ld] LDS tile laid out [q | k | v] (3*D columns).
-// Work item = (query row t, head h), h fastest across lanes so a wave's 8 heads x 8 rows read
-// each key row conflict-free and finish within 7 iterations of each other.  The output o[t, h]
-// OVERWRITES q[t, h] (only this item ever reads it).  Online softmax (single pass over keys);
+// Causal multi-head self-attention on a [LP][ld] LDS tile laid out [q | k | v] (blocks D columns apart),
+// on the f32 matrix core.  Work item = (head h, 16-row query tile ti), dealt to the waves head-fastest
+// (H % NW == 0: every wave owns whole heads, so the causal triangle is balanced by construction).
+//   scores are produced TRANSPOSED, S^T[s][t] = K[s,:] . Q[t,:] (A = K tile, B = Q tile): in the MFMA output
+//   layout lane (i, kq) then holds keys s = kq*4 + r of query t = i, so that
+//     * the softmax statistics of query t are a reduction over registers r and lane groups kq (2 shuffles),
+//     * P^T is directly the B operand of O^T[c][t] += V^T[c][s] P^T[s][t] (no LDS round trip, no transpose),
+//     * the running rescale exp(m_old - m_new) of query t applies to this lane's own accumulator column.
+// Online softmax over the key tiles tj <= ti; the output o[t, h] OVERWRITES q[t, h] (only this item reads it);
 // optional log-sum-exp per (h, t) for the backward pass.
 //   torch.nn.MultiheadAttention as called at transformer.py:64-70: q scaled by hd^-0.5, float
 //   additive mask = strictly-upper-triangular -inf  => keys s <= t only.
 // ------------------------------------------------------------------------------------------
+// One chunk of NT (<= 4) consecutive key tiles of one (head, query-tile) item; DIAG: the last tile of the chunk is
+// the diagonal one (keys s > t masked).  Scores live in the log2 domain (q is pre-scaled by hd^-0.5 * log2 e), so
+// every probability is one v_exp_f32.  The NT score tiles are independent MFMA chains and share ONE pair of
+// max / sum reductions across the four lane groups.
+template <int HD, int NT, bool DIAG>
+__device__ __forceinline__ void attention_forward_chunk(const float* kbase, const float* vbase, int ld, int s_first, int trow,
+                                                        const float (&qf)[HD / 4], float& m, float& l,
+                                                        f32x4 (&acc)[(HD + 15) / 16][2], bool rescale, const Thr& t) {
+    constexpr int KS = HD / 4, CT = (HD + 15) / 16;
+    f32x4 st[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        st[u] = zero4();
+        const float* kp = kbase + (s_first + u * 16 + t.i) * ld + t.kq * KS;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) st[u] = mfma16(kp[s], qf[s], st[u]);
+    }
+    // st[u][r] = S^T[s_first + u*16 + kq*4 + r][t]
+    if (DIAG) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (s_first + (NT - 1) * 16 + t.kq * 4 + r > trow) st[NT - 1][r] = -INFINITY;
+    }
+    float tmax = st[0][0];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[u][r]);
+    tmax = kq_max(tmax);
+    const float mn = fmaxf(m, tmax);             // finite: the first key of the chunk is never masked
+    float ps = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[u][r] = DTQN_EXP2(st[u][r] - mn); ps += st[u][r]; }
+    ps = kq_sum(ps);
+    if (rescale) {
+        const float corr = DTQN_EXP2(m - mn);
+        l = l * corr + ps;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[ct][0][e] *= corr; acc[ct][1][e] *= corr; }
+    } else {
+        l = ps;
+    }
+    m = mn;
+    // O^T[c][t] += V^T[c][s] P^T[s][t]: A = V[s][ct*16 + i] (rows c >= HD of O^T are never stored: any in-range
+    // column will do there), B = p
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = vbase + (s_first + u * 16 + t.kq * 4 + r) * ld;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + t.i;
+                acc[ct][r & 1] = mfma16(vp[c < HD ? c : 0], st[u][r], acc[ct][r & 1]);
+            }
+        }
+}
+
 template <int HD, int NW>
-__device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
+__device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D, int H, int LP, int n,
+                                                       float* __restrict__ lse_out, const Thr& t) {
+    constexpr int KS = HD / 4;                  // MFMA steps of the score contraction (4 columns of q/k per step)
+    constexpr int CT = (HD + 15) / 16;          // 16-row tiles of O^T (rows = head columns c)
+    const float scale = 1.4426950408889634f / sqrtf((float)HD);        // hd^-0.5 * log2(e)
+    const int MT = LP / 16;
+    const int last_tile = (n - 1) / 16;         // query tiles beyond it hold only pad rows
+    for (int item = t.wave; item < H * MT; item += NW) {
+        const int h = item % H, ti = item / H;
+        const int t0 = ti * 16, trow = t0 + t.i;
+        float* qbase = Ws + h * HD;
+        if (ti > last_tile) {                   // pad rows: o = 0, lse = 0
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + t.kq * 4;
+                if (c < HD) st4(qbase + trow * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+            if (lse_out != nullptr && t.kq == 0) lse_out[h * LP + trow] = 0.f;
+            continue;
+        }
+        const float* kbase = Ws + D + h * HD;
+        const float* vbase = kbase + D;
+        float qf[KS];                           // B operand: Q[t0 + i][kq*KS + s], pre-scaled
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[s] = qbase[trow * ld + t.kq * KS + s] * scale;
+        f32x4 acc[CT][2];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = zero4(); acc[ct][1] = zero4(); }
+        float m = -INFINITY, l = 0.f;
+        int tc0 = 0;
+        for (; tc0 + 4 <= ti; tc0 += 4)
+            attention_forward_chunk<HD, 4, false>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t);
+        switch (ti - tc0) {                     // the remaining 1..4 tiles end on the diagonal
+            case 0: attention_forward_chunk<HD, 1, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
+            case 1: attention_forward_chunk<HD, 2, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
+            case 2: attention_forward_chunk<HD, 3, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
+            default: attention_forward_chunk<HD, 4, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
+        }
+        // lane (i, kq) holds O^T[c = ct*16 + kq*4 + e][t = t0 + i]: four consecutive output columns of row t
+        const bool live = trow < n;
+        const float inv = live ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + t.kq * 4;
+            if (c < HD)
+                st4(qbase + trow * ld + c, make_float4((acc[ct][0][0] + acc[ct][1][0]) * inv, (acc[ct][0][1] + acc[ct][1][1]) * inv,
+                                                       (acc[ct][0][2] + acc[ct][1][2]) * inv, (acc[ct][0][3] + acc[ct][1][3]) * inv));
+        }
+        if (lse_out != nullptr && t.kq == 0) lse_out[h * LP + trow] = live ? m * 0.6931471805599453f + __logf(l) : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same attention on the VALU: work item = (query row t, head h), h fastest across lanes so a wave's
+// 8 heads x 8 rows read each key row conflict-free and finish within 7 iterations of each other; blocked
+// online softmax.  For head_dim 8 half of every 16-wide MFMA tile of O^T would be padding and the softmax
+// bookkeeping of the 16x16 score tiles costs as many VALU slots as the dot products they replace: measured
+// inside the whole-sequence kernels (cfg 1) this version is 1.5 % faster per update, so narrow heads use it;
+// heads of 16 columns and more use the matrix-core version above (tools/microbench/attn_bench.hip).
+// ------------------------------------------------------------------------------------------
+template <int HD, int NW>
+__device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t) {
     const float scale = 1.0f / sqrtf((float)HD);
     const int nblocks = (LP * H + 63) / 64;
@@ -570,6 +736,15 @@ __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int 
         for (int c = 0; c < HD; c += 4) st4(qp + c, make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv));
         if (lse_out != nullptr) lse_out[h * LP + row] = m + __logf(l);
     }
+}
+
+
+constexpr int kAttnMfmaMinHeadDim = 16;
+template <int HD, int NW>
+__device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
+                                                  float* __restrict__ lse_out, const Thr& t) {
+    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t);
+    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t);
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.

@@ -19,6 +19,7 @@
 
 #define DTQN_HIPEMU 1
 #define DTQN_ASM_KEEP(x) ((void)(x))   /* device-only register keep-alive (dtqn_device.hpp) */
+#define DTQN_EXP2(x) exp2f(x)          /* v_exp_f32 (dtqn_device.hpp) */
 
 // ---- qualifiers -------------------------------------------------------------
 #define __global__
@@ -86,6 +87,25 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
     int l = hipemu::lane_id();
     return hipemu_shfl_from(v, (l & ~(width - 1)) | (src & (width - 1)));
 }
+// gfx950 v_permlane32_swap / v_permlane16_swap applied to two copies of the same register (dtqn_device.hpp):
+// [0] holds the value of the partner-aligned lower half / even row, [1] the upper half / odd row
+struct hipemu_pair { float v[2]; float operator[](int k) const { return v[k]; } };
+static inline hipemu_pair hipemu_lane_swap32(float x) {
+    const int l = hipemu::lane_id();
+    hipemu_pair r;
+    r.v[0] = hipemu_shfl_from(x, l & 31);
+    r.v[1] = hipemu_shfl_from(x, (l & 31) | 32);
+    return r;
+}
+static inline hipemu_pair hipemu_lane_swap16(float x) {
+    const int l = hipemu::lane_id();
+    hipemu_pair r;
+    r.v[0] = hipemu_shfl_from(x, l & ~16);
+    r.v[1] = hipemu_shfl_from(x, l | 16);
+    return r;
+}
+#define DTQN_LANE_SWAP32(x) hipemu_lane_swap32(x)
+#define DTQN_LANE_SWAP16(x) hipemu_lane_swap16(x)
 template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
     int l = hipemu::lane_id();
     int s = l + (int)d;
