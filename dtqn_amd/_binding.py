@@ -95,6 +95,9 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
         "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],
+        "dtqn_td_row_split": [P(DtqnNet), i32],
+        "dtqn_td_xch_floats": [P(DtqnNet), i32],
+        "dtqn_td_xch_flags": [P(DtqnNet), i32],
         "dtqn_td_forward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_backward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_wgrad": [P(DtqnNet), P(DtqnTd), vp],

@@ -30,12 +30,19 @@ struct BwdArgs {
     int batch, history;
     float gamma;
     long long* prof;             // debug stage clock
+    float* xch;                  // row-split hand-over buffer / flags (RS == 2 only)
+    int32_t* xflags;
 };
 
-template <int D, int MT, int HD, int NW, bool GRU>
+// RS = row slices per sequence (see dtqn_forward.hip).  RS == 2: the workgroup owns rows [R0, R0 + LP); attention is
+// the only stage that looks below R0 (keys / values of the lower rows, read from the forward's record) and the only one
+// that hands something over: the upper slice's contribution to dK | dV of the lower rows (slice 1 -> slice 0).
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
+    static_assert(RS == 1 || (RS == 2 && !GRU), "row split covers the residual gate only");
     constexpr int NT = NW * 64;
-    constexpr int LP = MT * 16;
+    constexpr int LP = MT * 16;                   // rows this workgroup owns
+    constexpr int LPF = LP * RS;                  // padded rows of the whole sequence (= net.lp)
     constexpr int LDX = D + 4;
     constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
     constexpr int NG = D / GW;
@@ -47,27 +54,34 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     using Own = Owned<D, MT, MGX, NW>;          // fixed ownership of a [LP][D] register-accumulated output
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
-    const int b = (int)blockIdx.x;
-    const int L = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
+    const int b = (int)blockIdx.x / RS;
+    const int slice = RS - 1 - ((int)blockIdx.x - b * RS);     // the upper slice (the producer of this kernel) first
+    const int R0 = slice * LP;
+    const int Lfull = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
+    const int L = Lfull - R0 < LP ? Lfull - R0 : LP;   // live rows of this slice (may be <= 0)
     const bool ident = net.identity != 0;
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     const float* __restrict__ theta = a.theta;
     const float* rec = a.act + (size_t)b * net.act_stride;
     float* grec = a.grd + (size_t)b * net.grd_stride;
-    float* srec = a.small + (size_t)b * net.sp_stride;
+    float* srec = a.small + ((size_t)b * RS + slice) * net.sp_stride;
+    // a [LPF][w] record tensor at the first row of this slice; ReLU ballot records at its first row tile
+    auto rf = [&](const float* base, int off, int w) -> const float* { return base + off + (size_t)R0 * w; };
+    auto gf = [&](float* base, int off, int w) -> float* { return base + off + (size_t)R0 * w; };
+    auto mf = [&](const float* base, int off, int ctiles) -> const float* { return base + off + (size_t)(R0 / 16) * ctiles * 8; };
 
     float* DX = reinterpret_cast<float*>(dtqn_smem);   // dL/d(residual stream)        [LP][LDX]
     float* T2 = DX + LP * LDX;                         // narrow temp                   [LP][LDX]
-    float* W5 = T2 + LP * LDX;                         // wide temp                     [LP][LD5]
-    float* dq_s = W5 + LP * LD5;                       // dL/dQ                         [LP][AP]
-    float* delta_s = dq_s + LP * AP;                   // attention row terms           [GW/HD][LP]
-    float* lse_s = delta_s + (GW / HD) * LP;
-    float* red = lse_s + (GW / HD) * LP;               // LN column-sum scratch         [PARTS][2][D]
+    float* W5 = T2 + LP * LDX;                         // wide temp, attention tiles on GLOBAL rows [LPF][LD5]
+    float* dq_s = W5 + LPF * LD5;                      // dL/dQ                         [LP][AP]
+    float* delta_s = dq_s + LP * AP;                   // attention row terms           [GW/HD][LPF] (global rows)
+    float* lse_s = delta_s + (GW / HD) * LPF;
+    float* red = lse_s + (GW / HD) * LPF;              // LN column-sum scratch         [PARTS][2][D]
     constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
     float* st_s = red + PARTS * 2 * D;                 // LayerNorm (mean, rstd) of this layer [2][LP][2]
     float* DU = st_s + 4 * LP;                         // identity only: branch grad    [LP][LDX]
 
-    const int ep = a.ep_idx[b], st0 = a.start[b];
+    const int ep = a.ep_idx[b], st0 = a.start[b] + R0;
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
@@ -76,23 +90,23 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     g_h1.prefetch(theta + net.off_head1_w, D, t);
     TileRegs<NW, LP, D> tr;                                // saved-activation tile in flight
     TileRegs<NW, LP, D> trh;
-    trh.load(rec + net.ao_hh, D, t);
-    if (!ident) tr.load(rec + net.ao_layer0 + (size_t)(net.num_layers - 1) * net.act_layer_stride + net.al_s2, D, t);
+    trh.load(rf(rec, net.ao_hh, D), D, t);
+    if (!ident) tr.load(rf(rec, net.ao_layer0 + (net.num_layers - 1) * net.act_layer_stride + net.al_s2, D), D, t);
 
     // ---------------- B0: double-DQN target, loss, dL/dQ, statistics (dtqn.py:219-253) ----------------
     {
-        const float* q0 = a.q3 + ((size_t)0 * a.batch + b) * LP * AP;
-        const float* q1 = a.q3 + ((size_t)1 * a.batch + b) * LP * AP;
-        const float* q2 = a.q3 + ((size_t)2 * a.batch + b) * LP * AP;
+        const float* q0 = a.q3 + (((size_t)0 * a.batch + b) * LPF + R0) * AP;
+        const float* q1 = a.q3 + (((size_t)1 * a.batch + b) * LPF + R0) * AP;
+        const float* q2 = a.q3 + (((size_t)2 * a.batch + b) * LPF + R0) * AP;
         const float inv_count = 1.0f / ((float)a.batch * (float)a.history);
         for (int idx = t.tid; idx < LP * AP; idx += NT) dq_s[idx] = 0.f;
         __syncthreads();
         if (t.wave == 0)
-            td_loss_wave(q0, q1, q2, AP, A, L, LP, a.history, a.gamma, inv_count,
+            td_loss_wave(q0, q1, q2, AP, A, Lfull - R0, LP, a.history, a.gamma, inv_count,     // window test in slice-local rows
                          a.actions + (size_t)ep * a.act_ep_stride + st0, a.rewards + (size_t)ep * a.rew_ep_stride + st0,
-                         a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + (size_t)b * 8, t.lane);
+                         a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + ((size_t)b * RS + slice) * 8, t.lane);
         __syncthreads();
-        for (int idx = t.tid; idx < LP * AP; idx += NT) grec[net.go_dq + idx] = dq_s[idx];
+        for (int idx = t.tid; idx < LP * AP; idx += NT) gf(grec, net.go_dq, AP)[idx] = dq_s[idx];
     }
 
     DTQN_PROF(a.prof, ps++);   // loss done
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     }
     __syncthreads();
     g_h1.retire();
-    tile_store<NW>(T2, LDX, grec + net.go_dhh, LP, D, t);
+    tile_store<NW>(T2, LDX, gf(grec, net.go_dhh, D), LP, D, t);
     g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
     __syncthreads();
     DTQN_PROF(a.prof, ps++);   // head done
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         g_dh.prefetch(W2, 4 * D, t);
         // (mean, rstd) of both LayerNorms of this layer -> LDS (published by the next barrier)
         for (int idx = t.tid; idx < 4 * LP; idx += NT)
-            st_s[idx] = idx < 2 * LP ? lrec[net.al_st1 + idx] : lrec[net.al_st2 + idx - 2 * LP];
+            st_s[idx] = idx < 2 * LP ? rf(lrec, net.al_st1, 2)[idx] : rf(lrec, net.al_st2, 2)[idx - 2 * LP];
 
         if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
             tr.to_lds(T2, LDX, t);
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             __syncthreads();
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
-        tr.load(lrec + net.al_s1, D, t);               // needed after the FFN: in flight during it
+        tr.load(rf(lrec, net.al_s1, D), D, t);         // needed after the FFN: in flight during it
         // mlp gate.  res: s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0], the skip path keeps DX.
         // gru: DX <- dL/dx (skip path), T2 <- dL/dy, then the same ReLU mask.
         if (gru) {
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             __syncthreads();
         }
         {
-            const float* m2 = lrec + net.al_m2;
+            const float* m2 = mf(lrec, net.al_m2, D / 16);
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
@@ -174,11 +188,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float w1f[2][NC / 4];
-            const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(lrec + net.al_mh);
+            const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(mf(lrec, net.al_mh, 4 * D / 16));
             constexpr int MGH = pick_mg(NC / 16, MT, NW);
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
                 g_dh.retire();
-                if (c0 == 0) tile_store<NW>(T2, LDX, lgrd + net.gl_df, LP, D, t);
+                if (c0 == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_df, D), LP, D, t);
                 unsigned long long mw[MGH][4];         // ReLU ballots of the item's accumulator registers
                 g_dh.run(T2, LDX, t,
                          [&](int kt, int mg) {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                     for (int q = 0; q < NC / 4; ++q) DTQN_ASM_KEEP(w1f[0][q]);
                 }
-                tile_store<NW>(W5, LD5, lgrd + net.gl_dhp + c0, LP, NC, t, 4 * D);
+                tile_store<NW>(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
                     if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
@@ -229,12 +243,20 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         // LayerNorm in front of / behind the FFN  (T2 is free again: nobody reads df any more)
         tr.to_lds(T2, LDX, t);                         // s1
         // q | k | v (| o) of head group 0 go in flight now; they land in W5 after the LayerNorm backward
-        TileRegs<NW, LP, GW> tq, tk, tv, to;
-        {
-            const float* qkv0 = lrec + net.al_qkv;
-            tq.load(qkv0, 3 * D, t); tk.load(qkv0 + D, 3 * D, t); tv.load(qkv0 + 2 * D, 3 * D, t);
-            if (OST) to.load(lrec + net.al_o, D, t);
-        }
+        // q, o: this slice's rows; k, v: every row up to the end of the slice, in LP-row chunks (chunk j = rows j*LP..)
+        TileRegs<NW, LP, GW> tq, to, tk[RS], tv[RS];
+        auto load_group = [&](int g) {
+            const float* qkv0 = lrec + net.al_qkv + g * GW;
+            tq.load(qkv0 + (size_t)R0 * 3 * D, 3 * D, t);
+#pragma unroll
+            for (int j = 0; j < RS; ++j)
+                if (j <= slice) {
+                    tk[j].load(qkv0 + (size_t)j * LP * 3 * D + D, 3 * D, t);
+                    tv[j].load(qkv0 + (size_t)j * LP * 3 * D + 2 * D, 3 * D, t);
+                }
+            if (OST) to.load(rf(lrec, net.al_o, D) + g * GW, D, t);
+        };
+        load_group(0);
         const float* __restrict__ Wo = th + net.lo_out_w;
         const float* __restrict__ Win = th + net.lo_in_w;
         StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             __syncthreads();
         }
         {
-            const float* m1 = lrec + net.al_m1;
+            const float* m1 = mf(lrec, net.al_m1, D / 16);
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
@@ -268,18 +290,24 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float winf[2][GW / 4];
-            const float* qkv = lrec + net.al_qkv;
-            const float* o_g = lrec + net.al_o;
+            const float* o_g = rf(lrec, net.al_o, D);
+            float* W5r = W5 + R0 * LD5;                // this slice's rows of the attention tiles
             constexpr int MGO = pick_mg(GW / 16, MT, NW);
             for (int g = 0; g < NG; ++g) {
                 // q, k, v (o) of this head group -> W5   (W5 is free: the FFN / previous group are behind a barrier)
-                tq.to_lds(W5, LD5, t); tk.to_lds(W5 + GW, LD5, t); tv.to_lds(W5 + 2 * GW, LD5, t);
-                if (OST) to.to_lds(W5 + 5 * GW, LD5, t);
+                tq.to_lds(W5r, LD5, t);
+#pragma unroll
+                for (int j = 0; j < RS; ++j)
+                    if (j <= slice) {
+                        tk[j].to_lds(W5 + j * LP * LD5 + GW, LD5, t);
+                        tv[j].to_lds(W5 + j * LP * LD5 + 2 * GW, LD5, t);
+                    }
+                if (OST) to.to_lds(W5r + 5 * GW, LD5, t);
                 // log-sum-exp of this group's heads -> LDS
-                for (int idx = t.tid; idx < (GW / HD) * LP; idx += NT) lse_s[idx] = lrec[net.al_lse + g * (GW / HD) * LP + idx];
+                for (int idx = t.tid; idx < (GW / HD) * LPF; idx += NT) lse_s[idx] = lrec[net.al_lse + g * (GW / HD) * LPF + idx];
                 __syncthreads();                   // da (T2) visible
                 g_do.retire();
-                if (g == 0) tile_store<NW>(T2, LDX, lgrd + net.gl_da, LP, D, t);
+                if (g == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_da, D), LP, D, t);
                 // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW];  delta = do . o per (row, head)
                 float ov[MGO][4];
                 g_do.run(T2, LDX, t,
@@ -293,19 +321,25 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                              }
                          },
                          [&](int r, int c, float v) {
-                             W5[r * LD5 + 3 * GW + c] = v;
-                             float p = v * (OST ? W5[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
+                             W5r[r * LD5 + 3 * GW + c] = v;
+                             float p = v * (OST ? W5r[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
 #pragma unroll
                              for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
-                             if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LP + r] = p;
+                             if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
                          });
                 // first W_in fragment of this wave in flight during the attention passes
                 if (Own::valid(t.wave, 0))
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
-                attention_backward_group<HD, NW>(W5, LD5, GW, LP, L, delta_s, lse_s, t);
+                attention_backward_group<HD, NW>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
                 __syncthreads();
+                if (RS == 2) {   // the upper queries' share of dK | dV of the lower rows: slice 1 -> slice 0
+                    float* xb = a.xch + (((size_t)b * net.num_layers + l) * NG + g) * LP * 2 * GW;
+                    int32_t* flag = a.xflags + ((size_t)b * net.num_layers + l) * 4 + g;
+                    if (slice == 1) xch_send<NW>(W5 + GW, LD5, xb, LP, 2 * GW, flag, t);
+                    else xch_recv<NW, true>(W5 + GW, LD5, xb, LP, 2 * GW, flag, t);
+                }
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
                 if (Own::valid(t.wave, 0)) {
 #pragma unroll
@@ -315,8 +349,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
                     const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
-                    const float* sp = W5 + r * LD5 + (which == 0 ? 4 * GW : which * GW) + c;
-                    st4(lgrd + net.gl_dqkv + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
+                    const float* sp = W5r + r * LD5 + (which == 0 ? 4 * GW : which * GW) + c;
+                    st4(gf(lgrd, net.gl_dqkv, 3 * D) + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
                 }
                 // du1 += dq W_in[q rows] + dk W_in[k rows] + dv W_in[v rows]: 3 fragments per owned item, double-buffered
 #pragma unroll
@@ -328,25 +362,23 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                         if (nq < Own::PER_WAVE && Own::valid(t.wave, nq))
                             frag_dyw_fetch<GW>(winf[(step + 1) & 1], Win + (size_t)(np * D + g * GW) * D + Own::nt(t.wave, nq) * 16 + t.i, D, t);
                         if (Own::valid(t.wave, q)) {
-                            const float* rows = W5 + Own::mg(t.wave, q) * MGX * 16 * LD5 + (part == 0 ? 4 * GW : part * GW);
+                            const float* rows = W5r + Own::mg(t.wave, q) * MGX * 16 * LD5 + (part == 0 ? 4 * GW : part * GW);
                             frag_dyw_mma<GW, MGX>(rows, LD5, winf[step & 1], t, xacc[q]);
                         }
                     }
                 }
                 if (g + 1 < NG) {
                     g_do.prefetch(Wo + (g + 1) * GW, D, t);
-                    const float* qkvn = qkv + (g + 1) * GW;
-                    tq.load(qkvn, 3 * D, t); tk.load(qkvn + D, 3 * D, t); tv.load(qkvn + 2 * D, 3 * D, t);
-                    if (OST) to.load(o_g + (g + 1) * GW, D, t);
+                    load_group(g + 1);
                 }
                 __syncthreads();
             }
             // next stage's saved activation goes in flight now: s2 of the layer below (post-LN), or the
             // LN1 input of this layer (identity)
             if (!ident) {
-                if (l > 0) tr.load(rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2, D, t);
+                if (l > 0) tr.load(rf(rec, net.ao_layer0 + (l - 1) * net.act_layer_stride + net.al_s2, D), D, t);
             } else {
-                tr.load(l == 0 ? rec + net.ao_x0 : rec + net.ao_layer0 + (size_t)(l - 1) * net.act_layer_stride + net.al_s2, D, t);
+                tr.load(l == 0 ? rf(rec, net.ao_x0, D) : rf(rec, net.ao_layer0 + (l - 1) * net.act_layer_stride + net.al_s2, D), D, t);
             }
             float* dst = ident ? DU : DX;
 #pragma unroll
@@ -376,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 
     // ---------------- embedding: dL/dx0 -> record; table / action-embedding partials ----------------
     DTQN_PROF(a.prof, ps++);
-    tile_store<NW>(DX, LDX, grec + net.go_dx0, LP, D, t);
+    tile_store<NW>(DX, LDX, gf(grec, net.go_dx0, D), LP, D, t);
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
     if (net.discrete) {
@@ -407,10 +439,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         for (int idx = t.tid; idx < A * adim; idx += NT) {
             const int v = idx / adim, c = idx - v * adim;
             float g = 0.f;
-            if (L == 1) {
+            if (Lfull == 1) {
                 if ((int)act_rows[0] == v) g = DX[c];
             } else {
-                for (int r = 1; r < L; ++r)
+                for (int r = R0 > 0 ? 0 : 1; r < L; ++r)      // global row >= 1: the action that led to this observation
                     if ((int)act_rows[r - 1] == v) g += DX[r * LDX + c];
             }
             srec[net.so_act + idx] = g;
@@ -431,22 +463,22 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU>
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
 static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU>), dim3(a.batch), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>), dim3(a.batch * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW>
 static int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     if (a.net.gate == DTQN_GATE_GRU) {
-        if constexpr (D <= 64) return launch_bwd2<D, MT, HD, NW, true>(a, stream);
+        if constexpr (D <= 64) return launch_bwd2<D, MT, HD, NW, true, 1>(a, stream);
         else return DTQN_ERR_CONFIG;
     }
-    return launch_bwd2<D, MT, HD, NW, false>(a, stream);
+    return launch_bwd2<D, MT, HD, NW, false, 1>(a, stream);
 }
 
 }  // namespace dtqn
@@ -475,8 +507,16 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.ep_idx = td->ep_idx; a.start = td->start;
     a.batch = td->batch; a.history = td->history; a.gamma = td->gamma;
     a.prof = dtqn_debug_profile_buffer() ? static_cast<long long*>(dtqn_debug_profile_buffer()) + 64 : nullptr;
+    a.xch = td->xch; a.xflags = td->xflags;
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
+    if (td->row_split == 2) {   // two workgroups per sequence (dtqn_td_row_split)
+        if (net->lp != 64 || net->gate != DTQN_GATE_RES || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (D == 64 && HD == 8) return launch_bwd2<64, 2, 8, 8, false, 2>(a, s);
+        if (D == 64 && HD == 16) return launch_bwd2<64, 2, 16, 8, false, 2>(a, s);
+        if (D == 128 && HD == 16) return launch_bwd2<128, 2, 16, 8, false, 2>(a, s);
+        return DTQN_ERR_CONFIG;
+    }
 #define DTQN_BWD_CASE(d, mt, hd, nw) \
     if (D == d && MT == mt && HD == hd && NW == nw) return launch_bwd<d, mt, hd, nw>(a, s);
     DTQN_BWD_CASE(64, 4, 8, 4)
@@ -485,6 +525,7 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     DTQN_BWD_CASE(128, 4, 16, 4)
     DTQN_BWD_CASE(128, 4, 16, 8)
     DTQN_BWD_CASE(64, 4, 16, 8)
+    DTQN_BWD_CASE(64, 2, 8, 8)
     DTQN_BWD_CASE(16, 1, 8, 4)
     DTQN_BWD_CASE(16, 1, 8, 8)
     DTQN_BWD_CASE(32, 2, 8, 4)

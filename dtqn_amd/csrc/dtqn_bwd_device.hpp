@@ -105,17 +105,20 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld, int GW, int LP, int n,
                                                               const float* delta_s, const float* lse_s, const Thr& t,
-                                                              float* dq_base = nullptr, int dq_ld = 0) {
+                                                              float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
-    // caller cannot afford a fifth LDS tile
+    // caller cannot afford a fifth LDS tile.  Row slices as in the VALU version: queries [row0, row0 + LP)
+    // (row0 a multiple of 16), keys [0, row0 + LP), global rows everywhere.
     if (dq_base == nullptr) { dq_base = W5 + 4 * GW; dq_ld = ld; }
+    if (sl_ld == 0) sl_ld = LP;
     constexpr int KS = HD / 4, CT = (HD + 15) / 16;
     constexpr float LOG2E = 1.4426950408889634f;
     const int HG = GW / HD, MT = LP / 16, last_tile = (n - 1) / 16;
+    const int T0 = row0 / 16, MTK = T0 + MT;                 // first query tile; number of key tiles
     const float scale = 1.0f / sqrtf((float)HD), scale2 = scale * LOG2E;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int item = t.wave; item < HG * MT; item += NW) {
-        const int h = item % HG, ti = item / HG;
+        const int h = item % HG, ti = T0 + item / HG;
         const int t0 = ti * 16, trow = t0 + t.i;
         float* dqp = dq_base + (size_t)trow * dq_ld + h * HD;
         if (ti > last_tile) {
@@ -130,7 +133,7 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
             qf[s] = W5[trow * ld + h * HD + t.kq * KS + s] * scale2;
             dof[s] = W5[trow * ld + 3 * GW + h * HD + t.kq * KS + s];
         }
-        const float lse2 = lse_s[h * LP + trow] * LOG2E, delta = delta_s[h * LP + trow];
+        const float lse2 = lse_s[h * sl_ld + trow] * LOG2E, delta = delta_s[h * sl_ld + trow];
         f32x4 acc[CT][2];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { acc[ct][0] = zero4(); acc[ct][1] = zero4(); }
@@ -171,12 +174,13 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
         }
     }
     __syncthreads();
-    for (int item = t.wave; item < HG * MT; item += NW) {
+    const int ti_hi = last_tile < MTK - 1 ? last_tile : MTK - 1;      // last query tile of this slice with live rows
+    for (int item = t.wave; item < HG * MTK; item += NW) {
         const int h = item % HG, tj = item / HG;
         const int s0 = tj * 16, srow = s0 + t.i;
         float* kout = W5 + srow * ld + GW + h * HD;
         float* vout = kout + GW;
-        if (tj > last_tile) {
+        if (tj > ti_hi) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 if (ct * 16 + t.kq * 4 < HD) { st4(kout + ct * 16 + t.kq * 4, z4); st4(vout + ct * 16 + t.kq * 4, z4); }
@@ -191,7 +195,7 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
         f32x4 acck[CT][2], accv[CT][2];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) { acck[ct][0] = zero4(); acck[ct][1] = zero4(); accv[ct][0] = zero4(); accv[ct][1] = zero4(); }
-        for (int ti = tj; ti <= last_tile; ++ti) {
+        for (int ti = tj > T0 ? tj : T0; ti <= ti_hi; ++ti) {
             const int t0 = ti * 16;
             const float* qp = W5 + (t0 + t.i) * ld + h * HD + t.kq * KS;
             const float* dop = qp + 3 * GW;
@@ -202,7 +206,7 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
                 dp = mfma16(dop[s], vf[s], dp);
             }
             // st[r] = S[t0 + kq*4 + r][s0 + i]
-            const float4 l4 = ld4(lse_s + h * LP + t0 + t.kq * 4), d4 = ld4(delta_s + h * LP + t0 + t.kq * 4);
+            const float4 l4 = ld4(lse_s + h * sl_ld + t0 + t.kq * 4), d4 = ld4(delta_s + h * sl_ld + t0 + t.kq * 4);
             const float lse4[4] = {l4.x, l4.y, l4.z, l4.w}, del4[4] = {d4.x, d4.y, d4.z, d4.w};
             float p[4], ds[4];
 #pragma unroll
@@ -247,15 +251,19 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
 template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
-                                                         float* dq_base = nullptr, int dq_ld = 0) {
+                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
-    // caller cannot afford a fifth LDS tile
+    // caller cannot afford a fifth LDS tile.
+    // Row slices: queries [row0, row0 + LP) against keys [0, row0 + LP); all tile rows are GLOBAL rows, delta_s /
+    // lse_s are [head][sl_ld] indexed by global row.  dk / dv then hold only this slice's queries' contribution.
     if (dq_base == nullptr) { dq_base = W5 + 4 * GW; dq_ld = ld; }
+    if (sl_ld == 0) sl_ld = LP;
     const int HG = GW / HD;
     const float scale = 1.0f / sqrtf((float)HD);
-    const int nblocks = (LP * HG + 63) / 64;
-    const bool one_round = nblocks <= NW && (64 % HG) == 0;
-    const int nlive = (n * HG + 63) / 64;
+    const int q_hi = n < row0 + LP ? n : row0 + LP;          // queries of this slice: [row0, q_hi)
+    int nblocks = (LP * HG + 63) / 64;
+    bool one_round = nblocks <= NW && (64 % HG) == 0;
+    int nlive = ((q_hi > row0 ? q_hi - row0 : 0) * HG + 63) / 64;
     for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
         int item = it0;
         if (one_round) {
@@ -264,7 +272,8 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
             item = blk * 64 + t.lane;
             if (item >= LP * HG) continue;
         }
-        const int row = item / HG, hl = item - row * HG;
+        const int rl = item / HG, hl = item - rl * HG;
+        const int row = row0 + rl;
         float* dqp = dq_base + (size_t)row * dq_ld + hl * HD;
         float dq[HD];
 #pragma unroll
@@ -279,7 +288,7 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
                 q[c] = x.x * scale; q[c + 1] = x.y * scale; q[c + 2] = x.z * scale; q[c + 3] = x.w * scale;
                 dO[c] = g.x; dO[c + 1] = g.y; dO[c + 2] = g.z; dO[c + 3] = g.w;
             }
-            const float delta = delta_s[hl * LP + row], lse = lse_s[hl * LP + row];
+            const float delta = delta_s[hl * sl_ld + row], lse = lse_s[hl * sl_ld + row];
             const float* kbase = W5 + GW + hl * HD;
             for (int s = 0; s <= row; ++s) {
                 const float* kp = kbase + s * ld;
@@ -303,13 +312,17 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
             st4(dqp + c, make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale));
     }
     __syncthreads();
-    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * HG); it0 += NW * 64) {
+    const int KR = row0 + LP;                                // key rows of pass 2
+    nblocks = (KR * HG + 63) / 64;
+    one_round = nblocks <= NW && (64 % HG) == 0;
+    nlive = ((q_hi < KR ? q_hi : KR) * HG + 63) / 64;
+    for (int it0 = t.tid; it0 < (one_round ? NW * 64 : KR * HG); it0 += NW * 64) {
         int item = it0;
         if (one_round) {
             const int blk = balanced_block<NW>(t.wave, nblocks, nlive, true);
             if (blk < 0) continue;
             item = blk * 64 + t.lane;
-            if (item >= LP * HG) continue;
+            if (item >= KR * HG) continue;
         }
         const int srow = item / HG, hl = item - srow * HG;
         float* kp = W5 + srow * ld + GW + hl * HD;
@@ -317,7 +330,7 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
         float dk[HD], dv[HD];
 #pragma unroll
         for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
-        if (srow < n) {
+        if (srow < q_hi) {
             float k[HD], v[HD];
 #pragma unroll
             for (int c = 0; c < HD; c += 4) {
@@ -325,7 +338,8 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
                 k[c] = x.x; k[c + 1] = x.y; k[c + 2] = x.z; k[c + 3] = x.w;
                 v[c] = y.x; v[c + 1] = y.y; v[c + 2] = y.z; v[c + 3] = y.w;
             }
-            for (int row = n - 1; row >= srow; --row) {
+            const int q_lo = srow > row0 ? srow : row0;
+            for (int row = q_hi - 1; row >= q_lo; --row) {
                 const float* qp = W5 + row * ld + hl * HD;
                 const float* dop = qp + 3 * GW;
                 float sc = 0.f, dp = 0.f;
@@ -338,8 +352,8 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
                 }
 #pragma unroll
                 for (int c = 0; c < HD; ++c) { sc = fmaf(qq[c], k[c], sc); dp = fmaf(dd[c], v[c], dp); }
-                const float p = __expf(sc - lse_s[hl * LP + row]);
-                const float ds = p * (dp - delta_s[hl * LP + row]);
+                const float p = __expf(sc - lse_s[hl * sl_ld + row]);
+                const float ds = p * (dp - delta_s[hl * sl_ld + row]);
 #pragma unroll
                 for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(p, dd[c], dv[c]); }
             }
@@ -356,9 +370,9 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
 template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
-                                                         float* dq_base = nullptr, int dq_ld = 0) {
-    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld);
-    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld);
+                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
+    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
+    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
 }
 
 // Double-DQN target, MSE and dL/dQ of ONE sequence, executed by one wave (dtqn/agents/dtqn.py:219-253).

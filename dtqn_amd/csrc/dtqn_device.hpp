@@ -54,6 +54,13 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 #define DTQN_LANE_SWAP32(x) dtqn_lane_swap32(x)
 #define DTQN_LANE_SWAP16(x) dtqn_lane_swap16(x)
 #endif
+// Agent-scope (whole GPU, across XCDs) relaxed atomics: the two workgroups that share a sequence in row-split mode
+// hand tiles to each other through global memory with these (sc1 loads / stores: coherent without L2 write-backs).
+#ifndef DTQN_AGENT_LOAD
+#define DTQN_AGENT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DTQN_AGENT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define DTQN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#endif
 // 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range reduction code)
 #ifndef DTQN_EXP2
 #define DTQN_EXP2(x) __builtin_amdgcn_exp2f(x)
@@ -599,14 +606,15 @@ __device__ __forceinline__ void attention_forward_chunk(const float* kbase, cons
 
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D, int H, int LP, int n,
-                                                       float* __restrict__ lse_out, const Thr& t) {
+                                                       float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
+    if (lse_ld == 0) lse_ld = LP;               // query rows [row0, row0 + LP), row0 a multiple of 16
     constexpr int KS = HD / 4;                  // MFMA steps of the score contraction (4 columns of q/k per step)
     constexpr int CT = (HD + 15) / 16;          // 16-row tiles of O^T (rows = head columns c)
     const float scale = 1.4426950408889634f / sqrtf((float)HD);        // hd^-0.5 * log2(e)
     const int MT = LP / 16;
     const int last_tile = (n - 1) / 16;         // query tiles beyond it hold only pad rows
     for (int item = t.wave; item < H * MT; item += NW) {
-        const int h = item % H, ti = item / H;
+        const int h = item % H, ti = row0 / 16 + item / H;
         const int t0 = ti * 16, trow = t0 + t.i;
         float* qbase = Ws + h * HD;
         if (ti > last_tile) {                   // pad rows: o = 0, lse = 0
@@ -615,7 +623,7 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
                 const int c = ct * 16 + t.kq * 4;
                 if (c < HD) st4(qbase + trow * ld + c, make_float4(0.f, 0.f, 0.f, 0.f));
             }
-            if (lse_out != nullptr && t.kq == 0) lse_out[h * LP + trow] = 0.f;
+            if (lse_out != nullptr && t.kq == 0) lse_out[h * lse_ld + trow] = 0.f;
             continue;
         }
         const float* kbase = Ws + D + h * HD;
@@ -646,7 +654,7 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
                 st4(qbase + trow * ld + c, make_float4((acc[ct][0][0] + acc[ct][1][0]) * inv, (acc[ct][0][1] + acc[ct][1][1]) * inv,
                                                        (acc[ct][0][2] + acc[ct][1][2]) * inv, (acc[ct][0][3] + acc[ct][1][3]) * inv));
         }
-        if (lse_out != nullptr && t.kq == 0) lse_out[h * LP + trow] = live ? m * 0.6931471805599453f + __logf(l) : 0.f;
+        if (lse_out != nullptr && t.kq == 0) lse_out[h * lse_ld + trow] = live ? m * 0.6931471805599453f + __logf(l) : 0.f;
     }
 }
 
@@ -660,11 +668,14 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
 // ------------------------------------------------------------------------------------------
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D, int H, int LP, int n,
-                                                  float* __restrict__ lse_out, const Thr& t) {
+                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
+    // query rows [row0, row0 + LP) of the tile (a row slice of the sequence when row0 > 0); keys 0 .. row
+    if (lse_ld == 0) lse_ld = LP;
     const float scale = 1.0f / sqrtf((float)HD);
     const int nblocks = (LP * H + 63) / 64;
     const bool one_round = nblocks <= NW && (64 % H) == 0;
-    const int nlive = (n * H + 63) / 64;
+    const int nloc = n - row0 < 0 ? 0 : (n - row0 > LP ? LP : n - row0);
+    const int nlive = (nloc * H + 63) / 64;
     for (int it0 = t.tid; it0 < (one_round ? NW * 64 : LP * H); it0 += NW * 64) {
         int item = it0;
         if (one_round) {
@@ -673,12 +684,13 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
             item = blk * 64 + t.lane;
             if (item >= LP * H) continue;
         }
-        const int row = item / H, h = item - row * H;
+        const int rl = item / H, h = item - rl * H;
+        const int row = row0 + rl;
         float* qp = Ws + row * ld + h * HD;
         if (row >= n) {
 #pragma unroll
             for (int c = 0; c < HD; ++c) qp[c] = 0.f;
-            if (lse_out != nullptr) lse_out[h * LP + row] = 0.f;
+            if (lse_out != nullptr) lse_out[h * lse_ld + row] = 0.f;
             continue;
         }
         float q[HD], acc[HD];
@@ -734,7 +746,7 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
         const float inv = 1.0f / l;
 #pragma unroll
         for (int c = 0; c < HD; c += 4) st4(qp + c, make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv));
-        if (lse_out != nullptr) lse_out[h * LP + row] = m + __logf(l);
+        if (lse_out != nullptr) lse_out[h * lse_ld + row] = m + __logf(l);
     }
 }
 
@@ -742,9 +754,9 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
 constexpr int kAttnMfmaMinHeadDim = 16;
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
-                                                  float* __restrict__ lse_out, const Thr& t) {
-    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t);
-    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t);
+                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
+    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
+    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.
@@ -764,6 +776,34 @@ __device__ __forceinline__ void tile_load(float* s, int ld, const float* __restr
         const int r = idx / c4, c = (idx - r * c4) * 4;
         st4(s + r * ld + c, ld4(g + (size_t)r * cols + c));
     }
+}
+
+// Row-split hand-over of a [rows][cols] tile between the two workgroups of a sequence.  The producer publishes the
+// LDS tile and raises the flag; the consumer waits for the flag, pulls the tile into its own LDS and lowers the
+// flag again (so the next launch starts from 0).  ADD: accumulate into the destination instead of overwriting.
+// The producer always has the LOWER blockIdx of the pair, so it is dispatched no later than its consumer.
+template <int NW>
+__device__ __forceinline__ void xch_send(const float* s, int ld, float* g, int rows, int cols, int32_t* flag, const Thr& t) {
+    for (int idx = t.tid; idx < rows * cols; idx += NW * 64) {
+        const int r = idx / cols, c = idx - r * cols;
+        DTQN_AGENT_STORE(g + idx, s[r * ld + c]);
+    }
+    __syncthreads();                               // every wave's stores are acknowledged (s_waitcnt vmcnt(0)) ...
+    if (t.tid == 0) DTQN_AGENT_STORE(flag, (int32_t)1);   // ... before the flag becomes visible
+}
+template <int NW, bool ADD>
+__device__ __forceinline__ void xch_recv(float* s, int ld, const float* g, int rows, int cols, int32_t* flag, const Thr& t) {
+    if (t.tid == 0)
+        while (DTQN_AGENT_LOAD(flag) == 0) DTQN_SPIN_PAUSE();
+    __syncthreads();
+    for (int idx = t.tid; idx < rows * cols; idx += NW * 64) {
+        const int r = idx / cols, c = idx - r * cols;
+        const float v = DTQN_AGENT_LOAD(g + idx);
+        if (ADD) s[r * ld + c] += v;
+        else s[r * ld + c] = v;
+    }
+    __syncthreads();
+    if (t.tid == 0) DTQN_AGENT_STORE(flag, (int32_t)0);
 }
 
 // Waves per workgroup for a given network.  More waves = more matrix-core issue slots per CU for the one

@@ -27,43 +27,60 @@ struct FwdArgs {
     long long q_which_stride, q_seq_stride;
     int q_row_stride;
     float* act;                 // nullptr: inference; else activation records for which == 0
+    float* xch;                 // row-split hand-over buffer / flags (RS == 2 only)
+    int32_t* xflags;
     long long* prof;            // debug stage clock (see dtqn_debug_set_profile_buffer)
 };
 
 __device__ __forceinline__ int lds_ldx(int D) { return D + 4; }
 __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 
-template <int D, int MT, int HD, int NW, bool GRU>
+// RS = row slices per sequence.  RS == 1: the workgroup owns the whole sequence (LP = its padded length).
+// RS == 2 (latency mode, dtqn_td_row_split): the workgroup owns rows [R0, R0 + LP) of the sequence, LP = half the
+// padded length; every stage is row-local except attention, whose K | V of the rows below R0 come from the partner
+// workgroup (slice 0 -> slice 1 hand-over through a.xch).  Record tensors keep their full-sequence layout: a slice
+// addresses them at row R0.
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+    static_assert(RS == 1 || (RS == 2 && !GRU), "row split covers the residual gate only");
     constexpr int NT = NW * 64;                    // threads per workgroup
-    constexpr int LP = MT * 16;
+    constexpr int LP = MT * 16;                    // rows this workgroup owns
+    constexpr int LPF = LP * RS;                   // padded rows of the whole sequence (= net.lp)
     constexpr int LDX = D + 4, LDW = 3 * D + 4;
     constexpr int NC = 2 * D;                      // FFN hidden columns per pass
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
-    const int which = (int)blockIdx.x / a.batch;
-    const int b = (int)blockIdx.x - which * a.batch;
+    const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;     // slice 0 (the producer) first
+    const int R0 = slice * LP;
+    const int which = seq / a.batch;
+    const int b = seq - which * a.batch;
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
-    const int n = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
+    const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
+    const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
     const bool ident = net.identity != 0;
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     float* rec = (a.act != nullptr && which == 0) ? a.act + (size_t)b * net.act_stride : nullptr;
+    // a [LPF][w] record tensor at the first row of this slice
+    auto rf = [&](float* base, int off, int w) -> float* { return base != nullptr ? base + off + (size_t)R0 * w : nullptr; };
+    // ReLU ballot record (64-bit word per accumulator register, dtqn_device.hpp ballot_store) at the slice's first row tile
+    auto mf = [&](float* base, int off, int ctiles) -> float* { return base != nullptr ? base + off + (size_t)(R0 / 16) * ctiles * 8 : nullptr; };
 
     float* Xs = reinterpret_cast<float*>(dtqn_smem);   // residual stream            [LP][LDX]
-    float* Ws = Xs + LP * LDX;                         // q|k|v, FFN hidden, staging [LP][LDW]
-    float* Us = Ws + LP * LDW;                         // identity only: LN output   [LP][LDX]
+    float* Ws = Xs + LP * LDX;                         // q|k|v (GLOBAL rows), FFN hidden, staging [LPF][LDW]
+    float* Us = Ws + LPF * LDW;                        // identity only: LN output   [LP][LDX]
+    float* AW = Ws + R0 * LDW;                         // this slice's rows of the attention tile
 
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // ---------------- window gather + embedding ----------------
     const int ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
-    const int row0 = (a.start != nullptr ? a.start[b] : 0) + (which > 0 ? 1 : 0);
+    const int row0 = (a.start != nullptr ? a.start[b] : 0) + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
     const int KE = net.ke, KEP = net.kep;
     const float* __restrict__ We = theta + net.off_obs_w;
     const float* __restrict__ be = theta + net.off_obs_b;
-    const float* __restrict__ pos = theta + net.off_pos;
+    const float* __restrict__ pos = theta + net.off_pos + (size_t)R0 * D;
     if (!net.discrete && KE <= 8) {
         // continuous observations: every token row is a handful of floats read straight from the replay
         // window; a single pass, no LDS staging, no barrier
@@ -72,8 +89,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             float v = 0.f;
             if (r < n) {
                 if (d < adim) {
-                    if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
-                    else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;
                     const float* e = obs_rows + (size_t)r * O;
@@ -84,12 +101,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 v += pos[r * D + d];
             }
             Xs[r * LDX + d] = v;
-            if (rec != nullptr) rec[net.ao_x0 + idx] = v;
+            if (rec != nullptr) rf(rec, net.ao_x0, D)[idx] = v;
         }
         if (rec != nullptr)
             for (int idx = t.tid; idx < LP * KEP; idx += NT) {
                 const int r = idx / KEP, k = idx - r * KEP;
-                rec[net.ao_ein + idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
+                rf(rec, net.ao_ein, KEP)[idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
             }
     } else {
         float* ein = Ws;                               // [LP][KEP] embedding-linear input (wavefront-level gather)
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 }
             }
             ein[idx] = v;
-            if (rec != nullptr) rec[net.ao_ein + idx] = v;
+            if (rec != nullptr) rf(rec, net.ao_ein, KEP)[idx] = v;
         }
         __syncthreads();
         for (int idx = t.tid; idx < LP * D; idx += NT) {
@@ -116,8 +133,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             if (r < n) {
                 if (d < adim) {
                     // previous-action embedding rolled right by one, row 0 zeroed unless n == 1 (dtqn.py:184-192)
-                    if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
-                    else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;
                     const float* e = ein + r * KEP;
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 v += pos[r * D + d];
             }
             Xs[r * LDX + d] = v;
-            if (rec != nullptr) rec[net.ao_x0 + idx] = v;
+            if (rec != nullptr) rf(rec, net.ao_x0, D)[idx] = v;
         }
     }
     DTQN_PROF(a.prof, ps++);   // embed done; Xs is published by the barrier that opens layer 0
@@ -151,36 +168,42 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         g_qkv.prefetch(th + net.lo_in_w, D, t);
         __syncthreads();                               // residual stream of the previous stage visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t,
-                                  nullptr, lrec ? lrec + net.al_u1 : nullptr);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+                                  nullptr, rf(lrec, net.al_u1, D));
             __syncthreads();
             src = Us;
         }
         g_qkv.retire();
-        if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, lrec + net.al_u1, LP, D, t);
+        if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
             const float* __restrict__ bin = th + net.lo_in_b;
-            g_qkv.run(src, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = v + bin[c]; });
+            g_qkv.run(src, LDX, t, [&](int r, int c, float v) { AW[r * LDW + c] = v + bin[c]; });
         }
         StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_out;
         g_out.prefetch(th + net.lo_out_w, D, t);       // in flight during attention
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // qkv done
         if (lrec != nullptr) {                         // q|k|v -> record before attention overwrites q
-            tile_store<NW>(Ws, LDW, lrec + net.al_qkv, LP, 3 * D, t);
+            tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        attention_forward<HD, NW>(Ws, LDW, D, H, LP, n, lrec ? lrec + net.al_lse : nullptr, t);
+        if (RS == 2) {                                 // K | V of the lower rows: slice 0 -> slice 1
+            float* xb = a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D;
+            int32_t* flag = a.xflags + (size_t)seq * net.num_layers + l;
+            if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+            else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+        }
+        attention_forward<HD, NW>(Ws, LDW, D, H, LP, nfull, lrec ? lrec + net.al_lse : nullptr, t, R0, LPF);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
         g_out.retire();
-        if (lrec != nullptr) tile_store<NW>(Ws, LDW, lrec + net.al_o, LP, D, t);
+        if (lrec != nullptr) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
         // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
         {
             const float* __restrict__ bo = th + net.lo_out_b;
-            float* m_g = lrec ? lrec + net.al_m1 : nullptr;
-            g_out.run(Ws, LDW, t, [&](int r, int c, float v) {
+            float* m_g = mf(lrec, net.al_m1, D / 16);
+            g_out.run(AW, LDW, t, [&](int r, int c, float v) {
                 const float y = fmaxf(v + bo[c], 0.f);
                 if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                 if (gru) Ws[r * LDW + D + c] = y;          // y tile for the GRU gate (k columns are free now)
@@ -199,12 +222,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // out-proj done
         if (!ident) {  // x = LN1(x); s1 (input) and u2 (output) go to the record from the LN registers
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, lrec ? lrec + net.al_st1 : nullptr, t,
-                                  lrec ? lrec + net.al_s1 : nullptr, lrec ? lrec + net.al_u2 : nullptr);
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t,
-                                  lrec ? lrec + net.al_s1 : nullptr, lrec ? lrec + net.al_u2 : nullptr);
+            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Us;
         }
         __syncthreads();
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < MG2; ++m) facc[q][m] = zero4();
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
-            float* mh_g = lrec ? lrec + net.al_mh : nullptr;
+            float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
                 g_f1.retire();
                 g_f1.run(src, LDX, t, [&](int r, int c, float v) {
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
 #pragma unroll
                     for (int s = 0; s < NC / 16; ++s) retire4(w2f[0][s]);
                 }
-                if (lrec != nullptr) tile_store<NW>(Ws, LDW, lrec + net.al_h + c0, LP, NC, t, 4 * D);
+                if (lrec != nullptr) tile_store<NW>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
                     if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 __syncthreads();                       // everyone is done reading this chunk of the hidden
             }
             const float* __restrict__ b2 = th + net.lo_f2_b;
-            float* m_g = lrec ? lrec + net.al_m2 : nullptr;
+            float* m_g = mf(lrec, net.al_m2, D / 16);
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
                 if (Own::valid(t.wave, q)) {
@@ -269,10 +292,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         DTQN_PROF(a.prof, ps++);   // FFN done
         __syncthreads();
         if (!ident) {  // x = LN2(x); s2 from the LN registers
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, lrec ? lrec + net.al_st2 : nullptr, t,
-                                  lrec ? lrec + net.al_s2 : nullptr, nullptr);
+            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s2, D), nullptr);
         } else if (lrec != nullptr) {
-            tile_store<NW>(Xs, LDX, lrec + net.al_s2, LP, D, t);
+            tile_store<NW>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
         }
         // the residual stream is published by the barrier that opens the next layer / the head
     }
@@ -283,18 +306,18 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     __syncthreads();
     DTQN_PROF(a.prof, ps++);       // layers done
     g_head.retire();
-    if (rec != nullptr) tile_store<NW>(Xs, LDX, rec + net.ao_xf, LP, D, t);
+    if (rec != nullptr) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
     {
         const float* __restrict__ bh = theta + net.off_head1_b;
         g_head.run(Xs, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v + bh[c], 0.f); });
     }
     __syncthreads();
-    if (rec != nullptr) tile_store<NW>(Ws, LDW, rec + net.ao_hh, LP, D, t);
+    if (rec != nullptr) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* __restrict__ b2 = theta + net.off_head2_b;
-        float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride;
-        for (int idx = t.tid; idx < n * A; idx += NT) {
+        float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride + (size_t)R0 * a.q_row_stride;
+        for (int idx = t.tid; idx < (n < LP ? n : LP) * A; idx += NT) {
             const int r = idx / A, ac = idx - r * A;
             const float* hrow = Ws + r * LDW;
             const float* w = W2 + (size_t)ac * D;
@@ -317,34 +340,42 @@ static size_t fwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU>
-static int launch_fwd2(const FwdArgs& a, int nblocks, hipStream_t stream) {
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
+static int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU>), dim3(nblocks), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW>
-static int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
+static int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
     if (a.net.gate == DTQN_GATE_GRU) {
-        if constexpr (D <= 64) return launch_fwd2<D, MT, HD, NW, true>(a, nblocks, stream);
+        if constexpr (D <= 64) return launch_fwd2<D, MT, HD, NW, true, 1>(a, nseq, stream);
         else return DTQN_ERR_CONFIG;
     }
-    return launch_fwd2<D, MT, HD, NW, false>(a, nblocks, stream);
+    return launch_fwd2<D, MT, HD, NW, false, 1>(a, nseq, stream);
 }
 
-static int dispatch_fwd(const FwdArgs& a, int nblocks, hipStream_t stream) {
+static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t stream) {
     const int D = a.net.d_model, MT = a.net.lp / 16, HD = a.net.head_dim, NW = waves_for(a.net);
+    if (row_split == 2) {      // two workgroups per sequence (dtqn_td_row_split): 32-row slices of a 64-row tile, 8 waves
+        if (a.net.lp != 64 || a.net.gate != DTQN_GATE_RES || a.net.identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (D == 64 && HD == 8) return launch_fwd2<64, 2, 8, 8, false, 2>(a, nseq, stream);
+        if (D == 64 && HD == 16) return launch_fwd2<64, 2, 16, 8, false, 2>(a, nseq, stream);
+        if (D == 128 && HD == 16) return launch_fwd2<128, 2, 16, 8, false, 2>(a, nseq, stream);
+        return DTQN_ERR_CONFIG;
+    }
 #define DTQN_FWD_CASE(d, mt, hd, nw) \
-    if (D == d && MT == mt && HD == hd && NW == nw) return launch_fwd<d, mt, hd, nw>(a, nblocks, stream);
+    if (D == d && MT == mt && HD == hd && NW == nw) return launch_fwd<d, mt, hd, nw>(a, nseq, stream);
     DTQN_FWD_CASE(64, 4, 8, 4)
     DTQN_FWD_CASE(64, 4, 8, 8)
     DTQN_FWD_CASE(64, 4, 8, 16)
     DTQN_FWD_CASE(128, 4, 16, 4)
     DTQN_FWD_CASE(128, 4, 16, 8)
     DTQN_FWD_CASE(64, 4, 16, 8)
+    DTQN_FWD_CASE(64, 2, 8, 8)
     DTQN_FWD_CASE(16, 1, 8, 4)
     DTQN_FWD_CASE(16, 1, 8, 8)
     DTQN_FWD_CASE(32, 2, 8, 4)
@@ -382,8 +413,9 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
     a.q_seq_stride = (long long)n * net->num_actions;
     a.q_row_stride = net->num_actions;
     a.act = nullptr;
+    a.xch = nullptr; a.xflags = nullptr;
     a.prof = nullptr;
-    return dispatch_fwd(a, batch, (hipStream_t)stream);
+    return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
 }
 
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
@@ -403,6 +435,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.q_seq_stride = (long long)net->lp * net->ap;
     a.q_row_stride = net->ap;
     a.act = td->act;
+    a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
-    return dispatch_fwd(a, 3 * td->batch, (hipStream_t)stream);
+    return dispatch_fwd(a, 3 * td->batch, td->row_split == 2 ? 2 : 1, (hipStream_t)stream);
 }

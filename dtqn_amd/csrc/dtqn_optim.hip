@@ -83,6 +83,7 @@ struct AdamArgs {
     float* stats_ring;
     int32_t* step_counter;
     int n, n_norm_blocks, batch, history, tuf, ring_slots;
+    int n_stat_parts;            // batch * row_split per-workgroup statistics partials
     float lr, beta1, beta2, eps, clip, grad_scale;
 };
 
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     if (blockIdx.x == 0) {
         // statistics of dtqn.py:245-253,263, reduced over the per-sequence partials
         float se = 0.f, sq = 0.f, sy = 0.f, mxq = -INFINITY, mnq = INFINITY, mxy = -INFINITY, mny = INFINITY;
-        for (int b = tid; b < a.batch; b += kOptThreads) {
+        for (int b = tid; b < a.n_stat_parts; b += kOptThreads) {
             const float* sp = a.stats_partial + (size_t)b * 8;
             se += sp[0]; sq += sp[1]; mxq = fmaxf(mxq, sp[2]); mnq = fminf(mnq, sp[3]);
             sy += sp[4]; mxy = fmaxf(mxy, sp[5]); mny = fminf(mny, sp[6]);
@@ -217,6 +218,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.step_counter = td->step_counter;
     a.stats_ring = td->stats_ring; a.ring_slots = td->stats_ring_slots > 0 ? td->stats_ring_slots : 1;
     a.n = net->n_trainable; a.n_norm_blocks = td->n_norm_blocks; a.batch = td->batch; a.history = td->history;
+    a.n_stat_parts = td->batch * (td->row_split > 1 ? td->row_split : 1);
     a.tuf = td->target_update_frequency;
     a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;
     a.grad_scale = td->grad_scale;

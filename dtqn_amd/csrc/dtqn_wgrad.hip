@@ -22,6 +22,7 @@ struct WgradArgs {
     const float* small;     // [B][sp_stride] per-sequence partials of the backward kernel
     int batch, n_split, n_jobs;
     int n_small;            // elements of the small-partials index space (LN affine, tables, learned pos table)
+    int row_split;          // small-partial records per sequence (one per workgroup of the backward kernel)
 };
 
 // Extra blocks of the same launch: sum the backward kernel's per-sequence partials (LayerNorm gamma/beta,
@@ -57,7 +58,8 @@ __device__ __forceinline__ void small_partials_block(const WgradArgs& a, int sb,
             stride = (size_t)net.grd_stride;
         }
         float v = 0.f;
-        for (int b = b_lo; b < b_hi; ++b) v += base[(size_t)b * stride + src];
+        const int per = base == a.small ? a.row_split : 1;    // the grd record is per sequence, the small record per workgroup
+        for (int b = b_lo * per; b < b_hi * per; ++b) v += base[(size_t)b * stride + src];
         out[dst] = v;
     }
 }
@@ -188,6 +190,7 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
     a.act = td->act; a.grd = td->grd; a.gsplit = td->gsplit; a.small = td->small;
     a.batch = td->batch; a.n_split = td->n_split; a.n_jobs = net->n_wjobs;
+    a.row_split = td->row_split > 1 ? td->row_split : 1;
     a.n_small = net->num_layers * 4 * net->d_model + (net->discrete ? net->vocab * net->embed_per_obs : 0) +
                 (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
                 (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);

@@ -93,11 +93,16 @@ class TdEngine:
         # whole-sequence kernels only save the training forward's
         self.act = torch.zeros((3 if net.tiled else 1) * Bn * net.act_stride, **f32)
         self.grd = torch.zeros(Bn * net.grd_stride, **f32)
-        self.small = torch.zeros(Bn * net.sp_stride, **f32)
+        # latency mode for small batches: two workgroups per sequence (include/dtqn_hip.h, dtqn_td_row_split)
+        self.row_split = int(self.lib.dtqn_td_row_split(ctypes.byref(net), Bn))
+        RS = self.row_split
+        self.small = torch.zeros(Bn * RS * net.sp_stride, **f32)
         self.q3 = torch.zeros(3 * Bn * net.lp * net.ap, **f32)
         self.gsplit = torch.zeros(self.n_split * nt, **f32)
         self.norm_partial = torch.zeros(self.n_norm_blocks, **f32)
-        self.stats_partial = torch.zeros(Bn * 8, **f32)
+        self.stats_partial = torch.zeros(Bn * RS * 8, **f32)
+        self.xch = torch.zeros(max(1, self.lib.dtqn_td_xch_floats(ctypes.byref(net), Bn)), **f32)
+        self.xflags = torch.zeros(max(1, self.lib.dtqn_td_xch_flags(ctypes.byref(net), Bn)), dtype=torch.int32, device=dev)
         self.stats = torch.zeros(len(STAT_NAMES), **f32)
         self.step_counter = torch.zeros(4, dtype=torch.int32, device=dev)
         self.RING_SLOTS = 256
@@ -121,6 +126,7 @@ class TdEngine:
         td.stats_partial, td.stats = self.stats_partial.data_ptr(), self.stats.data_ptr()
         td.stats_ring, td.stats_ring_slots = self.stats_ring.data_ptr(), self.RING_SLOTS
         td.step_counter, td.wjobs = self.step_counter.data_ptr(), self.wjobs.data_ptr()
+        td.xch, td.xflags, td.row_split = self.xch.data_ptr(), self.xflags.data_ptr(), RS
         td.batch = Bn
         td.history = int(net.ctx_len if history is None else history)
         td.n_split, td.n_norm_blocks = self.n_split, self.n_norm_blocks
@@ -140,7 +146,7 @@ class TdEngine:
             raise RuntimeError(f"{what} failed with DTQN status {rc}")
 
     def workspace_bytes(self) -> int:
-        ts = (self.act, self.grd, self.small, self.q3, self.gsplit, self.norm_partial, self.stats_partial)
+        ts = (self.act, self.grd, self.small, self.q3, self.gsplit, self.norm_partial, self.stats_partial, self.xch)
         return sum(t.numel() * t.element_size() for t in ts)
 
     def set_indices(self, ep_idx, start):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 1
+#define DTQN_ABI_VERSION 2
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -214,11 +214,11 @@ typedef struct DtqnTd {
     /* workspaces */
     float* act;               /* [B][act_stride] */
     float* grd;               /* [B][grd_stride] */
-    float* small;             /* [B][sp_stride] */
+    float* small;             /* [B * row_split][sp_stride] */
     float* q3;                /* [3][B][LP][AP]: Q_pol(o), Q_pol(o'), Q_tgt(o') */
     float* gsplit;            /* [n_split][n_trainable] split-K partials of the weight gradients */
     float* norm_partial;      /* [n_norm_blocks] per-block sum of squares of grad */
-    float* stats_partial;     /* [B][8] */
+    float* stats_partial;     /* [B * row_split][8] */
     float* stats;             /* [12]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, step, target-synced, non-finite flag */
     float* stats_ring;        /* optional [stats_ring_slots][12] in PINNED HOST memory (device-visible): every call of
                                * dtqn_td_clip_adam also writes its statistics to slot (call_index % slots), entry 9 (the
@@ -226,6 +226,8 @@ typedef struct DtqnTd {
                                * enqueueing a device->host copy and an event per update */
     int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls */
     const DtqnWJob* wjobs;    /* device copy of the job table */
+    float* xch;               /* row-split exchange buffer, dtqn_td_xch_floats(net, B) floats (row_split > 1 only) */
+    int32_t* xflags;          /* row-split hand-over flags, dtqn_td_xch_flags(net, B) ints, ZEROED once by the caller */
     /* hyper-parameters */
     int32_t batch;            /* B (local) */
     int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
@@ -233,6 +235,8 @@ typedef struct DtqnTd {
     int32_t n_norm_blocks;
     int32_t stats_ring_slots;
     int32_t target_update_frequency;
+    int32_t row_split;        /* workgroups per sequence in the forward / backward kernels: the value
+                               * dtqn_td_row_split(net, B) returned (1 = one workgroup per sequence) */
     float gamma;
     float lr;
     float beta1;
@@ -242,8 +246,18 @@ typedef struct DtqnTd {
     float grad_scale;         /* multiplies the reduced gradient before clipping (1/world_size for DP) */
 } DtqnTd;
 
+/* Small-batch latency mode.  With B sampled sequences only 3B / B workgroups exist in the forward / backward
+ * kernels, far fewer than the 256 CUs.  When this returns 2 the kernels run TWO workgroups per sequence, each
+ * owning half of its rows (projections, LayerNorm, FFN, head and loss are row-local); causal attention is the one
+ * place rows meet: the forward hands K | V of the lower rows to the upper slice, the backward hands the upper
+ * queries' dK | dV contribution to the lower slice, through `xch` guarded by `xflags` (agent-scope atomics).
+ * Returns 1 when the shape / variant / batch does not profit (the chip is already full) or is not covered. */
+int dtqn_td_row_split(const DtqnNet* net, int batch);
+int dtqn_td_xch_floats(const DtqnNet* net, int batch);
+int dtqn_td_xch_flags(const DtqnNet* net, int batch);
+
 /* The three forwards (dtqn.py:215,226,230) fused with the window gather (replay_buffer.py:160-167).
- * Grid = 3*B workgroups.  Writes q3 and the act record of the policy(o) pass. */
+ * Grid = 3*B*row_split workgroups.  Writes q3 and the act record of the policy(o) pass. */
 int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* Double-DQN target, MSE, dL/dQ (dtqn.py:219-243) and the data-gradient chain of loss.backward()
  * (dtqn.py:256).  Writes the grd / small records and stats_partial. */

@@ -20,6 +20,12 @@
 #define DTQN_HIPEMU 1
 #define DTQN_ASM_KEEP(x) ((void)(x))   /* device-only register keep-alive (dtqn_device.hpp) */
 #define DTQN_EXP2(x) exp2f(x)          /* v_exp_f32 (dtqn_device.hpp) */
+/* agent-scope atomics of the row-split hand-over (dtqn_device.hpp): blocks may run on different host threads */
+template <typename T> static inline T hipemu_agent_load(const T* p) { T v; __atomic_load(const_cast<T*>(p), &v, __ATOMIC_ACQUIRE); return v; }
+template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
+#define DTQN_AGENT_LOAD(p) hipemu_agent_load(p)
+#define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
+#define DTQN_SPIN_PAUSE() ((void)0)
 
 // ---- qualifiers -------------------------------------------------------------
 #define __global__

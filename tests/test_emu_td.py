@@ -61,3 +61,23 @@ def test_td_update_tiled_path(emu, kw, run, monkeypatch):
                                                history=run.get("history"), tuf=run.get("tuf", 10_000))
     assert net.tiled == 1 and net.lp % 64 == 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+SPLIT = [
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
+    dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=55, action_dim=8, pos="sin"),
+    dict(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, discrete=True, vocab_sizes=9),
+]
+
+
+@pytest.mark.parametrize("kw", SPLIT)
+def test_td_update_row_split(emu, kw, monkeypatch):
+    """Latency mode: two workgroups per sequence (rows 0-31 / 32-63) with the K|V and dK|dV hand-over between them.
+    Same checks as one workgroup per sequence, including a short history window that lives entirely in the upper slice."""
+    monkeypatch.setenv("DTQN_ROW_SPLIT", "1")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=8, batch=3, T=80, n_eps=7, mask=-5 if not kw.get("discrete") else 8,
+                                               history=None if kw["num_heads"] == 8 else 11, tuf=2)
+    assert eng.row_split == 2 and net.lp == 64
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    assert int(eng.xflags.sum()) == 0                      # every hand-over flag was lowered again
