@@ -10,6 +10,10 @@
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
 
+#ifndef DTQN_SPLIT_ATTN_MFMA
+#define DTQN_SPLIT_ATTN_MFMA 1
+#endif
+
 namespace dtqn {
 
 struct BwdArgs {
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
-                attention_backward_group<HD, NW>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
+                attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
                 __syncthreads();
                 if (RS == 2) {   // the upper queries' share of dK | dV of the lower rows: slice 1 -> slice 0
                     float* xb = a.xch + (((size_t)b * net.num_layers + l) * NG + g) * LP * 2 * GW;

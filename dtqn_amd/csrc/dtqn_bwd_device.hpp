@@ -367,11 +367,11 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
     }
 }
 
-template <int HD, int NW>
+template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
                                                          float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
-    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
+    if constexpr (MFMA) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
     else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
 }
 

@@ -27,9 +27,10 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 }  // namespace dtqn
 
-// stage timestamp (debug): workgroup 0, thread 0 only; PROF costs one uniform branch when disabled
+// stage timestamp (debug): thread 0 of workgroups 0 and 1 (the two row slices of sequence 0 in latency mode), 32 slots
+// each; PROF costs one uniform branch when disabled
 #define DTQN_PROF(buf, slot) \
-    do { if ((buf) != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (buf)[slot] = (long long)wall_clock64(); } while (0)
+    do { if ((buf) != nullptr && blockIdx.x < 2 && threadIdx.x == 0) (buf)[blockIdx.x * 32 + (slot)] = (long long)wall_clock64(); } while (0)
 
 // Keep-alive for prefetched registers: forces the compiler to place its s_waitcnt for the loads that
 // produced `x` HERE (the test-only host build defines it away).
@@ -752,10 +753,10 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
 
 
 constexpr int kAttnMfmaMinHeadDim = 16;
-template <int HD, int NW>
+template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
-    if constexpr (HD >= kAttnMfmaMinHeadDim) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
+    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
     else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
 }
 

@@ -9,6 +9,10 @@
 #include "dtqn_device.hpp"
 #include "dtqn_gru.hpp"
 
+#ifndef DTQN_SPLIT_ATTN_MFMA
+#define DTQN_SPLIT_ATTN_MFMA 1
+#endif
+
 namespace dtqn {
 
 struct FwdArgs {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
             else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
         }
-        attention_forward<HD, NW>(Ws, LDW, D, H, LP, nfull, lrec ? lrec + net.al_lse : nullptr, t, R0, LPF);
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, lrec ? lrec + net.al_lse : nullptr, t, R0, LPF);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
         g_out.retire();

@@ -20,14 +20,17 @@ N = 20
 for _ in range(N):
     prof.zero_(); eng.forward_backward(rep); torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
-    for base in (0, 64):
-        seg = p[base:base + 64]; n = int((seg > 0).sum())
+    for base in (0, 32, 64, 96):
+        seg = p[base:base + 32]; n = int((seg > 0).sum())
+        if n < 2:
+            continue
         acc[base + 1:base + n] += np.diff(seg[:n]) / 100.0     # 100 MHz -> us
         acc[base] += (seg[n - 1] - seg[0]) / 100.0
-fw = ["total", "embed"] + [f"L{l}:{s}" for l in range(2) for s in ("qkv", "attn", "outproj", "LN1", "FFN", "LN2")] + ["head+Q"]
+fw = ["total", "embed"] + [f"L{l}:{s}" for l in range(2) for s in ("qkv", "attn", "outproj", "LN1", "FFN")] + ["head+Q"]
 bw = ["total", "loss", "head"] + [f"L{l}:{s}" for l in (1, 0) for s in ("LN2b", "FFNb", "LN1b", "dO", "attnb", "dqkvWin")] + ["tail"]
+print(f"row_split = {eng.row_split}")
 for name, base, labels in (("forward", 0, fw), ("backward", 64, bw)):
-    print(f"== {name} (B={Bn}, workgroup 0, mean of {N})")
+    print(f"== {name} (B={Bn}, workgroups 0 | 1, mean of {N})")
     for i, lab in enumerate(labels):
-        print(f"  {lab:12s} {acc[base + i] / N:8.2f} us")
+        print(f"  {lab:12s} {acc[base + i] / N:8.2f} us   {acc[base + 32 + i] / N:8.2f} us")
 lib.dtqn_debug_set_profile_buffer(None)
