@@ -403,11 +403,8 @@ __device__ __forceinline__ void td_loss_wave(const float* q0, const float* q1, c
             se = fmaf(diff, diff, se);
         }
     }
-    for (int m = 32; m >= 1; m >>= 1) {
-        sq += __shfl_xor(sq, m); sy += __shfl_xor(sy, m); se += __shfl_xor(se, m);
-        mnq = fminf(mnq, __shfl_xor(mnq, m)); mxq = fmaxf(mxq, __shfl_xor(mxq, m));
-        mny = fminf(mny, __shfl_xor(mny, m)); mxy = fmaxf(mxy, __shfl_xor(mxy, m));
-    }
+    sq = wave_sum(sq); sy = wave_sum(sy); se = wave_sum(se);
+    mnq = wave_min(mnq); mxq = wave_max(mxq); mny = wave_min(mny); mxy = wave_max(mxy);
     if (lane == 0) {
         sp[0] = se; sp[1] = sq; sp[2] = mxq; sp[3] = mnq; sp[4] = sy; sp[5] = mxy; sp[6] = mny; sp[7] = 0.f;
     }

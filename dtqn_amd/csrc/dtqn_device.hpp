@@ -61,6 +61,13 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 #define DTQN_AGENT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_AGENT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+// all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
+// for global stores)
+#define DTQN_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+// DPP rotate of a 16-lane row by n lanes (VALU-rate; 0x120 + n = row_ror:n)
+#ifndef DTQN_ROW_ROR
+#define DTQN_ROW_ROR(x, n) __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(x), 0x120 + (n), 0xf, 0xf, true))
 #endif
 // 2^x on the transcendental unit (v_exp_f32: -inf -> 0, no range reduction code)
 #ifndef DTQN_EXP2
@@ -110,6 +117,19 @@ __device__ __forceinline__ float kq_sum(float v) {
     const auto b = DTQN_LANE_SWAP16(v);
     return b[0] + b[1];
 }
+// All-reduce over the 64 lanes of a wave without touching LDS: halves and rows with the lane-swap instructions, the
+// 16 lanes of a row with four DPP rotations.  Every lane ends up with the result.
+#define DTQN_WAVE_ALLREDUCE(v, OP)                                   \
+    do {                                                            \
+        const auto a_ = DTQN_LANE_SWAP32(v); v = OP(a_[0], a_[1]);  \
+        const auto b_ = DTQN_LANE_SWAP16(v); v = OP(b_[0], b_[1]);  \
+        v = OP(v, DTQN_ROW_ROR(v, 8)); v = OP(v, DTQN_ROW_ROR(v, 4)); \
+        v = OP(v, DTQN_ROW_ROR(v, 2)); v = OP(v, DTQN_ROW_ROR(v, 1)); \
+    } while (0)
+__device__ __forceinline__ float dtqn_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum(float v) { DTQN_WAVE_ALLREDUCE(v, dtqn_addf); return v; }
+__device__ __forceinline__ float wave_max(float v) { DTQN_WAVE_ALLREDUCE(v, fmaxf); return v; }
+__device__ __forceinline__ float wave_min(float v) { DTQN_WAVE_ALLREDUCE(v, fminf); return v; }
 __device__ __forceinline__ void ballot_store(float* mask_rec, int ctiles, int row, int col, bool on, int lane) {
     const unsigned long long bits = __ballot(on ? 1 : 0);
     if (lane == 0) reinterpret_cast<unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)] = bits;
@@ -789,8 +809,9 @@ __device__ __forceinline__ void xch_send(const float* s, int ld, float* g, int r
         const int r = idx / cols, c = idx - r * cols;
         DTQN_AGENT_STORE(g + idx, s[r * ld + c]);
     }
-    __syncthreads();                               // every wave's stores are acknowledged (s_waitcnt vmcnt(0)) ...
-    if (t.tid == 0) DTQN_AGENT_STORE(flag, (int32_t)1);   // ... before the flag becomes visible
+    DTQN_WAIT_VMEM();                              // every wave's stores are acknowledged at agent scope ...
+    __syncthreads();                               // ... and every wave got here ...
+    if (t.tid == 0) DTQN_AGENT_STORE(flag, (int32_t)1);   // ... before the flag is raised
 }
 template <int NW, bool ADD>
 __device__ __forceinline__ void xch_recv(float* s, int ld, const float* g, int rows, int cols, int32_t* flag, const Thr& t) {

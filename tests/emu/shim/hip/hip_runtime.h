@@ -26,6 +26,7 @@ template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomi
 #define DTQN_AGENT_LOAD(p) hipemu_agent_load(p)
 #define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
 #define DTQN_SPIN_PAUSE() ((void)0)
+#define DTQN_WAIT_VMEM() ((void)0)
 
 // ---- qualifiers -------------------------------------------------------------
 #define __global__
@@ -110,6 +111,8 @@ static inline hipemu_pair hipemu_lane_swap16(float x) {
     r.v[1] = hipemu_shfl_from(x, l | 16);
     return r;
 }
+static inline float hipemu_row_ror(float x, int n) { const int l = hipemu::lane_id(); return hipemu_shfl_from(x, (l & ~15) | ((l - n) & 15)); }
+#define DTQN_ROW_ROR(x, n) hipemu_row_ror(x, n)
 #define DTQN_LANE_SWAP32(x) hipemu_lane_swap32(x)
 #define DTQN_LANE_SWAP16(x) hipemu_lane_swap16(x)
 template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
