@@ -13,6 +13,7 @@ What changed underneath:
 from __future__ import annotations
 
 import ctypes
+import os
 import random
 from enum import Enum
 from typing import Callable, Optional, Tuple, Union
@@ -75,6 +76,7 @@ class DtqnAgent:
         self.obs_context_type = np.int_ if is_discrete_env else np.float32
         self.obs_tensor_type = torch.long if is_discrete_env else torch.float32
         self.sampler, self.sample_seed = sampler, int(sample_seed)
+        self._separate_sample_launch = os.environ.get("DTQN_SAMPLE_LAUNCH", "0") == "1"
         if sampler not in ("reference", "device"):
             raise ValueError("sampler must be 'reference' (Python `random` stream) or 'device'")
         self.engine = TdEngine(self.policy_network.net, batch_size, lr=learning_rate, gamma=gamma, history=history,
@@ -225,7 +227,10 @@ class DtqnAgent:
             eng.set_indices(*rb.sample_indices(self.batch_size))
         else:
             n_valid, exclude = rb.valid_range()
-            eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed, sp)
+            if self._separate_sample_launch:          # DTQN_SAMPLE_LAUNCH=1: A/B knob, one extra launch per update
+                eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed, sp)
+            else:
+                eng.sample_in_forward(n_valid, exclude, self.sample_seed)      # the forward kernel draws its own windows
         if self._actor_inflight:
             # the gradient kernels overlap the actor forward; only the optimizer kernel (which overwrites theta)
             # has to wait for it

@@ -799,6 +799,30 @@ __device__ __forceinline__ void tile_load(float* s, int ld, const float* __restr
     }
 }
 
+// splitmix64-style counter hash -> 32 random bits per (seed, step, element, draw)
+__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t step, uint32_t elem, uint32_t draw) {
+    unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^
+                           ((unsigned long long)elem << 20) ^ draw;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// The window draw of ReplayBuffer.sample (replay_buffer.py:141-158) for batch element b of update `step`:
+// episode uniform over the finished slots [0, n_valid) minus `exclude`, start uniform on {0 .. max(0, len - L)}.
+__device__ __forceinline__ void replay_draw(const int32_t* __restrict__ ep_len, int n_valid, int exclude, int ctx_len,
+                                            uint32_t seed, uint32_t step, int b, int& ep, int& start) {
+    const bool skip = exclude >= 0 && exclude < n_valid;
+    const uint32_t choices = (uint32_t)(n_valid - (skip ? 1 : 0));
+    uint32_t e = (uint32_t)(((unsigned long long)hash_u32(seed, step, (uint32_t)b, 0) * choices) >> 32);
+    if (skip && (int)e >= exclude) e += 1;
+    const int len = ep_len[e];
+    const uint32_t span = (uint32_t)(len - ctx_len > 0 ? len - ctx_len : 0) + 1u;
+    ep = (int)e;
+    start = (int)(((unsigned long long)hash_u32(seed, step, (uint32_t)b, 1) * span) >> 32);
+}
+
 // Row-split hand-over of a [rows][cols] tile between the two workgroups of a sequence.  The producer publishes the
 // LDS tile and raises the flag; the consumer waits for the flag, pulls the tile into its own LDS and lowers the
 // flag again (so the next launch starts from 0).  ADD: accumulate into the destination instead of overwriting.

@@ -33,6 +33,13 @@ struct FwdArgs {
     float* act;                 // nullptr: inference; else activation records for which == 0
     float* xch;                 // row-split hand-over buffer / flags (RS == 2 only)
     int32_t* xflags;
+    // in-kernel window draw (DtqnTd.sample_in_kernel): ep_len != nullptr
+    const int32_t* ep_len;
+    const int32_t* step_counter;
+    int32_t* ep_out;
+    int32_t* start_out;
+    int s_n_valid, s_exclude;
+    uint32_t s_seed;
     long long* prof;            // debug stage clock (see dtqn_debug_set_profile_buffer)
 };
 
@@ -77,8 +84,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // ---------------- window gather + embedding ----------------
-    const int ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
-    const int row0 = (a.start != nullptr ? a.start[b] : 0) + (which > 0 ? 1 : 0) + R0;
+    int ep, st;
+    if (a.ep_len != nullptr) {
+        // every workgroup of sequence b (three passes, row slices) evaluates the same counter-based draw; one of them
+        // leaves it for the backward kernel
+        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, (uint32_t)a.step_counter[1], b, ep, st);
+        if (which == 0 && slice == 0 && t.tid == 0) { a.ep_out[b] = ep; a.start_out[b] = st; }
+    } else {
+        ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
+        st = a.start != nullptr ? a.start[b] : 0;
+    }
+    const int row0 = st + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
     const int KE = net.ke, KEP = net.kep;
@@ -425,6 +441,8 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
     a.q_row_stride = net->num_actions;
     a.act = nullptr;
     a.xch = nullptr; a.xflags = nullptr;
+    a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
+    a.s_n_valid = 0; a.s_exclude = -1; a.s_seed = 0;
     a.prof = nullptr;
     return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
 }
@@ -432,7 +450,19 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (rp->obs_dim != net->obs_dim || rp->max_steps < net->ctx_len) return DTQN_ERR_ARG;
-    if (net->tiled) return tiled_td_forward(net, rp, td, (hipStream_t)stream);
+    const bool draw = td->sample_in_kernel != 0;
+    if (draw) {
+        const bool skip = td->sample_exclude >= 0 && td->sample_exclude < td->sample_n_valid;
+        if (td->sample_n_valid - (skip ? 1 : 0) < 1 || !td->step_counter) return DTQN_ERR_ARG;
+    }
+    if (net->tiled) {       // the multi-kernel path reads the windows from td->ep_idx / td->start: draw them first
+        if (draw) {
+            const int rc = dtqn_replay_sample(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed,
+                                              td->step_counter, td->ep_idx, td->start, stream);
+            if (rc != DTQN_OK) return rc;
+        }
+        return tiled_td_forward(net, rp, td, (hipStream_t)stream);
+    }
     FwdArgs a;
     a.net = *net;
     a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;
@@ -440,6 +470,9 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim;
     a.act_ep_stride = rp->max_steps + 1;
     a.ep_idx = td->ep_idx; a.start = td->start;
+    a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
+    a.ep_out = td->ep_idx; a.start_out = td->start;
+    a.s_n_valid = td->sample_n_valid; a.s_exclude = td->sample_exclude; a.s_seed = td->sample_seed;
     a.n = net->ctx_len; a.batch = td->batch;
     a.q_out = td->q3;
     a.q_which_stride = (long long)td->batch * net->lp * net->ap;

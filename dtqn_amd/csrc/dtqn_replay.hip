@@ -48,17 +48,6 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
     }
 }
 
-// splitmix64-style counter hash -> 32 random bits per (seed, step, element, draw)
-__device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t step, uint32_t elem, uint32_t draw) {
-    unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^
-                           ((unsigned long long)elem << 20) ^ draw;
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
-}
-
 struct SampleArgs {
     const int32_t* ep_len;
     int n_valid, exclude, ctx_len, batch;
@@ -72,15 +61,8 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_sample_kernel(Sample
     const int b = (int)blockIdx.x * DTQN_THREADS + (int)threadIdx.x;
     if (b >= a.batch) return;
     const uint32_t step = a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : 0u;
-    const bool skip = a.exclude >= 0 && a.exclude < a.n_valid;
-    const uint32_t choices = (uint32_t)(a.n_valid - (skip ? 1 : 0));
-    // valid_episodes = [0, n_valid) \ {exclude}; random.choice -> uniform (replay_buffer.py:141-148)
-    uint32_t e = (uint32_t)(((unsigned long long)hash_u32(a.seed, step, (uint32_t)b, 0) * choices) >> 32);
-    if (skip && (int)e >= a.exclude) e += 1;
-    // start uniform on {0 .. max(0, len - L)} inclusive (:149-155)
-    const int len = a.ep_len[e];
-    const uint32_t span = (uint32_t)(len - a.ctx_len > 0 ? len - a.ctx_len : 0) + 1u;
-    const uint32_t s = (uint32_t)(((unsigned long long)hash_u32(a.seed, step, (uint32_t)b, 1) * span) >> 32);
+    int e, s;
+    replay_draw(a.ep_len, a.n_valid, a.exclude, a.ctx_len, a.seed, step, b, e, s);
     a.ep_idx[b] = (int32_t)e;
     a.start[b] = (int32_t)s;
 }

@@ -151,10 +151,18 @@ class TdEngine:
 
     def set_indices(self, ep_idx, start):
         """Host-drawn (episode, start) pairs (reference RNG stream) -> device."""
+        self.td.sample_in_kernel = 0
         self.ep_idx.copy_(torch.as_tensor(np.asarray(ep_idx, dtype=np.int32)), non_blocking=True)
         self.start.copy_(torch.as_tensor(np.asarray(start, dtype=np.int32)), non_blocking=True)
 
+    def sample_in_forward(self, n_valid: int, exclude: int, seed: int) -> None:
+        """Let the next dtqn_td_forward / dtqn_td_update draw its own windows (no sampling launch): the same draw as
+        sample_on_device for the same (seed, step counter)."""
+        td = self.td
+        td.sample_in_kernel, td.sample_n_valid, td.sample_exclude, td.sample_seed = 1, int(n_valid), int(exclude), seed & 0xFFFFFFFF
+
     def sample_on_device(self, replay: DeviceReplay, n_valid: int, exclude: int, seed: int, stream=None):
+        self.td.sample_in_kernel = 0
         self._check(self.lib.dtqn_replay_sample(ctypes.byref(replay.view), int(n_valid), int(exclude), self.net.ctx_len,
                                                 self.batch, ctypes.c_uint32(seed & 0xFFFFFFFF), _p(self.step_counter),
                                                 _p(self.ep_idx), _p(self.start), stream if stream is not None else self._stream()),

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 2
+#define DTQN_ABI_VERSION 3
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -209,8 +209,9 @@ typedef struct DtqnTd {
     float* adam_m;            /* [n_trainable] */
     float* adam_v;            /* [n_trainable] */
     /* sampled windows */
-    const int32_t* ep_idx;    /* [B] */
-    const int32_t* start;     /* [B] */
+    int32_t* ep_idx;          /* [B] sampled (episode, start) pairs: INPUT when sample_in_kernel == 0 (drawn by the host or by
+                               * dtqn_replay_sample), OUTPUT of dtqn_td_forward when sample_in_kernel == 1 */
+    int32_t* start;           /* [B] */
     /* workspaces */
     float* act;               /* [B][act_stride] */
     float* grd;               /* [B][grd_stride] */
@@ -235,6 +236,12 @@ typedef struct DtqnTd {
     int32_t n_norm_blocks;
     int32_t stats_ring_slots;
     int32_t target_update_frequency;
+    int32_t sample_in_kernel; /* 1: dtqn_td_forward draws the windows itself -- the same counter-based draw as dtqn_replay_sample
+                               * (seed = sample_seed, step = step_counter[1]) evaluated by every workgroup for its own sequence:
+                               * no separate sampling launch in front of the update */
+    int32_t sample_n_valid;   /* finished episode slots [0, n_valid) */
+    int32_t sample_exclude;   /* slot in progress (excluded), or -1 */
+    uint32_t sample_seed;
     int32_t row_split;        /* workgroups per sequence in the forward / backward kernels: the value
                                * dtqn_td_row_split(net, B) returned (1 = one workgroup per sequence) */
     float gamma;

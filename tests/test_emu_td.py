@@ -2,6 +2,7 @@
 gradients, reduce, clip + Adam) on the test-only HIP emulation, against the oracle."""
 import numpy as np
 import pytest
+import torch
 
 from dtqn_amd import _binding as B
 from oracle import dtqn_oracle as O
@@ -81,3 +82,23 @@ def test_td_update_row_split(emu, kw, monkeypatch):
     assert eng.row_split == 2 and net.lp == 64
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
     assert int(eng.xflags.sum()) == 0                      # every hand-over flag was lowered again
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_in_kernel_window_draw_equals_sample_kernel(emu, split, monkeypatch):
+    """dtqn_td_forward with sample_in_kernel draws exactly the windows dtqn_replay_sample draws for the same
+    (seed, step counter), leaves them in ep_idx / start for the backward, and produces the same update."""
+    monkeypatch.setenv("DTQN_ROW_SPLIT", split)
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=4, batch=4, T=90, n_eps=9, mask=-5)
+    eng.step_counter[1] = 7
+    eng.sample_on_device(rep, 9, 3, 12345)
+    ref = (eng.ep_idx.clone(), eng.start.clone())
+    assert 3 not in ref[0].tolist() and len(set(ref[0].tolist())) > 1
+    eng.forward_backward(rep)
+    grad_ref = eng.grad.clone()
+    eng.ep_idx.zero_(); eng.start.zero_()
+    eng.sample_in_forward(9, 3, 12345)
+    eng.forward_backward(rep)
+    assert torch.equal(eng.ep_idx, ref[0]) and torch.equal(eng.start, ref[1])
+    assert torch.equal(eng.grad, grad_ref)
