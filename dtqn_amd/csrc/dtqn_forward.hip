@@ -269,14 +269,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
             float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+                // the second GEMM's first weight fragment does not depend on the hidden: in flight during the first GEMM
+                if (Own::valid(t.wave, 0))
+                    frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
                 g_f1.retire();
                 g_f1.run(src, LDX, t, [&](int r, int c, float v) {
                     const float hv = fmaxf(v + b1[c0 + c], 0.f);
                     if (mh_g != nullptr) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
                     Ws[r * LDW + c] = hv;
                 });
-                if (Own::valid(t.wave, 0))
-                    frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
+                // ... and the next chunk's first W1 fragment is in flight during the second GEMM
+                if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t);
                 __syncthreads();                       // hidden chunk visible
                 if (Own::valid(t.wave, 0)) {
 #pragma unroll
@@ -290,7 +293,6 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                     if (Own::valid(t.wave, q))
                         frag_xwT_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW, w2f[q & 1], t, facc[q]);
                 }
-                if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t);
                 __syncthreads();                       // everyone is done reading this chunk of the hidden
             }
             const float* __restrict__ b2 = th + net.lo_f2_b;
