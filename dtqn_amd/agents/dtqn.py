@@ -23,6 +23,7 @@ import torch
 
 from .. import dist as ddp
 from ..buffers.replay_buffer import ReplayBuffer
+from .. import _binding as B
 from ..learner import STAT_NAMES, TdEngine
 from ..utils.context import Context
 from ..utils.logging_utils import DeferredRunningAverage, RunningAverage
@@ -102,6 +103,7 @@ class DtqnAgent:
         self._stat_sinks = {"td_error": self.td_errors, "grad_norm": self.grad_norms, "qvalue_max": self.qvalue_max,
                             "qvalue_mean": self.qvalue_mean, "qvalue_min": self.qvalue_min, "target_max": self.target_max,
                             "target_mean": self.target_mean, "target_min": self.target_min}
+        self._stat_index = (STAT_NAMES.index("nonfinite"), [(name, STAT_NAMES.index(name)) for name in self._stat_sinks])
         cuda = self.device.type == "cuda"
         self._calls_issued = 0        # dtqn_td_clip_adam launches so far
         self._calls_read = 0          # ... whose statistics have been consumed from the pinned ring
@@ -111,16 +113,31 @@ class DtqnAgent:
         # actor staging: rolling context -> pinned -> device, Q row -> pinned
         L, O, A = context_len, env_obs_length, num_actions
         pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
-        self._ctx_obs_h, self._ctx_act_h = pin(torch.zeros(L, O)), pin(torch.zeros(L, dtype=torch.uint8))
-        self._ctx_obs_d = torch.zeros(L, O, device=self.device)
-        self._ctx_act_d = torch.zeros(L, dtype=torch.uint8, device=self.device)
+        # one packed staging buffer [L*O f32 | L u8] -> ONE host-to-device copy per action
+        nbytes = L * O * 4 + L
+        self._ctx_h = pin(torch.zeros(nbytes, dtype=torch.uint8))
+        self._ctx_d = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._ctx_obs_np = self._ctx_h.numpy()[:L * O * 4].view(np.float32).reshape(L, O)
+        self._ctx_act_np = self._ctx_h.numpy()[L * O * 4:]
+        self._ctx_hp, self._ctx_dp = ctypes.c_void_p(self._ctx_h.data_ptr()), ctypes.c_void_p(self._ctx_d.data_ptr())
         self._q_d = torch.zeros(L, A, device=self.device)
-        self._actor_ws = None
+        self._q_p = ctypes.c_void_p(self._q_d.data_ptr())
+        self._actor_ws, self._actor_ws_p = None, None
         self._q_h = pin(torch.zeros(A))
+        self._q_np = self._q_h.numpy()
+        self._q_hp = ctypes.c_void_p(self._q_h.data_ptr())
         # pipelined mode (begin_action / train / finish_action): the actor forward of step t+1 runs on its own
         # stream CONCURRENTLY with TD update t+1; it reads the weights produced by update t, and update t+1's
         # optimizer kernel waits for it (write-after-read on theta)
+        self._theta_p = ctypes.c_void_p(self.engine.theta_pol.data_ptr())
+        # all learner work is issued on the stream that is current NOW (normally the default stream); binding it spares
+        # a current-stream lookup per launch in the step loop
+        self._main_stream = torch.cuda.current_stream(self.device) if cuda else None
+        self._main_ptr = ctypes.c_void_p(self._main_stream.cuda_stream) if cuda else None
+        if cuda:
+            self.engine.bind_stream(self._main_stream)
         self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
+        self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream) if cuda else None
         self._ev_update_done = torch.cuda.Event() if cuda else None
         self._ev_actor_done = torch.cuda.Event() if cuda else None
         self._actor_inflight = False
@@ -144,26 +161,20 @@ class DtqnAgent:
         """Stage the unpadded prefix of the rolling context and launch the batch-1 forward; returns n."""
         ctx = self.context
         n = min(ctx.max_length, ctx.timestep + 1)
-        self._ctx_obs_h[:n] = torch.from_numpy(np.asarray(ctx.obs[:n], dtype=np.float32))
-        self._ctx_act_h[:n] = torch.from_numpy(np.asarray(ctx.action[:n, 0], dtype=np.uint8))
-        self._ctx_obs_d[:n].copy_(self._ctx_obs_h[:n], non_blocking=True)
-        self._ctx_act_d[:n].copy_(self._ctx_act_h[:n], non_blocking=True)
+        self._ctx_obs_np[:n] = ctx.obs[:n]
+        self._ctx_act_np[:n] = ctx.action[:n, 0]
         eng = self.engine
-        if eng.net.tiled:       # long contexts / wide models: row-block tiled kernels over a private workspace
-            if self._actor_ws is None:
-                need = eng.lib.dtqn_forward_workspace_floats(ctypes.byref(eng.net), 1)
-                self._actor_ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            rc = eng.lib.dtqn_forward_tiled(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
-                                            ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
-                                            1, n, ctypes.c_void_p(self._q_d.data_ptr()), ctypes.c_void_p(self._actor_ws.data_ptr()),
-                                            stream_ptr)
-        else:
-            rc = eng.lib.dtqn_forward(ctypes.byref(eng.net), ctypes.c_void_p(eng.theta_pol.data_ptr()),
-                                      ctypes.c_void_p(self._ctx_obs_d.data_ptr()), ctypes.c_void_p(self._ctx_act_d.data_ptr()),
-                                      1, n, ctypes.c_void_p(self._q_d.data_ptr()), stream_ptr)
+        if eng.net.tiled and self._actor_ws is None:      # long contexts / wide models: row-block kernels over a private workspace
+            need = eng.lib.dtqn_forward_workspace_floats(eng._net_ref, 1)
+            self._actor_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._actor_ws_p = ctypes.c_void_p(self._actor_ws.data_ptr())
+        # pinned context -> device, forward, Q of the LAST timestep -> pinned: one library call, all on `stream_ptr`
+        rc = eng.lib.dtqn_actor_forward(eng._net_ref, self._theta_p, self._ctx_hp, self._ctx_dp, n, self._q_p, self._q_hp,
+                                        self._actor_ws_p, stream_ptr)
+        if rc == B.DEFINES["DTQN_ERR_ARG"]:
+            raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         if rc != 0:
-            raise RuntimeError(f"dtqn_forward failed with DTQN status {rc}")
-        self._q_h.copy_(self._q_d[n - 1], non_blocking=True)         # Q of the LAST timestep
+            raise RuntimeError(f"dtqn_actor_forward failed with DTQN status {rc}")
         return n
 
     @torch.no_grad()
@@ -171,9 +182,9 @@ class DtqnAgent:
         if RNG.rng.random() < epsilon:
             return RNG.rng.integers(self.num_actions)
         self._launch_actor_forward(self.engine._stream())
-        if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()
-        return int(np.argmax(self._q_h.numpy()))                         # first max, like torch.argmax
+        if self._main_stream is not None:
+            self._main_stream.synchronize()
+        return int(np.argmax(self._q_np))                                # first max, like torch.argmax
 
     # ---- pipelined actor (same action semantics: the policy after the previous update) ----------------
     @torch.no_grad()
@@ -185,24 +196,23 @@ class DtqnAgent:
         if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
             return self._sync_forward_action()
         if not getattr(self, "_update_recorded", True):       # order the actor behind the last TD update (pipelined mode only)
-            self._ev_update_done.record(torch.cuda.current_stream(self.device))
+            self._ev_update_done.record(self._main_stream)
             self._update_recorded = True
         self._actor_stream.wait_event(self._ev_update_done)
-        with torch.cuda.stream(self._actor_stream):
-            self._launch_actor_forward(ctypes.c_void_p(self._actor_stream.cuda_stream))
-            self._ev_actor_done.record(self._actor_stream)
+        self._launch_actor_forward(self._actor_ptr)        # no torch op inside: no stream context needed
+        self._ev_actor_done.record(self._actor_stream)
         self._actor_inflight = True
         return None
 
     def _sync_forward_action(self) -> int:
         self._launch_actor_forward(self.engine._stream())
-        return int(np.argmax(self._q_h.numpy()))
+        return int(np.argmax(self._q_np))
 
     def finish_action(self, pending) -> int:
         if pending is not None:
             return pending
         self._actor_stream.synchronize()
-        return int(np.argmax(self._q_h.numpy()))
+        return int(np.argmax(self._q_np))
 
     def context_reset(self, obs: np.ndarray) -> None:
         self.context.reset(obs)
@@ -220,9 +230,9 @@ class DtqnAgent:
         if not rb.can_sample(self.batch_size):
             return
         self.eval_off()
-        rb.commit()
         eng = self.engine
         sp = eng._stream()
+        rb.commit(sp, self._main_stream)
         if self.sampler == "reference":
             eng.set_indices(*rb.sample_indices(self.batch_size))
         else:
@@ -238,7 +248,7 @@ class DtqnAgent:
             if self.dp is not None:
                 self.dp.allreduce_gradient()
                 eng.recompute_gradnorm()
-            torch.cuda.current_stream(self.device).wait_event(self._ev_actor_done)
+            self._main_stream.wait_event(self._ev_actor_done)
             eng.clip_adam()
             self._actor_inflight = False
         elif self.dp is None:
@@ -267,8 +277,7 @@ class DtqnAgent:
     def _drain_stats(self, block: bool) -> None:
         eng = self.engine
         ring, slots = eng.stats_ring_np, eng.RING_SLOTS
-        i_nonfinite = STAT_NAMES.index("nonfinite")
-        idx = [(name, STAT_NAMES.index(name)) for name in self._stat_sinks]
+        i_nonfinite, idx = self._stat_index
         while self._calls_read < self._calls_issued:
             k = self._calls_read + 1
             row = ring[(k - 1) % slots]

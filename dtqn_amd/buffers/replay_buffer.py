@@ -56,7 +56,11 @@ class ReplayBuffer:
             self._stage.append(dict(
                 rec_h=rec_h, obs_h=obs_h, rec_np=rec_h.numpy().view(RECORD_DTYPE), obs_np=obs_h.numpy().reshape(C, O),
                 rec_d=torch.zeros_like(rec_h, device=self.device), obs_d=torch.zeros_like(obs_h, device=self.device),
-                event=torch.cuda.Event() if cuda else None, busy=False))
+                event=torch.cuda.Event() if cuda else None, busy=False, views={}))
+            self._stage[-1]["rec_p"] = ctypes.c_void_p(self._stage[-1]["rec_d"].data_ptr())
+            self._stage[-1]["obs_p"] = ctypes.c_void_p(self._stage[-1]["obs_d"].data_ptr())
+            self._stage[-1]["rec_hp"] = ctypes.c_void_p(rec_h.data_ptr())
+            self._stage[-1]["obs_hp"] = ctypes.c_void_p(obs_h.data_ptr())
         self._cur, self._n = 0, 0
 
     # ---- producer side (replay_buffer.py:71-98) ----------------------------------------------
@@ -90,21 +94,20 @@ class ReplayBuffer:
     def flush(self) -> None:
         self.pos = [self.pos[0] + 1, 0]
 
-    def commit(self) -> None:
-        """Ship the queued records to the GPU: one H2D copy pair + one scatter kernel."""
+    def commit(self, stream_ptr=None, stream=None) -> None:
+        """Ship the queued records to the GPU (dtqn_replay_push) on torch's current stream, or on the raw stream
+        handle `stream_ptr` when the caller already has it."""
         if self._n == 0:
             return
         st, n = self._stage[self._cur], self._n
-        nb, no = n * RECORD_DTYPE.itemsize, n * self.env_obs_length
-        st["rec_d"][:nb].copy_(st["rec_h"][:nb], non_blocking=True)
-        st["obs_d"][:no].copy_(st["obs_h"][:no], non_blocking=True)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
-        rc = self._lib.dtqn_replay_apply(ctypes.byref(self.dev.view), ctypes.c_void_p(st["rec_d"].data_ptr()),
-                                         ctypes.c_void_p(st["obs_d"].data_ptr()), n, stream)
+        if stream_ptr is None and self.device.type == "cuda":
+            stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # the scatter kernel reads the pinned staging in place: one launch, no copy
+        rc = self._lib.dtqn_replay_push(self.dev.view_ref, st["rec_hp"], st["obs_hp"], n, stream_ptr)
         if rc != 0:
-            raise RuntimeError(f"dtqn_replay_apply failed with DTQN status {rc}")
+            raise RuntimeError(f"dtqn_replay_push failed with DTQN status {rc}")
         if st["event"] is not None:
-            st["event"].record()
+            st["event"].record(stream) if stream is not None else st["event"].record()
             st["busy"] = True
         self._cur = (self._cur + 1) % len(self._stage)
         self._n = 0

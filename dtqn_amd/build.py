@@ -46,9 +46,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", "-I" + os.path.join(REPO, "include"),
                "-I" + CSRC, info, s, "-o", o]
         if s.endswith(".cpp"):
-            cmd[1:2] = []          # plain host C++: no offload arch needed
+            cmd[1:2] = []          # host-only C++ (may call the HIP runtime API): no offload arch needed
             cmd.insert(1, "-x")
             cmd.insert(2, "c++")
+            cmd.insert(3, "-D__HIP_PLATFORM_AMD__")
+            cmd.insert(4, "-I/opt/rocm/include")
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for s, p in procs:

@@ -1,4 +1,6 @@
 // Entry points that only sequence other entry points (no device code of their own).
+#include <hip/hip_runtime.h>
+
 #include <cstdlib>
 
 #include "dtqn_hip.h"
@@ -47,4 +49,42 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
     if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;
     return dtqn_td_clip_adam(net, td, stream);
+}
+
+// Rollout staging (north_star: "pinned hipMemcpyAsync into the device buffer").  Every HIP API call costs the host
+// loop microseconds, so a step of the actor loop is one library call each, with as few runtime calls inside as possible:
+//  * the producer's scatter kernel reads its records and observation rows straight out of the PINNED host staging
+//    (device-mapped memory, a few dozen bytes per step): no copy is enqueued at all;
+//  * the actor's context goes over with one hipMemcpyAsync (it is re-read by every lane of the embedding stage, so it
+//    has to be in device memory), and the Q-values of the last row come back by the forward kernel writing them into
+//    pinned host memory itself.
+namespace dtqn {
+int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
+                  float* q_out, float* q_last_host, void* stream);
+}
+
+extern "C" int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, const float* obs_host, int n,
+                                void* stream) {
+    if (!rp || n < 0) return DTQN_ERR_ARG;
+    if (n == 0) return DTQN_OK;
+    if (!recs_host || !obs_host) return DTQN_ERR_ARG;
+    return dtqn_replay_apply(rp, recs_host, obs_host, n, stream);
+}
+
+extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n,
+                                  float* q_dev, float* q_last_host, float* workspace, void* stream) {
+    if (!net || !theta || !ctx_host || !ctx_dev || !q_dev || !q_last_host) return DTQN_ERR_ARG;
+    if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
+    hipStream_t s = (hipStream_t)stream;
+    const size_t obs_bytes = sizeof(float) * (size_t)net->ctx_len * net->obs_dim;
+    if (hipMemcpyAsync(ctx_dev, ctx_host, obs_bytes + (size_t)net->ctx_len, hipMemcpyHostToDevice, s) != hipSuccess) return DTQN_ERR_LAUNCH;
+    const float* obs = static_cast<const float*>(ctx_dev);
+    const uint8_t* actions = static_cast<const uint8_t*>(ctx_dev) + obs_bytes;
+    if (!net->tiled) return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream);
+    const int rc = dtqn_forward_tiled(net, theta, obs, actions, 1, n, q_dev, workspace, stream);
+    if (rc != DTQN_OK) return rc;
+    if (hipMemcpyAsync(q_last_host, q_dev + (size_t)(n - 1) * net->num_actions, sizeof(float) * net->num_actions,
+                       hipMemcpyDeviceToHost, s) != hipSuccess)
+        return DTQN_ERR_LAUNCH;
+    return DTQN_OK;
 }

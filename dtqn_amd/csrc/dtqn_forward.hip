@@ -30,6 +30,7 @@ struct FwdArgs {
     float* q_out;               // which-major
     long long q_which_stride, q_seq_stride;
     int q_row_stride;
+    float* q_last_host;         // optional, PINNED host memory [num_actions]: Q of the last live row of sequence 0 (actor)
     float* act;                 // nullptr: inference; else activation records for which == 0
     float* xch;                 // row-split hand-over buffer / flags (RS == 2 only)
     int32_t* xflags;
@@ -357,6 +358,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
             }
             q[r * a.q_row_stride + ac] = acc;
+            // the actor only needs Q[:, -1] (dtqn.py:103): written straight into host memory, no copy enqueued behind the kernel
+            if (a.q_last_host != nullptr && seq == 0 && R0 + r == nfull - 1) a.q_last_host[ac] = acc;
         }
     }
     DTQN_PROF(a.prof, ps++);       // end
@@ -372,8 +375,12 @@ static size_t fwd_lds_bytes(const DtqnNet* net) {
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 static int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>),
+    static size_t attr_lds = 0;              // raise the limit once per instantiation (and size): the call is a driver round trip
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
@@ -423,8 +430,16 @@ extern "C" int dtqn_lds_bytes_forward(const DtqnNet* net, int /*training*/) {
     return b <= 160 * 1024 ? (int)b : 0;
 }
 
+namespace dtqn {
+int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
+                  float* q_out, float* q_last_host, void* stream);
+}
 extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                             int batch, int n, float* q_out, void* stream) {
+    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream);
+}
+int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
+                        float* q_out, float* q_last_host, void* stream) {
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->tiled) return DTQN_ERR_CONFIG;                             // use dtqn_forward_tiled
@@ -441,6 +456,7 @@ extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float*
     a.q_which_stride = 0;
     a.q_seq_stride = (long long)n * net->num_actions;
     a.q_row_stride = net->num_actions;
+    a.q_last_host = q_last_host;
     a.act = nullptr;
     a.xch = nullptr; a.xflags = nullptr;
     a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
@@ -480,6 +496,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.q_which_stride = (long long)td->batch * net->lp * net->ap;
     a.q_seq_stride = (long long)net->lp * net->ap;
     a.q_row_stride = net->ap;
+    a.q_last_host = nullptr;
     a.act = td->act;
     a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());

@@ -44,6 +44,7 @@ class DeviceReplay:
         self.view.ep_len = self.ep_len.data_ptr()
         self.view.num_episodes, self.view.max_steps, self.view.obs_dim = E, T, O
         self.view.obs_mask = float(obs_mask)
+        self.view_ref = ctypes.byref(self.view)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.obs, self.actions, self.rewards, self.dones, self.ep_len))
@@ -65,6 +66,7 @@ class TdEngine:
             self.lib = _test_lib
             self.device = torch.device("cpu")
         self.net = net
+        self._bound_stream = None
         self.batch = int(batch)
         dev = self.device
         nt, nth = net.n_trainable, net.n_theta
@@ -134,12 +136,21 @@ class TdEngine:
         td.gamma, td.lr, td.beta1, td.beta2, td.eps = float(gamma), float(lr), float(betas[0]), float(betas[1]), float(eps)
         td.grad_norm_clip, td.grad_scale = float(grad_norm_clip), 1.0
         self.td = td
+        self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
 
     # -- helpers ------------------------------------------------------------------------------
     def _stream(self):
+        """HIP stream the kernels are issued on: torch's current stream, or the one pinned with bind_stream()."""
+        if self._bound_stream is not None:
+            return self._bound_stream
         if self.device.type == "cuda":
             return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         return None
+
+    def bind_stream(self, stream: "Optional[torch.cuda.Stream]") -> None:
+        """Issue every launch of this engine on `stream` from now on (None: back to torch's current stream).  Saves the
+        per-call current-stream lookup in tight loops; the caller then keeps its torch work on the same stream."""
+        self._bound_stream = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
     def _check(self, rc: int, what: str):
         if rc != 0:
@@ -170,11 +181,11 @@ class TdEngine:
 
     # -- the update, whole or in stages (stages are what the data-parallel wrapper interleaves) --
     def update(self, replay: DeviceReplay, stream=None):
-        self._check(self.lib.dtqn_td_update(ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td),
+        self._check(self.lib.dtqn_td_update(self._net_ref, replay.view_ref, self._td_ref,
                                             stream if stream is not None else self._stream()), "dtqn_td_update")
 
     def forward_backward(self, replay: DeviceReplay):
-        s, n, r, t = self._stream(), ctypes.byref(self.net), ctypes.byref(replay.view), ctypes.byref(self.td)
+        s, n, r, t = self._stream(), self._net_ref, replay.view_ref, self._td_ref
         self._check(self.lib.dtqn_td_forward(n, r, t, s), "dtqn_td_forward")
         self._check(self.lib.dtqn_td_backward(n, r, t, s), "dtqn_td_backward")
         self._check(self.lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad")
@@ -184,7 +195,7 @@ class TdEngine:
         self._check(self.lib.dtqn_td_gradnorm(ctypes.byref(self.net), ctypes.byref(self.td), self._stream()), "dtqn_td_gradnorm")
 
     def clip_adam(self):
-        self._check(self.lib.dtqn_td_clip_adam(ctypes.byref(self.net), ctypes.byref(self.td), self._stream()), "dtqn_td_clip_adam")
+        self._check(self.lib.dtqn_td_clip_adam(self._net_ref, self._td_ref, self._stream()), "dtqn_td_clip_adam")
 
     def target_sync(self):
         self._check(self.lib.dtqn_target_sync(ctypes.byref(self.net), _p(self.theta_pol), _p(self.theta_tgt), self._stream()),

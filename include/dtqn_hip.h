@@ -253,6 +253,21 @@ typedef struct DtqnTd {
     float grad_scale;         /* multiplies the reduced gradient before clipping (1/world_size for DP) */
 } DtqnTd;
 
+/* ---- host <-> device staging of the rollout (pinned hipMemcpyAsync inside the library: one call per step) ----------- */
+
+/* Producer side of observe() / context_reset(): applies n queued records and their observation rows to the replay.
+ * recs_host / obs_host are PINNED (device-mapped) host staging; the scatter kernel reads them in place, so no copy is
+ * enqueued.  The staging may be reused once work queued on `stream` after this call has completed. */
+int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, const float* obs_host, int n, void* stream);
+
+/* get_action (dtqn/agents/dtqn.py:76-107): ctx_host is a PINNED buffer [ctx_len * obs_dim floats | ctx_len action bytes]
+ * holding the n live rows of the rolling context; it is copied to ctx_dev (same layout), DTQN.forward runs on the n rows
+ * (q_dev [ctx_len][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, 1) floats for tiled nets, else NULL) and
+ * the Q-values of the LAST row land in the pinned q_last_host[num_actions] (written by the forward kernel itself; valid
+ * once `stream` has drained).  All asynchronous on `stream`. */
+int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n, float* q_dev,
+                       float* q_last_host, float* workspace, void* stream);
+
 /* Small-batch latency mode.  With B sampled sequences only 3B / B workgroups exist in the forward / backward
  * kernels, far fewer than the 256 CUs.  When this returns 2 the kernels run TWO workgroups per sequence, each
  * owning half of its rows (projections, LayerNorm, FFN, head and loss are row-local); causal attention is the one
