@@ -164,10 +164,10 @@ class DtqnAgent:
         self._ctx_obs_np[:n] = ctx.obs[:n]
         self._ctx_act_np[:n] = ctx.action[:n, 0]
         eng = self.engine
-        if eng.net.tiled and self._actor_ws is None:      # long contexts / wide models: row-block kernels over a private workspace
+        if self._actor_ws is None:       # tiled kernels' scratch, or the hand-over tiles of the two-workgroup latency mode
             need = eng.lib.dtqn_forward_workspace_floats(eng._net_ref, 1)
-            self._actor_ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            self._actor_ws_p = ctypes.c_void_p(self._actor_ws.data_ptr())
+            self._actor_ws = torch.zeros(max(1, need), dtype=torch.float32, device=self.device)
+            self._actor_ws_p = ctypes.c_void_p(self._actor_ws.data_ptr()) if need > 0 else None
         # pinned context -> device, forward, Q of the LAST timestep -> pinned: one library call, all on `stream_ptr`
         rc = eng.lib.dtqn_actor_forward(eng._net_ref, self._theta_p, self._ctx_hp, self._ctx_dp, n, self._q_p, self._q_hp,
                                         self._actor_ws_p, stream_ptr)

@@ -60,7 +60,7 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
 //    pinned host memory itself.
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
 }
 
 extern "C" int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, const float* obs_host, int n,
@@ -80,7 +80,14 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
     if (hipMemcpyAsync(ctx_dev, ctx_host, obs_bytes + (size_t)net->ctx_len, hipMemcpyHostToDevice, s) != hipSuccess) return DTQN_ERR_LAUNCH;
     const float* obs = static_cast<const float*>(ctx_dev);
     const uint8_t* actions = static_cast<const uint8_t*>(ctx_dev) + obs_bytes;
-    if (!net->tiled) return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream);
+    if (!net->tiled) {
+        // batch 1 is the extreme of the small-batch regime: two workgroups for the one sequence once its upper half has
+        // live rows (workspace = [hand-over tiles | flags], zeroed once by the caller)
+        const bool split = workspace != nullptr && n > net->lp / 2 && dtqn_td_row_split(net, 1) == 2;
+        float* xch = split ? workspace : nullptr;
+        int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, 1)) : nullptr;
+        return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags);
+    }
     const int rc = dtqn_forward_tiled(net, theta, obs, actions, 1, n, q_dev, workspace, stream);
     if (rc != DTQN_OK) return rc;
     if (hipMemcpyAsync(q_last_host, q_dev + (size_t)(n - 1) * net->num_actions, sizeof(float) * net->num_actions,

@@ -432,14 +432,15 @@ extern "C" int dtqn_lds_bytes_forward(const DtqnNet* net, int /*training*/) {
 
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
 }
 extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                             int batch, int n, float* q_out, void* stream) {
-    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream);
+    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream, nullptr, nullptr);
 }
+// xch / xflags != nullptr: latency mode, two workgroups per sequence (the caller decided it pays: dtqn_actor_forward)
 int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                        float* q_out, float* q_last_host, void* stream) {
+                        float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags) {
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->tiled) return DTQN_ERR_CONFIG;                             // use dtqn_forward_tiled
@@ -458,11 +459,11 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.q_row_stride = net->num_actions;
     a.q_last_host = q_last_host;
     a.act = nullptr;
-    a.xch = nullptr; a.xflags = nullptr;
+    a.xch = xch; a.xflags = xflags;
     a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
     a.s_n_valid = 0; a.s_exclude = -1; a.s_seed = 0;
     a.prof = nullptr;
-    return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
+    return dispatch_fwd(a, batch, xch != nullptr && xflags != nullptr ? 2 : 1, (hipStream_t)stream);
 }
 
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {

@@ -262,7 +262,8 @@ int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, co
 
 /* get_action (dtqn/agents/dtqn.py:76-107): ctx_host is a PINNED buffer [ctx_len * obs_dim floats | ctx_len action bytes]
  * holding the n live rows of the rolling context; it is copied to ctx_dev (same layout), DTQN.forward runs on the n rows
- * (q_dev [ctx_len][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, 1) floats for tiled nets, else NULL) and
+ * (q_dev [ctx_len][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, 1) floats, ZEROED once by the caller,
+ * or NULL when that is 0: scratch of the tiled kernels, or the hand-over tiles of the two-workgroup latency mode) and
  * the Q-values of the LAST row land in the pinned q_last_host[num_actions] (written by the forward kernel itself; valid
  * once `stream` has drained).  All asynchronous on `stream`. */
 int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n, float* q_dev,

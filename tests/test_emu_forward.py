@@ -110,3 +110,39 @@ def test_tiled_forward_path(emu, kw, monkeypatch):
         assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
     # the whole-sequence kernels refuse a tiled net, and the training entry points are not built for it
     assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), None) == B.DEFINES["DTQN_ERR_CONFIG"]
+
+
+@pytest.mark.parametrize("kw", [dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
+                                dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=55, action_dim=8)])
+def test_actor_forward_one_call(emu, kw, monkeypatch):
+    """dtqn_actor_forward: packed pinned context -> device -> forward -> Q[:, -1] in host memory, with the two-workgroup
+    latency mode (workspace given, n > 32) and without; both against the oracle."""
+    monkeypatch.setenv("DTQN_ROW_SPLIT", "1")
+    cfg = O.NetCfg(**kw)
+    params = O.init_params(cfg, seed=3, perturb=True)
+    net = net_from_cfg(emu, cfg)
+    theta = pack_theta(net, params)
+    L, Odim, A = cfg.history_len, cfg.obs_dim, cfg.num_actions
+    need = emu.dtqn_forward_workspace_floats(ctypes.byref(net), 1)
+    assert need > 0 and net.tiled == 0
+    ws = np.zeros(need, dtype=np.float32)
+    rng = np.random.default_rng(11)
+    for n in (1, 20, 33, L):
+        obs = rng.uniform(-1, 1, size=(1, n, Odim)).astype(np.float32)
+        act = rng.integers(0, A, size=(1, n, 1))
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act, dtype=torch.long)).numpy()[0, -1]
+        ctx_h = np.zeros(L * Odim * 4 + L, dtype=np.uint8)
+        ctx_h[:L * Odim * 4].view(np.float32).reshape(L, Odim)[:n] = obs[0]
+        ctx_h[L * Odim * 4:][:n] = act[0, :, 0]
+        for workspace in (ws, None):
+            ctx_d = np.zeros_like(ctx_h)
+            q_d = np.full((L, A), np.nan, dtype=np.float32)
+            q_last = np.full(A, np.nan, dtype=np.float32)
+            rc = emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), n, ptr(q_d), ptr(q_last),
+                                        None if workspace is None else ptr(workspace), None)
+            assert rc == 0
+            assert np.abs(q_last - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, workspace is None)
+            assert np.array_equal(q_last, q_d[n - 1])
+        assert not ws[emu.dtqn_td_xch_floats(ctypes.byref(net), 1):].any()      # hand-over flags lowered again
+    assert emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), L + 1, ptr(q_d), ptr(q_last), None, None) == B.DEFINES["DTQN_ERR_ARG"]
