@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 One "step" = one DtqnAgent.train() = one TD update (sample windows -> 3 forwards -> double-DQN loss
--> backward -> clip -> Adam) on a device-resident synthetic replay of the shape SURVEY.md section 8d
-prescribes.  Workload at every N: BASELINE.json's metric configuration, DiscreteCarFlag-v0 shapes,
+-> backward -> clip -> Adam; five launches, the window draw is part of the forward kernel) on a device-resident
+synthetic replay of the shape SURVEY.md section 8d prescribes.  Workload at every N: BASELINE.json's metric configuration, DiscreteCarFlag-v0 shapes,
 context 50, d_model 64, 8 heads, 2 layers, batch 32 PER GPU (weak scaling: each rank owns its
 replay shard and batch; the only exchange is the flat-gradient all-reduce over RCCL).
 Rank 0 prints ONE JSON line.
@@ -139,7 +139,7 @@ def pmc_traffic(kernel: str, batch: int):
         return None
     d = json.load(open(path))
     for k, v in d.items():
-        if k.startswith(kernel):
+        if kernel in k:
             return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     return None
 
