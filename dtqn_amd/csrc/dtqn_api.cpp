@@ -30,7 +30,10 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
                          (net->d_model == 64 || net->d_model == 128);
     if (!covered) return 1;
     if (e != nullptr && e[0] == '1') return 2;
-    return 3 * batch * 2 <= 256 ? 2 : 1;                      // 256 CUs: all 3*B*2 forward workgroups resident
+    if (e != nullptr && e[0] == '4') return 4;
+    // 256 CUs: all 3*B*2 forward (and B*4 backward) workgroups resident at once.  The value is the number of row slices
+    // of the BACKWARD kernel (4 x 16 rows); the forward kernel never uses more than two (2 x 32 rows).
+    return 3 * batch * 2 <= 256 ? 4 : 1;
 }
 extern "C" int dtqn_td_xch_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
@@ -83,7 +86,7 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
     if (!net->tiled) {
         // batch 1 is the extreme of the small-batch regime: two workgroups for the one sequence once its upper half has
         // live rows (workspace = [hand-over tiles | flags], zeroed once by the caller)
-        const bool split = workspace != nullptr && n > net->lp / 2 && dtqn_td_row_split(net, 1) == 2;
+        const bool split = workspace != nullptr && n > net->lp / 2 && dtqn_td_row_split(net, 1) >= 2;
         float* xch = split ? workspace : nullptr;
         int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, 1)) : nullptr;
         return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags);

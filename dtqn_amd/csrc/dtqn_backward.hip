@@ -34,7 +34,7 @@ struct BwdArgs {
     int batch, history;
     float gamma;
     long long* prof;             // debug stage clock
-    float* xch;                  // row-split hand-over buffer / flags (RS == 2 only)
+    float* xch;                  // row-split hand-over buffer / flags (RS > 1 only)
     int32_t* xflags;
 };
 
@@ -43,7 +43,7 @@ struct BwdArgs {
 // that hands something over: the upper slice's contribution to dK | dV of the lower rows (slice 1 -> slice 0).
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
-    static_assert(RS == 1 || (RS == 2 && !GRU), "row split covers the residual gate only");
+    static_assert(RS == 1 || ((RS == 2 || RS == 4) && !GRU), "row split covers the residual gate only");
     constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;                   // rows this workgroup owns
     constexpr int LPF = LP * RS;                  // padded rows of the whole sequence (= net.lp)
@@ -336,13 +336,30 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
-                attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
+                attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS > 1 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
                 __syncthreads();
-                if (RS == 2) {   // the upper queries' share of dK | dV of the lower rows: slice 1 -> slice 0
-                    float* xb = a.xch + (((size_t)b * net.num_layers + l) * NG + g) * LP * 2 * GW;
-                    int32_t* flag = a.xflags + ((size_t)b * net.num_layers + l) * 4 + g;
-                    if (slice == 1) xch_send<NW>(W5 + GW, LD5, xb, LP, 2 * GW, flag, t);
-                    else xch_recv<NW, true>(W5 + GW, LD5, xb, LP, 2 * GW, flag, t);
+                if (RS > 1) {
+                    // every slice s holds, in the k / v tiles of the rows BELOW it, its queries' share of their dK | dV: one
+                    // hand-over per pair (s -> r), r < s, LP rows each; a slice first sends (it waits for nobody to do
+                    // so), then adds what the slices above it sent, in slice order (deterministic)
+                    constexpr int PAIRS = RS * (RS - 1) / 2;
+                    const size_t grp = ((size_t)b * net.num_layers + l) * NG + g;
+                    float* xg = a.xch + grp * PAIRS * LP * 2 * GW;
+                    int32_t* fg = a.xflags + grp * PAIRS;
+                    auto pair_id = [](int s_, int r_) { return s_ * (s_ - 1) / 2 + r_; };
+                    if (slice > 0) {
+                        for (int idx = t.tid; idx < R0 * 2 * GW; idx += NT) {
+                            const int r = idx / (2 * GW), c = idx - r * 2 * GW;        // r: global row < R0
+                            float* dst = xg + (size_t)pair_id(slice, r / LP) * LP * 2 * GW + (size_t)(r % LP) * 2 * GW + c;
+                            DTQN_AGENT_STORE(dst, W5[r * LD5 + GW + c]);
+                        }
+                        DTQN_WAIT_VMEM();
+                        __syncthreads();
+                        if (t.tid < slice) DTQN_AGENT_STORE(fg + pair_id(slice, t.tid), (int32_t)1);
+                    }
+                    for (int sndr = slice + 1; sndr < RS; ++sndr)
+                        xch_recv<NW, true>(W5r + GW, LD5, xg + (size_t)pair_id(sndr, slice) * LP * 2 * GW, LP, 2 * GW,
+                                           fg + pair_id(sndr, slice), t);
                 }
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
                 if (Own::valid(t.wave, 0)) {
@@ -518,8 +535,14 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.xch = td->xch; a.xflags = td->xflags;
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
-    if (td->row_split == 2) {   // two workgroups per sequence (dtqn_td_row_split)
+    if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)
         if (net->lp != 64 || net->gate != DTQN_GATE_RES || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (td->row_split == 4) {
+            if (D == 64 && HD == 8) return launch_bwd2<64, 1, 8, 8, false, 4>(a, s);
+            if (D == 64 && HD == 16) return launch_bwd2<64, 1, 16, 8, false, 4>(a, s);
+            if (D == 128 && HD == 16) return launch_bwd2<128, 1, 16, 8, false, 4>(a, s);
+            return DTQN_ERR_CONFIG;
+        }
         if (D == 64 && HD == 8) return launch_bwd2<64, 2, 8, 8, false, 2>(a, s);
         if (D == 64 && HD == 16) return launch_bwd2<64, 2, 16, 8, false, 2>(a, s);
         if (D == 128 && HD == 16) return launch_bwd2<128, 2, 16, 8, false, 2>(a, s);
@@ -534,6 +557,7 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     DTQN_BWD_CASE(128, 4, 16, 8)
     DTQN_BWD_CASE(64, 4, 16, 8)
     DTQN_BWD_CASE(64, 2, 8, 8)
+    DTQN_BWD_CASE(64, 1, 8, 8)
     DTQN_BWD_CASE(16, 1, 8, 4)
     DTQN_BWD_CASE(16, 1, 8, 8)
     DTQN_BWD_CASE(32, 2, 8, 4)

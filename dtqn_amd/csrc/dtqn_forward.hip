@@ -412,6 +412,7 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     DTQN_FWD_CASE(128, 4, 16, 8)
     DTQN_FWD_CASE(64, 4, 16, 8)
     DTQN_FWD_CASE(64, 2, 8, 8)
+    DTQN_FWD_CASE(64, 1, 8, 8)
     DTQN_FWD_CASE(16, 1, 8, 4)
     DTQN_FWD_CASE(16, 1, 8, 8)
     DTQN_FWD_CASE(32, 2, 8, 4)
@@ -501,5 +502,5 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.act = td->act;
     a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
-    return dispatch_fwd(a, 3 * td->batch, td->row_split == 2 ? 2 : 1, (hipStream_t)stream);
+    return dispatch_fwd(a, 3 * td->batch, td->row_split >= 2 ? 2 : 1, (hipStream_t)stream);   // the forward never uses more than two slices
 }

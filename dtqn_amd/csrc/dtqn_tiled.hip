@@ -781,7 +781,7 @@ using namespace dtqn;
 extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
     if (!net->tiled)       // whole-sequence kernels: only dtqn_actor_forward's latency mode wants a (ZEROED) workspace
-        return dtqn_td_row_split(net, batch) == 2 ? dtqn_td_xch_floats(net, batch) + dtqn_td_xch_flags(net, batch) : 0;
+        return dtqn_td_row_split(net, batch) >= 2 ? dtqn_td_xch_floats(net, batch) + dtqn_td_xch_flags(net, batch) : 0;
     const long long fl = (long long)batch * rec_map(*net, false).stride;
     return fl < 0x7fffffffLL ? (int)fl : 0;
 }

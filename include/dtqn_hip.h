@@ -274,7 +274,9 @@ int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_h
  * owning half of its rows (projections, LayerNorm, FFN, head and loss are row-local); causal attention is the one
  * place rows meet: the forward hands K | V of the lower rows to the upper slice, the backward hands the upper
  * queries' dK | dV contribution to the lower slice, through `xch` guarded by `xflags` (agent-scope atomics).
- * Returns 1 when the shape / variant / batch does not profit (the chip is already full) or is not covered. */
+ * A return value of 4 means four 16-row slices in the backward kernel (pairwise dK | dV hand-overs from every slice to
+ * the slices below it) and two in the forward.  Returns 1 when the shape / variant / batch does not profit (the chip
+ * is already full) or is not covered. */
 int dtqn_td_row_split(const DtqnNet* net, int batch);
 int dtqn_td_xch_floats(const DtqnNet* net, int batch);
 int dtqn_td_xch_flags(const DtqnNet* net, int batch);

@@ -9,7 +9,8 @@ from oracle import dtqn_oracle as O
 from helpers import make_td_case
 from dtqn_amd import engine
 lib = engine.get_lib(); engine.require_gpu()
-for L, Bn in ((50, 32), (25, 64), (32, 64)):
+os.environ['DTQN_ROW_SPLIT'] = '0'
+for L, Bn in ((50, 32), (32, 64), (16, 128)):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=L)
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=1, batch=Bn, T=200, n_eps=300, mask=-5, device="cuda", test_lib=False)
     eps, starts = host.sample_indices(Bn); eng.set_indices(eps, starts)
