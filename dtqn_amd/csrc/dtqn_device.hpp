@@ -386,15 +386,23 @@ struct StageXwT {
     static constexpr int ITEMS = NTILES * MGROUPS;
     static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
     float4 bf[2][K / 16];
+    float bv[2];                    // bias of the item's output column, fetched with its weight fragment
     const float* W;
+    const float* bias;
     int ldw;
     __device__ __forceinline__ void fetch(int q, const Thr& t) {
         const int item = t.wave + q * NW;
-        if (item < ITEMS) frag_xwT_fetch<K>(bf[q & 1], W + (size_t)((item / MGROUPS) * 16 + t.i) * ldw, t);
+        if (item < ITEMS) {
+            frag_xwT_fetch<K>(bf[q & 1], W + (size_t)((item / MGROUPS) * 16 + t.i) * ldw, t);
+            bv[q & 1] = bias != nullptr ? bias[(item / MGROUPS) * 16 + t.i] : 0.f;
+        }
     }
-    __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t) {
+    // bias_ (optional, indexed by output column): added to every value handed to the epilogue; loading it here keeps
+    // its L2 round trip off the tail of the item's MFMA chain
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t, const float* __restrict__ bias_ = nullptr) {
         W = W_;
         ldw = ldw_;
+        bias = bias_;
         fetch(0, t);
     }
     // wait for the prefetched first fragment NOW (call before issuing stores: CDNA4's vmcnt also counts
@@ -402,6 +410,7 @@ struct StageXwT {
     __device__ __forceinline__ void retire() {
 #pragma unroll
         for (int s = 0; s < K / 16; ++s) retire4(bf[0][s]);
+        DTQN_ASM_KEEP(bv[0]);
     }
     template <typename Epi>
     __device__ __forceinline__ void run(const float* Xs, int lda, const Thr& t, Epi epi) {
@@ -418,7 +427,7 @@ struct StageXwT {
 #pragma unroll
                 for (int m = 0; m < MG; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, nt * 16 + t.i, acc[m][r]);
+                    for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, nt * 16 + t.i, acc[m][r] + bv[q & 1]);
             }
         }
     }
@@ -478,13 +487,15 @@ struct StageDyW {
 // torch.nn.LayerNorm as used at dtqn/networks/transformer.py:28-29).  4 lanes per row.
 // Optionally records (mean, rstd) per row to st_out[row*2..] (global).
 // ------------------------------------------------------------------------------------------
-template <int D, int NW>
+// LPT: compile-time upper bound of LP (rows): with fewer rows more lanes share a row, every lane stays busy and the
+// stores of the pass are unconditional (the compiler can then count them for later s_waitcnt's)
+template <int D, int NW, int LPT = DTQN_MAX_LP>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t,
                                                float* __restrict__ save_in = nullptr, float* __restrict__ save_out = nullptr) {
     constexpr int THREADS = NW * 64;
-    constexpr int LPR = (THREADS / DTQN_MAX_LP) < (D / 4) ? (THREADS / DTQN_MAX_LP) : (D / 4);   // lanes per row (4, 8 or 16)
+    constexpr int LPR = (THREADS / LPT) < (D / 4) ? (THREADS / LPT) : (D / 4);                  // lanes per row (4, 8 or 16)
     constexpr int NV = D / (4 * LPR);                                                           // float4 chunks per lane
     constexpr int ROWS = THREADS / LPR;
     for (int base = 0; base < LP; base += ROWS) {

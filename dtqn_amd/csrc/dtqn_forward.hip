@@ -186,10 +186,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         float* lrec = rec != nullptr ? rec + net.ao_layer0 + (size_t)l * net.act_layer_stride : nullptr;
         const float* src = Xs;
         StageXwT<D, MT, pick_mg(3 * D / 16, MT, NW), NW, 3 * D / 16> g_qkv;
-        g_qkv.prefetch(th + net.lo_in_w, D, t);
+        g_qkv.prefetch(th + net.lo_in_w, D, t, th + net.lo_in_b);
         __syncthreads();                               // residual stream of the previous stage visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
                                   nullptr, rf(lrec, net.al_u1, D));
             __syncthreads();
             src = Us;
@@ -198,18 +198,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
-            const float* __restrict__ bin = th + net.lo_in_b;
             // latency mode: the lower slice streams its K | V to the partner straight from the accumulators
             float* xb = RS == 2 ? a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D : nullptr;
             g_qkv.run(src, LDX, t, [&](int r, int c, float v) {
-                const float y = v + bin[c];
+                const float y = v;                         // bias already added by the stage
                 AW[r * LDW + c] = y;
                 if (RS == 2 && slice == 0 && c >= D) DTQN_AGENT_STORE(xb + (size_t)r * 2 * D + (c - D), y);
             });
         }
         if (RS == 2 && slice == 0) DTQN_WAIT_VMEM();   // K | V stores acknowledged before the barrier that precedes the flag
         StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_out;
-        g_out.prefetch(th + net.lo_out_w, D, t);       // in flight during attention
+        g_out.prefetch(th + net.lo_out_w, D, t, th + net.lo_out_b);       // in flight during attention
         __syncthreads();
         if (RS == 2 && slice == 0 && t.tid == 0) DTQN_AGENT_STORE(a.xflags + (size_t)seq * net.num_layers + l, (int32_t)1);
         DTQN_PROF(a.prof, ps++);   // qkv done
@@ -229,10 +228,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         if (lrec != nullptr) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
         // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
         {
-            const float* __restrict__ bo = th + net.lo_out_b;
             float* m_g = mf(lrec, net.al_m1, D / 16);
             g_out.run(AW, LDW, t, [&](int r, int c, float v) {
-                const float y = fmaxf(v + bo[c], 0.f);
+                const float y = fmaxf(v, 0.f);
                 if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                 if (gru) Ws[r * LDW + D + c] = y;          // y tile for the GRU gate (k columns are free now)
                 else Xs[r * LDX + c] += y;                 // ResGate: x + y  (gates.py:40-41)
@@ -246,15 +244,15 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         const float* __restrict__ b1 = th + net.lo_f1_b;
         const float* __restrict__ W2 = th + net.lo_f2_w;
         StageXwT<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_f1;
-        g_f1.prefetch(W1, D, t);                       // in flight during LN1
+        g_f1.prefetch(W1, D, t, b1);                   // in flight during LN1
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // out-proj done
         if (!ident) {  // x = LN1(x); s1 (input) and u2 (output) go to the record from the LN registers
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Us;
         }
@@ -267,20 +265,25 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             for (int q = 0; q < Own::PER_WAVE; ++q)
 #pragma unroll
                 for (int m = 0; m < MG2; ++m) facc[q][m] = zero4();
+            float b2v[Own::PER_WAVE];                  // FFN-2 bias of the owned columns: loaded now, used after both chunks
+#pragma unroll
+            for (int q = 0; q < Own::PER_WAVE; ++q)
+                b2v[q] = Own::valid(t.wave, q) ? (th + net.lo_f2_b)[Own::nt(t.wave, q) * 16 + t.i] : 0.f;
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
             float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
-            for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+#pragma unroll
+            for (int c0 = 0; c0 < 4 * D; c0 += NC) {       // unrolled: exact s_waitcnt counts across the chunk boundary
                 // the second GEMM's first weight fragment does not depend on the hidden: in flight during the first GEMM
                 if (Own::valid(t.wave, 0))
                     frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
                 g_f1.retire();
                 g_f1.run(src, LDX, t, [&](int r, int c, float v) {
-                    const float hv = fmaxf(v + b1[c0 + c], 0.f);
+                    const float hv = fmaxf(v, 0.f);
                     if (mh_g != nullptr) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
                     Ws[r * LDW + c] = hv;
                 });
                 // ... and the next chunk's first W1 fragment is in flight during the second GEMM
-                if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t);
+                if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t, b1 + c0 + NC);
                 __syncthreads();                       // hidden chunk visible
                 if (Own::valid(t.wave, 0)) {
 #pragma unroll
@@ -296,7 +299,6 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 }
                 __syncthreads();                       // everyone is done reading this chunk of the hidden
             }
-            const float* __restrict__ b2 = th + net.lo_f2_b;
             float* m_g = mf(lrec, net.al_m2, D / 16);
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
-                            const float y = fmaxf(facc[q][m][r4] + b2[c], 0.f);
+                            const float y = fmaxf(facc[q][m][r4] + b2v[q], 0.f);
                             if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                             if (gru) Ws[r * LDW + D + c] = y;
                             else Xs[r * LDX + c] += y;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         DTQN_PROF(a.prof, ps++);   // FFN done
         __syncthreads();
         if (!ident) {  // x = LN2(x); s2 from the LN registers
-            layernorm_rows<D, NW>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s2, D), nullptr);
         } else if (lrec != nullptr) {
             tile_store<NW>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
@@ -332,14 +334,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
 
     // ---------------- Q head: Linear(D,D) -> ReLU -> Linear(D,A)  (dtqn.py:149-153,216) ----------------
     StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_head;
-    g_head.prefetch(theta + net.off_head1_w, D, t);
+    g_head.prefetch(theta + net.off_head1_w, D, t, theta + net.off_head1_b);
     __syncthreads();
     DTQN_PROF(a.prof, ps++);       // layers done
     g_head.retire();
     if (rec != nullptr) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
     {
-        const float* __restrict__ bh = theta + net.off_head1_b;
-        g_head.run(Xs, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v + bh[c], 0.f); });
+        g_head.run(Xs, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v, 0.f); });
     }
     __syncthreads();
     if (rec != nullptr) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
