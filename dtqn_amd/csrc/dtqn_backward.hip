@@ -348,10 +348,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     int32_t* fg = a.xflags + grp * PAIRS;
                     auto pair_id = [](int s_, int r_) { return s_ * (s_ - 1) / 2 + r_; };
                     if (slice > 0) {
-                        for (int idx = t.tid; idx < R0 * 2 * GW; idx += NT) {
-                            const int r = idx / (2 * GW), c = idx - r * 2 * GW;        // r: global row < R0
-                            float* dst = xg + (size_t)pair_id(slice, r / LP) * LP * 2 * GW + (size_t)(r % LP) * 2 * GW + c;
-                            DTQN_AGENT_STORE(dst, W5[r * LD5 + GW + c]);
+                        // rows [0, R0) in receiver order are exactly pairs pair_id(slice, 0 .. slice-1): one contiguous region
+                        const DtqnRsrc rs = DTQN_XCH_RSRC(xg + (size_t)pair_id(slice, 0) * LP * 2 * GW, R0 * 2 * GW * 4);
+                        constexpr int C4 = 2 * GW / 4;
+                        for (int idx = t.tid; idx < R0 * C4; idx += NT) {
+                            const int r = idx / C4, c = (idx - r * C4) * 4;            // r: global row < R0
+                            dtqn_xch_store4(rs, idx * 16, ld4(W5 + r * LD5 + GW + c));
                         }
                         DTQN_WAIT_VMEM();
                         __syncthreads();

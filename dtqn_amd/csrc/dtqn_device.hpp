@@ -67,6 +67,19 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 // all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
 // for global stores)
 #define DTQN_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// 16-byte write-through (sc1) stores / L1-bypassing (sc1) loads through a buffer descriptor: a dword sc1 store is one
+// fabric write of its own and costs ~6x a 16-byte one per byte (MI355X_MICROARCH.md, inter-workgroup visibility)
+typedef unsigned dtqn_u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t DtqnRsrc;
+#define DTQN_XCH_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+__device__ __forceinline__ void dtqn_xch_store4(DtqnRsrc r, int byte_off, float4 v) {
+    dtqn_u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, 16);
+}
+__device__ __forceinline__ float4 dtqn_xch_load4(DtqnRsrc r, int byte_off) {
+    const dtqn_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
 #endif
 // DPP rotate of a 16-lane row by n lanes (VALU-rate; 0x120 + n = row_ror:n)
 #ifndef DTQN_ROW_ROR
@@ -843,9 +856,11 @@ __device__ __forceinline__ void replay_draw(const int32_t* __restrict__ ep_len, 
 // The producer always has the LOWER blockIdx of the pair, so it is dispatched no later than its consumer.
 template <int NW>
 __device__ __forceinline__ void xch_send(const float* s, int ld, float* g, int rows, int cols, int32_t* flag, const Thr& t) {
-    for (int idx = t.tid; idx < rows * cols; idx += NW * 64) {
-        const int r = idx / cols, c = idx - r * cols;
-        DTQN_AGENT_STORE(g + idx, s[r * ld + c]);
+    const DtqnRsrc rs = DTQN_XCH_RSRC(g, rows * cols * 4);
+    const int c4 = cols >> 2;
+    for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
+        const int r = idx / c4, c = (idx - r * c4) * 4;
+        dtqn_xch_store4(rs, idx * 16, ld4(s + r * ld + c));
     }
     DTQN_WAIT_VMEM();                              // every wave's stores are acknowledged at agent scope ...
     __syncthreads();                               // ... and every wave got here ...
@@ -856,11 +871,18 @@ __device__ __forceinline__ void xch_recv(float* s, int ld, const float* g, int r
     if (t.tid == 0)
         while (DTQN_AGENT_LOAD(flag) == 0) DTQN_SPIN_PAUSE();
     __syncthreads();
-    for (int idx = t.tid; idx < rows * cols; idx += NW * 64) {
-        const int r = idx / cols, c = idx - r * cols;
-        const float v = DTQN_AGENT_LOAD(g + idx);
-        if (ADD) s[r * ld + c] += v;
-        else s[r * ld + c] = v;
+    const DtqnRsrc rs = DTQN_XCH_RSRC(g, rows * cols * 4);
+    const int c4 = cols >> 2;
+    for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
+        const int r = idx / c4, c = (idx - r * c4) * 4;
+        const float4 v = dtqn_xch_load4(rs, idx * 16);
+        float* d = s + r * ld + c;
+        if (ADD) {
+            const float4 o = ld4(d);
+            st4(d, make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w));
+        } else {
+            st4(d, v);
+        }
     }
     __syncthreads();
     if (t.tid == 0) DTQN_AGENT_STORE(flag, (int32_t)0);

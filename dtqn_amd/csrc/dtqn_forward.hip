@@ -198,28 +198,21 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
-            // latency mode: the lower slice streams its K | V to the partner straight from the accumulators
-            float* xb = RS == 2 ? a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D : nullptr;
-            g_qkv.run(src, LDX, t, [&](int r, int c, float v) {
-                const float y = v;                         // bias already added by the stage
-                AW[r * LDW + c] = y;
-                if (RS == 2 && slice == 0 && c >= D) DTQN_AGENT_STORE(xb + (size_t)r * 2 * D + (c - D), y);
-            });
+            g_qkv.run(src, LDX, t, [&](int r, int c, float v) { AW[r * LDW + c] = v; });   // bias added by the stage
         }
-        if (RS == 2 && slice == 0) DTQN_WAIT_VMEM();   // K | V stores acknowledged before the barrier that precedes the flag
         StageXwT<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_out;
         g_out.prefetch(th + net.lo_out_w, D, t, th + net.lo_out_b);       // in flight during attention
         __syncthreads();
-        if (RS == 2 && slice == 0 && t.tid == 0) DTQN_AGENT_STORE(a.xflags + (size_t)seq * net.num_layers + l, (int32_t)1);
         DTQN_PROF(a.prof, ps++);   // qkv done
         if (lrec != nullptr) {                         // q|k|v -> record before attention overwrites q
             tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        if (RS == 2) {                                 // K | V of the lower rows: slice 0 (sent from its epilogue) -> slice 1
+        if (RS == 2) {                                 // K | V of the lower rows: slice 0 -> slice 1 (16-byte write-through stores)
             float* xb = a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D;
             int32_t* flag = a.xflags + (size_t)seq * net.num_layers + l;
-            if (slice == 1) xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+            if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+            else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
         }
         attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, lrec ? lrec + net.al_lse : nullptr, t, R0, LPF);
         __syncthreads();

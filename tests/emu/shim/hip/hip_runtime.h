@@ -45,6 +45,11 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+/* 16-byte hand-over stores / loads through a buffer descriptor (dtqn_device.hpp) */
+struct DtqnRsrc { char* base; };
+#define DTQN_XCH_RSRC(ptr, bytes) DtqnRsrc{reinterpret_cast<char*>(const_cast<float*>(ptr))}
+static inline void dtqn_xch_store4(DtqnRsrc r, int byte_off, float4 v) { std::memcpy(r.base + byte_off, &v, 16); }
+static inline float4 dtqn_xch_load4(DtqnRsrc r, int byte_off) { float4 v; std::memcpy(&v, r.base + byte_off, 16); return v; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef int hipError_t;
