@@ -91,6 +91,13 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     __shared__ float red[kOptThreads / 64];
     __shared__ double pw[2];
     const int tid = (int)threadIdx.x;
+    // this thread's gradient / moments / parameters go in flight first: they do not depend on the norm, and the norm
+    // reduction below (two barriers) would otherwise sit in front of their round trip
+    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    const bool mine = p0 < a.n;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g4 = mine ? ld4(a.grad + p0) : z4;
+    float4 m4 = mine ? ld4(a.m + p0) : z4, v4 = mine ? ld4(a.v + p0) : z4, p4 = mine ? ld4(a.theta + p0) : z4;
     // every block re-derives the global norm from the per-block partials (a few hundred floats)
     float part = 0.f;
     for (int i = tid; i < a.n_norm_blocks; i += kOptThreads) part += a.norm_partial[i];
@@ -107,10 +114,7 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     const float coef = fminf(1.0f, a.clip / (norm + 1e-6f)) * a.grad_scale;
     const float step_size = a.lr / bc1;
     const bool sync_target = finite && a.tuf > 0 && (k % a.tuf) == 0;
-    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
-    if (finite && p0 < a.n) {
-        const float4 g4 = ld4(a.grad + p0);
-        float4 m4 = ld4(a.m + p0), v4 = ld4(a.v + p0), p4 = ld4(a.theta + p0);
+    if (finite && mine) {
         const float g[4] = {g4.x * coef, g4.y * coef, g4.z * coef, g4.w * coef};
         float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll

@@ -109,8 +109,29 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
         const int s_lo = sub * steps_per_sub, s_hi = min(LP / 4, s_lo + steps_per_sub);
         const float* yp = ybase + (size_t)b * ystride + (size_t)lyr * job.dy_lstride + (size_t)t.kq * job.ldy + ycol;
         const float* xp = xbase + (size_t)b * xstride + (size_t)lyr * job.x_lstride + (size_t)t.kq * job.ldx + xcol;
-        // explicit 2-deep pipeline: the operands of step s+1 are in flight while step s multiplies
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s_hi - s_lo == 4) {
+            // the common shape (64-row records: four 4-token steps per unit): all eight operand loads of the unit go in
+            // flight at once -- the records come from other XCDs' kernels (memory-side latency), the MFMAs are short
+            float4 av[4], bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                av[k] = yok ? ld4(yp + (size_t)4 * (s_lo + k) * job.ldy) : z4;
+                bv[k] = xok ? ld4(xp + (size_t)4 * (s_lo + k) * job.ldx) : z4;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bsum.x += av[k].x; bsum.y += av[k].y; bsum.z += av[k].z; bsum.w += av[k].w;
+                const float aa[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
+                const float bb[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
+#pragma unroll
+                for (int cn = 0; cn < 4; ++cn)
+#pragma unroll
+                    for (int ck = 0; ck < 4; ++ck) acc[cn][ck] = mfma16(aa[cn], bb[ck], acc[cn][ck]);
+            }
+            continue;
+        }
+        // general shape: explicit 2-deep pipeline, the operands of step s+1 are in flight while step s multiplies
         float4 av = (yok && s_lo < s_hi) ? ld4(yp + (size_t)4 * s_lo * job.ldy) : z4;
         float4 bv = (xok && s_lo < s_hi) ? ld4(xp + (size_t)4 * s_lo * job.ldx) : z4;
 #pragma unroll 2
