@@ -1,6 +1,6 @@
 """Experiment: the five launches of one TD update captured in a HIP graph vs issued one by one."""
 import ctypes, sys, os, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import dtqn_oracle as O

@@ -1,6 +1,6 @@
 """Launch one stage of the TD update N times (for rocprofv3 --pmc passes).  usage: run_stage.py <stage> [iters] [batch]"""
 import ctypes, sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from oracle import dtqn_oracle as O

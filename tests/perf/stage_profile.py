@@ -1,6 +1,6 @@
 """Per-stage wall-clock breakdown of workgroup 0 of the TD forward / backward kernels (debug aid)."""
 import ctypes, sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import dtqn_oracle as O

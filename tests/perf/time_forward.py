@@ -1,7 +1,7 @@
 """Quick wall-clock of the forward kernel at cfg-1/2 shapes (3*B workgroups, like the TD forward)."""
 import ctypes, sys, os, json, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from dtqn_amd import engine, _binding as B
 from oracle import dtqn_oracle as O

@@ -2,7 +2,7 @@
 8 waves per workgroup (DTQN_WAVES=8), against the real cfg-1 shape."""
 import ctypes, sys, os
 os.environ["DTQN_WAVES"] = "8"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import dtqn_oracle as O

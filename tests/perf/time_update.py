@@ -1,6 +1,6 @@
 """Wall-clock of one TD update and of each stage (cfg-1/2 shapes, synthetic replay)."""
 import ctypes, sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import dtqn_oracle as O
