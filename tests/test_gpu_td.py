@@ -48,6 +48,16 @@ def test_td_update_vs_oracle(lib, kw, run):
                                                mask=run["mask"], history=run.get("history"), tuf=run.get("tuf", 10_000),
                                                device="cuda", test_lib=False)
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
+    assert int(eng.xflags.sum()) == 0          # latency mode: every hand-over flag was lowered again
+
+
+def test_latency_mode_is_on_for_the_metric_config(lib):
+    """BASELINE config 1 (batch 32, 64-row tile): four backward / two forward workgroups per sequence; batch 256: one."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    net = net_from_cfg(lib, cfg)
+    import ctypes
+    assert lib.dtqn_td_row_split(ctypes.byref(net), 32) == 4
+    assert lib.dtqn_td_row_split(ctypes.byref(net), 256) == 1
 
 
 def test_golden_G1_full_update(lib):
