@@ -388,8 +388,12 @@ static int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
     return launch_fwd2<D, MT, HD, NW, false, 1>(a, nseq, stream);
 }
 
-static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t stream) {
-    const int D = a.net.d_model, MT = a.net.lp / 16, HD = a.net.head_dim, NW = waves_for(a.net);
+// mt_rows: row tiles the launch really needs (0 = the network's padded context).  Inference on a short prefix of the
+// context (the actor early in an episode) runs the instantiation with fewer row tiles when there is one.
+static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t stream, int mt_rows = 0) {
+    const int D = a.net.d_model, HD = a.net.head_dim;
+    const int MT = mt_rows > 0 ? mt_rows : a.net.lp / 16;
+    const int NW = mt_rows > 0 ? 8 : waves_for(a.net);
     if (row_split == 2) {      // two workgroups per sequence (dtqn_td_row_split): 32-row slices of a 64-row tile, 8 waves
         if (a.net.lp != 64 || a.net.gate != DTQN_GATE_RES || a.net.identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
         if (D == 64 && HD == 8) return launch_fwd2<64, 2, 8, 8, false, 2>(a, nseq, stream);
@@ -407,6 +411,10 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     DTQN_FWD_CASE(64, 4, 16, 8)
     DTQN_FWD_CASE(64, 2, 8, 8)
     DTQN_FWD_CASE(64, 1, 8, 8)
+    DTQN_FWD_CASE(64, 2, 16, 8)
+    DTQN_FWD_CASE(64, 1, 16, 8)
+    DTQN_FWD_CASE(128, 2, 16, 8)
+    DTQN_FWD_CASE(128, 1, 16, 8)
     DTQN_FWD_CASE(16, 1, 8, 4)
     DTQN_FWD_CASE(16, 1, 8, 8)
     DTQN_FWD_CASE(32, 2, 8, 4)
@@ -458,7 +466,13 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
     a.s_n_valid = 0; a.s_exclude = -1; a.s_seed = 0;
     a.prof = nullptr;
-    return dispatch_fwd(a, batch, xch != nullptr && xflags != nullptr ? 2 : 1, (hipStream_t)stream);
+    if (xch != nullptr && xflags != nullptr) return dispatch_fwd(a, batch, 2, (hipStream_t)stream);
+    // short prefix of a 64-row context: 16- or 32-row instantiation (same kernel, fewer row tiles), else the full tile
+    if (net->lp == 64 && n <= 32 && net->gate == DTQN_GATE_RES) {
+        const int rc = dispatch_fwd(a, batch, 1, (hipStream_t)stream, n <= 16 ? 1 : 2);
+        if (rc != DTQN_ERR_CONFIG) return rc;
+    }
+    return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
 }
 
 extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
