@@ -148,6 +148,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     DTQN_PROF(a.prof, ps++);   // head done
 
     // ---------------- layers, last to first ----------------
+    // (mean, rstd) of a layer's two LayerNorms, one float per thread, fetched a whole layer ahead of their use
+    static_assert(4 * LP <= NT, "one statistics value per thread");
+    auto st_fetch = [&](int l) -> float {
+        const float* lr = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
+        if (t.tid >= 4 * LP) return 0.f;
+        return t.tid < 2 * LP ? rf(lr, net.al_st1, 2)[t.tid] : rf(lr, net.al_st2, 2)[t.tid - 2 * LP];
+    };
+    float st_next = st_fetch(net.num_layers - 1);
     for (int l = net.num_layers - 1; l >= 0; --l) {
         const float* __restrict__ th = layer_theta(net, theta, l);
         const float* lrec = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
@@ -157,9 +165,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         const float* __restrict__ W2 = th + net.lo_f2_w;
         StageDyW<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16> g_dh;      // dh = df W2[:, chunk]
         g_dh.prefetch(W2, 4 * D, t);
-        // (mean, rstd) of both LayerNorms of this layer -> LDS (published by the next barrier)
-        for (int idx = t.tid; idx < 4 * LP; idx += NT)
-            st_s[idx] = idx < 2 * LP ? rf(lrec, net.al_st1, 2)[idx] : rf(lrec, net.al_st2, 2)[idx - 2 * LP];
+        // (mean, rstd) of both LayerNorms of this layer -> LDS (published by the next barrier); the previous layer's
+        // reads of st_s ended behind a barrier, and the next layer's values go in flight now
+        if (t.tid < 4 * LP) st_s[t.tid] = st_next;
+        if (l > 0) st_next = st_fetch(l - 1);
 
         if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
             tr.to_lds(T2, LDX, t);
