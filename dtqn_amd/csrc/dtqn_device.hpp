@@ -148,7 +148,9 @@ __device__ __forceinline__ float wave_max(float v) { DTQN_WAVE_ALLREDUCE(v, fmax
 __device__ __forceinline__ float wave_min(float v) { DTQN_WAVE_ALLREDUCE(v, fminf); return v; }
 __device__ __forceinline__ void ballot_store(float* mask_rec, int ctiles, int row, int col, bool on, int lane) {
     const unsigned long long bits = __ballot(on ? 1 : 0);
-    if (lane == 0) reinterpret_cast<unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)] = bits;
+    // every lane stores the same 8 bytes to the same address (one transaction): no exec-masked region around the store
+    (void)lane;
+    reinterpret_cast<unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)] = bits;
 }
 __device__ __forceinline__ bool mask_bit(const float* mask_rec, int ctiles, int row, int col) {
     const unsigned long long w = reinterpret_cast<const unsigned long long*>(mask_rec)[((row >> 4) * ctiles + (col >> 4)) * 4 + (row & 3)];
@@ -385,6 +387,11 @@ struct Owned {
     static constexpr int ITEMS = (D / 16) * MGROUPS;
     static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
     __device__ static __forceinline__ bool valid(int wave, int q) { return wave + q * NW < ITEMS; }
+    // the same with the test folded away for full rounds of items (wave < NW always, so ITEMS >= (q+1)*NW needs none):
+    // the guarded code is then unconditional and the compiler can count its loads / stores for later s_waitcnt's.
+    // Used by the forward kernel only: the <D=128, 16-row slice> backward instantiation computed a wrong stream
+    // gradient with it on the GPU (not on the emulation) -- unexplained, so the backward keeps the runtime test.
+    __device__ static __forceinline__ bool valid_fast(int wave, int q) { return ITEMS >= (q + 1) * NW || wave + q * NW < ITEMS; }
     __device__ static __forceinline__ int nt(int wave, int q) { return (wave + q * NW) / MGROUPS; }
     __device__ static __forceinline__ int mg(int wave, int q) { return (wave + q * NW) % MGROUPS; }
 };
@@ -405,7 +412,7 @@ struct StageXwT {
     int ldw;
     __device__ __forceinline__ void fetch(int q, const Thr& t) {
         const int item = t.wave + q * NW;
-        if (item < ITEMS) {
+        if (ITEMS >= (q + 1) * NW || item < ITEMS) {
             frag_xwT_fetch<K>(bf[q & 1], W + (size_t)((item / MGROUPS) * 16 + t.i) * ldw, t);
             bv[q & 1] = bias != nullptr ? bias[(item / MGROUPS) * 16 + t.i] : 0.f;
         }
@@ -431,7 +438,7 @@ struct StageXwT {
         for (int q = 0; q < PER_WAVE; ++q) {
             if (q + 1 < PER_WAVE) fetch(q + 1, t);
             const int item = t.wave + q * NW;
-            if (item < ITEMS) {
+            if (ITEMS >= (q + 1) * NW || item < ITEMS) {
                 const int nt = item / MGROUPS, mg = item - nt * MGROUPS;
                 f32x4 acc[MG];
 #pragma unroll
@@ -502,7 +509,8 @@ struct StageDyW {
 // ------------------------------------------------------------------------------------------
 // LPT: compile-time upper bound of LP (rows): with fewer rows more lanes share a row, every lane stays busy and the
 // stores of the pass are unconditional (the compiler can then count them for later s_waitcnt's)
-template <int D, int NW, int LPT = DTQN_MAX_LP>
+// SAVE = false: st_out / save_in / save_out are ignored at compile time (no conditional stores in the instruction stream)
+template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t,
@@ -513,7 +521,7 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
     constexpr int ROWS = THREADS / LPR;
     for (int base = 0; base < LP; base += ROWS) {
         const int row = base + t.tid / LPR, part = t.tid % LPR;
-        const bool valid = row < LP;
+        const bool valid = (ROWS <= LPT && LPT % ROWS == 0) ? true : row < LP;   // LPT rows exactly tiled by the lanes: no tail
         const float* sp = src + (valid ? row : 0) * ld + part * 4;
         float4 v[NV];
         float sum = 0.f;
@@ -522,7 +530,7 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
             v[j] = ld4(sp + 4 * LPR * j);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
-        if (save_in != nullptr && valid) {   // dense [LP][D] record of the LN input
+        if (SAVE && save_in != nullptr && valid) {   // dense [LP][D] record of the LN input
 #pragma unroll
             for (int j = 0; j < NV; ++j) st4(save_in + (size_t)row * D + part * 4 + 4 * LPR * j, v[j]);
         }
@@ -549,9 +557,9 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
                 o.z = (v[j].z - mean) * rstd * g.z + b.z;
                 o.w = (v[j].w - mean) * rstd * g.w + b.w;
                 st4(dp + 4 * LPR * j, o);
-                if (save_out != nullptr) st4(save_out + (size_t)row * D + part * 4 + 4 * LPR * j, o);
+                if (SAVE && save_out != nullptr) st4(save_out + (size_t)row * D + part * 4 + 4 * LPR * j, o);
             }
-            if (st_out != nullptr && part == 0) {
+            if (SAVE && st_out != nullptr && part == 0) {
                 st_out[row * 2 + 0] = mean;
                 st_out[row * 2 + 1] = rstd;
             }

@@ -52,8 +52,11 @@ __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 // padded length; every stage is row-local except attention, whose K | V of the rows below R0 come from the partner
 // workgroup (slice 0 -> slice 1 hand-over through a.xch).  Record tensors keep their full-sequence layout: a slice
 // addresses them at row R0.
-template <int D, int MT, int HD, int NW, bool GRU, int RS>
-__global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+// TRAIN: this workgroup saves the activation record (policy(o) pass of a TD update).  A template parameter, not a
+// pointer test: every record store is then unconditional code, and the compiler can count the stores that sit between a
+// prefetched weight fragment and its s_waitcnt instead of falling back to vmcnt(0) (measured: -6 % on the inference pass).
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool TRAIN>
+__device__ __forceinline__ void forward_body(const FwdArgs& a) {
     static_assert(RS == 1 || (RS == 2 && !GRU), "row split covers the residual gate only");
     constexpr int NT = NW * 64;                    // threads per workgroup
     constexpr int LP = MT * 16;                    // rows this workgroup owns
@@ -71,11 +74,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
     const bool ident = net.identity != 0;
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
-    float* rec = (a.act != nullptr && which == 0) ? a.act + (size_t)b * net.act_stride : nullptr;
+    float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
     // a [LPF][w] record tensor at the first row of this slice
-    auto rf = [&](float* base, int off, int w) -> float* { return base != nullptr ? base + off + (size_t)R0 * w : nullptr; };
+    auto rf = [&](float* base, int off, int w) -> float* { return TRAIN ? base + off + (size_t)R0 * w : nullptr; };
     // ReLU ballot record (64-bit word per accumulator register, dtqn_device.hpp ballot_store) at the slice's first row tile
-    auto mf = [&](float* base, int off, int ctiles) -> float* { return base != nullptr ? base + off + (size_t)(R0 / 16) * ctiles * 8 : nullptr; };
+    auto mf = [&](float* base, int off, int ctiles) -> float* { return TRAIN ? base + off + (size_t)(R0 / 16) * ctiles * 8 : nullptr; };
 
     float* Xs = reinterpret_cast<float*>(dtqn_smem);   // residual stream            [LP][LDX]
     float* Ws = Xs + LP * LDX;                         // q|k|v (GLOBAL rows), FFN hidden, staging [LPF][LDW]
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 v += pos[r * D + d];
             }
             Xs[r * LDX + d] = v;
-            if (rec != nullptr) rf(rec, net.ao_x0, D)[idx] = v;
+            if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
         }
-        if (rec != nullptr)
+        if (TRAIN)
             for (int idx = t.tid; idx < LP * KEP; idx += NT) {
                 const int r = idx / KEP, k = idx - r * KEP;
                 rf(rec, net.ao_ein, KEP)[idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 }
             }
             ein[idx] = v;
-            if (rec != nullptr) rf(rec, net.ao_ein, KEP)[idx] = v;
+            if (TRAIN) rf(rec, net.ao_ein, KEP)[idx] = v;
         }
         __syncthreads();
         for (int idx = t.tid; idx < LP * D; idx += NT) {
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                 v += pos[r * D + d];
             }
             Xs[r * LDX + d] = v;
-            if (rec != nullptr) rf(rec, net.ao_x0, D)[idx] = v;
+            if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
         }
     }
     DTQN_PROF(a.prof, ps++);   // embed done; Xs is published by the barrier that opens layer 0
@@ -183,19 +186,19 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     using Own = Owned<D, MT, MG2, NW>;                 // fixed ownership of the FFN-2 output tile
     for (int l = 0; l < net.num_layers; ++l) {
         const float* __restrict__ th = layer_theta(net, theta, l);
-        float* lrec = rec != nullptr ? rec + net.ao_layer0 + (size_t)l * net.act_layer_stride : nullptr;
+        float* lrec = TRAIN ? rec + net.ao_layer0 + (size_t)l * net.act_layer_stride : nullptr;
         const float* src = Xs;
         StageXwT<D, MT, pick_mg(3 * D / 16, MT, NW), NW, 3 * D / 16> g_qkv;
         g_qkv.prefetch(th + net.lo_in_w, D, t, th + net.lo_in_b);
         __syncthreads();                               // residual stream of the previous stage visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW, LP>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
                                   nullptr, rf(lrec, net.al_u1, D));
             __syncthreads();
             src = Us;
         }
         g_qkv.retire();
-        if (lrec != nullptr && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
+        if (TRAIN && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
         // packed in-projection: qkv = u W_in^T + b_in
         {
             g_qkv.run(src, LDX, t, [&](int r, int c, float v) { AW[r * LDW + c] = v; });   // bias added by the stage
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         g_out.prefetch(th + net.lo_out_w, D, t, th + net.lo_out_b);       // in flight during attention
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // qkv done
-        if (lrec != nullptr) {                         // q|k|v -> record before attention overwrites q
+        if (TRAIN) {                         // q|k|v -> record before attention overwrites q
             tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
@@ -214,24 +217,24 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
             else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
         }
-        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, lrec ? lrec + net.al_lse : nullptr, t, R0, LPF);
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
         g_out.retire();
-        if (lrec != nullptr) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
+        if (TRAIN) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
         // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
         {
             float* m_g = mf(lrec, net.al_m1, D / 16);
             g_out.run(AW, LDW, t, [&](int r, int c, float v) {
                 const float y = fmaxf(v, 0.f);
-                if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                 if (gru) Ws[r * LDW + D + c] = y;          // y tile for the GRU gate (k columns are free now)
                 else Xs[r * LDX + c] += y;                 // ResGate: x + y  (gates.py:40-41)
             });
         }
         if (gru) {                                         // x <- GRUGate(x, y)  (gates.py:26-31)
             __syncthreads();
-            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_attn, net, lrec ? lrec + net.al_gate1 : nullptr, t);
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_attn, net, TRAIN ? lrec + net.al_gate1 : nullptr, t);
         }
         const float* __restrict__ W1 = th + net.lo_f1_w;
         const float* __restrict__ b1 = th + net.lo_f1_b;
@@ -241,11 +244,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // out-proj done
         if (!ident) {  // x = LN1(x); s1 (input) and u2 (output) go to the record from the LN registers
-            layernorm_rows<D, NW, LP>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, th + net.lo_ln1_w, th + net.lo_ln1_b, rf(lrec, net.al_st1, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW, LP>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Us;
         }
@@ -261,33 +264,33 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             float b2v[Own::PER_WAVE];                  // FFN-2 bias of the owned columns: loaded now, used after both chunks
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q)
-                b2v[q] = Own::valid(t.wave, q) ? (th + net.lo_f2_b)[Own::nt(t.wave, q) * 16 + t.i] : 0.f;
+                b2v[q] = Own::valid_fast(t.wave, q) ? (th + net.lo_f2_b)[Own::nt(t.wave, q) * 16 + t.i] : 0.f;
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
             float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
 #pragma unroll
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {       // unrolled: exact s_waitcnt counts across the chunk boundary
                 // the second GEMM's first weight fragment does not depend on the hidden: in flight during the first GEMM
-                if (Own::valid(t.wave, 0))
+                if (Own::valid_fast(t.wave, 0))
                     frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
                 g_f1.retire();
                 g_f1.run(src, LDX, t, [&](int r, int c, float v) {
                     const float hv = fmaxf(v, 0.f);
-                    if (mh_g != nullptr) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
+                    if (TRAIN) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
                     Ws[r * LDW + c] = hv;
                 });
                 // ... and the next chunk's first W1 fragment is in flight during the second GEMM
                 if (c0 + NC < 4 * D) g_f1.prefetch(W1 + (size_t)(c0 + NC) * D, D, t, b1 + c0 + NC);
                 __syncthreads();                       // hidden chunk visible
-                if (Own::valid(t.wave, 0)) {
+                if (Own::valid_fast(t.wave, 0)) {
 #pragma unroll
                     for (int s = 0; s < NC / 16; ++s) retire4(w2f[0][s]);
                 }
-                if (lrec != nullptr) tile_store<NW>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
+                if (TRAIN) tile_store<NW>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
-                    if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
+                    if (q + 1 < Own::PER_WAVE && Own::valid_fast(t.wave, q + 1))
                         frag_xwT_fetch<NC>(w2f[(q + 1) & 1], W2 + (size_t)(Own::nt(t.wave, q + 1) * 16 + t.i) * 4 * D + c0, t);
-                    if (Own::valid(t.wave, q))
+                    if (Own::valid_fast(t.wave, q))
                         frag_xwT_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW, w2f[q & 1], t, facc[q]);
                 }
                 __syncthreads();                       // everyone is done reading this chunk of the hidden
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
             float* m_g = mf(lrec, net.al_m2, D / 16);
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
-                if (Own::valid(t.wave, q)) {
+                if (Own::valid_fast(t.wave, q)) {
                     const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
                     for (int m = 0; m < MG2; ++m)
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
                             const float y = fmaxf(facc[q][m][r4] + b2v[q], 0.f);
-                            if (m_g != nullptr) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                            if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                             if (gru) Ws[r * LDW + D + c] = y;
                             else Xs[r * LDX + c] += y;
                         }
@@ -312,14 +315,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         }
         if (gru) {
             __syncthreads();
-            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_mlp, net, lrec ? lrec + net.al_gate2 : nullptr, t);
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_mlp, net, TRAIN ? lrec + net.al_gate2 : nullptr, t);
         }
         DTQN_PROF(a.prof, ps++);   // FFN done
         __syncthreads();
         if (!ident) {  // x = LN2(x); s2 from the LN registers
-            layernorm_rows<D, NW, LP>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, th + net.lo_ln2_w, th + net.lo_ln2_b, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s2, D), nullptr);
-        } else if (lrec != nullptr) {
+        } else if (TRAIN) {
             tile_store<NW>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
         }
         // the residual stream is published by the barrier that opens the next layer / the head
@@ -331,12 +334,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     __syncthreads();
     DTQN_PROF(a.prof, ps++);       // layers done
     g_head.retire();
-    if (rec != nullptr) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
+    if (TRAIN) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
     {
         g_head.run(Xs, LDX, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v, 0.f); });
     }
     __syncthreads();
-    if (rec != nullptr) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
+    if (TRAIN) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
     {
         const float* __restrict__ W2 = theta + net.off_head2_w;
         const float* __restrict__ b2 = theta + net.off_head2_b;
@@ -357,6 +360,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
         }
     }
     DTQN_PROF(a.prof, ps++);       // end
+}
+
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
+__global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+    const int which = ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
+    if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true>(a);
+    else forward_body<D, MT, HD, NW, GRU, RS, false>(a);
 }
 
 static size_t fwd_lds_bytes(const DtqnNet* net) {
