@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     const int R0 = slice * LP;
     const int Lfull = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
     const int L = Lfull - R0 < LP ? Lfull - R0 : LP;   // live rows of this slice (may be <= 0)
-    const bool ident = net.identity != 0;
+    const bool ident = RS > 1 ? false : net.identity != 0;     // row slices are dispatched for post-LN nets only: folds away
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     const float* __restrict__ theta = a.theta;
     const float* rec = a.act + (size_t)b * net.act_stride;
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             float w1f[2][NC / 4];
             const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(mf(lrec, net.al_mh, 4 * D / 16));
             constexpr int MGH = pick_mg(NC / 16, MT, NW);
-            for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+#pragma unroll
+            for (int c0 = 0; c0 < 4 * D; c0 += NC) {   // unrolled: exact s_waitcnt counts across the chunk boundary
                 g_dh.retire();
                 if (c0 == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_df, D), LP, D, t);
                 unsigned long long mw[MGH][4];         // ReLU ballots of the item's accumulator registers

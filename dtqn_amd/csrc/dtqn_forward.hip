@@ -72,7 +72,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
-    const bool ident = net.identity != 0;
+    const bool ident = RS > 1 ? false : net.identity != 0;     // row slices are dispatched for post-LN nets only: folds away
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
     // a [LPF][w] record tensor at the first row of this slice
