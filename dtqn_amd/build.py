@@ -30,7 +30,8 @@ def _digest() -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every source under dtqn_amd/csrc for gfx950 and link libdtqn_hip.so next to them."""
-    tag = _digest()
+    prof = os.environ.get("DTQN_BUILD_PROF", "0") == "1"     # debug build with the stage clocks (tests/perf/stage_profile.py)
+    tag = _digest() + ("+prof" if prof else "")
     stamp = LIB + ".stamp"
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == tag:
         return LIB
@@ -44,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for s in _sources():
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", "-I" + os.path.join(REPO, "include"),
-               "-I" + CSRC, info, s, "-o", o]
+               "-I" + CSRC, info, s, "-o", o] + (["-DDTQN_ENABLE_PROF"] if prof else [])
         if s.endswith(".cpp"):
             cmd[1:2] = []          # host-only C++ (may call the HIP runtime API): no offload arch needed
             cmd.insert(1, "-x")

@@ -30,10 +30,16 @@ int forward_infer(const DtqnNet* net, const float* theta, const float* obs, cons
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
 }  // namespace dtqn
 
-// stage timestamp (debug): thread 0 of workgroups 0 and 1 (the two row slices of sequence 0 in latency mode), 32 slots
-// each; PROF costs one uniform branch when disabled
+// Stage timestamps (debug): thread 0 of workgroups 0 and 1 (two row slices of sequence 0 in latency mode), 32 slots
+// each.  Compiled in only with -DDTQN_ENABLE_PROF (DTQN_BUILD_PROF=1 python -m dtqn_amd.build): every mark is a
+// conditional global store, and a conditional store between a prefetch and its use makes the compiler wait with
+// vmcnt(0) there -- the product build must not carry them.
+#ifdef DTQN_ENABLE_PROF
 #define DTQN_PROF(buf, slot) \
     do { if ((buf) != nullptr && blockIdx.x < 2 && threadIdx.x == 0) (buf)[blockIdx.x * 32 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define DTQN_PROF(buf, slot) ((void)(slot))
+#endif
 
 // Keep-alive for prefetched registers: forces the compiler to place its s_waitcnt for the loads that
 // produced `x` HERE (the test-only host build defines it away).
