@@ -307,7 +307,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             const float* o_g = rf(lrec, net.al_o, D);
             float* W5r = W5 + R0 * LD5;                // this slice's rows of the attention tiles
             constexpr int MGO = pick_mg(GW / 16, MT, NW);
-            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {          // unrolled: the g == 0 / g + 1 < NG cases fold
                 // q, k, v (o) of this head group -> W5   (W5 is free: the FFN / previous group are behind a barrier)
                 tq.to_lds(W5r, LD5, t);
 #pragma unroll

@@ -1,4 +1,5 @@
-"""Per-stage wall-clock breakdown of workgroup 0 of the TD forward / backward kernels (debug aid)."""
+"""Per-stage wall-clock breakdown of workgroups 0 / 1 of the TD forward / backward kernels (debug aid).
+Needs a library built with the stage clocks: DTQN_BUILD_PROF=1 python -m dtqn_amd.build (the product build has none)."""
 import ctypes, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
