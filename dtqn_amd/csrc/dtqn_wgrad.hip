@@ -103,34 +103,59 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     constexpr int NSUB = 4;
     const int steps_per_sub = (LP / 4 + NSUB - 1) / NSUB;
     const int units = (b_hi - b_lo) * NSUB * job.n_layers;
-    for (int u = t.wave; u < units; u += DTQN_WAVES) {
+    // the common shape (64-row records: four 4-token steps per unit): the eight operand loads of a unit go in flight at
+    // once, and the NEXT unit's loads are issued before this unit's MFMAs -- the records come from other XCDs' kernels
+    // (memory-side latency), the MFMAs are short
+    const bool fast = LP == 64;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto unit_ptrs = [&](int u, const float*& yp, const float*& xp, int& s_lo, int& s_hi) {
         const int lyr = u / ((b_hi - b_lo) * NSUB), ul = u - lyr * (b_hi - b_lo) * NSUB;
         const int b = b_lo + ul / NSUB, sub = ul - (ul / NSUB) * NSUB;
-        const int s_lo = sub * steps_per_sub, s_hi = min(LP / 4, s_lo + steps_per_sub);
-        const float* yp = ybase + (size_t)b * ystride + (size_t)lyr * job.dy_lstride + (size_t)t.kq * job.ldy + ycol;
-        const float* xp = xbase + (size_t)b * xstride + (size_t)lyr * job.x_lstride + (size_t)t.kq * job.ldx + xcol;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s_hi - s_lo == 4) {
-            // the common shape (64-row records: four 4-token steps per unit): all eight operand loads of the unit go in
-            // flight at once -- the records come from other XCDs' kernels (memory-side latency), the MFMAs are short
-            float4 av[4], bv[4];
+        s_lo = sub * steps_per_sub;
+        s_hi = min(LP / 4, s_lo + steps_per_sub);
+        yp = ybase + (size_t)b * ystride + (size_t)lyr * job.dy_lstride + (size_t)t.kq * job.ldy + ycol;
+        xp = xbase + (size_t)b * xstride + (size_t)lyr * job.x_lstride + (size_t)t.kq * job.ldx + xcol;
+    };
+    if (fast) {
+        float4 av[2][4], bv[2][4];
+        auto unit_load = [&](int u, float4 (&a4)[4], float4 (&b4)[4]) {
+            const float *yp, *xp;
+            int s_lo, s_hi;
+            unit_ptrs(u, yp, xp, s_lo, s_hi);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                av[k] = yok ? ld4(yp + (size_t)4 * (s_lo + k) * job.ldy) : z4;
-                bv[k] = xok ? ld4(xp + (size_t)4 * (s_lo + k) * job.ldx) : z4;
+                a4[k] = yok ? ld4(yp + (size_t)4 * (s_lo + k) * job.ldy) : z4;
+                b4[k] = xok ? ld4(xp + (size_t)4 * (s_lo + k) * job.ldx) : z4;
             }
+        };
+        auto unit_mma = [&](const float4 (&a4)[4], const float4 (&b4)[4]) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                bsum.x += av[k].x; bsum.y += av[k].y; bsum.z += av[k].z; bsum.w += av[k].w;
-                const float aa[4] = {av[k].x, av[k].y, av[k].z, av[k].w};
-                const float bb[4] = {bv[k].x, bv[k].y, bv[k].z, bv[k].w};
+                bsum.x += a4[k].x; bsum.y += a4[k].y; bsum.z += a4[k].z; bsum.w += a4[k].w;
+                const float aa[4] = {a4[k].x, a4[k].y, a4[k].z, a4[k].w};
+                const float bb[4] = {b4[k].x, b4[k].y, b4[k].z, b4[k].w};
 #pragma unroll
                 for (int cn = 0; cn < 4; ++cn)
 #pragma unroll
                     for (int ck = 0; ck < 4; ++ck) acc[cn][ck] = mfma16(aa[cn], bb[ck], acc[cn][ck]);
             }
-            continue;
+        };
+        int u = t.wave;
+        if (u < units) unit_load(u, av[0], bv[0]);
+        for (; u < units; u += 2 * DTQN_WAVES) {           // two units per trip: buffers alternate without dynamic indexing
+            const int u1 = u + DTQN_WAVES, u2 = u + 2 * DTQN_WAVES;
+            if (u1 < units) unit_load(u1, av[1], bv[1]);
+            unit_mma(av[0], bv[0]);
+            if (u1 < units) {
+                if (u2 < units) unit_load(u2, av[0], bv[0]);
+                unit_mma(av[1], bv[1]);
+            }
         }
+    }
+    for (int u = fast ? units : t.wave; u < units; u += DTQN_WAVES) {
+        const float *yp, *xp;
+        int s_lo, s_hi;
+        unit_ptrs(u, yp, xp, s_lo, s_hi);
         // general shape: explicit 2-deep pipeline, the operands of step s+1 are in flight while step s multiplies
         float4 av = (yok && s_lo < s_hi) ? ld4(yp + (size_t)4 * s_lo * job.ldy) : z4;
         float4 bv = (xok && s_lo < s_hi) ? ld4(xp + (size_t)4 * s_lo * job.ldx) : z4;
