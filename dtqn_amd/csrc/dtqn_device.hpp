@@ -470,7 +470,7 @@ struct StageDyW {
     int ldw;
     __device__ __forceinline__ void fetch(int q, const Thr& t) {
         const int item = t.wave + q * NW;
-        if (item < ITEMS) frag_dyw_fetch<NN>(bf[q & 1], W + (item / MGROUPS) * 16 + t.i, ldw, t);
+        if (ITEMS >= (q + 1) * NW || item < ITEMS) frag_dyw_fetch<NN>(bf[q & 1], W + (item / MGROUPS) * 16 + t.i, ldw, t);
     }
     __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t) {
         W = W_;
@@ -492,7 +492,7 @@ struct StageDyW {
         for (int q = 0; q < PER_WAVE; ++q) {
             if (q + 1 < PER_WAVE) fetch(q + 1, t);
             const int item = t.wave + q * NW;
-            if (item < ITEMS) {
+            if (ITEMS >= (q + 1) * NW || item < ITEMS) {
                 const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
                 pre(kt, mg);
                 f32x4 acc[MG];
