@@ -26,8 +26,8 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 1;
     const char* e = getenv("DTQN_ROW_SPLIT");                 // tests / tuning: 0 = never, 1 = whenever covered
     if (e != nullptr && e[0] == '0') return 1;
-    const bool covered = !net->tiled && net->lp == 64 && net->gate == DTQN_GATE_RES && !net->identity &&
-                         (net->d_model == 64 || net->d_model == 128);
+    const bool covered = !net->tiled && net->lp == 64 && !net->identity &&
+                         (net->d_model == 64 || (net->d_model == 128 && net->gate == DTQN_GATE_RES));   // GRU: D <= 64
     if (!covered) return 1;
     if (e != nullptr && e[0] == '1') return 2;
     if (e != nullptr && e[0] == '4') return 4;

@@ -43,7 +43,7 @@ struct BwdArgs {
 // that hands something over: the upper slice's contribution to dK | dV of the lower rows (slice 1 -> slice 0).
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
-    static_assert(RS == 1 || ((RS == 2 || RS == 4) && !GRU), "row split covers the residual gate only");
+    static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
     constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;                   // rows this workgroup owns
     constexpr int LPF = LP * RS;                  // padded rows of the whole sequence (= net.lp)
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         // mlp gate.  res: s2 = x1 + relu(f)  ->  df = ds2 * [y2 > 0], the skip path keeps DX.
         // gru: DX <- dL/dx (skip path), T2 <- dL/dy, then the same ReLU mask.
         if (gru) {
-            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_mlp, net, lrec + net.al_gate2, lgrd + net.gl_gate2, t);
+            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_mlp, net, lrec + net.al_gate2, lgrd + net.gl_gate2, t, LPF, R0);
             __syncthreads();
         }
         {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
         // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
         if (gru) {
-            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_attn, net, lrec + net.al_gate1, lgrd + net.gl_gate1, t);
+            gru_gate_backward<D, MT, NW>(DX, T2, LDX, W5, LD5, theta + net.off_gate_attn, net, lrec + net.al_gate1, lgrd + net.gl_gate1, t, LPF, R0);
             __syncthreads();
         }
         {
@@ -549,7 +549,17 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
     if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)
-        if (net->lp != 64 || net->gate != DTQN_GATE_RES || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (net->lp != 64 || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (net->gate == DTQN_GATE_GRU) {
+            if (td->row_split == 4) {
+                if (D == 64 && HD == 8) return launch_bwd2<64, 1, 8, 8, true, 4>(a, s);
+                if (D == 64 && HD == 16) return launch_bwd2<64, 1, 16, 8, true, 4>(a, s);
+                return DTQN_ERR_CONFIG;
+            }
+            if (D == 64 && HD == 8) return launch_bwd2<64, 2, 8, 8, true, 2>(a, s);
+            if (D == 64 && HD == 16) return launch_bwd2<64, 2, 16, 8, true, 2>(a, s);
+            return DTQN_ERR_CONFIG;
+        }
         if (td->row_split == 4) {
             if (D == 64 && HD == 8) return launch_bwd2<64, 1, 8, 8, false, 4>(a, s);
             if (D == 64 && HD == 16) return launch_bwd2<64, 1, 16, 8, false, 4>(a, s);

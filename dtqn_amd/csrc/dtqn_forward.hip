@@ -57,7 +57,7 @@ __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 // prefetched weight fragment and its s_waitcnt instead of falling back to vmcnt(0) (measured: -6 % on the inference pass).
 template <int D, int MT, int HD, int NW, bool GRU, int RS, bool TRAIN>
 __device__ __forceinline__ void forward_body(const FwdArgs& a) {
-    static_assert(RS == 1 || (RS == 2 && !GRU), "row split covers the residual gate only");
+    static_assert(RS == 1 || RS == 2, "one or two row slices");
     constexpr int NT = NW * 64;                    // threads per workgroup
     constexpr int LP = MT * 16;                    // rows this workgroup owns
     constexpr int LPF = LP * RS;                   // padded rows of the whole sequence (= net.lp)
@@ -234,7 +234,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
         }
         if (gru) {                                         // x <- GRUGate(x, y)  (gates.py:26-31)
             __syncthreads();
-            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_attn, net, TRAIN ? lrec + net.al_gate1 : nullptr, t);
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_attn, net, TRAIN ? lrec + net.al_gate1 : nullptr, t, LPF, R0);
         }
         const float* __restrict__ W1 = th + net.lo_f1_w;
         const float* __restrict__ b1 = th + net.lo_f1_b;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
         }
         if (gru) {
             __syncthreads();
-            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_mlp, net, TRAIN ? lrec + net.al_gate2 : nullptr, t);
+            gru_gate_forward<D, MT, NW>(Xs, LDX, Ws, LDW, theta + net.off_gate_mlp, net, TRAIN ? lrec + net.al_gate2 : nullptr, t, LPF, R0);
         }
         DTQN_PROF(a.prof, ps++);   // FFN done
         __syncthreads();
@@ -405,7 +405,12 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     const int MT = mt_rows > 0 ? mt_rows : a.net.lp / 16;
     const int NW = mt_rows > 0 ? 8 : waves_for(a.net);
     if (row_split == 2) {      // two workgroups per sequence (dtqn_td_row_split): 32-row slices of a 64-row tile, 8 waves
-        if (a.net.lp != 64 || a.net.gate != DTQN_GATE_RES || a.net.identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (a.net.lp != 64 || a.net.identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (a.net.gate == DTQN_GATE_GRU) {
+            if (D == 64 && HD == 8) return launch_fwd2<64, 2, 8, 8, true, 2>(a, nseq, stream);
+            if (D == 64 && HD == 16) return launch_fwd2<64, 2, 16, 8, true, 2>(a, nseq, stream);
+            return DTQN_ERR_CONFIG;
+        }
         if (D == 64 && HD == 8) return launch_fwd2<64, 2, 8, 8, false, 2>(a, nseq, stream);
         if (D == 64 && HD == 16) return launch_fwd2<64, 2, 16, 8, false, 2>(a, nseq, stream);
         if (D == 128 && HD == 16) return launch_fwd2<128, 2, 16, 8, false, 2>(a, nseq, stream);

@@ -16,16 +16,20 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // Caller: barrier before (x and y visible) and after (Xs updated).
 template <int D, int MT, int NW>
 __device__ __forceinline__ void gru_gate_forward(float* Xs, int ldx, float* Ws, int ldw, const float* __restrict__ gw,
-                                                 const DtqnNet& net, float* __restrict__ grec, const Thr& t) {
+                                                 const DtqnNet& net, float* __restrict__ grec, const Thr& t,
+                                                 int lpf = MT * 16, int r0 = 0) {
+    // row slices: the record tensors are [lpf][D] (whole sequence), this workgroup's LP rows start at row r0
     constexpr int LP = MT * 16;
     constexpr int MG = pick_mg(D / 16, MT, NW);
     using Own = Owned<D, MT, MG, NW>;
+    const size_t TS = (size_t)lpf * D;          // one record tensor
+    if (grec != nullptr) grec += (size_t)r0 * D;
     float* Z = Ws;
     const float* Y = Ws + D;
     float* RX = Ws + 2 * D;
     if (grec != nullptr) {
-        tile_store<NW>(Xs, ldx, grec + 4 * LP * D, LP, D, t);
-        tile_store<NW>(Y, ldw, grec + 5 * LP * D, LP, D, t);
+        tile_store<NW>(Xs, ldx, grec + 4 * TS, LP, D, t);
+        tile_store<NW>(Y, ldw, grec + 5 * TS, LP, D, t);
     }
     const float* __restrict__ Wz = gw + net.go_w_z;
     const float* __restrict__ Uz = gw + net.go_u_z;
@@ -61,9 +65,9 @@ __device__ __forceinline__ void gru_gate_forward(float* Xs, int ldx, float* Ws, 
                     Z[r * ldw + c] = z;
                     RX[r * ldw + c] = rx;
                     if (grec != nullptr) {
-                        grec[0 * LP * D + r * D + c] = z;
-                        grec[1 * LP * D + r * D + c] = rr;
-                        grec[3 * LP * D + r * D + c] = rx;
+                        grec[0 * TS + r * D + c] = z;
+                        grec[1 * TS + r * D + c] = rr;
+                        grec[3 * TS + r * D + c] = rx;
                     }
                 }
         }
@@ -93,7 +97,7 @@ __device__ __forceinline__ void gru_gate_forward(float* Xs, int ldx, float* Ws, 
                     const float hc = tanhf(ah[m][r4]);
                     const float z = Z[r * ldw + c], x = Xs[r * ldx + c];
                     Xs[r * ldx + c] = (1.0f - z) * x + z * hc;
-                    if (grec != nullptr) grec[2 * LP * D + r * D + c] = hc;
+                    if (grec != nullptr) grec[2 * TS + r * D + c] = hc;
                 }
         }
     }
@@ -105,9 +109,13 @@ __device__ __forceinline__ void gru_gate_forward(float* Xs, int ldx, float* Ws, 
 template <int D, int MT, int NW>
 __device__ __forceinline__ void gru_gate_backward(float* DX, float* T2, int ldx, float* W5, int ld5,
                                                   const float* __restrict__ gw, const DtqnNet& net,
-                                                  const float* __restrict__ grec, float* __restrict__ ggrd, const Thr& t) {
+                                                  const float* __restrict__ grec, float* __restrict__ ggrd, const Thr& t,
+                                                  int lpf = MT * 16, int r0 = 0) {
     constexpr int LP = MT * 16;
     constexpr int NT = NW * 64;
+    const size_t TS = (size_t)lpf * D;          // one record tensor; this workgroup's rows start at r0
+    grec += (size_t)r0 * D;
+    ggrd += (size_t)r0 * D;
     constexpr int MG = pick_mg(D / 16, MT, NW);
     using Own = Owned<D, MT, MG, NW>;
     float* A = W5;             // dz_pre
@@ -117,7 +125,7 @@ __device__ __forceinline__ void gru_gate_backward(float* DX, float* T2, int ldx,
     float* RT = W5 + 4 * D;    // r
     for (int idx = t.tid; idx < LP * D; idx += NT) {
         const int r = idx / D, c = idx - r * D;
-        const float z = grec[0 * LP * D + idx], rr = grec[1 * LP * D + idx], hc = grec[2 * LP * D + idx], x = grec[4 * LP * D + idx];
+        const float z = grec[0 * TS + idx], rr = grec[1 * TS + idx], hc = grec[2 * TS + idx], x = grec[4 * TS + idx];
         const float g = DX[r * ldx + c];
         const float dzp = g * (hc - x) * z * (1.0f - z);
         const float dhp = g * z * (1.0f - hc * hc);
@@ -126,8 +134,8 @@ __device__ __forceinline__ void gru_gate_backward(float* DX, float* T2, int ldx,
         XT[r * ld5 + c] = x;
         RT[r * ld5 + c] = rr;
         DX[r * ldx + c] = g * (1.0f - z);
-        ggrd[0 * LP * D + idx] = dzp;
-        ggrd[2 * LP * D + idx] = dhp;
+        ggrd[0 * TS + idx] = dzp;
+        ggrd[2 * TS + idx] = dhp;
     }
     __syncthreads();
     // d(r*x) = dh_pre U_g ;  dr_pre = d(r*x) * x * r(1-r) ;  dx += d(r*x) * r
@@ -139,7 +147,7 @@ __device__ __forceinline__ void gru_gate_backward(float* DX, float* T2, int ldx,
             const float drp = v * x * rr * (1.0f - rr);
             C[r * ld5 + c] = drp;
             DX[r * ldx + c] += v * rr;
-            ggrd[1 * LP * D + r * D + c] = drp;
+            ggrd[1 * TS + r * D + c] = drp;
         });
     }
     __syncthreads();

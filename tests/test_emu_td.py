@@ -66,6 +66,7 @@ def test_td_update_tiled_path(emu, kw, run, monkeypatch):
 
 SPLIT = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50, gate="gru", action_dim=4),
     dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=55, action_dim=8, pos="sin"),
     dict(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, discrete=True, vocab_sizes=9),
 ]

@@ -163,12 +163,12 @@ def test_golden_G3_tiled_update(lib, name):
     assert moved > 10 * err and err <= 2e-2 * scale, (moved, err)
 
 
-@pytest.mark.parametrize("split,D", [("4", 64), ("4", 128), ("1", 128)])
-def test_gradient_is_bit_reproducible_in_latency_mode(lib, split, D, monkeypatch):
+@pytest.mark.parametrize("split,D,gate", [("4", 64, "res"), ("4", 128, "res"), ("1", 128, "res"), ("4", 64, "gru")])
+def test_gradient_is_bit_reproducible_in_latency_mode(lib, split, D, gate, monkeypatch):
     """No atomics, fixed reduction and hand-over orders: the gradient of a fixed batch is bit-identical over many
     repetitions, whatever the inter-workgroup timing (a cheap detector for races in the row-slice hand-overs)."""
     monkeypatch.setenv("DTQN_ROW_SPLIT", split)
-    cfg = O.NetCfg(obs_dim=3, num_actions=5, inner_embed_size=D, num_heads=8, history_len=50)
+    cfg = O.NetCfg(obs_dim=3, num_actions=5, inner_embed_size=D, num_heads=8, history_len=50, gate=gate)
     Bn = 32 if D == 64 else 16
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=3, batch=Bn, T=120, n_eps=40, mask=-5, device="cuda", test_lib=False)
     assert eng.row_split == (4 if split == "4" else 2)
