@@ -151,7 +151,9 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = DTQN_EXP2(st[r] - lse2);
-                if (s0 + t.kq * 4 + r > trow) p = 0.f;
+                // masked keys, and PAD query rows (t >= n: their saved lse is 0, so exp2 can overflow and inf * 0 would
+                // put a NaN into dq of a pad row, which the weight-gradient contraction over all padded rows would pick up)
+                if (s0 + t.kq * 4 + r > trow || trow >= n) p = 0.f;
                 ds[r] = p * (dp[r] - delta);
             }
 #pragma unroll
