@@ -106,14 +106,18 @@ def test_in_kernel_window_draw_equals_sample_kernel(emu, split, monkeypatch):
     assert torch.equal(eng.grad, grad_ref)
 
 
-@pytest.mark.parametrize("split,heads", [("4", 8), ("0", 4)])
+@pytest.mark.parametrize("split,heads", [("4", 8), ("0", 4), ("tiled", 4)])
 def test_pad_rows_with_overflowing_scores_stay_out_of_the_gradient(emu, split, heads, monkeypatch):
     """Regression: the padded query rows of a window (context 50 in a 64-row tile) carry bias-only activations; with
     large in-projection biases their recomputed attention probabilities overflow (their saved log-sum-exp is 0).  They
     must contribute exactly nothing: a 1 M-step training run once died of inf * 0 = NaN in dQ of a pad row."""
-    monkeypatch.setenv("DTQN_ROW_SPLIT", split)
+    if split == "tiled":
+        monkeypatch.setenv("DTQN_FORCE_TILED", "1")       # the row-block tiled kernels share the attention backward
+    else:
+        monkeypatch.setenv("DTQN_ROW_SPLIT", split)
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=heads, num_layers=1, history_len=50)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=2, T=90, n_eps=5, mask=-5)
+    assert net.tiled == (1 if split == "tiled" else 0)
     # q / k biases of +-12 per column: pad rows (x = position row only -> after LN a fixed vector) get |q.k| * scale * log2(e) >> 128
     tab = B.param_table(net)
     off, shape = tab["transformer_layers.0.attention.in_proj_bias"]
