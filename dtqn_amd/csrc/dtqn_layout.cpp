@@ -45,12 +45,18 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->ap = up4(A);
     net->head_dim = D / H;
     net->ffn_chunk = 2 * D;
-    const int LP = net->lp;
     // kernels cover what fits the per-sequence LDS tile (DESIGN.md "coverage")
     if (net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
+    if (!net->tiled && (D == 128 || D == 256) && (dtqn_lds_bytes_backward(net) == 0 || net->gate == DTQN_GATE_GRU)) {
+        // the whole-sequence tile set of this variant (identity-reordered layers or the GRU gate at D = 128) exceeds
+        // 160 KB of LDS
+        net->tiled = 1;
+        net->lp = (L + 63) / 64 * 64;
+    }
+    const int LP = net->lp;
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
-        if (!(D == 64 || D == 128 || D == 256) || LP > 256 || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
+        if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;
         if (((size_t)LP * (4 * net->head_dim + 4) + 2 * (size_t)LP) * sizeof(float) > 160 * 1024) return DTQN_ERR_CONFIG;
     }
     if (A > DTQN_MAX_ACTIONS || (!net->tiled && net->kep > 3 * D)) return DTQN_ERR_CONFIG;
@@ -175,7 +181,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (gru) {
         // shared gate weights see the tokens of every layer: one job per (gate, matrix), looping over layers
         for (int g = 0; g < 2; ++g) for (int m = 0; m < 6; ++m) count(D, D);
-        if (D > 64) return DTQN_ERR_CONFIG;      // the GRU backward keeps five [LP][D] tiles in LDS (DESIGN.md coverage)
+        if (D > 64 && !net->tiled) return DTQN_ERR_CONFIG;   // the whole-sequence GRU backward keeps five [LP][D] tiles in LDS
     }
     count(D, D);
     count(A, D);
@@ -234,7 +240,10 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
             }
         }
     }
-    add(1, net->ao_xf, D, D, net->go_dhh, D, D, net->off_head1_w, net->off_head1_b);
+    // the head reads the final stream: ao_xf, except for identity-reordered layers on the row-block tiled path, whose last
+    // layer leaves it in its own s2 field
+    const int xf_off = net->tiled && net->identity ? net->ao_layer0 + (NL - 1) * net->act_layer_stride + net->al_s2 : net->ao_xf;
+    add(1, xf_off, D, D, net->go_dhh, D, D, net->off_head1_w, net->off_head1_b);
     add(1, net->ao_hh, D, D, net->go_dq, net->ap, A, net->off_head2_w, net->off_head2_b);
     return (j == net->n_wjobs && tile == net->n_wtiles) ? DTQN_OK : DTQN_ERR_CONFIG;
 }

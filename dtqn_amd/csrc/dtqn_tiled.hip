@@ -11,9 +11,12 @@
 //   * LayerNorm (forward and backward) are row-wise kernels.
 // The weight gradients, the reduction and Adam are the SAME kernels as on the whole-sequence path
 // (dtqn_wgrad.hip, dtqn_optim.hip): they only see the records.
-// Training coverage: post-LN (identity = False), residual gate.  Inference also covers identity = True.
+// Covers post-LN and identity-reordered layers, residual and GRU gates (the GRU gate as two-operand GEMMs with the gate
+// arithmetic in their epilogues); this is also where variants whose whole-sequence tile set exceeds LDS run
+// (identity or GRU at D >= 128).
 #include "dtqn_device.hpp"
 #include "dtqn_bwd_device.hpp"
+#include "dtqn_gru.hpp"
 
 namespace dtqn {
 
@@ -107,14 +110,21 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     }
 }
 
-// ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T + b) ------------------------------------------------
+// ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T [+ IN2[rows][K2] * W2[N][K2]^T] + b) ----------------------
 //   mode 0: OUT = y      mode 1: OUT = relu(y)      mode 2: OUT = RES + relu(y)   (residual gate)
 //   modes 1 / 2 optionally save the ReLU pattern as wave ballots (same word layout as the whole-sequence kernels)
+//   GRU gate (gates.py:26-31; RES = the stream x):
+//   mode 3: OUT = sigmoid(y);  OUT2 = OUT * RES (r * x) and OUT3 = RES (copy of x for the weight gradients) when given
+//   mode 4: OUT = tanh(y);     OUT2 = (1 - AUX) * RES + AUX * OUT          (AUX = z: the gate output)
 struct TlLinearArgs {
     Fld in, out, res, mask;            // mask.base == nullptr: no ballots
-    const float *Wa, *Wb, *ba, *bb;    // sequences >= split use Wb / bb
+    const float *Wa, *Wb, *ba, *bb;    // sequences >= split use Wb / bb; ba == nullptr: no bias
     int split;
     int K, N, rpb, mode;
+    Fld in2;                           // second operand pair (K2 == 0: none)
+    const float *W2a, *W2b;
+    int K2;
+    Fld aux, out2, out3;
 };
 template <int D>
 __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
@@ -126,28 +136,34 @@ __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
     const int col = ntile * 16 + t.i;
     const bool live = col < a.N;                                      // N is a multiple of 16: wave-uniform
     const float* __restrict__ W = s >= a.split ? a.Wb : a.Wa;
+    const float* __restrict__ W2 = s >= a.split ? a.W2b : a.W2a;
     const float* __restrict__ bias = s >= a.split ? a.bb : a.ba;
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = zero4();
     float4 bf[2][D / 16];
     const float* wrow = W + (size_t)(live ? col : 0) * a.K;
+    const float* wrow2 = a.K2 > 0 ? W2 + (size_t)(live ? col : 0) * a.K2 : nullptr;
     frag_xwT_fetch<D>(bf[0], wrow, t);
     const float* in0 = frow(a.in, s, row0);
-    const int nchunks = a.K / D;
+    const float* in20 = a.K2 > 0 ? frow(a.in2, s, row0) : nullptr;
+    const int nch1 = a.K / D, nchunks = nch1 + a.K2 / D;
     for (int kc = 0; kc < nchunks; ++kc) {
         __syncthreads();                                              // previous chunk's tile fully consumed
+        const float* src = kc < nch1 ? in0 + (size_t)kc * D : in20 + (size_t)(kc - nch1) * D;
+        const int ld = kc < nch1 ? a.in.ld : a.in2.ld;
         for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
-            st4(Xt + r * LDT + c, ld4(in0 + (size_t)r * a.in.ld + (size_t)kc * D + c));
+            st4(Xt + r * LDT + c, ld4(src + (size_t)r * ld + c));
         }
-        if (kc + 1 < nchunks) frag_xwT_fetch<D>(bf[(kc + 1) & 1], wrow + (size_t)(kc + 1) * D, t);
+        if (kc + 1 < nchunks)
+            frag_xwT_fetch<D>(bf[(kc + 1) & 1], kc + 1 < nch1 ? wrow + (size_t)(kc + 1) * D : wrow2 + (size_t)(kc + 1 - nch1) * D, t);
         __syncthreads();
         if (kc & 1) frag_xwT_mma<D, 4>(Xt, LDT, bf[1], t, acc);
         else frag_xwT_mma<D, 4>(Xt, LDT, bf[0], t, acc);
     }
     if (live) {
-        const float b = bias[col];
+        const float b = bias != nullptr ? bias[col] : 0.f;
         float* mrec = a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -158,6 +174,19 @@ __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
                 const float v = acc[m][r4] + b;
                 if (a.mode == 0) {
                     *op = v;
+                } else if (a.mode == 3) {
+                    const float g = sigmoidf_(v);
+                    *op = g;
+                    if (a.out2.base != nullptr) {
+                        const float x = frow(a.res, s, row)[col];
+                        frow(a.out2, s, row)[col] = g * x;
+                        if (a.out3.base != nullptr) frow(a.out3, s, row)[col] = x;
+                    }
+                } else if (a.mode == 4) {
+                    const float hc = tanhf(v);
+                    const float z = frow(a.aux, s, row)[col], x = frow(a.res, s, row)[col];
+                    *op = hc;
+                    frow(a.out2, s, row)[col] = (1.0f - z) * x + z * hc;
                 } else {
                     if (mrec != nullptr) ballot_store(mrec, a.N / 16, row, col, v > 0.f, t.lane);
                     const float y = fmaxf(v, 0.f);
@@ -167,13 +196,17 @@ __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
     }
 }
 
-// ---- backward linear: dX[rows][KOUT] (op)= dY[rows][N] * W[N][KOUT] --------------------------------------------
+// ---- backward linear: dX[rows][KOUT] (op)= sum_p dY_p[rows][N] * W_p[N][KOUT],  p < nsrc <= 3 ------------------
 //   mode 0: OUT = v      mode 1: OUT = v where the saved ReLU ballot of OUT's forward twin is set, else 0
 //   mode 2: OUT += v
+//   (nsrc > 1: the GRU gate, whose dx and dy each collect several matrix products -- gates.py:26-31)
 struct TlDxArgs {
     Fld dy, out, mask;
     const float* W;
     int N, KOUT, rpb, mode;
+    int nsrc;
+    Fld dy2, dy3;
+    const float *W2, *W3;
 };
 template <int KC>
 __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
@@ -188,17 +221,24 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = zero4();
     float bf[2][KC / 4];
-    const float* wcol = a.W + (live ? col : 0);
-    frag_dyw_fetch<KC>(bf[0], wcol, a.KOUT, t);
-    const float* dy0 = frow(a.dy, s, row0);
-    const int nchunks = a.N / KC;
+    const int cl = live ? col : 0;
+    const int per = a.N / KC, nchunks = per * a.nsrc;
+    // chunk kc = (operand pair p, contraction chunk j)
+    auto wchunk = [&](int kc) {
+        const int p = kc / per, j = kc - p * per;
+        return (p == 0 ? a.W : p == 1 ? a.W2 : a.W3) + cl + (size_t)j * KC * a.KOUT;
+    };
+    frag_dyw_fetch<KC>(bf[0], wchunk(0), a.KOUT, t);
     for (int kc = 0; kc < nchunks; ++kc) {
         __syncthreads();
+        const int p = kc / per, j = kc - p * per;
+        const Fld& dyf = p == 0 ? a.dy : p == 1 ? a.dy2 : a.dy3;
+        const float* dy0 = frow(dyf, s, row0) + (size_t)j * KC;
         for (int idx = t.tid; idx < TROWS * (KC / 4); idx += TNT) {
             const int r = idx / (KC / 4), c = (idx - r * (KC / 4)) * 4;
-            st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * a.dy.ld + (size_t)kc * KC + c));
+            st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * dyf.ld + c));
         }
-        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf[(kc + 1) & 1], wcol + (size_t)(kc + 1) * KC * a.KOUT, a.KOUT, t);
+        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf[(kc + 1) & 1], wchunk(kc + 1), a.KOUT, t);
         __syncthreads();
         if (kc & 1) frag_dyw_mma<KC, 4>(Yt, LDT, bf[1], t, acc);
         else frag_dyw_mma<KC, 4>(Yt, LDT, bf[0], t, acc);
@@ -318,7 +358,8 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_kernel(TlLnArgs a) {
 }
 
 // backward, one workgroup per sequence walking its row blocks (the gamma / beta partial of the sequence is
-// accumulated across the blocks); dst may alias dy
+// accumulated across the blocks); dst may alias dy; accumulate: dst += dL/d(LN input) (identity-reordered layers, where
+// the LayerNorm sits on the branch and the residual stream gradient passes by it)
 struct TlLnBwdArgs {
     Fld dy, xin, st, dst;
     const float* gamma;
@@ -326,6 +367,7 @@ struct TlLnBwdArgs {
     long long small_stride;
     int dgb_off;
     int rpb;
+    int accumulate;
 };
 template <int D>
 __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
@@ -335,7 +377,7 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
     float* dgb = a.small + (size_t)s * a.small_stride + a.dgb_off;
     for (int rb = 0; rb < a.rpb; ++rb) {
         const int row0 = rb * TROWS;
-        layernorm_backward<D, TNW>(frow(a.dy, s, row0), frow(a.xin, s, row0), frow(a.dst, s, row0), false, D, TROWS,
+        layernorm_backward<D, TNW>(frow(a.dy, s, row0), frow(a.xin, s, row0), frow(a.dst, s, row0), a.accumulate != 0, D, TROWS,
                                    a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2, a.gamma, dgb, red, t, rb > 0);
         __syncthreads();
     }
@@ -359,6 +401,50 @@ __global__ __launch_bounds__(TNT) void tl_mask_kernel(TlMaskArgs a) {
         o.z = mask_bit(mrec, a.D / 16, r, c + 2) ? v.z : 0.f;
         o.w = mask_bit(mrec, a.D / 16, r, c + 3) ? v.w : 0.f;
         st4(frow(a.dst, s, r) + c, o);
+    }
+}
+
+// ---- GRU gate backward, elementwise parts (the matrix products run through tl_dx_kernel) ------------------------------------
+//   step 1: dz_pre = g (h - x) z (1 - z);  dh_pre = g z (1 - h^2);  g <- g (1 - z)              (g = dL/d(gate output), in place)
+//   step 2: t = dh_pre U_g (given);  dr_pre = t x r (1 - r);  g += t r
+struct TlGateBwdArgs {
+    Fld g, t;                          // stream gradient; step 2: d(r * x)
+    Fld z, r, h, x;                    // the gate's saved record
+    Fld dz, dr, dh;                    // its gradient record (pre-activations)
+    int D, rpb, step;
+};
+__global__ __launch_bounds__(TNT) void tl_gate_bwd_kernel(TlGateBwdArgs a) {
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int c4 = a.D / 4;
+    for (int idx = (int)threadIdx.x; idx < TROWS * c4; idx += TNT) {
+        const int r = row0 + idx / c4, c = (idx % c4) * 4;
+        float* gp = frow(a.g, s, r) + c;
+        const float4 g4 = ld4(gp), x4 = ld4(frow(a.x, s, r) + c);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w}, x[4] = {x4.x, x4.y, x4.z, x4.w};
+        float o0[4], o1[4], o2[4];
+        if (a.step == 1) {
+            const float4 z4 = ld4(frow(a.z, s, r) + c), h4 = ld4(frow(a.h, s, r) + c);
+            const float z[4] = {z4.x, z4.y, z4.z, z4.w}, h[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o0[q] = g[q] * (h[q] - x[q]) * z[q] * (1.0f - z[q]);
+                o1[q] = g[q] * z[q] * (1.0f - h[q] * h[q]);
+                o2[q] = g[q] * (1.0f - z[q]);
+            }
+            st4(frow(a.dz, s, r) + c, make_float4(o0[0], o0[1], o0[2], o0[3]));
+            st4(frow(a.dh, s, r) + c, make_float4(o1[0], o1[1], o1[2], o1[3]));
+            st4(gp, make_float4(o2[0], o2[1], o2[2], o2[3]));
+        } else {
+            const float4 t4 = ld4(frow(a.t, s, r) + c), r4 = ld4(frow(a.r, s, r) + c);
+            const float tv[4] = {t4.x, t4.y, t4.z, t4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o0[q] = tv[q] * x[q] * rr[q] * (1.0f - rr[q]);
+                o2[q] = g[q] + tv[q] * rr[q];
+            }
+            st4(frow(a.dr, s, r) + c, make_float4(o0[0], o0[1], o0[2], o0[3]));
+            st4(gp, make_float4(o2[0], o2[1], o2[2], o2[3]));
+        }
     }
 }
 
@@ -605,10 +691,35 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), 0, stream, e);
     }
     auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
-        TlLinearArgs a;
+        TlLinearArgs a = {};
         a.in = in; a.out = out; a.res = res; a.mask = mask;
         a.Wa = theta_a + w_off; a.Wb = theta_b + w_off; a.ba = theta_a + b_off; a.bb = theta_b + b_off;
         a.split = split; a.K = K; a.N = N; a.rpb = rpb; a.mode = mode;
+        return launch_linear<D>(a, S, stream);
+    };
+    // out = GRUGate(x, y) (gates.py:26-31): three two-operand GEMMs with the gate arithmetic as their epilogues.
+    // grec: the gate's record (z, r, h~, r*x, x, y), y already in place.
+    const bool gru = net.gate == DTQN_GATE_GRU;
+    const int LPD = lpb * D;
+    auto gate = [&](Fld x, int grec, int gw, Fld out) -> int {
+        const Fld z = F(grec, D), r = F(grec + LPD, D), h = F(grec + 2 * LPD, D), rx = F(grec + 3 * LPD, D), y = F(grec + 5 * LPD, D);
+        auto pair = [&](Fld in2, int w_off, int u_off, int b_off) {
+            TlLinearArgs a = {};
+            a.in = y; a.K = D; a.Wa = theta_a + gw + w_off; a.Wb = theta_b + gw + w_off;
+            a.in2 = in2; a.K2 = D; a.W2a = theta_a + gw + u_off; a.W2b = theta_b + gw + u_off;
+            if (b_off >= 0) { a.ba = theta_a + gw + b_off; a.bb = theta_b + gw + b_off; }
+            a.split = split; a.N = D; a.rpb = rpb; a.res = x;
+            return a;
+        };
+        TlLinearArgs a = pair(x, net.go_w_r, net.go_u_r, -1);
+        a.mode = 3; a.out = r; a.out2 = rx; a.out3 = training ? F(grec + 4 * LPD, D) : nofld();
+        int rc2 = launch_linear<D>(a, S, stream);
+        if (rc2 != DTQN_OK) return rc2;
+        a = pair(x, net.go_w_z, net.go_u_z, net.go_b_z);
+        a.mode = 3; a.out = z;
+        if ((rc2 = launch_linear<D>(a, S, stream)) != DTQN_OK) return rc2;
+        a = pair(rx, net.go_w_g, net.go_u_g, -1);
+        a.mode = 4; a.out = h; a.aux = z; a.out2 = out;
         return launch_linear<D>(a, S, stream);
     };
     auto lnorm = [&](Fld s_, Fld d_, Fld st, int w_off, int b_off) {
@@ -634,17 +745,31 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             at.D = D; at.lpb = lpb; at.n = n;
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
-        // s1 = stream + relu(o W_o^T + b)
-        if ((rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, s1, 2, stream_in,
-                         training ? F(ab + net.al_m1, 0) : nofld())) != DTQN_OK) return rc;
+        // s1 = gate(stream, relu(o W_o^T + b))
+        if (!gru) {
+            rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, s1, 2, stream_in,
+                        training ? F(ab + net.al_m1, 0) : nofld());
+        } else {
+            rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, F(ab + net.al_gate1 + 5 * LPD, D), 1, nofld(),
+                        training ? F(ab + net.al_m1, 0) : nofld());
+            if (rc == DTQN_OK) rc = gate(stream_in, ab + net.al_gate1, net.off_gate_attn, s1);
+        }
+        if (rc != DTQN_OK) return rc;
         if (!ident) rc = lnorm(s1, u2, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b);
         else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
         if (rc != DTQN_OK) return rc;
         if ((rc = linear(u2, D, 4 * D, tb + net.lo_f1_w, tb + net.lo_f1_b, F(ab + net.al_h, 4 * D), 1, nofld(),
                          training ? F(ab + net.al_mh, 0) : nofld())) != DTQN_OK) return rc;
-        // s2 = (post-LN: u2 | identity: s1) + relu(h W_2^T + b)
-        if ((rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, s2, 2, ident ? s1 : u2,
-                         training ? F(ab + net.al_m2, 0) : nofld())) != DTQN_OK) return rc;
+        // s2 = gate(post-LN: u2 | identity: s1, relu(h W_2^T + b))
+        if (!gru) {
+            rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, s2, 2, ident ? s1 : u2,
+                        training ? F(ab + net.al_m2, 0) : nofld());
+        } else {
+            rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, F(ab + net.al_gate2 + 5 * LPD, D), 1, nofld(),
+                        training ? F(ab + net.al_m2, 0) : nofld());
+            if (rc == DTQN_OK) rc = gate(ident ? s1 : u2, ab + net.al_gate2, net.off_gate_mlp, s2);
+        }
+        if (rc != DTQN_OK) return rc;
         if (!ident) {
             const Fld nxt = last ? F(rm.xf, D) : F(L0(l + 1) + net.al_u1, D);
             if ((rc = lnorm(s2, nxt, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b)) != DTQN_OK) return rc;
@@ -663,7 +788,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     return DTQN_OK;
 }
 
-// Data-gradient chain of the B TRAIN sequences (records [0, B) of td->act), post-LN / residual gate.
+// Data-gradient chain of the B TRAIN sequences (records [0, B) of td->act), residual gate; post-LN (transformer.py:63-78)
+// or identity-reordered (transformer.py:86-101) layers.
 // The gradient of the residual stream lives in grd.go_dx0 throughout (it IS dL/dx0 at the end).
 template <int D>
 static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const DtqnTd& td, hipStream_t stream) {
@@ -692,37 +818,68 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
     }
     const Fld G = FG(net.go_dx0, D);
     auto dx = [&](Fld dy, int N, int w_off, int KOUT, Fld out, int mode, Fld mask) {
-        TlDxArgs a;
-        a.dy = dy; a.out = out; a.mask = mask; a.W = theta + w_off; a.N = N; a.KOUT = KOUT; a.rpb = rpb; a.mode = mode;
+        TlDxArgs a = {};
+        a.dy = dy; a.out = out; a.mask = mask; a.W = theta + w_off; a.N = N; a.KOUT = KOUT; a.rpb = rpb; a.mode = mode; a.nsrc = 1;
         return launch_dx<KC>(a, B, stream);
     };
-    auto ln_bwd = [&](Fld xin, Fld st, int gamma_off, int dgb_off) {
+    auto ln_bwd = [&](Fld dy, Fld xin, Fld st, int gamma_off, int dgb_off, bool accumulate) {
         TlLnBwdArgs a;
-        a.dy = G; a.xin = xin; a.st = st; a.dst = G; a.gamma = theta + gamma_off;
-        a.small = td.small; a.small_stride = net.sp_stride; a.dgb_off = dgb_off; a.rpb = rpb;
+        a.dy = dy; a.xin = xin; a.st = st; a.dst = G; a.gamma = theta + gamma_off;
+        a.small = td.small; a.small_stride = net.sp_stride; a.dgb_off = dgb_off; a.rpb = rpb; a.accumulate = accumulate ? 1 : 0;
         return launch_ln_bwd<D>(a, B, stream);
     };
-    auto mask = [&](Fld m, Fld dst) {
+    auto mask = [&](Fld m, Fld dst) -> int {
         TlMaskArgs a;
         a.src = G; a.dst = dst; a.mask = m; a.D = D; a.rpb = rpb;
         TL_LAUNCH(tl_mask_kernel, dim3(B * rpb), dim3(TNT), 0, stream, a);
         return DTQN_OK;
+    };
+    const bool ident = net.identity != 0, gru = net.gate == DTQN_GATE_GRU;
+    const Fld T = FG(net.go_do, D);                       // branch-gradient scratch (dO of the attention; LN inputs' gradients)
+    const int LPD = lpb * D;
+    // dL/d(gate output) in G  ->  G = the part that flows on along the stream (dL/dx), dst = dL/d(sub-layer output):
+    // ResGate: G stays, dst = G * [y > 0].  GRUGate (gates.py:26-31): the chain of dtqn_gru.hpp as GEMMs over the records.
+    auto gate_bwd = [&](int grec, int ggrd, int gw, Fld m, Fld dst) -> int {
+        if (!gru) return mask(m, dst);
+        const Fld dz = FG(ggrd, D), dr = FG(ggrd + LPD, D), dh = FG(ggrd + 2 * LPD, D);
+        TlGateBwdArgs e = {};
+        e.g = G; e.t = T; e.z = FA(grec, D); e.r = FA(grec + LPD, D); e.h = FA(grec + 2 * LPD, D); e.x = FA(grec + 4 * LPD, D);
+        e.dz = dz; e.dr = dr; e.dh = dh; e.D = D; e.rpb = rpb; e.step = 1;
+        TL_LAUNCH(tl_gate_bwd_kernel, dim3(B * rpb), dim3(TNT), 0, stream, e);
+        int rc2 = dx(dh, D, gw + net.go_u_g, D, T, 0, nofld());                      // d(r * x) = dh_pre U_g
+        if (rc2 != DTQN_OK) return rc2;
+        e.step = 2;
+        TL_LAUNCH(tl_gate_bwd_kernel, dim3(B * rpb), dim3(TNT), 0, stream, e);
+        TlDxArgs a = {};
+        a.N = D; a.KOUT = D; a.rpb = rpb;
+        a.dy = dz; a.W = theta + gw + net.go_u_z; a.dy2 = dr; a.W2 = theta + gw + net.go_u_r; a.nsrc = 2;
+        a.out = G; a.mode = 2;                                                        // dx += dz_pre U_z + dr_pre U_r
+        if ((rc2 = launch_dx<KC>(a, B, stream)) != DTQN_OK) return rc2;
+        a.dy = dh; a.W = theta + gw + net.go_w_g; a.dy2 = dz; a.W2 = theta + gw + net.go_w_z; a.dy3 = dr; a.W3 = theta + gw + net.go_w_r;
+        a.nsrc = 3; a.out = dst; a.mode = 1; a.mask = m;                              // dy, through the ReLU of the sub-layer output
+        return launch_dx<KC>(a, B, stream);
     };
     if ((rc = dx(FG(net.go_dhh, D), D, net.off_head1_w, D, G, 0, nofld())) != DTQN_OK) return rc;       // dL/dxf
     for (int l = net.num_layers - 1; l >= 0; --l) {
         const int tb = net.off_layer0 + l * net.layer_stride;
         const int ab = net.ao_layer0 + l * net.act_layer_stride, gb = net.go_layer0 + l * net.grd_layer_stride;
         const int sm = net.so_ln + l * 4 * D;
-        // x_out = LN2(s2)
-        if ((rc = ln_bwd(FA(ab + net.al_s2, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D)) != DTQN_OK) return rc;
-        // s2 = u2 + relu(f):  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  du2 = ds2 + dh' W1
-        if ((rc = mask(FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
+        // post-LN: x_out = LN2(s2)
+        if (!ident && (rc = ln_bwd(G, FA(ab + net.al_s2, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, false)) != DTQN_OK) return rc;
+        // s2 = (u2 | s1) + relu(f):  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  du2 = dh' W1
+        if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
         if ((rc = dx(FG(gb + net.gl_df, D), D, tb + net.lo_f2_w, 4 * D, FG(gb + net.gl_dhp, 4 * D), 1, FA(ab + net.al_mh, 0))) != DTQN_OK) return rc;
-        if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, G, 2, nofld())) != DTQN_OK) return rc;
-        // u2 = LN1(s1)
-        if ((rc = ln_bwd(FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm)) != DTQN_OK) return rc;
-        // s1 = x + relu(a):  da = ds1 * [a > 0];  dO = da W_o;  attention backward;  dx = ds1 + dqkv W_in
-        if ((rc = mask(FA(ab + net.al_m1, 0), FG(gb + net.gl_da, D))) != DTQN_OK) return rc;
+        if (!ident) {
+            // the stream IS u2: ds2 + du2, then u2 = LN1(s1)
+            if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+            if ((rc = ln_bwd(G, FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, false)) != DTQN_OK) return rc;
+        } else {
+            // u2 = LN2(s1) sits on the branch: ds1 = ds2 + LN2'(du2)
+            if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, T, 0, nofld())) != DTQN_OK) return rc;
+            if ((rc = ln_bwd(T, FA(ab + net.al_s1, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, true)) != DTQN_OK) return rc;
+        }
+        // s1 = x + relu(a):  da = ds1 * [a > 0];  dO = da W_o;  attention backward;  du1 = dqkv W_in
+        if ((rc = gate_bwd(ab + net.al_gate1, gb + net.gl_gate1, net.off_gate_attn, FA(ab + net.al_m1, 0), FG(gb + net.gl_da, D))) != DTQN_OK) return rc;
         if ((rc = dx(FG(gb + net.gl_da, D), D, tb + net.lo_out_w, D, FG(net.go_do, D), 0, nofld())) != DTQN_OK) return rc;
         {
             TlAttnBwdArgs a;
@@ -731,7 +888,14 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             a.D = D; a.lpb = lpb; a.n = L;
             if ((rc = launch_attn_bwd(a, B, H, HD, stream)) != DTQN_OK) return rc;
         }
-        if ((rc = dx(FG(gb + net.gl_dqkv, 3 * D), 3 * D, tb + net.lo_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+        if (!ident) {
+            if ((rc = dx(FG(gb + net.gl_dqkv, 3 * D), 3 * D, tb + net.lo_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+        } else {
+            // u1 = LN1(x): dx = ds1 + LN1'(du1)
+            const Fld stream_in = l == 0 ? FA(net.ao_x0, D) : FA(net.ao_layer0 + (l - 1) * net.act_layer_stride + net.al_s2, D);
+            if ((rc = dx(FG(gb + net.gl_dqkv, 3 * D), 3 * D, tb + net.lo_in_w, D, T, 0, nofld())) != DTQN_OK) return rc;
+            if ((rc = ln_bwd(T, stream_in, FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, true)) != DTQN_OK) return rc;
+        }
     }
     if (net.discrete || net.action_dim > 0) {
         TlEmbedBwdArgs a;
@@ -746,7 +910,6 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
 }
 
 int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream) {
-    if (net->identity || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;     // training coverage of the tiled path
     EmbedSrc src;
     src.obs = rp->obs; src.actions = rp->actions;
     src.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim; src.act_ep_stride = rp->max_steps + 1;
@@ -765,7 +928,6 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
 }
 
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream) {
-    if (net->identity || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
     switch (net->d_model) {
         case 64: return backward_records<64>(*net, *rp, *td, stream);
         case 128: return backward_records<128>(*net, *rp, *td, stream);
@@ -791,7 +953,7 @@ extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const 
     if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
-    if (!net->tiled || net->gate != DTQN_GATE_RES) return DTQN_ERR_CONFIG;
+    if (!net->tiled) return DTQN_ERR_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     EmbedSrc src;
     src.obs = obs; src.actions = actions;

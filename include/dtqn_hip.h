@@ -70,7 +70,8 @@ typedef struct DtqnNet {
     int32_t head_dim;
     int32_t ffn_chunk;        /* columns of the 4D hidden processed per LDS pass */
     int32_t tiled;            /* 0: one workgroup holds a whole sequence in LDS (L <= 64, D <= 128);
-                               * 1: row-block tiled kernels over global-memory tensors (L <= 256, D <= 256; forward only) */
+                               * 1: row-block tiled kernels over the per-sequence records (L <= 256, D <= 256, and GRU gates /
+                               *    identity layers at D >= 128, whose whole-sequence tile set exceeds LDS); forward and training */
     /* ---- derived: theta layout (floats) ---- */
     int32_t off_act_emb;      /* [A][a]            action_embedding.embedding.0.weight */
     int32_t off_obs_tab;      /* [V][e]            obs_embedding.observation_embedding.0.weight */

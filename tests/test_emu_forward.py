@@ -79,6 +79,7 @@ TILED = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50),
     dict(obs_dim=6, num_actions=6, inner_embed_size=64, num_heads=4, history_len=70, discrete=True, vocab_sizes=12, identity=True, pos="sin"),
     dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=2, history_len=130, discrete=True, vocab_sizes=22, action_dim=8),
+    dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=2, history_len=70, gate="gru"),
 ]
 
 
@@ -110,6 +111,29 @@ def test_tiled_forward_path(emu, kw, monkeypatch):
         assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
     # the whole-sequence kernels refuse a tiled net, and the training entry points are not built for it
     assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), None) == B.DEFINES["DTQN_ERR_CONFIG"]
+
+
+def test_variants_beyond_the_lds_tile_take_the_tiled_path(emu):
+    """GRU gates and identity-reordered layers at D = 128 need more LDS than one workgroup has on the whole-sequence
+    kernels: dtqn_net_init routes them to the row-block tiled path (forward and training); D = 64 stays whole-sequence."""
+    for kw, tiled in ((dict(inner_embed_size=128, gate="gru"), 1), (dict(inner_embed_size=128, identity=True), 1),
+                      (dict(inner_embed_size=128), 0), (dict(inner_embed_size=64, gate="gru", identity=True), 0)):
+        cfg = O.NetCfg(obs_dim=3, num_actions=3, num_heads=8, num_layers=1, history_len=50, **kw)
+        net = net_from_cfg(emu, cfg)
+        assert net.tiled == tiled and net.lp == 64, kw
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, num_layers=1, history_len=9, gate="gru")
+    net = net_from_cfg(emu, cfg)
+    params = O.init_params(cfg, seed=3, perturb=True)
+    theta = pack_theta(net, params)
+    rng = np.random.default_rng(5)
+    obs = rng.uniform(-1, 1, size=(1, 9, 3)).astype(np.float32)
+    act = np.zeros((1, 9), dtype=np.uint8)
+    with torch.no_grad():
+        ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act[..., None], dtype=torch.long)).numpy()
+    q = np.full((1, 9, 3), np.nan, dtype=np.float32)
+    ws = np.zeros(emu.dtqn_forward_workspace_floats(ctypes.byref(net), 1), dtype=np.float32)
+    assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 1, 9, ptr(q), ptr(ws), None) == 0
+    assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("kw", [dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),

@@ -49,6 +49,16 @@ TILED = [
      dict(batch=2, T=90, mask=-5, history=9, tuf=2)),
     (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=2, num_layers=1, history_len=12, discrete=True, vocab_sizes=9, action_dim=8),
      dict(batch=3, T=20, mask=8)),
+    # identity-reordered layers (transformer.py:86-101): the LayerNorms sit on the branches
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, num_layers=2, history_len=70, identity=True),
+     dict(batch=2, T=90, mask=-5, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=8, num_layers=1, history_len=12, discrete=True, vocab_sizes=9, action_dim=4,
+          identity=True, pos="sin"), dict(batch=3, T=20, mask=8, history=5)),
+    # GRU gates (gates.py:26-31), shared by both layers
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, num_layers=2, history_len=20, gate="gru"),
+     dict(batch=2, T=30, mask=-5, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=8, num_layers=2, history_len=70, discrete=True, vocab_sizes=9, action_dim=4,
+          gate="gru", identity=True), dict(batch=2, T=90, mask=8, history=30)),
 ]
 
 

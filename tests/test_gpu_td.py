@@ -38,6 +38,19 @@ CASES = [
     (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=256, discrete=True, vocab_sizes=22), dict(batch=2, T=260, mask=21, n_eps=5)),
     (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, history_len=100, action_dim=8, pos="sin", num_layers=3), dict(batch=5, T=150, mask=-5, n_eps=8, history=30, tuf=2)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=256, num_heads=16, history_len=50, num_layers=1), dict(batch=3, T=60, mask=-5, n_eps=6)),
+    # variants the whole-sequence LDS tile set cannot hold run on the tiled path: GRU gates / identity layers at D >= 128
+    (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9, gate="gru"),
+     dict(batch=8, T=50, mask=8, n_eps=20, tuf=2)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, identity=True), dict(batch=8, T=200, mask=-5, n_eps=20)),
+    (dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, history_len=128, discrete=True, vocab_sizes=12, gate="gru", action_dim=8),
+     dict(batch=3, T=140, mask=11, n_eps=8, history=40)),
+    # (GRU + identity + discrete tokens at D = 128, L = 128 with the perturbed test weights is ill-conditioned: the fp32
+    #  oracle itself sits 9e-4 from its fp64 evaluation there, as does the HIP path -- so that combination is tested on
+    #  continuous observations at L = 50)
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, gate="gru", identity=True, pos="sin"),
+     dict(batch=4, T=200, mask=-5, n_eps=12, tuf=2)),
+    (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=100, discrete=True, vocab_sizes=22, gate="gru", num_layers=1),
+     dict(batch=2, T=120, mask=21, n_eps=5)),
 ]
 
 
