@@ -20,6 +20,7 @@ struct ReduceArgs {
     float* norm_partial;
     int32_t* step_counter;
     int batch, n_split;
+    int n_parts;              // length of norm_partial (>= gridDim.x): the tail is zeroed
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
@@ -39,6 +40,8 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_reduce_kernel(ReduceArgs a) 
     const int tid = (int)threadIdx.x;
     const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
     if (blockIdx.x == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];   // publish the step count of the previous update
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kOptThreads) a.norm_partial[i] = 0.f;
     float v[kOptVec] = {0.f, 0.f, 0.f, 0.f};
     if (p0 < net.n_trainable) {
         // every gradient element (weight / bias GEMM blocks and the per-sequence partials folded in by the
@@ -56,12 +59,14 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_reduce_kernel(ReduceArgs a) 
 struct NormArgs {
     const float* grad;
     float* norm_partial;
-    int n;
+    int n, n_parts;
 };
 __global__ __launch_bounds__(kOptThreads) void dtqn_gradnorm_kernel(NormArgs a) {
     __shared__ float red[kOptThreads / 64];
     const int tid = (int)threadIdx.x;
     const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kOptThreads) a.norm_partial[i] = 0.f;
     float ss = 0.f;
     if (p0 < a.n) {
         const float4 g = ld4(a.grad + p0);
@@ -82,7 +87,7 @@ struct AdamArgs {
     float* stats;
     float* stats_ring;
     int32_t* step_counter;
-    int n, n_norm_blocks, batch, history, tuf, ring_slots;
+    int n, n_norm_parts, batch, history, tuf, ring_slots;
     int n_stat_parts;            // batch * row_split per-workgroup statistics partials
     float lr, beta1, beta2, eps, clip, grad_scale;
 };
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     float4 m4 = mine ? ld4(a.m + p0) : z4, v4 = mine ? ld4(a.v + p0) : z4, p4 = mine ? ld4(a.theta + p0) : z4;
     // every block re-derives the global norm from the per-block partials (a few hundred floats)
     float part = 0.f;
-    for (int i = tid; i < a.n_norm_blocks; i += kOptThreads) part += a.norm_partial[i];
+    for (int i = tid; i < a.n_norm_parts; i += kOptThreads) part += a.norm_partial[i];
     const float total = block_sum(part, red, tid);
     const float norm = sqrtf(total) * a.grad_scale;
     const bool finite = isfinite(norm);
@@ -193,11 +198,12 @@ static int opt_blocks(int n) { return (n + kOptBlockElems - 1) / kOptBlockElems;
 extern "C" int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td) return DTQN_ERR_ARG;
     if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
+    if (dtqn_td_wgrad_is_direct(net, td->batch)) return DTQN_OK;      // the direct weight-gradient kernel wrote grad itself
     ReduceArgs a;
     a.net = *net;
     a.gsplit = td->gsplit; a.small = td->small; a.grd = td->grd; a.grad = td->grad;
     a.norm_partial = td->norm_partial; a.step_counter = td->step_counter;
-    a.batch = td->batch; a.n_split = td->n_split;
+    a.batch = td->batch; a.n_split = td->n_split; a.n_parts = dtqn_td_norm_partials(net);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_reduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
@@ -207,7 +213,7 @@ extern "C" int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stre
     if (!net || !td) return DTQN_ERR_ARG;
     if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
     NormArgs a;
-    a.grad = td->grad; a.norm_partial = td->norm_partial; a.n = net->n_trainable;
+    a.grad = td->grad; a.norm_partial = td->norm_partial; a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_gradnorm_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
@@ -221,7 +227,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.norm_partial = td->norm_partial; a.stats_partial = td->stats_partial; a.stats = td->stats;
     a.step_counter = td->step_counter;
     a.stats_ring = td->stats_ring; a.ring_slots = td->stats_ring_slots > 0 ? td->stats_ring_slots : 1;
-    a.n = net->n_trainable; a.n_norm_blocks = td->n_norm_blocks; a.batch = td->batch; a.history = td->history;
+    a.n = net->n_trainable; a.n_norm_parts = dtqn_td_norm_partials(net); a.batch = td->batch; a.history = td->history;
     a.n_stat_parts = td->batch * (td->row_split > 1 ? td->row_split : 1);
     a.tuf = td->target_update_frequency;
     a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;

@@ -224,13 +224,298 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     }
 }
 
+// ---- small batches: one launch, no split-K -----------------------------------------------------------------------------
+// With B * LP <= kDirectMaxTokens the token axis is short enough for ONE workgroup to contract it all, so the splits and
+// the dtqn_td_reduce launch disappear: the output is cut into many SMALL tiles instead (16 dY columns x 32 X columns, a
+// few hundred workgroups), each written straight into `grad` together with its sum of squares for the global norm.
+// Small tiles re-read the records once per tile; to keep those re-reads inside one L2, consecutive tiles (= the tiles of
+// one weight matrix, which share their dY / X columns) are dealt to the SAME XCD: workgroup b runs on XCD b % 8
+// (round-robin dispatch) and takes tile (b % 8) * per_xcd + b / 8 (direct_plan).  Inside a matrix the tiles run along its
+// SHORTER tile axis first, so that a run of consecutive tiles touches as few distinct column blocks as possible.
+constexpr int kDirectWaves = 8;
+constexpr int kDirectThreads = kDirectWaves * 64;
+constexpr int kDirectMaxTokens = 4096;
+constexpr int kDTN = 16, kDTK = 32;         // tile: dY columns x X columns
+constexpr int kDGroup = 8;                  // 16-token units in flight per wave and buffer
+constexpr int kDSmall = 128;                // per-sequence-partial elements per workgroup
+
+struct WgradDirectArgs {
+    DtqnNet net;
+    DtqnWJob jobs[kMaxWJobs];
+    int dtile0[kMaxWJobs];  // first direct tile of each job
+    const float* act;
+    const float* grd;
+    float* grad;            // [n_trainable]
+    const float* small;
+    float* norm_partial;    // [n_parts]
+    int32_t* step_counter;
+    int batch, n_jobs, n_small, row_split;
+    int n_tiles, n_parts;
+    int slots;              // tile workgroups per XCD: workgroup b (on XCD b % 8) takes tile xcd_tile0[b % 8] + b / 8
+    int xcd_tile0[8], xcd_ntiles[8];
+    int xcd_map;            // 0: tile = workgroup index (A/B timing)
+};
+
+__global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(WgradDirectArgs a) {
+    const Thr t = make_thr();
+    const DtqnNet& net = a.net;
+    const int LP = net.lp, tid = t.tid;
+    float* red = reinterpret_cast<float*>(dtqn_smem);                     // [8] block reduction of the sum of squares
+    float* slabs = red + 8;
+    float ss = 0.f;                                                       // this thread's share of sum(g^2)
+    const int b = (int)blockIdx.x, tile_blocks = a.slots * 8;
+    if (b == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];        // publish the step count of the previous update
+    if (b == 0)                                                           // partials nobody writes this time
+        for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kDirectThreads) a.norm_partial[i] = 0.f;
+    const int tile = b >= tile_blocks ? a.n_tiles : !a.xcd_map ? b : b / 8 < a.xcd_ntiles[b % 8] ? a.xcd_tile0[b % 8] + b / 8 : a.n_tiles;
+    if (b >= tile_blocks) {
+        // per-sequence partials of the backward kernel (LayerNorm affine, embedding tables, learned positions = dL/dx0)
+        const int D = net.d_model;
+        const int n_ln = net.num_layers * 4 * D;
+        const int n_tab = net.discrete ? net.vocab * net.embed_per_obs : 0;
+        const int n_act = net.action_dim > 0 ? net.num_actions * net.action_dim : 0;
+        // kDSmall elements per workgroup, two per lane; wave p sums records p, p + 8, ... (independent loads in flight),
+        // then the eight partial sums are added in wave order
+        const int sb = b - tile_blocks;
+        int dst[2] = {-1, -1};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = sb * kDSmall + h * 64 + t.lane;
+            float v = 0.f;
+            if (e < a.n_small) {
+                int src;
+                const float* base = a.small;
+                size_t stride = (size_t)net.sp_stride;
+                if (e < n_ln) {
+                    const int l = e / (4 * D);
+                    dst[h] = net.off_layer0 + l * net.layer_stride + (e - l * 4 * D);
+                    src = net.so_ln + e;
+                } else if (e < n_ln + n_tab) {
+                    dst[h] = net.off_obs_tab + (e - n_ln);
+                    src = net.so_tab + (e - n_ln);
+                } else if (e < n_ln + n_tab + n_act) {
+                    dst[h] = net.off_act_emb + (e - n_ln - n_tab);
+                    src = net.so_act + (e - n_ln - n_tab);
+                } else {
+                    dst[h] = net.off_pos + (e - n_ln - n_tab - n_act);
+                    src = net.go_dx0 + (e - n_ln - n_tab - n_act);
+                    base = a.grd;
+                    stride = (size_t)net.grd_stride;
+                }
+                const int cnt = a.batch * (base == a.small ? a.row_split : 1);
+#pragma unroll 8
+                for (int q = t.wave; q < cnt; q += kDirectWaves) v += base[(size_t)q * stride + src];
+            }
+            slabs[(h * kDirectWaves + t.wave) * 64 + t.lane] = v;
+        }
+        __syncthreads();
+        if (t.wave < 2 && dst[t.wave] >= 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < kDirectWaves; ++w) tot += slabs[(t.wave * kDirectWaves + w) * 64 + t.lane];
+            a.grad[dst[t.wave]] = tot;
+            ss = tot * tot;
+        }
+    } else if (tile < a.n_tiles) {
+        int j = 0;
+        for (int k = 1; k < a.n_jobs; ++k)
+            if (a.dtile0[k] <= tile) j = k;
+        const DtqnWJob& job = a.jobs[j];
+        const int tiles_k = (job.K + kDTK - 1) / kDTK;
+        const int local = tile - a.dtile0[j];
+        const int tiles_n = (job.N + kDTN - 1) / kDTN;
+        const bool k_major = tiles_k > tiles_n;                            // e.g. ffn.2: 4 x 8 tiles, walk the 4 first
+        const int bn = k_major ? local % tiles_n : local / tiles_k, bk = k_major ? local / tiles_n : local - bn * tiles_k;
+        const int nbase = bn * kDTN, kbase = bk * kDTK;
+        const float* xbase = (job.x_in_act ? a.act : a.grd) + job.x_off;
+        const size_t xstride = job.x_in_act ? (size_t)net.act_stride : (size_t)net.grd_stride;
+        const float* ybase = a.grd + job.dy_off;
+        const size_t ystride = (size_t)net.grd_stride;
+        // MFMA 16x16x4: A[n = i][token = kq] = dY[4s + kq][nbase + i];  B[token = kq][k-tile c, column i] = X[4s + kq][kbase + 2i + c]
+        const int ycol = nbase + t.i, xcol = kbase + 2 * t.i;
+        const bool yok = ycol < job.ldy, xok = xcol < job.ldx;            // ldx is a multiple of 4: the whole float2 is in range
+        f32x4 acc[2] = {zero4(), zero4()};
+        float bsum = 0.f;
+        const int nsub = LP / 16;                                         // 16-token units per sequence
+        const int per_layer = a.batch * nsub, units = per_layer * job.n_layers;
+        const int mine = (units - t.wave + kDirectWaves - 1) / kDirectWaves;   // units w, w + 8, ... of this wave
+        float av[2][kDGroup][4];
+        float2 bv[2][kDGroup][4];
+        auto group_load = [&](int g, float (&a4)[kDGroup][4], float2 (&b4)[kDGroup][4]) {
+#pragma unroll
+            for (int q = 0; q < kDGroup; ++q) {
+                const int m = g * kDGroup + q;
+                const bool live = m < mine;
+                const int u = live ? m * kDirectWaves + t.wave : 0;
+                const int lyr = u / per_layer, ul = u - lyr * per_layer;
+                const int sq = ul / nsub, sub = ul - sq * nsub;
+                const float* yp = ybase + (size_t)sq * ystride + (size_t)lyr * job.dy_lstride + (size_t)(sub * 16 + t.kq) * job.ldy + ycol;
+                const float* xp = xbase + (size_t)sq * xstride + (size_t)lyr * job.x_lstride + (size_t)(sub * 16 + t.kq) * job.ldx + xcol;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a4[q][k] = (live && yok) ? yp[(size_t)4 * k * job.ldy] : 0.f;
+                    b4[q][k] = (live && xok) ? *reinterpret_cast<const float2*>(xp + (size_t)4 * k * job.ldx) : make_float2(0.f, 0.f);
+                }
+            }
+        };
+        auto group_mma = [&](const float (&a4)[kDGroup][4], const float2 (&b4)[kDGroup][4]) {
+#pragma unroll
+            for (int q = 0; q < kDGroup; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    bsum += a4[q][k];
+                    acc[0] = mfma16(a4[q][k], b4[q][k].x, acc[0]);
+                    acc[1] = mfma16(a4[q][k], b4[q][k].y, acc[1]);
+                }
+        };
+        const int ngroups = (mine + kDGroup - 1) / kDGroup;
+        if (ngroups > 0) group_load(0, av[0], bv[0]);
+        for (int g = 0; g < ngroups; g += 2) {                            // buffers alternate without dynamic indexing
+            if (g + 1 < ngroups) group_load(g + 1, av[1], bv[1]);
+            group_mma(av[0], bv[0]);
+            if (g + 1 < ngroups) {
+                if (g + 2 < ngroups) group_load(g + 2, av[0], bv[0]);
+                group_mma(av[1], bv[1]);
+            }
+        }
+        // bias: sum over the 4 token phases of this lane's dY column
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        // cross-wave sum through LDS, fixed order: slab[n][k] (+ a bias row) per wave
+        constexpr int SLD = kDTK + 4;
+        float* slab = slabs + (size_t)t.wave * (kDTN + 1) * SLD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float2*>(slab + (t.kq * 4 + r) * SLD + 2 * t.i) = make_float2(acc[0][r], acc[1][r]);
+        if (t.kq == 0) slab[kDTN * SLD + t.i] = bsum;
+        __syncthreads();
+        if (tid < kDTN * (kDTK / 4)) {
+            const int nl = tid / (kDTK / 4), k4 = (tid % (kDTK / 4)) * 4;
+            const int n = nbase + nl, k = kbase + k4;
+            if (n < job.N && k < job.K) {
+                float4 v = ld4(slabs + nl * SLD + k4);
+#pragma unroll
+                for (int wv = 1; wv < kDirectWaves; ++wv) {
+                    const float4 x = ld4(slabs + (size_t)wv * (kDTN + 1) * SLD + nl * SLD + k4);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                }
+                float* op = a.grad + job.w_off + (size_t)n * job.K + k;
+                if (k + 3 < job.K && (job.K & 3) == 0) {
+                    st4(op, v);
+                    ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int c = 0; c < 4; ++c)
+                        if (k + c < job.K) { op[c] = vv[c]; ss += vv[c] * vv[c]; }
+                }
+            }
+        } else if (tid >= 256 && tid < 256 + kDTN && job.b_off >= 0 && bk == 0) {
+            const int nl = tid - 256, n = nbase + nl;
+            if (n < job.N) {
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < kDirectWaves; ++wv) v += slabs[(size_t)wv * (kDTN + 1) * SLD + kDTN * SLD + nl];
+                a.grad[job.b_off + n] = v;
+                ss = v * v;
+            }
+        }
+    }
+    // sum of squares of everything this workgroup wrote (fixed order: lanes, then waves)
+    ss = wave_sum(ss);
+    __syncthreads();
+    if (t.lane == 0) red[t.wave] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < kDirectWaves; ++w) tot += red[w];
+        a.norm_partial[b] = tot;
+    }
+}
+
+// direct tiles of a net: per job ceil(N / 16) * ceil(K / 32)
+static int direct_tiles(const DtqnNet* net, const DtqnWJob* jobs, int* dtile0) {
+    int tiles = 0;
+    for (int j = 0; j < net->n_wjobs; ++j) {
+        if (dtile0) dtile0[j] = tiles;
+        tiles += ((jobs[j].N + kDTN - 1) / kDTN) * ((jobs[j].K + kDTK - 1) / kDTK);
+    }
+    return tiles;
+}
+static int small_elems(const DtqnNet* net) {
+    return net->num_layers * 4 * net->d_model + (net->discrete ? net->vocab * net->embed_per_obs : 0) +
+           (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
+           (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);
+}
+struct DirectPlan {
+    int dtile0[kMaxWJobs];
+    int n_tiles, slots, grid;
+    int xcd_tile0[8], xcd_ntiles[8];
+};
+// Which tiles each XCD takes: eight equal runs of consecutive tiles.  (Measured at cfg 1, batch 32: tile = workgroup
+// index, i.e. every XCD sees every matrix, 116.7 us / update; equal runs 113.3; whole matrices per XCD, which leaves
+// XCDs with 8 - 32 tiles, 116.4.)  DTQN_WGRAD_XCD=0 gives the first for A/B timing.
+static DirectPlan direct_plan(const DtqnNet* net, const DtqnWJob* jobs) {
+    DirectPlan p;
+    p.n_tiles = direct_tiles(net, jobs, p.dtile0);
+    const int per = (p.n_tiles + 7) / 8;
+    for (int x = 0; x < 8; ++x) {
+        p.xcd_tile0[x] = x * per < p.n_tiles ? x * per : p.n_tiles;
+        p.xcd_ntiles[x] = p.n_tiles - p.xcd_tile0[x] < per ? p.n_tiles - p.xcd_tile0[x] : per;
+    }
+    p.slots = per;
+    p.grid = p.slots * 8 + (small_elems(net) + kDSmall - 1) / kDSmall;
+    return p;
+}
+
 }  // namespace dtqn
 
 using namespace dtqn;
 
+// One launch, no splits, no dtqn_td_reduce: when the whole batch is at most kDirectMaxTokens tokens (DTQN_WGRAD_DIRECT=0/1
+// overrides, for A/B timing).
+extern "C" int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch) {
+    if (!net || batch < 1 || net->n_wjobs > kMaxWJobs) return 0;
+    const char* e = getenv("DTQN_WGRAD_DIRECT");
+    if (e != nullptr) return atoi(e) != 0 ? 1 : 0;
+    return (long long)batch * net->lp <= kDirectMaxTokens ? 1 : 0;
+}
+
+// Length of DtqnTd.norm_partial: the sum-of-squares partials of whichever kernel assembles `grad` (dtqn_td_reduce /
+// dtqn_td_gradnorm: one per Adam block; the direct weight-gradient kernel: one per workgroup).
+extern "C" int dtqn_td_norm_partials(const DtqnNet* net) {
+    if (!net || net->n_wjobs > kMaxWJobs) return 0;
+    DtqnWJob jobs[kMaxWJobs];
+    if (dtqn_net_wjobs(net, jobs) != DTQN_OK) return 0;
+    const int opt = (net->n_trainable + 1023) / 1024, dir = direct_plan(net, jobs).grid;
+    return opt > dir ? opt : dir;
+}
+
+static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream) {
+    WgradDirectArgs a;
+    a.net = *net;
+    if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
+    const DirectPlan plan = direct_plan(net, a.jobs);
+    a.n_tiles = plan.n_tiles; a.slots = plan.slots;
+    for (int j = 0; j < net->n_wjobs; ++j) a.dtile0[j] = plan.dtile0[j];
+    for (int x = 0; x < 8; ++x) { a.xcd_tile0[x] = plan.xcd_tile0[x]; a.xcd_ntiles[x] = plan.xcd_ntiles[x]; }
+    a.act = td->act; a.grd = td->grd; a.grad = td->grad; a.small = td->small;
+    a.norm_partial = td->norm_partial; a.step_counter = td->step_counter;
+    a.batch = td->batch; a.n_jobs = net->n_wjobs; a.n_small = small_elems(net);
+    a.row_split = td->row_split > 1 ? td->row_split : 1;
+    a.n_parts = dtqn_td_norm_partials(net);
+    const char* xm = getenv("DTQN_WGRAD_XCD");
+    a.xcd_map = xm != nullptr ? atoi(xm) : 1;
+    const int grid = plan.grid;
+    const size_t lds = (8 + (size_t)kDirectWaves * (kDTN + 1) * (kDTK + 4)) * sizeof(float);
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    hipLaunchKernelGGL(dtqn_wgrad_direct_kernel, dim3(grid), dim3(kDirectThreads), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
 extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td || td->batch < 1 || td->n_split < 1) return DTQN_ERR_ARG;
     if (net->n_wjobs > kMaxWJobs) return DTQN_ERR_CONFIG;
+    if (dtqn_td_wgrad_is_direct(net, td->batch)) return wgrad_direct(net, td, (hipStream_t)stream);
     WgradArgs a;
     a.net = *net;
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;

@@ -101,7 +101,7 @@ class TdEngine:
         self.small = torch.zeros(Bn * RS * net.sp_stride, **f32)
         self.q3 = torch.zeros(3 * Bn * net.lp * net.ap, **f32)
         self.gsplit = torch.zeros(self.n_split * nt, **f32)
-        self.norm_partial = torch.zeros(self.n_norm_blocks, **f32)
+        self.norm_partial = torch.zeros(max(self.n_norm_blocks, int(self.lib.dtqn_td_norm_partials(ctypes.byref(net)))), **f32)
         self.stats_partial = torch.zeros(Bn * RS * 8, **f32)
         self.xch = torch.zeros(max(1, self.lib.dtqn_td_xch_floats(ctypes.byref(net), Bn)), **f32)
         self.xflags = torch.zeros(max(1, self.lib.dtqn_td_xch_flags(ctypes.byref(net), Bn)), dtype=torch.int32, device=dev)

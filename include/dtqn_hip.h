@@ -219,7 +219,7 @@ typedef struct DtqnTd {
     float* small;             /* [B * row_split][sp_stride] */
     float* q3;                /* [3][B][LP][AP]: Q_pol(o), Q_pol(o'), Q_tgt(o') */
     float* gsplit;            /* [n_split][n_trainable] split-K partials of the weight gradients */
-    float* norm_partial;      /* [n_norm_blocks] per-block sum of squares of grad */
+    float* norm_partial;      /* [dtqn_td_norm_partials()] per-workgroup sums of squares of grad */
     float* stats_partial;     /* [B * row_split][8] */
     float* stats;             /* [12]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, step, target-synced, non-finite flag */
     float* stats_ring;        /* optional [stats_ring_slots][12] in PINNED HOST memory (device-visible): every call of
@@ -288,11 +288,16 @@ int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, 
 /* Double-DQN target, MSE, dL/dQ (dtqn.py:219-243) and the data-gradient chain of loss.backward()
  * (dtqn.py:256).  Writes the grd / small records and stats_partial. */
 int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
-/* Weight gradients: token-contraction GEMMs over act x grd into gsplit. */
+/* Weight gradients (the parameter half of loss.backward(), dtqn.py:256): token-contraction GEMMs over act x grd.
+ * Large batches: split over the batch into gsplit, summed by dtqn_td_reduce.  Small batches
+ * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
 int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
+int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch);
 /* Sums gsplit / small partials into grad (mean-loss scaling is already in dL/dQ), writes
  * norm_partial.  After this call `grad` is ready for a data-parallel all-reduce. */
 int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* Number of floats DtqnTd.norm_partial must hold (>= n_norm_blocks). */
+int dtqn_td_norm_partials(const DtqnNet* net);
 /* Recomputes norm_partial from `grad` (used after an all-reduce changed it). */
 int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stream);
 /* clip_grad_norm_(1.0) + Adam + step counters + hard target sync every tuf steps

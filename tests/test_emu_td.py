@@ -37,6 +37,22 @@ def test_td_update_small_variants(emu, kw, run):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
 
 
+@pytest.mark.parametrize("kw,run", [CASES[1], CASES[2], CASES[6]])
+def test_td_update_split_weight_gradients(emu, kw, run, monkeypatch):
+    """Small batches take the one-launch weight-gradient kernel (16 x 32 tiles straight into grad); this forces the
+    large-batch path (64 x 64 tiles per batch split + dtqn_td_reduce) on the same cases."""
+    import ctypes
+    monkeypatch.setenv("DTQN_WGRAD_DIRECT", "0")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=9, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), run["batch"]) == 0
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    monkeypatch.delenv("DTQN_WGRAD_DIRECT")
+    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), run["batch"]) == 1
+    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 4096 // net.lp + 1) == 0
+
+
 def test_td_update_cfg1_size(emu):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=4, T=200, n_eps=8, mask=-5)

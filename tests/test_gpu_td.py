@@ -64,6 +64,27 @@ def test_td_update_vs_oracle(lib, kw, run):
     assert int(eng.xflags.sum()) == 0          # latency mode: every hand-over flag was lowered again
 
 
+@pytest.mark.parametrize("kw,run", [CASES[2], CASES[6], CASES[9], CASES[13]])
+def test_td_update_split_weight_gradients(lib, kw, run, monkeypatch):
+    """The large-batch weight-gradient path (64 x 64 tiles per batch split + dtqn_td_reduce) forced on small batches,
+    which otherwise take the one-launch kernel; and a batch large enough to take it by itself."""
+    monkeypatch.setenv("DTQN_WGRAD_DIRECT", "0")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9),
+                                               mask=run["mask"], history=run.get("history"), tuf=run.get("tuf", 10_000),
+                                               device="cuda", test_lib=False)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+def test_td_update_batch_256(lib):
+    """BASELINE config 2 (batch 256: one workgroup per sequence, split weight gradients) against the oracle."""
+    import ctypes
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=3, batch=256, T=200, n_eps=300, mask=-5, device="cuda", test_lib=False)
+    assert lib.dtqn_td_wgrad_is_direct(ctypes.byref(net), 256) == 0 and eng.row_split == 1
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+
+
 def test_latency_mode_is_on_for_the_metric_config(lib):
     """BASELINE config 1 (batch 32, 64-row tile): four backward / two forward workgroups per sequence; batch 256: one."""
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
