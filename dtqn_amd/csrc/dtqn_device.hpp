@@ -73,6 +73,9 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 // all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
 // for global stores)
 #define DTQN_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// instruction-scheduling fence: keeps a block of prefetch loads ahead of the arithmetic that follows it (the machine
+// scheduler otherwise sinks loads next to their uses to save registers, which serialises their latencies)
+#define DTQN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // 16-byte write-through (sc1) stores / L1-bypassing (sc1) loads through a buffer descriptor: a dword sc1 store is one
 // fabric write of its own and costs ~6x a 16-byte one per byte (MI355X_MICROARCH.md, inter-workgroup visibility)
 typedef unsigned dtqn_u32x4 __attribute__((ext_vector_type(4)));

@@ -341,42 +341,71 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
         const int mine = (units - t.wave + kDirectWaves - 1) / kDirectWaves;   // units w, w + 8, ... of this wave
         float av[2][kDGroup][4];
         float2 bv[2][kDGroup][4];
-        auto group_load = [&](int g, float (&a4)[kDGroup][4], float2 (&b4)[kDGroup][4]) {
+        // every load is issued unconditionally (out-of-range columns / units read a valid stand-in address and are zeroed
+        // afterwards): a load under a branch would hide the number of outstanding loads from the compiler and turn
+        // every wait into "wait for all of them"
+        const int ycol_c = yok ? ycol : 0, xcol_c = xok ? xcol : 0;
+        // units w, w + 8, ... of this wave, walked incrementally as (layer, sequence, 16-token block): no divisions in
+        // front of the loads; all of it is wave-uniform (scalar registers)
+        const int wv = __builtin_amdgcn_readfirstlane(t.wave);
+        int u_lyr = 0, u_sq = wv / nsub, u_sub = wv - u_sq * nsub, u_m = 0;
+        while (u_sq >= a.batch) { u_sq -= a.batch; ++u_lyr; }
+        const int inc_sq = kDirectWaves / nsub, inc_sub = kDirectWaves - inc_sq * nsub;
+        const float* ylane = ybase + (size_t)t.kq * job.ldy + ycol_c;
+        const float* xlane = xbase + (size_t)t.kq * job.ldx + xcol_c;
+        auto group_load = [&](float (&a4)[kDGroup][4], float2 (&b4)[kDGroup][4]) {
 #pragma unroll
             for (int q = 0; q < kDGroup; ++q) {
-                const int m = g * kDGroup + q;
-                const bool live = m < mine;
-                const int u = live ? m * kDirectWaves + t.wave : 0;
-                const int lyr = u / per_layer, ul = u - lyr * per_layer;
-                const int sq = ul / nsub, sub = ul - sq * nsub;
-                const float* yp = ybase + (size_t)sq * ystride + (size_t)lyr * job.dy_lstride + (size_t)(sub * 16 + t.kq) * job.ldy + ycol;
-                const float* xp = xbase + (size_t)sq * xstride + (size_t)lyr * job.x_lstride + (size_t)(sub * 16 + t.kq) * job.ldx + xcol;
+                const bool live = u_m < mine;                             // past the end: re-read unit (0, 0, 0), zeroed in group_mma
+                const int lyr = live ? u_lyr : 0, sq = live ? u_sq : 0, sub = live ? u_sub : 0;
+                const float* yp = ylane + (size_t)sq * ystride + (size_t)lyr * job.dy_lstride + (size_t)(sub * 16) * job.ldy;
+                const float* xp = xlane + (size_t)sq * xstride + (size_t)lyr * job.x_lstride + (size_t)(sub * 16) * job.ldx;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    a4[q][k] = (live && yok) ? yp[(size_t)4 * k * job.ldy] : 0.f;
-                    b4[q][k] = (live && xok) ? *reinterpret_cast<const float2*>(xp + (size_t)4 * k * job.ldx) : make_float2(0.f, 0.f);
+                    a4[q][k] = yp[(size_t)4 * k * job.ldy];
+                    b4[q][k] = *reinterpret_cast<const float2*>(xp + (size_t)4 * k * job.ldx);
                 }
+                ++u_m;
+                u_sub += inc_sub; u_sq += inc_sq;
+                if (u_sub >= nsub) { u_sub -= nsub; ++u_sq; }
+                while (u_sq >= a.batch) { u_sq -= a.batch; ++u_lyr; }
             }
         };
-        auto group_mma = [&](const float (&a4)[kDGroup][4], const float2 (&b4)[kDGroup][4]) {
+        auto group_mma = [&](int g, const float (&a4)[kDGroup][4], const float2 (&b4)[kDGroup][4]) {
 #pragma unroll
-            for (int q = 0; q < kDGroup; ++q)
+            for (int q = 0; q < kDGroup; ++q) {
+                const float keep = (yok && g * kDGroup + q < mine) ? 1.f : 0.f;     // zero A: the product and the bias sum vanish
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    bsum += a4[q][k];
-                    acc[0] = mfma16(a4[q][k], b4[q][k].x, acc[0]);
-                    acc[1] = mfma16(a4[q][k], b4[q][k].y, acc[1]);
+                    const float av_ = keep != 0.f ? a4[q][k] : 0.f;
+                    bsum += av_;
+                    acc[0] = mfma16(av_, b4[q][k].x, acc[0]);
+                    acc[1] = mfma16(av_, b4[q][k].y, acc[1]);
                 }
+            }
         };
         const int ngroups = (mine + kDGroup - 1) / kDGroup;
-        if (ngroups > 0) group_load(0, av[0], bv[0]);
-        for (int g = 0; g < ngroups; g += 2) {                            // buffers alternate without dynamic indexing
-            if (g + 1 < ngroups) group_load(g + 1, av[1], bv[1]);
-            group_mma(av[0], bv[0]);
-            if (g + 1 < ngroups) {
-                if (g + 2 < ngroups) group_load(g + 2, av[0], bv[0]);
-                group_mma(av[1], bv[1]);
-            }
+        if (ngroups > 0) group_load(av[0], bv[0]);
+        DTQN_SCHED_FENCE();
+        int g = 0;
+        for (; g + 2 < ngroups; g += 2) {                                 // buffers alternate without dynamic indexing
+            group_load(av[1], bv[1]);
+            DTQN_SCHED_FENCE();
+            group_mma(g, av[0], bv[0]);
+            DTQN_SCHED_FENCE();
+            group_load(av[0], bv[0]);
+            DTQN_SCHED_FENCE();
+            group_mma(g + 1, av[1], bv[1]);
+            DTQN_SCHED_FENCE();
+        }
+        if (g + 1 < ngroups) {                                            // last pair (cfg 1: the only one -- all 16 units in flight at once)
+            group_load(av[1], bv[1]);
+            DTQN_SCHED_FENCE();
+            group_mma(g, av[0], bv[0]);
+            DTQN_SCHED_FENCE();
+            group_mma(g + 1, av[1], bv[1]);
+        } else if (g < ngroups) {
+            group_mma(g, av[0], bv[0]);
         }
         // bias: sum over the 4 token phases of this lane's dY column
         bsum += __shfl_xor(bsum, 16);

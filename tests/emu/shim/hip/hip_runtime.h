@@ -27,6 +27,7 @@ template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomi
 #define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
 #define DTQN_SPIN_PAUSE() ((void)0)
 #define DTQN_WAIT_VMEM() ((void)0)
+#define DTQN_SCHED_FENCE() ((void)0)
 
 // ---- qualifiers -------------------------------------------------------------
 #define __global__
