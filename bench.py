@@ -100,8 +100,8 @@ def fill_synthetic_replay(agent, seed: int, c) -> None:
 
 
 def time_kernels(agent, iters: int = 50) -> dict:
-    """Average duration of each launch of one update (five at large batches; three at small ones, where one kernel
-    does weight gradients + clip + Adam), HIP events on the launch stream."""
+    """Average duration of each launch of one update (five; four when the one-launch weight-gradient kernel of small
+    batches makes dtqn_td_reduce a no-op), HIP events on the launch stream."""
     eng, rep = agent.engine, agent.replay_buffer.dev
     lib = eng.lib
     n, r, t = ctypes.byref(eng.net), ctypes.byref(rep.view), ctypes.byref(eng.td)
@@ -112,11 +112,7 @@ def time_kernels(agent, iters: int = 50) -> dict:
               "dtqn_wgrad_kernel": lambda: lib.dtqn_td_wgrad(n, t, s),
               "dtqn_reduce_kernel": lambda: lib.dtqn_td_reduce(n, t, s),
               "dtqn_clip_adam_kernel": lambda: lib.dtqn_td_clip_adam(n, t, s)}
-    if lib.dtqn_td_update_is_fused(n, eng.batch):
-        # weight gradients + clip + Adam + statistics are ONE launch (grid-wide norm exchange inside the kernel)
-        stages = {"dtqn_forward_kernel": stages["dtqn_forward_kernel"], "dtqn_backward_kernel": stages["dtqn_backward_kernel"],
-                  "dtqn_wgrad_direct_kernel<fused adam>": lambda: lib.dtqn_td_wgrad_adam(n, t, s)}
-    elif lib.dtqn_td_wgrad_is_direct(n, eng.batch):
+    if lib.dtqn_td_wgrad_is_direct(n, eng.batch):
         stages["dtqn_wgrad_direct_kernel"] = stages.pop("dtqn_wgrad_kernel")
         del stages["dtqn_reduce_kernel"]
         stages["dtqn_clip_adam_kernel"] = stages.pop("dtqn_clip_adam_kernel")      # keep launch order

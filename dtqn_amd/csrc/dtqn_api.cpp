@@ -44,12 +44,11 @@ extern "C" int dtqn_td_xch_flags(const DtqnNet* net, int batch) {
     return 3 * batch * net->num_layers * 4;                   // backward: one per 64-column head group (<= 4)
 }
 
-// DtqnAgent.train() after sampling (dtqn/agents/dtqn.py:215-269) on one GPU: three launches at the metric configuration, five at large batches.
+// DtqnAgent.train() after sampling (dtqn/agents/dtqn.py:215-269) on one GPU: five launches.
 extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     int rc;
     if ((rc = dtqn_td_forward(net, rp, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_backward(net, rp, td, stream)) != DTQN_OK) return rc;
-    if (dtqn_td_update_is_fused(net, td->batch)) return dtqn_td_wgrad_adam(net, td, stream);     // three launches
     if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;
     return dtqn_td_clip_adam(net, td, stream);

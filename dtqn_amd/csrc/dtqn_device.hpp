@@ -69,7 +69,6 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 #ifndef DTQN_AGENT_LOAD
 #define DTQN_AGENT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_AGENT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define DTQN_AGENT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
 // for global stores)

@@ -4,7 +4,6 @@
 // DqnAgent.target_update (dtqn/agents/dtqn.py:257-269, dtqn/agents/dqn.py:64,208-210), plus the seven
 // `.item()` statistics of dtqn.py:245-253,263 (reduced on the device, read back asynchronously).
 #include "dtqn_device.hpp"
-#include "dtqn_adam_device.hpp"
 
 namespace dtqn {
 
@@ -77,9 +76,24 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_gradnorm_kernel(NormArgs a) 
     if (tid == 0) a.norm_partial[blockIdx.x] = ss;
 }
 
+struct AdamArgs {
+    float* theta;
+    float* theta_tgt;
+    const float* grad;
+    float* m;
+    float* v;
+    const float* norm_partial;
+    const float* stats_partial;
+    float* stats;
+    float* stats_ring;
+    int32_t* step_counter;
+    int n, n_norm_parts, batch, history, tuf, ring_slots;
+    int n_stat_parts;            // batch * row_split per-workgroup statistics partials
+    float lr, beta1, beta2, eps, clip, grad_scale;
+};
+
 __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a) {
     __shared__ float red[kOptThreads / 64];
-    __shared__ float mm4[4 * kOptThreads / 64];
     __shared__ double pw[2];
     const int tid = (int)threadIdx.x;
     // this thread's gradient / moments / parameters go in flight first: they do not depend on the norm, and the norm
@@ -93,19 +107,76 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     float part = 0.f;
     for (int i = tid; i < a.n_norm_parts; i += kOptThreads) part += a.norm_partial[i];
     const float total = block_sum(part, red, tid);
-    const AdamCoef c = adam_coef(a, total, a.step_counter[0] + 1, pw, tid);   // 1-based index of this optimizer step
-    if (c.finite && mine) {
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float norm = sqrtf(total) * a.grad_scale;
+    const bool finite = isfinite(norm);
+    const int k = a.step_counter[0] + 1;                      // 1-based index of this optimizer step
+    if (tid == 0) {
+        pw[0] = 1.0 - pow((double)a.beta1, (double)k);
+        pw[1] = 1.0 - pow((double)a.beta2, (double)k);
+    }
+    __syncthreads();
+    const float bc1 = (float)pw[0], bc2_sqrt = (float)sqrt(pw[1]);
+    const float coef = fminf(1.0f, a.clip / (norm + 1e-6f)) * a.grad_scale;
+    const float step_size = a.lr / bc1;
+    const bool sync_target = finite && a.tuf > 0 && (k % a.tuf) == 0;
+    if (finite && mine) {
+        const float g[4] = {g4.x * coef, g4.y * coef, g4.z * coef, g4.w * coef};
         float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) adam_elem(a, c, g[q], mm[q], vv[q], pp[q]);
+        for (int c = 0; c < 4; ++c) {
+            mm[c] = mm[c] + (g[c] - mm[c]) * (1.0f - a.beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
+            vv[c] = vv[c] * a.beta2 + (1.0f - a.beta2) * g[c] * g[c];           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+            const float denom = sqrtf(vv[c]) / bc2_sqrt + a.eps;
+            pp[c] = pp[c] - step_size * (mm[c] / denom);
+        }
         st4(a.m + p0, make_float4(mm[0], mm[1], mm[2], mm[3]));
         st4(a.v + p0, make_float4(vv[0], vv[1], vv[2], vv[3]));
         const float4 pn = make_float4(pp[0], pp[1], pp[2], pp[3]);
         st4(a.theta + p0, pn);
-        if (c.sync_target) st4(a.theta_tgt + p0, pn);         // hard target update every tuf steps (dqn.py:208-210)
+        if (sync_target) st4(a.theta_tgt + p0, pn);           // hard target update every tuf steps (dqn.py:208-210)
     }
-    if (blockIdx.x == 0) adam_statistics<kOptThreads>(a, c, red, mm4, tid);
+    if (blockIdx.x == 0) {
+        // statistics of dtqn.py:245-253,263, reduced over the per-sequence partials
+        float se = 0.f, sq = 0.f, sy = 0.f, mxq = -INFINITY, mnq = INFINITY, mxy = -INFINITY, mny = INFINITY;
+        for (int b = tid; b < a.n_stat_parts; b += kOptThreads) {
+            const float* sp = a.stats_partial + (size_t)b * 8;
+            se += sp[0]; sq += sp[1]; mxq = fmaxf(mxq, sp[2]); mnq = fminf(mnq, sp[3]);
+            sy += sp[4]; mxy = fmaxf(mxy, sp[5]); mny = fminf(mny, sp[6]);
+        }
+        se = block_sum(se, red, tid); sq = block_sum(sq, red, tid); sy = block_sum(sy, red, tid);
+        for (int mk = 32; mk >= 1; mk >>= 1) {
+            mxq = fmaxf(mxq, __shfl_xor(mxq, mk)); mnq = fminf(mnq, __shfl_xor(mnq, mk));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, mk)); mny = fminf(mny, __shfl_xor(mny, mk));
+        }
+        __shared__ float mm4[4][kOptThreads / 64];
+        if ((tid & 63) == 0) { mm4[0][tid >> 6] = mxq; mm4[1][tid >> 6] = mnq; mm4[2][tid >> 6] = mxy; mm4[3][tid >> 6] = mny; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kOptThreads / 64; ++w) {
+                mxq = fmaxf(mxq, mm4[0][w]); mnq = fminf(mnq, mm4[1][w]); mxy = fmaxf(mxy, mm4[2][w]); mny = fminf(mny, mm4[3][w]);
+            }
+            const float cnt = (float)a.batch * (float)a.history;
+            a.stats[0] = se / cnt;          // TD error (MSE loss)
+            a.stats[1] = norm;              // pre-clip gradient norm
+            a.stats[2] = mxq; a.stats[3] = sq / cnt; a.stats[4] = mnq;
+            a.stats[5] = mxy; a.stats[6] = sy / cnt; a.stats[7] = mny;
+            a.stats[8] = fminf(1.0f, a.clip / (norm + 1e-6f));
+            a.stats[9] = (float)k;
+            a.stats[10] = sync_target ? 1.f : 0.f;
+            a.stats[11] = finite ? 0.f : 1.f;
+            if (finite) a.step_counter[1] = k;
+            const int call = a.step_counter[2] + 1;       // every call counts, also a skipped (non-finite) one
+            a.step_counter[2] = call;
+            if (a.stats_ring != nullptr) {
+                // host-visible copy: payload first, fence, then the tag the host polls
+                float* slot = a.stats_ring + (size_t)((call - 1) % a.ring_slots) * 12;
+                for (int i = 0; i < 12; ++i)
+                    if (i != 9) slot[i] = a.stats[i];
+                __threadfence_system();
+                slot[9] = (float)call;
+            }
+        }
+    }
 }
 
 struct CopyArgs {
@@ -151,7 +222,16 @@ extern "C" int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stre
 extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td) return DTQN_ERR_ARG;
     if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
-    const AdamArgs a = adam_args(net, td, dtqn_td_norm_partials(net));
+    AdamArgs a;
+    a.theta = td->theta_pol; a.theta_tgt = td->theta_tgt; a.grad = td->grad; a.m = td->adam_m; a.v = td->adam_v;
+    a.norm_partial = td->norm_partial; a.stats_partial = td->stats_partial; a.stats = td->stats;
+    a.step_counter = td->step_counter;
+    a.stats_ring = td->stats_ring; a.ring_slots = td->stats_ring_slots > 0 ? td->stats_ring_slots : 1;
+    a.n = net->n_trainable; a.n_norm_parts = dtqn_td_norm_partials(net); a.batch = td->batch; a.history = td->history;
+    a.n_stat_parts = td->batch * (td->row_split > 1 ? td->row_split : 1);
+    a.tuf = td->target_update_frequency;
+    a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;
+    a.grad_scale = td->grad_scale;
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_clip_adam_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;

@@ -9,7 +9,6 @@
 // coalesced 16 B/lane load, 16 MFMAs per pair of loads.  The four waves take different sequences
 // and are summed through LDS; splits are summed by dtqn_td_reduce (deterministic, no atomics).
 #include "dtqn_device.hpp"
-#include "dtqn_adam_device.hpp"
 
 namespace dtqn {
 
@@ -255,17 +254,8 @@ struct WgradDirectArgs {
     int slots;              // tile workgroups per XCD: workgroup b (on XCD b % 8) takes tile xcd_tile0[b % 8] + b / 8
     int xcd_tile0[8], xcd_ntiles[8];
     int xcd_map;            // 0: tile = workgroup index (A/B timing)
-    AdamArgs adam;          // FUSED only: clip + Adam on the values each workgroup holds, after a grid-wide norm exchange
-    uint32_t* barrier;      // FUSED only: arrival count (low 16 bits) | epoch (high 16 bits)
 };
 
-// FUSED (single-GPU update, every workgroup resident at once): the kernel goes on into clip + Adam.  Each workgroup
-// keeps the gradient values it just produced in registers, publishes its sum of squares with a write-through store,
-// arrives at a grid-wide counter, and once everybody has arrived reads all partials back (fixed order: the same norm in
-// every workgroup), then updates ITS parameters / moments (prefetched before the wait) -- the dtqn_clip_adam launch and
-// its ~5 us kernel boundary disappear.  Only the few hundred partial sums cross workgroups, through sc1 atomics; the
-// gradient itself never does.  The last workgroup also reduces the statistics (dtqn.py:245-253,263).
-template <bool FUSED>
 __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(WgradDirectArgs a) {
     const Thr t = make_thr();
     const DtqnNet& net = a.net;
@@ -273,14 +263,6 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
     float* red = reinterpret_cast<float*>(dtqn_smem);                     // [8] block reduction of the sum of squares
     float* slabs = red + 8;
     float ss = 0.f;                                                       // this thread's share of sum(g^2)
-    float hv[4] = {0.f, 0.f, 0.f, 0.f};                                   // FUSED: the gradient values this thread produced,
-    int hp = 0, hn = 0;                                                   //   parameters [hp, hp + hn)
-    unsigned epoch0 = 0;
-    int k_step = 0;
-    if (FUSED) {
-        k_step = a.adam.step_counter[1] + 1;                              // 1-based index of this optimizer step
-        if (tid == 0) epoch0 = DTQN_AGENT_LOAD(a.barrier) >> 16;
-    }
     const int b = (int)blockIdx.x, tile_blocks = a.slots * 8;
     if (b == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];        // publish the step count of the previous update
     if (b == 0)                                                           // partials nobody writes this time
@@ -333,7 +315,6 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
             for (int w = 0; w < kDirectWaves; ++w) tot += slabs[(t.wave * kDirectWaves + w) * 64 + t.lane];
             a.grad[dst[t.wave]] = tot;
             ss = tot * tot;
-            hv[0] = tot; hp = dst[t.wave]; hn = 1;
         }
     } else if (tile < a.n_tiles) {
         int j = 0;
@@ -448,16 +429,13 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
                     v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                 }
                 float* op = a.grad + job.w_off + (size_t)n * job.K + k;
-                hv[0] = v.x; hv[1] = v.y; hv[2] = v.z; hv[3] = v.w;
-                hp = job.w_off + n * job.K + k;
                 if (k + 3 < job.K && (job.K & 3) == 0) {
                     st4(op, v);
                     ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                    hn = 4;
                 } else {
                     const float vv[4] = {v.x, v.y, v.z, v.w};
                     for (int c = 0; c < 4; ++c)
-                        if (k + c < job.K) { op[c] = vv[c]; ss += vv[c] * vv[c]; hn = c + 1; }
+                        if (k + c < job.K) { op[c] = vv[c]; ss += vv[c] * vv[c]; }
                 }
             }
         } else if (tid >= 256 && tid < 256 + kDTN && job.b_off >= 0 && bk == 0) {
@@ -468,7 +446,6 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
                 for (int wv = 0; wv < kDirectWaves; ++wv) v += slabs[(size_t)wv * (kDTN + 1) * SLD + kDTN * SLD + nl];
                 a.grad[job.b_off + n] = v;
                 ss = v * v;
-                hv[0] = v; hp = job.b_off + n; hn = 1;
             }
         }
     }
@@ -477,78 +454,11 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
     __syncthreads();
     if (t.lane == 0) red[t.wave] = ss;
     __syncthreads();
-    if (!FUSED) {
-        if (tid == 0) {
-            float tot = 0.f;
-            for (int w = 0; w < kDirectWaves; ++w) tot += red[w];
-            a.norm_partial[b] = tot;
-        }
-        return;
-    }
-    // ---- FUSED: clip + Adam on the held values ----
-    const AdamArgs& ad = a.adam;
-    float* mm4 = slabs + (size_t)kDirectWaves * (kDTN + 1) * (kDTK + 4);
-    double* pw = reinterpret_cast<double*>(mm4 + 4 * kDirectWaves);
-    int* tmo = reinterpret_cast<int*>(pw + 2);
-    // moments and parameters of the held elements go in flight before the wait
-    float hm[4] = {0.f, 0.f, 0.f, 0.f}, hs[4] = {0.f, 0.f, 0.f, 0.f}, hq[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = hn == 4 && (hp & 3) == 0;
-    if (vec) {
-        const float4 m4 = ld4(ad.m + hp), v4 = ld4(ad.v + hp), p4 = ld4(ad.theta + hp);
-        hm[0] = m4.x; hm[1] = m4.y; hm[2] = m4.z; hm[3] = m4.w;
-        hs[0] = v4.x; hs[1] = v4.y; hs[2] = v4.z; hs[3] = v4.w;
-        hq[0] = p4.x; hq[1] = p4.y; hq[2] = p4.z; hq[3] = p4.w;
-    } else {
-        for (int q = 0; q < hn; ++q) { hm[q] = ad.m[hp + q]; hs[q] = ad.v[hp + q]; hq[q] = ad.theta[hp + q]; }
-    }
     if (tid == 0) {
         float tot = 0.f;
         for (int w = 0; w < kDirectWaves; ++w) tot += red[w];
-        DTQN_AGENT_STORE(a.norm_partial + b, tot);
-        DTQN_WAIT_VMEM();                                                 // the partial is out before this workgroup counts as arrived
-        const unsigned nblk = gridDim.x;
-        const unsigned old = DTQN_AGENT_ADD(a.barrier, 1u);
-        int timed_out = 0;
-        if ((old & 0xffffu) == nblk - 1u) {
-            DTQN_AGENT_ADD(a.barrier, 0x10000u - nblk);                   // last one in: count back to 0, next epoch
-        } else {
-            int spins = 0;
-            while ((DTQN_AGENT_LOAD(a.barrier) >> 16) == epoch0) {
-                DTQN_SPIN_PAUSE();
-                if (++spins > (1 << 22)) { timed_out = 1; break; }       // never hang the GPU: skip the update, flag it
-            }
-        }
-        *tmo = timed_out;
+        a.norm_partial[b] = tot;
     }
-    __syncthreads();
-    const bool timed_out = *tmo != 0;
-    float part = 0.f;
-    for (int i = tid; i < (int)gridDim.x; i += kDirectThreads) part += DTQN_AGENT_LOAD(a.norm_partial + i);
-    part = wave_sum(part);
-    __syncthreads();
-    if (t.lane == 0) red[t.wave] = part;
-    __syncthreads();
-    float total = 0.f;
-    for (int w = 0; w < kDirectWaves; ++w) total += red[w];
-    if (timed_out) total = INFINITY;                                      // reported like a non-finite norm (stats[11])
-    __syncthreads();
-    const AdamCoef c = adam_coef(ad, total, k_step, pw, tid);
-    if (c.finite && hn > 0) {
-        for (int q = 0; q < hn; ++q) adam_elem(ad, c, hv[q], hm[q], hs[q], hq[q]);
-        if (vec) {
-            st4(ad.m + hp, make_float4(hm[0], hm[1], hm[2], hm[3]));
-            st4(ad.v + hp, make_float4(hs[0], hs[1], hs[2], hs[3]));
-            const float4 pn = make_float4(hq[0], hq[1], hq[2], hq[3]);
-            st4(ad.theta + hp, pn);
-            if (c.sync_target) st4(ad.theta_tgt + hp, pn);                // hard target update every tuf steps (dqn.py:208-210)
-        } else {
-            for (int q = 0; q < hn; ++q) {
-                ad.m[hp + q] = hm[q]; ad.v[hp + q] = hs[q]; ad.theta[hp + q] = hq[q];
-                if (c.sync_target) ad.theta_tgt[hp + q] = hq[q];
-            }
-        }
-    }
-    if (b == (int)gridDim.x - 1) adam_statistics<kDirectThreads>(ad, c, red, mm4, tid);
 }
 
 // direct tiles of a net: per job ceil(N / 16) * ceil(K / 32)
@@ -609,7 +519,7 @@ extern "C" int dtqn_td_norm_partials(const DtqnNet* net) {
     return opt > dir ? opt : dir;
 }
 
-static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream, bool fused) {
+static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream) {
     WgradDirectArgs a;
     a.net = *net;
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
@@ -625,40 +535,16 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
     const char* xm = getenv("DTQN_WGRAD_XCD");
     a.xcd_map = xm != nullptr ? atoi(xm) : 1;
     const int grid = plan.grid;
-    const size_t lds = (8 + (size_t)kDirectWaves * (kDTN + 1) * (kDTK + 4) + 4 * kDirectWaves + 8) * sizeof(float);
+    const size_t lds = (8 + (size_t)kDirectWaves * (kDTN + 1) * (kDTK + 4)) * sizeof(float);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    if (fused) {
-        a.adam = adam_args(net, td, grid);
-        a.barrier = reinterpret_cast<uint32_t*>(td->step_counter + 3);
-        hipLaunchKernelGGL(dtqn_wgrad_direct_kernel<true>, dim3(grid), dim3(kDirectThreads), lds, stream, a);
-    } else {
-        hipLaunchKernelGGL(dtqn_wgrad_direct_kernel<false>, dim3(grid), dim3(kDirectThreads), lds, stream, a);
-    }
+    hipLaunchKernelGGL(dtqn_wgrad_direct_kernel, dim3(grid), dim3(kDirectThreads), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
-}
-
-// Weight gradients + clip + Adam + statistics in one launch: single-GPU updates whose direct weight-gradient grid is
-// small enough for every workgroup to be resident at once (the grid-wide norm exchange needs that); DTQN_FUSED_ADAM=0
-// turns it off (A/B timing).
-constexpr int kFusedMaxGrid = 240;
-extern "C" int dtqn_td_update_is_fused(const DtqnNet* net, int batch) {
-    if (!dtqn_td_wgrad_is_direct(net, batch)) return 0;
-    const char* e = getenv("DTQN_FUSED_ADAM");
-    if (e != nullptr && atoi(e) == 0) return 0;
-    DtqnWJob jobs[kMaxWJobs];
-    if (dtqn_net_wjobs(net, jobs) != DTQN_OK) return 0;
-    return direct_plan(net, jobs).grid <= kFusedMaxGrid ? 1 : 0;
-}
-extern "C" int dtqn_td_wgrad_adam(const DtqnNet* net, const DtqnTd* td, void* stream) {
-    if (!net || !td || td->batch < 1 || !td->step_counter) return DTQN_ERR_ARG;
-    if (!dtqn_td_update_is_fused(net, td->batch)) return DTQN_ERR_CONFIG;
-    return wgrad_direct(net, td, (hipStream_t)stream, true);
 }
 
 extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td || td->batch < 1 || td->n_split < 1) return DTQN_ERR_ARG;
     if (net->n_wjobs > kMaxWJobs) return DTQN_ERR_CONFIG;
-    if (dtqn_td_wgrad_is_direct(net, td->batch)) return wgrad_direct(net, td, (hipStream_t)stream, false);
+    if (dtqn_td_wgrad_is_direct(net, td->batch)) return wgrad_direct(net, td, (hipStream_t)stream);
     WgradArgs a;
     a.net = *net;
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;

@@ -293,12 +293,6 @@ int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
  * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
 int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
 int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch);
-/* dtqn_td_wgrad + dtqn_td_clip_adam in ONE launch (dtqn.py:256-269): the direct weight-gradient kernel goes on into
- * clip + Adam on the values each workgroup holds, after a grid-wide exchange of the norm partials.  Single-GPU updates
- * with a direct grid of at most 240 workgroups (dtqn_td_update_is_fused); dtqn_td_update uses it by itself.
- * step_counter[3] is the grid barrier word. */
-int dtqn_td_update_is_fused(const DtqnNet* net, int batch);
-int dtqn_td_wgrad_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
 /* Sums gsplit / small partials into grad (mean-loss scaling is already in dL/dQ), writes
  * norm_partial.  After this call `grad` is ready for a data-parallel all-reduce. */
 int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream);

@@ -235,10 +235,6 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     int nthr = (int)std::min<long>(nblocks, std::max(1u, std::thread::hardware_concurrency()));
     const char* nt = std::getenv("HIPEMU_THREADS");
     if (nt) nthr = std::max(1, std::min(nthr, std::atoi(nt)));
-    // kernels with a grid-wide barrier (the fused weight-gradient + Adam kernel) need every workgroup alive at once:
-    // HIPEMU_COOP=<max> runs up to <max> workgroups on their own host threads (small test grids only)
-    const char* coop = std::getenv("HIPEMU_COOP");
-    if (coop) nthr = (int)std::min<long>(nblocks, std::max(1, std::atoi(coop)));
     std::atomic<long> next{0};
     auto worker = [&]() {
         Block* pb = acquire_block();

@@ -17,7 +17,6 @@
 #include <cstring>
 #include <functional>
 
-#include <sched.h>
 #define DTQN_HIPEMU 1
 #define DTQN_ASM_KEEP(x) ((void)(x))   /* device-only register keep-alive (dtqn_device.hpp) */
 #define DTQN_EXP2(x) exp2f(x)          /* v_exp_f32 (dtqn_device.hpp) */
@@ -26,8 +25,7 @@ template <typename T> static inline T hipemu_agent_load(const T* p) { T v; __ato
 template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
 #define DTQN_AGENT_LOAD(p) hipemu_agent_load(p)
 #define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
-#define DTQN_AGENT_ADD(p, v) __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL)
-#define DTQN_SPIN_PAUSE() sched_yield()
+#define DTQN_SPIN_PAUSE() ((void)0)
 #define DTQN_WAIT_VMEM() ((void)0)
 #define DTQN_SCHED_FENCE() ((void)0)
 

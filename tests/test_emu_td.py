@@ -53,27 +53,6 @@ def test_td_update_split_weight_gradients(emu, kw, run, monkeypatch):
     assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 4096 // net.lp + 1) == 0
 
 
-@pytest.mark.parametrize("kw,run", [CASES[0], CASES[2], CASES[5]])
-def test_td_update_one_launch_wgrad_adam(emu, kw, run, monkeypatch):
-    """dtqn_td_update at small batches = forward, backward, and ONE launch for weight gradients + clip + Adam + statistics
-    (grid-wide exchange of the norm partials).  The emulation gives every workgroup its own host thread for it."""
-    import ctypes
-    monkeypatch.setenv("HIPEMU_COOP", "128")
-    monkeypatch.setenv("DTQN_FUSED_ADAM", "1")
-    cfg = O.NetCfg(**kw)
-    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=9, mask=run["mask"],
-                                               history=run.get("history"), tuf=2)
-    assert emu.dtqn_td_update_is_fused(ctypes.byref(net), run["batch"]) == 1
-    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3, one_call=True)
-    assert int(eng.step_counter[3]) >> 16 == 3 and int(eng.step_counter[3]) & 0xffff == 0      # barrier word: 3 epochs, nobody waiting
-    monkeypatch.setenv("DTQN_FUSED_ADAM", "0")                                                  # the same call, unfused
-    assert emu.dtqn_td_update_is_fused(ctypes.byref(net), run["batch"]) == 0
-    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=9, mask=run["mask"],
-                                               history=run.get("history"), tuf=2)
-    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2, one_call=True)
-    assert int(eng.step_counter[3]) == 0
-
-
 def test_td_update_cfg1_size(emu):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=4, T=200, n_eps=8, mask=-5)
