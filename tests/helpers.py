@@ -95,16 +95,22 @@ def make_td_case(lib, cfg, *, seed, batch, T, n_eps, mask, history=None, tuf=10_
     return net, oracle, host, eng, rep
 
 
-def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4):
+def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False):
     """Run n_updates on both sides from identical (episode, start) draws and compare every stage:
-    the three Q tensors, pre-clip gradients, statistics, parameters after the step."""
+    the three Q tensors, pre-clip gradients, statistics, parameters after the step.
+    one_call: the whole update through dtqn_td_update, as the agent's train() issues it, instead of stage by stage;
+    everything compared is still left behind by that call."""
     keys = O.trainable_keys(cfg)
     Bn, L, A = eng.batch, cfg.history_len, cfg.num_actions
     for it in range(n_updates):
         eps, starts = host.sample_indices(Bn)
         batch = oracle_batch(host, eps, starts, cfg.discrete)
         eng.set_indices(eps, starts)
-        eng.forward_backward(rep)
+        pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+        if one_call:
+            eng.update(rep)
+        else:
+            eng.forward_backward(rep)
         # --- Q-values of the three forwards
         # The gradient is discontinuous at every ReLU kink and at ties of the double-DQN argmax; two
         # correct fp32 implementations can sit on different sides of a kink whose pre-activation is
@@ -150,8 +156,8 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         gerr = np.abs(got - ref_flat).max()
         assert gerr <= grad_rtol * np.abs(ref_flat).max(), (it, gerr, np.abs(ref_flat).max(), probe)
         # --- optimizer step + statistics
-        pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
-        eng.clip_adam()
+        if not one_call:
+            eng.clip_adam()
         st = eng.read_stats()
         # teacher-force the oracle from the engine's pre-step parameters?  No: both sides started
         # identical and took identical steps so far; compare the step itself on solid elements.

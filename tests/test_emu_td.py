@@ -53,6 +53,15 @@ def test_td_update_split_weight_gradients(emu, kw, run, monkeypatch):
     assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 4096 // net.lp + 1) == 0
 
 
+@pytest.mark.parametrize("kw,run", [CASES[0], CASES[2], CASES[5]])
+def test_td_update_one_call(emu, kw, run):
+    """dtqn_td_update, the single call DtqnAgent.train() issues (forward, backward, weight gradients, clip + Adam)."""
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=9, mask=run["mask"],
+                                               history=run.get("history"), tuf=2)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3, one_call=True)
+
+
 def test_td_update_cfg1_size(emu):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=4, T=200, n_eps=8, mask=-5)

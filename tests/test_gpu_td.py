@@ -76,6 +76,37 @@ def test_td_update_split_weight_gradients(lib, kw, run, monkeypatch):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
 
 
+@pytest.mark.parametrize("kw,run", [CASES[0], CASES[2], CASES[3], CASES[6], CASES[4]])
+def test_td_update_one_call(lib, kw, run):
+    """dtqn_td_update as the agent's train() calls it: one library call, four launches at small batches."""
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9),
+                                               mask=run["mask"], history=run.get("history"), tuf=2, device="cuda", test_lib=False)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=4, one_call=True)
+    assert int(eng.xflags.sum()) == 0
+
+
+def test_one_call_update_is_bit_reproducible(lib):
+    """Two engines, same state, 20 updates each at BASELINE config 1 (latency mode, one-launch weight gradients):
+    identical parameters, moments, statistics."""
+    import random
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    outs = []
+    for rep_i in range(2):
+        net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=9, batch=32, T=200, n_eps=60, mask=-5, device="cuda", test_lib=False)
+        random.seed(5)                      # host.sample_indices draws from Python's `random` like the reference
+        for it in range(20):
+            eps, starts = host.sample_indices(32)
+            eng.set_indices(eps, starts)
+            eng.update(rep)
+        torch.cuda.synchronize()
+        st = eng.read_stats()
+        assert st["nonfinite"] == 0.0 and st["step"] == 20
+        outs.append((eng.theta_pol.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.stats.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_td_update_batch_256(lib):
     """BASELINE config 2 (batch 256: one workgroup per sequence, split weight gradients) against the oracle."""
     import ctypes
