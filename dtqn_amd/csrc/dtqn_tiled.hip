@@ -50,6 +50,11 @@ struct TlEmbedArgs {
     Fld x;                             // [LPB][D] embedded tokens + positions
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
 };
+// One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
+// concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
+// kEmbKC columns; thread (d, row group) keeps 64 / (TNT / D) row accumulators, so one W element feeds that many FMAs
+// and the e_in operand is a wave-wide LDS broadcast.
+constexpr int kEmbKC = 64;
 __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const DtqnNet& net = a.net;
     const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n;
@@ -63,50 +68,73 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     }
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row_first * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
-    float* xo = frow(a.x, s, rb * TROWS);
-    for (int idx = (int)threadIdx.x; idx < TROWS * D; idx += TNT) {
-        const int rl = idx / D, d = idx - rl * D, r = rb * TROWS + rl;
-        float v = 0.f;
-        if (r < n) {
-            if (d < adim) {
-                if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
-                else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
-            } else {
-                const float* w = theta + net.off_obs_w + (size_t)(d - adim) * KE;
-                float acc = theta[net.off_obs_b + d - adim];
-                if (net.discrete) {
-                    for (int j = 0; j < O; ++j) {
-                        int tok = (int)obs_rows[(size_t)r * O + j];
-                        tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
-                        const float* e = theta + net.off_obs_tab + tok * net.embed_per_obs;
-                        for (int cdim = 0; cdim < net.embed_per_obs; ++cdim) acc = fmaf(e[cdim], w[j * net.embed_per_obs + cdim], acc);
-                    }
-                } else {
-                    for (int k = 0; k < KE; ++k) acc = fmaf(obs_rows[(size_t)r * O + k], w[k], acc);
-                }
-                v = acc;
-            }
-            v += theta[net.off_pos + r * D + d];
-        }
-        xo[(size_t)rl * a.x.ld + d] = v;
-    }
-    if (a.ein.base != nullptr) {
-        float* eo = frow(a.ein, s, rb * TROWS);
-        for (int idx = (int)threadIdx.x; idx < TROWS * KEP; idx += TNT) {
-            const int rl = idx / KEP, k = idx - rl * KEP, r = rb * TROWS + rl;
+    const int tid = (int)threadIdx.x;
+    const int KC = KE < kEmbKC ? KE : kEmbKC, LDE = kEmbKC + 4, LDWE = kEmbKC + 1;
+    float* El = reinterpret_cast<float*>(dtqn_smem);                  // [64][LDE]   e_in chunk
+    float* Wl = El + TROWS * LDE;                                      // [D][LDWE]   W_e chunk (rows >= D - adim unused)
+    const int DO = D - adim;                                           // outputs of the embedding linear
+    const int rpp = TNT / D, NR = TROWS / rpp;                         // rows per pass, rows per thread (D in {64, 128, 256})
+    const int d = tid % D, rg = tid / D;                               // this thread: output column d, rows rg + rpp * i
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    float* eo = a.ein.base != nullptr ? frow(a.ein, s, rb * TROWS) : nullptr;
+    for (int k0 = 0; k0 < KE; k0 += KC) {
+        const int kc = KE - k0 < KC ? KE - k0 : KC;
+        __syncthreads();                                               // previous chunk consumed
+        for (int idx = tid; idx < TROWS * kc; idx += TNT) {
+            const int rl = idx / kc, k = k0 + (idx - rl * kc), r = rb * TROWS + rl;
             float v = 0.f;
-            if (r < n && k < KE) {
+            if (r < n) {
                 if (net.discrete) {
-                    const int j = k / net.embed_per_obs, cdim = k - j * net.embed_per_obs;
-                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    const int jj = k / net.embed_per_obs, cdim = k - jj * net.embed_per_obs;
+                    int tok = (int)obs_rows[(size_t)r * O + jj];
                     tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
                     v = theta[net.off_obs_tab + tok * net.embed_per_obs + cdim];
                 } else {
                     v = obs_rows[(size_t)r * O + k];
                 }
             }
-            eo[idx] = v;
+            El[rl * LDE + (k - k0)] = v;
+            if (eo != nullptr) eo[(size_t)rl * KEP + k] = v;
         }
+        for (int idx = tid; idx < DO * kc; idx += TNT) {
+            const int dd = idx / kc, k = idx - dd * kc;
+            Wl[dd * LDWE + k] = theta[net.off_obs_w + (size_t)dd * KE + k0 + k];
+        }
+        __syncthreads();
+        if (d >= adim) {
+            const float* wr = Wl + (d - adim) * LDWE;
+            for (int k = 0; k < kc; ++k) {
+                const float wv = wr[k];
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i < NR) acc[i] = fmaf(El[(rg + rpp * i) * LDE + k], wv, acc[i]);
+            }
+        }
+    }
+    if (eo != nullptr)                                                 // zero the padding columns [KE, KEP) of the saved input
+        for (int idx = tid; idx < TROWS * (KEP - KE); idx += TNT) {
+            const int rl = idx / (KEP - KE), k = KE + idx - rl * (KEP - KE);
+            eo[(size_t)rl * KEP + k] = 0.f;
+        }
+    float* xo = frow(a.x, s, rb * TROWS);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i >= NR) break;
+        const int rl = rg + rpp * i, r = rb * TROWS + rl;
+        float v = 0.f;
+        if (r < n) {
+            if (d < adim) {
+                // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192)
+                if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+            } else {
+                v = acc[i] + theta[net.off_obs_b + d - adim];
+            }
+            v += theta[net.off_pos + r * D + d];
+        }
+        xo[(size_t)rl * a.x.ld + d] = v;
     }
 }
 
@@ -126,8 +154,9 @@ struct TlLinearArgs {
     int K2;
     Fld aux, out2, out3;
 };
+// (second launch bound = waves per SIMD the register budget must allow: two resident workgroups up to D = 128)
 template <int D>
-__global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLinearArgs a) {
     constexpr int LDT = D + 4;
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDT] input tile of the current K chunk
     const Thr t = make_thr();
@@ -141,26 +170,37 @@ __global__ __launch_bounds__(TNT) void tl_linear_kernel(TlLinearArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = zero4();
-    float4 bf[2][D / 16];
+    // two weight fragments that alternate by NAME: indexing them with the chunk counter would put the array into
+    // scratch memory (dynamic register indexing does not exist) -- 272 / 528 bytes per lane before this was unrolled
+    float4 bf0[D / 16], bf1[D / 16];
     const float* wrow = W + (size_t)(live ? col : 0) * a.K;
     const float* wrow2 = a.K2 > 0 ? W2 + (size_t)(live ? col : 0) * a.K2 : nullptr;
-    frag_xwT_fetch<D>(bf[0], wrow, t);
+    frag_xwT_fetch<D>(bf0, wrow, t);
     const float* in0 = frow(a.in, s, row0);
     const float* in20 = a.K2 > 0 ? frow(a.in2, s, row0) : nullptr;
     const int nch1 = a.K / D, nchunks = nch1 + a.K2 / D;
-    for (int kc = 0; kc < nchunks; ++kc) {
-        __syncthreads();                                              // previous chunk's tile fully consumed
+    auto stage = [&](int kc) {                                        // chunk kc of the operand(s) -> LDS
         const float* src = kc < nch1 ? in0 + (size_t)kc * D : in20 + (size_t)(kc - nch1) * D;
         const int ld = kc < nch1 ? a.in.ld : a.in2.ld;
         for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
             st4(Xt + r * LDT + c, ld4(src + (size_t)r * ld + c));
         }
-        if (kc + 1 < nchunks)
-            frag_xwT_fetch<D>(bf[(kc + 1) & 1], kc + 1 < nch1 ? wrow + (size_t)(kc + 1) * D : wrow2 + (size_t)(kc + 1 - nch1) * D, t);
+    };
+    auto wfrag = [&](int kc) { return kc < nch1 ? wrow + (size_t)kc * D : wrow2 + (size_t)(kc - nch1) * D; };
+    for (int kc = 0; kc < nchunks; kc += 2) {
+        __syncthreads();                                              // previous chunk's tile fully consumed
+        stage(kc);
+        if (kc + 1 < nchunks) frag_xwT_fetch<D>(bf1, wfrag(kc + 1), t);
         __syncthreads();
-        if (kc & 1) frag_xwT_mma<D, 4>(Xt, LDT, bf[1], t, acc);
-        else frag_xwT_mma<D, 4>(Xt, LDT, bf[0], t, acc);
+        frag_xwT_mma<D, 4>(Xt, LDT, bf0, t, acc);
+        if (kc + 1 < nchunks) {
+            __syncthreads();
+            stage(kc + 1);
+            if (kc + 2 < nchunks) frag_xwT_fetch<D>(bf0, wfrag(kc + 2), t);
+            __syncthreads();
+            frag_xwT_mma<D, 4>(Xt, LDT, bf1, t, acc);
+        }
     }
     if (live) {
         const float b = bias != nullptr ? bias[col] : 0.f;
@@ -220,7 +260,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = zero4();
-    float bf[2][KC / 4];
+    float bf0[KC / 4], bf1[KC / 4];                                    // alternate by name (see tl_linear_kernel)
     const int cl = live ? col : 0;
     const int per = a.N / KC, nchunks = per * a.nsrc;
     // chunk kc = (operand pair p, contraction chunk j)
@@ -228,9 +268,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
         const int p = kc / per, j = kc - p * per;
         return (p == 0 ? a.W : p == 1 ? a.W2 : a.W3) + cl + (size_t)j * KC * a.KOUT;
     };
-    frag_dyw_fetch<KC>(bf[0], wchunk(0), a.KOUT, t);
-    for (int kc = 0; kc < nchunks; ++kc) {
-        __syncthreads();
+    auto stage = [&](int kc) {
         const int p = kc / per, j = kc - p * per;
         const Fld& dyf = p == 0 ? a.dy : p == 1 ? a.dy2 : a.dy3;
         const float* dy0 = frow(dyf, s, row0) + (size_t)j * KC;
@@ -238,10 +276,21 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
             const int r = idx / (KC / 4), c = (idx - r * (KC / 4)) * 4;
             st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * dyf.ld + c));
         }
-        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf[(kc + 1) & 1], wchunk(kc + 1), a.KOUT, t);
+    };
+    frag_dyw_fetch<KC>(bf0, wchunk(0), a.KOUT, t);
+    for (int kc = 0; kc < nchunks; kc += 2) {
         __syncthreads();
-        if (kc & 1) frag_dyw_mma<KC, 4>(Yt, LDT, bf[1], t, acc);
-        else frag_dyw_mma<KC, 4>(Yt, LDT, bf[0], t, acc);
+        stage(kc);
+        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf1, wchunk(kc + 1), a.KOUT, t);
+        __syncthreads();
+        frag_dyw_mma<KC, 4>(Yt, LDT, bf0, t, acc);
+        if (kc + 1 < nchunks) {
+            __syncthreads();
+            stage(kc + 1);
+            if (kc + 2 < nchunks) frag_dyw_fetch<KC>(bf0, wchunk(kc + 2), a.KOUT, t);
+            __syncthreads();
+            frag_dyw_mma<KC, 4>(Yt, LDT, bf1, t, acc);
+        }
     }
     if (live) {
         const unsigned long long* mrec =
@@ -541,7 +590,13 @@ struct TlEmbedBwdArgs {
     const int32_t* ep_idx;
     const int32_t* start;
 };
-__global__ __launch_bounds__(256) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
+// One workgroup per sequence, walking its 64-row blocks.  Discrete observations: d(e_in) = dx0[:, a:] W_e per block out
+// of LDS-staged tiles, then the scatter onto table rows: thread (k = j * e + c, row group) adds its rows into a private
+// [token][c] column of an LDS table (no two threads share an address), and the O * (row groups) private tables are summed
+// in a fixed order at the end -- deterministic, no atomics.
+// row groups of a 64-row block walked by different threads of the scatter: 4 if the thread count allows, else 2 or 1
+static __host__ __device__ inline int emb_row_groups(int ke) { return ke * 4 <= TNT ? 4 : ke * 2 <= TNT ? 2 : 1; }
+__global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
     const DtqnNet& net = a.net;
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
     const int D = net.d_model, L = net.ctx_len, A = net.num_actions, adim = net.action_dim, LP = net.lp;
@@ -551,31 +606,52 @@ __global__ __launch_bounds__(256) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
     if (net.discrete) {
-        const int KE = net.ke, KEP = net.kep, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim;
+        const int KE = net.ke, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim, DO = D - adim;
+        const int LDT = DO + 1, LDK = KE + 1, kEmbRQ = emb_row_groups(KE);
+        float* Tl = reinterpret_cast<float*>(dtqn_smem);       // [64][LDT]  dx0[:, a:] of the current row block
+        float* Wl = Tl + TROWS * LDT;                          // [DO][LDK]  W_e
+        float* dein = Wl + (size_t)DO * LDK;                   // [64][LDK]  dL/d(gathered table rows)
+        float* part = dein + TROWS * LDK;                      // [kEmbRQ][O][V][e] private scatter tables
         const float* __restrict__ We = a.theta + net.off_obs_w;
-        float* dein = reinterpret_cast<float*>(dtqn_smem);   // [LP][KEP]: dL/d(gathered table rows) = dx0[:, a:] W_e
-        for (int idx = tid; idx < LP * KEP; idx += 256) {
-            const int r = idx / KEP, k = idx - r * KEP;
-            float g = 0.f;
-            if (r < L && k < KE)
-                for (int d = 0; d < D - adim; ++d) g = fmaf(DX[(size_t)r * D + adim + d], We[(size_t)d * KE + k], g);
-            dein[idx] = g;
+        for (int idx = tid; idx < DO * KE; idx += TNT) Wl[(idx / KE) * LDK + idx % KE] = We[idx];
+        for (int idx = tid; idx < kEmbRQ * O * V * e; idx += TNT) part[idx] = 0.f;
+        for (int rb = 0; rb < LP / TROWS; ++rb) {
+            __syncthreads();                                   // previous block's tiles consumed (and Wl / part initialised)
+            for (int idx = tid; idx < TROWS * DO; idx += TNT) {
+                const int rl = idx / DO, dd = idx - rl * DO, r = rb * TROWS + rl;
+                Tl[rl * LDT + dd] = r < L ? DX[(size_t)r * D + adim + dd] : 0.f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < TROWS * KE; idx += TNT) {
+                const int rl = idx / KE, k = idx - rl * KE;
+                const float* tr = Tl + rl * LDT;
+                float g = 0.f;
+                for (int dd = 0; dd < DO; ++dd) g = fmaf(tr[dd], Wl[dd * LDK + k], g);
+                dein[rl * LDK + k] = g;
+            }
+            __syncthreads();
+            if (tid < KE * kEmbRQ) {
+                const int k = tid % KE, rq = tid / KE, jj = k / e, c = k - jj * e;
+                float* mine = part + ((size_t)(rq * O + jj) * V) * e + c;
+                for (int rl = rq * (TROWS / kEmbRQ); rl < (rq + 1) * (TROWS / kEmbRQ); ++rl) {
+                    const int r = rb * TROWS + rl;
+                    if (r < L) {
+                        int tok = (int)obs_rows[(size_t)r * O + jj];
+                        tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+                        mine[tok * e] += dein[rl * LDK + k];
+                    }
+                }
+            }
         }
         __syncthreads();
-        for (int idx = tid; idx < V * e; idx += 256) {
-            const int v = idx / e, c = idx - v * e;
+        for (int idx = tid; idx < V * e; idx += TNT) {
             float g = 0.f;
-            for (int r = 0; r < L; ++r)
-                for (int j = 0; j < O; ++j) {
-                    int tok = (int)obs_rows[(size_t)r * O + j];
-                    tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-                    if (tok == v) g += dein[r * KEP + j * e + c];
-                }
+            for (int q = 0; q < kEmbRQ * O; ++q) g += part[(size_t)q * V * e + idx];
             srec[net.so_tab + idx] = g;
         }
     }
     if (adim > 0) {
-        for (int idx = tid; idx < A * adim; idx += 256) {
+        for (int idx = tid; idx < A * adim; idx += TNT) {
             const int v = idx / adim, c = idx - v * adim;
             float g = 0.f;
             if (L == 1) {
@@ -688,7 +764,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.n = n; e.rpb = rpb;
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
-        TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), 0, stream, e);
+        const size_t elds = ((size_t)TROWS * (kEmbKC + 4) + (size_t)D * (kEmbKC + 1)) * sizeof(float);
+        TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
     auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
         TlLinearArgs a = {};
@@ -902,9 +979,11 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         a.net = net; a.theta = theta; a.grd = grd; a.small = td.small;
         a.obs = rp.obs; a.actions = rp.actions; a.obs_ep_stride = obs_ep_stride; a.act_ep_stride = act_ep_stride;
         a.ep_idx = td.ep_idx; a.start = td.start;
-        const size_t lds = net.discrete ? (size_t)lpb * net.kep * sizeof(float) : 0;
-        if (lds > 150 * 1024) return DTQN_ERR_CONFIG;
-        TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(256), lds, stream, a);
+        const int DO = D - net.action_dim;
+        const size_t lds = !net.discrete ? 0 : ((size_t)TROWS * (DO + 1) + (size_t)DO * (net.ke + 1) + (size_t)TROWS * (net.ke + 1) +
+                                                (size_t)emb_row_groups(net.ke) * net.obs_dim * net.vocab * net.embed_per_obs) * sizeof(float);
+        if (lds > 150 * 1024 || net.ke > TNT) return DTQN_ERR_CONFIG;
+        TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(TNT), lds, stream, a);
     }
     return DTQN_OK;
 }
