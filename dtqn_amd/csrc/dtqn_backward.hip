@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     constexpr int LDX = D + 4;
     constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
     constexpr int NG = D / GW;
-    constexpr int NC = 2 * D;                     // FFN hidden columns per pass
+    constexpr int NC = D >= 128 ? D : 2 * D;      // FFN hidden columns per pass (D = 128: 2D-wide fragments would be 128 VGPRs a pair)
     constexpr bool OST = D <= 64;                 // stage the attention output o in LDS too (sixth W5 tile) when it fits
     constexpr int W5C = ((OST ? 6 : 5) * GW > NC ? (OST ? 6 : 5) * GW : NC);
     constexpr int LD5 = W5C + 4;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 
 static size_t bwd_lds_bytes(const DtqnNet* net) {
     const int LP = net->lp, D = net->d_model, HD = net->head_dim;
-    const int GW = D >= 64 ? 64 : D, NC = 2 * D;
+    const int GW = D >= 64 ? 64 : D, NC = D >= 128 ? D : 2 * D;
     const int ntile = D <= 64 ? 6 : 5;
     const int W5C = ntile * GW > NC ? ntile * GW : NC;
     const int NT = waves_for(*net) * 64;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     constexpr int LP = MT * 16;                    // rows this workgroup owns
     constexpr int LPF = LP * RS;                   // padded rows of the whole sequence (= net.lp)
     constexpr int LDX = D + 4, LDW = 3 * D + 4;
-    constexpr int NC = 2 * D;                      // FFN hidden columns per pass
+    constexpr int NC = D >= 128 ? D : 2 * D;       // FFN hidden columns per pass (D = 128: two 2D-wide FFN-2 fragments alone would be 128 VGPRs)
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
     const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;     // slice 0 (the producer) first
