@@ -225,7 +225,7 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
 }
 
 // ---- small batches: one launch, no split-K -----------------------------------------------------------------------------
-// With B * LP <= kDirectMaxTokens the token axis is short enough for ONE workgroup to contract it all, so the splits and
+// With B * LP <= kDirectMaxTokens (2048) the token axis is short enough for ONE workgroup to contract it all, so the splits and
 // the dtqn_td_reduce launch disappear: the output is cut into many SMALL tiles instead (16 dY columns x 32 X columns, a
 // few hundred workgroups), each written straight into `grad` together with its sum of squares for the global norm.
 // Small tiles re-read the records once per tile; to keep those re-reads inside one L2, consecutive tiles (= the tiles of
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
 // SHORTER tile axis first, so that a run of consecutive tiles touches as few distinct column blocks as possible.
 constexpr int kDirectWaves = 8;
 constexpr int kDirectThreads = kDirectWaves * 64;
-constexpr int kDirectMaxTokens = 4096;
+constexpr int kDirectMaxTokens = 2048;
 constexpr int kDTN = 16, kDTK = 32;         // tile: dY columns x X columns
 constexpr int kDGroup = 8;                  // 16-token units in flight per wave and buffer
 constexpr int kDSmall = 128;                // per-sequence-partial elements per workgroup
@@ -506,7 +506,10 @@ extern "C" int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch) {
     if (!net || batch < 1 || net->n_wjobs > kMaxWJobs) return 0;
     const char* e = getenv("DTQN_WGRAD_DIRECT");
     if (e != nullptr) return atoi(e) != 0 ? 1 : 0;
-    return (long long)batch * net->lp <= kDirectMaxTokens ? 1 : 0;
+    // shared GRU gate matrices contract over the tokens of every layer (measured at cfg-1 shapes with GRU gates, 2 layers:
+    // 257 us per update direct, 247 us split)
+    const int layers = net->gate == DTQN_GATE_GRU ? net->num_layers : 1;
+    return (long long)batch * net->lp * layers <= kDirectMaxTokens ? 1 : 0;
 }
 
 // Length of DtqnTd.norm_partial: the sum-of-squares partials of whichever kernel assembles `grad` (dtqn_td_reduce /

@@ -50,7 +50,7 @@ def test_td_update_split_weight_gradients(emu, kw, run, monkeypatch):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
     monkeypatch.delenv("DTQN_WGRAD_DIRECT")
     assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), run["batch"]) == 1
-    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 4096 // net.lp + 1) == 0
+    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 2048 // net.lp + 1) == 0
 
 
 @pytest.mark.parametrize("kw,run", [CASES[0], CASES[2], CASES[5]])
