@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 One "step" = one DtqnAgent.train() = one TD update (sample windows -> 3 forwards -> double-DQN loss
--> backward -> clip -> Adam; five launches, the window draw is part of the forward kernel) on a device-resident
+-> backward -> clip -> Adam; four launches at batch 32, the window draw is part of the forward kernel) on a device-resident
 synthetic replay of the shape SURVEY.md section 8d prescribes.  Workload at every N: BASELINE.json's metric configuration, DiscreteCarFlag-v0 shapes,
 context 50, d_model 64, 8 heads, 2 layers, batch 32 PER GPU (weak scaling: each rank owns its
 replay shard and batch; the only exchange is the flat-gradient all-reduce over RCCL).
