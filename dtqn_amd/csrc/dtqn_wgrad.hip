@@ -2,7 +2,10 @@
 //
 // Replaces the parameter-gradient half of loss.backward() (dtqn/agents/dtqn.py:256).  The contraction
 // runs over the TOKEN axis (B*LP rows of the per-sequence act / grd records), so it is a real
-// GEMM with K_contract = B*LP: it goes on the f32 matrix core.  A workgroup owns one 64x64 block of
+// GEMM with K_contract = B*LP: it goes on the f32 matrix core.  Two kernels:
+//   * dtqn_wgrad_kernel (large batches): split-K over the batch, summed by dtqn_td_reduce;
+//   * dtqn_wgrad_direct_kernel (B*LP <= 2048 tokens, further down): small output tiles, no splits, writes grad itself.
+// dtqn_wgrad_kernel: a workgroup owns one 64x64 block of
 // one dW and one split of the batch; a 64-wide block is FOUR INTERLEAVED 16-row MFMA tiles
 // (tile c holds rows 4*i + c), so one lane's A operands for the four tiles are 4 consecutive floats
 // of one dY row and its B operands 4 consecutive floats of one X row: every global access is a
