@@ -51,7 +51,7 @@ class _AdamHandle:
         e = self._eng
         e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
         e.step_counter.fill_(int(sd["step"]))
-        e.step_counter[2] = 0          # statistics-ring call counter restarts with the loading agent's host counters
+        e.step_counter[2] = 0          # statistics-ring call counter: DtqnAgent.load_checkpoint restarts its host side too
 
 
 class DtqnAgent:
@@ -91,6 +91,7 @@ class DtqnAgent:
         self.replay_buffer = ReplayBuffer(buffer_size, env_obs_length=env_obs_length, obs_mask=obs_mask,
                                           max_episode_steps=max_env_steps, context_len=context_len, device=self.device, lib=lib)
         self.dp = ddp.DataParallel(self.engine) if ddp.is_distributed() else None
+        self._dp_ready = False
         if self.dp is not None:
             self.dp.broadcast_parameters()
         # logging (dqn.py:80-89), fed asynchronously
@@ -227,8 +228,15 @@ class DtqnAgent:
     # ---- learner (dtqn.py:162-269) --------------------------------------------------------------
     def train(self) -> None:
         rb = self.replay_buffer
-        if not rb.can_sample(self.batch_size):
-            return
+        if self.dp is None:
+            if not rb.can_sample(self.batch_size):
+                return
+        elif not self._dp_ready:
+            # every rank must enter (or skip) the gradient all-reduce together: the "nothing to sample yet" early return
+            # (dtqn.py:163-164) is decided collectively until all shards can sample -- can_sample never turns false again
+            if not ddp.agree_all(rb.can_sample(self.batch_size), self.device):
+                return
+            self._dp_ready = True
         self.eval_off()
         eng = self.engine
         sp = eng._stream()
@@ -281,12 +289,13 @@ class DtqnAgent:
         while self._calls_read < self._calls_issued:
             k = self._calls_read + 1
             row = ring[(k - 1) % slots]
-            if row[9] != float(k):
+            tag = float(k & 0x7FFFFF)                 # the kernel writes the call index modulo 2^23 (exact in f32)
+            if row[9] != tag:
                 if not block:
                     return
                 if self.device.type == "cuda":
-                    torch.cuda.current_stream(self.device).synchronize()
-                if row[9] != float(k):
+                    (self._main_stream if self._main_stream is not None else torch.cuda.current_stream(self.device)).synchronize()
+                if row[9] != tag:
                     raise RuntimeError(f"statistics of update call {k} never arrived (ring tag {row[9]})")
             vals = row.copy()
             self._calls_read = k
@@ -307,6 +316,16 @@ class DtqnAgent:
     def save_checkpoint(self, checkpoint_dir: str, wandb_id, episode_successes: RunningAverage,
                         episode_rewards: RunningAverage, episode_lengths: RunningAverage, eps) -> None:
         self._drain_stats(block=True)
+        rng_state = {"random_rng_state": random.getstate(), "rng_bit_generator_state": RNG.rng.bit_generator.state,
+                     "numpy_rng_state": np.random.get_state(), "torch_rng_state": torch.get_rng_state()}
+        r = ddp.rank()
+        if r > 0:
+            # data-parallel replica: parameters / optimizer / statistics are identical to rank 0's and are saved there;
+            # this rank's OWN state is its replay shard and its RNG streams
+            torch.save({"step": self.num_train_steps, "replay_buffer_pos": [self.replay_buffer.pos[0], 0], **rng_state},
+                       checkpoint_dir + f"_checkpoint.rank{r}.pt")
+            np.savez(checkpoint_dir + f"buffer.rank{r}.npz", **self.replay_buffer.export_arrays())
+            return
         self.save_mini_checkpoint(checkpoint_dir=checkpoint_dir, wandb_id=wandb_id)
         ra = lambda r: {"size": r.size, "q": list(r.q), "sum": r.sum}
         torch.save({
@@ -318,16 +337,39 @@ class DtqnAgent:
                                      ("qvalue_max", self.qvalue_max), ("qvalue_mean", self.qvalue_mean),
                                      ("qvalue_min", self.qvalue_min), ("target_max", self.target_max),
                                      ("target_mean", self.target_mean), ("target_min", self.target_min))},
-            "random_rng_state": random.getstate(), "rng_bit_generator_state": RNG.rng.bit_generator.state,
-            "numpy_rng_state": np.random.get_state(), "torch_rng_state": torch.get_rng_state(),
+            **rng_state,
         }, checkpoint_dir + "_checkpoint.pt")
         np.savez(checkpoint_dir + "buffer.npz", **self.replay_buffer.export_arrays())
 
     def load_checkpoint(self, checkpoint_dir: str) -> Tuple[str, RunningAverage, RunningAverage, RunningAverage, float]:
         ck = torch.load(checkpoint_dir + "_checkpoint.pt", weights_only=False)
+        # an agent that has already trained: finish and consume its outstanding updates, then restart the statistics
+        # ring (host counters, device call counter -- reset by optimizer.load_state_dict -- and the slot tags) together
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        try:
+            self._drain_stats(block=True)
+        except RuntimeError:
+            pass                                       # a non-finite norm of the abandoned run is not this load's business
+        self._calls_issued = self._calls_read = 0
+        self.engine.stats_ring.zero_()
+        self._actor_inflight = False
         self.num_train_steps = ck["step"]
-        self.replay_buffer.pos = ck["replay_buffer_pos"]
-        self.replay_buffer.import_arrays(dict(np.load(checkpoint_dir + "buffer.npz")))
+        shard, r = ck, ddp.rank()
+        buffer_file = checkpoint_dir + "buffer.npz"
+        reseed = False
+        if r > 0:
+            # replicas resume from their own replay shard and RNG streams; without a shard (checkpoint written by a
+            # smaller job) the replica takes rank 0's replay and re-seeds its streams so ranks do not draw the same batches
+            if os.path.exists(checkpoint_dir + f"_checkpoint.rank{r}.pt") and os.path.exists(checkpoint_dir + f"buffer.rank{r}.npz"):
+                shard = torch.load(checkpoint_dir + f"_checkpoint.rank{r}.pt", weights_only=False)
+                buffer_file = checkpoint_dir + f"buffer.rank{r}.npz"
+                if shard["step"] != ck["step"]:
+                    raise RuntimeError(f"rank {r} checkpoint shard is from step {shard['step']}, rank 0's from {ck['step']}")
+            else:
+                reseed = True
+        self.replay_buffer.pos = list(shard["replay_buffer_pos"])
+        self.replay_buffer.import_arrays(dict(np.load(buffer_file)))
         self.policy_network.load_state_dict(ck["policy_net_state_dict"])
         self.target_network.load_state_dict(ck["target_net_state_dict"])
         self.optimizer.load_state_dict(ck["optimizer_state_dict"])
@@ -338,10 +380,16 @@ class DtqnAgent:
             return dst
         for k in ("td_errors", "grad_norms", "qvalue_max", "qvalue_mean", "qvalue_min", "target_max", "target_mean", "target_min"):
             restore(getattr(self, k), ck[k])
-        random.setstate(ck["random_rng_state"])
-        RNG.rng.bit_generator.state = ck["rng_bit_generator_state"]
-        np.random.set_state(ck["numpy_rng_state"])
-        torch.set_rng_state(ck["torch_rng_state"])
+        random.setstate(shard["random_rng_state"])
+        RNG.rng.bit_generator.state = shard["rng_bit_generator_state"]
+        np.random.set_state(shard["numpy_rng_state"])
+        torch.set_rng_state(shard["torch_rng_state"])
+        if reseed:
+            base = int(ck["step"]) * 1000003 + r
+            random.seed(base)
+            RNG.rng = np.random.Generator(np.random.PCG64(base))
+            np.random.seed(base % (2 ** 32))
+        self._dp_ready = False
         out = [restore(RunningAverage(10), ck[k]) for k in ("episode_successes", "episode_rewards", "episode_lengths")]
         return ck["wandb_id"], out[0], out[1], out[2], ck["epsilon"]
 

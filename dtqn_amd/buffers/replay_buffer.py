@@ -150,8 +150,17 @@ class ReplayBuffer:
                     dones=d.dones.cpu().numpy(), eplens=self.episode_lengths.copy())
 
     def import_arrays(self, arrays: dict) -> None:
+        """Overwrite the device arrays (checkpoint load, synthetic fills).  Records still queued in the host staging
+        belong to the state being replaced and are dropped; shapes must match this buffer's (E, T+1, O) geometry."""
         d = self.dev
-        d.obs.copy_(torch.from_numpy(arrays["obss"])); d.actions.copy_(torch.from_numpy(arrays["actions"]))
-        d.rewards.copy_(torch.from_numpy(arrays["rewards"])); d.dones.copy_(torch.from_numpy(arrays["dones"]))
+        E, T, O = self.max_size, self.max_episode_steps, self.env_obs_length
+        want = {"obss": (E, T + 1, O), "actions": (E, T + 1), "rewards": (E, T), "dones": (E, T), "eplens": (E,)}
+        for k, shape in want.items():
+            if tuple(np.shape(arrays[k])) != shape:
+                raise ValueError(f"replay array {k!r} has shape {tuple(np.shape(arrays[k]))}, this buffer needs {shape}")
+        self._n = 0
+        as_t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt))
+        d.obs.copy_(as_t(arrays["obss"], np.float32)); d.actions.copy_(as_t(arrays["actions"], np.uint8))
+        d.rewards.copy_(as_t(arrays["rewards"], np.float32)); d.dones.copy_(as_t(arrays["dones"], np.uint8))
         self.episode_lengths[:] = arrays["eplens"]
         d.ep_len.copy_(torch.from_numpy(self.episode_lengths))

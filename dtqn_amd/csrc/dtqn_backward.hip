@@ -500,12 +500,8 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
-    static size_t attr_lds = 0;              // raise the limit once per instantiation (and size): the call is a driver round trip
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>), dim3(a.batch * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;

@@ -28,6 +28,22 @@ int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td
 // dtqn_forward with an optional pinned-host destination for Q of the last row of sequence 0 (dtqn_actor_forward)
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
+
+// Raise a kernel's dynamic-LDS limit once per (instantiation, device, size): the call is a driver round trip, and the
+// attribute is per device, so a second GPU used by the same process needs its own call (`cache` = one function-static
+// array per instantiation).
+constexpr int kMaxDevices = 16;
+inline void raise_lds_limit(const void* fn, size_t lds, size_t (&cache)[kMaxDevices]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {       // unknown device: always set
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return;
+    }
+    if (lds > cache[dev]) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        cache[dev] = lds;
+    }
+}
 }  // namespace dtqn
 
 // Stage timestamps (debug): thread 0 of workgroups 0 and 1 (two row slices of sequence 0 in latency mode), 32 slots

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
                 for (int i = 0; i < 12; ++i)
                     if (i != 9) slot[i] = a.stats[i];
                 __threadfence_system();
-                slot[9] = (float)call;
+                slot[9] = (float)(call & 0x7fffff);       // exact in f32 for any call count; the host compares modulo 2^23
             }
         }
     }

@@ -562,11 +562,8 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
                 (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);
     const int small_blocks = (a.n_small + 1023) / 1024;
     const size_t lds = (size_t)DTQN_WAVES * 65 * 68 * sizeof(float);
-    static size_t attr_lds = 0;              // raise the limit once per instantiation (and size): the call is a driver round trip
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    static size_t attr_lds[kMaxDevices] = {};    // per device
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(net->n_wtiles + small_blocks, td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;

@@ -36,6 +36,28 @@ def init_from_env(device_type: str = "cuda") -> tuple:
     return rank, world, local
 
 
+def rank() -> int:
+    return td.get_rank() if is_distributed() else 0
+
+
+def agree_all(flag: bool, device) -> bool:
+    """True iff `flag` is true on EVERY rank (one tiny all-reduce + a host read: use off the per-update path)."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def agree_any(flag: bool, device) -> bool:
+    """True iff `flag` is true on ANY rank."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return bool(t.item())
+
+
 class DataParallel:
     """Wraps a TdEngine: update() = local gradient kernels -> all-reduce -> clip + Adam."""
 

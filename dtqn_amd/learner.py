@@ -111,8 +111,17 @@ class TdEngine:
         ring = torch.zeros(self.RING_SLOTS, len(STAT_NAMES), dtype=torch.float32)
         self.stats_ring = ring.pin_memory() if dev.type == "cuda" else ring      # written by the optimizer kernel, polled by the host
         self.stats_ring_np = self.stats_ring.numpy()
-        self.ep_idx = torch.zeros(Bn, dtype=torch.int32, device=dev)
-        self.start = torch.zeros(Bn, dtype=torch.int32, device=dev)
+        # (episode, start) pairs: one [2][B] device array, so host-drawn pairs travel in ONE copy out of a small pinned ring
+        self._idx_dev = torch.zeros(2, Bn, dtype=torch.int32, device=dev)
+        self.ep_idx, self.start = self._idx_dev[0], self._idx_dev[1]
+        self.IDX_RING = 8
+        self._idx_ring, self._idx_i = [], 0
+        for _ in range(self.IDX_RING if dev.type == "cuda" else 1):
+            h = torch.zeros(2, Bn, dtype=torch.int32)
+            if dev.type == "cuda":
+                h = h.pin_memory()
+            self._idx_ring.append(dict(h=h, np=h.numpy(), event=torch.cuda.Event() if dev.type == "cuda" else None, busy=False))
+        self._bound_torch_stream = None
         jobs = (B.DtqnWJob * net.n_wjobs)()
         rc = self.lib.dtqn_net_wjobs(ctypes.byref(net), jobs)
         if rc != 0:
@@ -151,6 +160,7 @@ class TdEngine:
         """Issue every launch of this engine on `stream` from now on (None: back to torch's current stream).  Saves the
         per-call current-stream lookup in tight loops; the caller then keeps its torch work on the same stream."""
         self._bound_stream = None if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        self._bound_torch_stream = stream
 
     def _check(self, rc: int, what: str):
         if rc != 0:
@@ -163,8 +173,26 @@ class TdEngine:
     def set_indices(self, ep_idx, start):
         """Host-drawn (episode, start) pairs (reference RNG stream) -> device."""
         self.td.sample_in_kernel = 0
-        self.ep_idx.copy_(torch.as_tensor(np.asarray(ep_idx, dtype=np.int32)), non_blocking=True)
-        self.start.copy_(torch.as_tensor(np.asarray(start, dtype=np.int32)), non_blocking=True)
+        slot = self._idx_ring[self._idx_i % len(self._idx_ring)]
+        self._idx_i += 1
+        if slot["busy"]:
+            slot["event"].synchronize()              # the copy that last read this pinned slot has completed
+            slot["busy"] = False
+        slot["np"][0] = ep_idx
+        slot["np"][1] = start
+        if self.device.type != "cuda":
+            self._idx_dev.copy_(slot["h"])
+            return
+        # pinned -> device, asynchronous, on the stream the kernels are launched on (ordered before dtqn_td_forward)
+        bound = self._bound_torch_stream
+        if bound is None or bound == torch.cuda.current_stream(self.device):
+            self._idx_dev.copy_(slot["h"], non_blocking=True)
+            slot["event"].record()
+        else:
+            with torch.cuda.stream(bound):
+                self._idx_dev.copy_(slot["h"], non_blocking=True)
+                slot["event"].record()
+        slot["busy"] = True
 
     def sample_in_forward(self, n_valid: int, exclude: int, seed: int) -> None:
         """Let the next dtqn_td_forward / dtqn_td_update draw its own windows (no sampling launch): the same draw as

@@ -4,7 +4,9 @@ read directly.
 
 The module is a parameter CONTAINER plus an inference `forward`: every nn.Parameter is a view
 into `self.flat` (layout: include/dtqn_hip.h, DtqnNet), so `state_dict()` / `load_state_dict()` /
-`parameters()` behave like the reference's and checkpoints are interchangeable, while the engine
+`parameters()` behave like the reference's -- a policy / target `state_dict` saved by either implementation loads
+in the other (the FULL training checkpoints do not: the reference pickles joblib / torch-optimizer objects, dtqn_amd
+writes plain arrays) --, while the engine
 sees a single contiguous theta.  Training does not go through autograd: DtqnAgent.train() runs the
 fused HIP update on these same buffers.
 """

@@ -223,8 +223,8 @@ typedef struct DtqnTd {
     float* stats_partial;     /* [B * row_split][8] */
     float* stats;             /* [12]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, step, target-synced, non-finite flag */
     float* stats_ring;        /* optional [stats_ring_slots][12] in PINNED HOST memory (device-visible): every call of
-                               * dtqn_td_clip_adam also writes its statistics to slot (call_index % slots), entry 9 (the
-                               * 1-based call index, written last) being the completion tag; the host polls it instead of
+                               * dtqn_td_clip_adam also writes its statistics to slot ((call_index - 1) % slots), entry 9 (the
+                               * 1-based call index modulo 2^23 -- exact in f32 --, written last) being the completion tag; the host polls it instead of
                                * enqueueing a device->host copy and an event per update */
     int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls */
     const DtqnWJob* wjobs;    /* device copy of the job table */

@@ -73,6 +73,9 @@ def get_args(argv: Optional[Sequence[str]] = None):
     return p.parse_args(argv)
 
 
+TIME_CHECK_PERIOD = 256      # data-parallel runs: steps between collective --time-limit votes
+
+
 def evaluate(agent, eval_env, eval_episodes: int, render: Optional[bool] = None):
     """Greedy evaluation: (success rate, mean return, mean episode length)  (reference run.py:187-243)."""
     if render:
@@ -165,11 +168,21 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
             logger.log(log, step=timestep)
         if save_policy and timestep % 50_000 == 0 and is_main:
             torch.save(agent.policy_network.state_dict(), policy_path)
-        if time_remaining and time() - start >= time_remaining:
-            print(f"Reached time limit. Saving checkpoint with {agent.num_train_steps} steps completed.")
-            if is_main:
+        if time_remaining:
+            # one process: the wall clock decides.  Data parallel: every rank must leave on the SAME iteration (the others
+            # would block in the gradient all-reduce), so the ranks vote every TIME_CHECK_PERIOD steps
+            if not ddp.is_distributed():
+                stop = time() - start >= time_remaining
+            elif timestep % TIME_CHECK_PERIOD == 0:
+                stop = ddp.agree_any(time() - start >= time_remaining, agent.device)
+            else:
+                stop = False
+            if stop:
+                if is_main:
+                    print(f"Reached time limit. Saving checkpoint with {agent.num_train_steps} steps completed.")
+                # every rank writes: rank 0 the full checkpoint, replicas their replay shard and RNG streams
                 agent.save_checkpoint(policy_path, None, mean_success_rate, mean_reward, mean_episode_length, eps)
-            return
+                return
 
 
 def run_experiment(args):

@@ -505,6 +505,63 @@ def gen_G7():
     np.savez_compressed(os.path.join(HERE, "G7_misc.npz"), **out)
 
 
+def gen_G8():
+    """CSV logger rows (utils/logging_utils.py:42-109) for a scripted two-env log sequence incl. a resume (second
+    logger instance appends, writes no second header), and the initial-parameter statistics of DTQN.__init__
+    (utils/torch_utils.py:4-15 applied at dtqn/networks/dtqn.py:156): per state_dict entry mean / std / min / max of a
+    freshly constructed reference network, for the default, a GRU / action-embedding / discrete and a sinusoidal net."""
+    import argparse
+    import tempfile
+    from utils.logging_utils import CSVLogger as RefCSV
+    out = {"stamp": json.dumps(STAMP)}
+    envs = ["DiscreteCarFlag-v0", "Memory-5-v0"]
+    script = []
+    rng = np.random.Generator(np.random.PCG64(5))
+    for i in range(3):
+        row = {"losses/hours": float(rng.uniform(0, 2)), "losses/TD_Error": float(rng.uniform(0, 1)),
+               "losses/Grad_Norm": float(rng.uniform(0, 5)), "losses/Max_Q_Value": float(rng.normal()),
+               "losses/Mean_Q_Value": float(rng.normal()), "losses/Min_Q_Value": float(rng.normal()),
+               "losses/Max_Target_Value": float(rng.normal()), "losses/Mean_Target_Value": float(rng.normal()),
+               "losses/Min_Target_Value": float(rng.normal())}
+        for e in envs:
+            row.update({f"{e}/SuccessRate": float(rng.integers(0, 11)) / 10, f"{e}/EpisodeLength": float(rng.uniform(5, 200)),
+                        f"{e}/Return": float(rng.normal())})
+        script.append((row, 5000 * i))
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "run")
+        args = argparse.Namespace(envs=envs)
+        lg = RefCSV(path, args)
+        for row, step in script[:2]:
+            lg.log(row, step)
+        lg2 = RefCSV(path, args)                     # resume: files exist, no new header
+        lg2.log(*script[2])
+        out["csv_results"] = open(path + "_results.csv", newline="").read()
+        out["csv_losses"] = open(path + "_losses.csv", newline="").read()
+    out["csv_script"] = json.dumps([[r, s] for r, s in script])
+    out["csv_envs"] = json.dumps(envs)
+    # --- init statistics
+    cfgs = {"default": O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
+            "gru_a8_disc": O.NetCfg(obs_dim=10, num_actions=10, action_dim=8, inner_embed_size=128, num_heads=8, num_layers=2,
+                                    history_len=50, gate="gru", discrete=True, vocab_sizes=9),
+            "sin": O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=20, pos="sin")}
+    stats = {}
+    for name, cfg in cfgs.items():
+        torch.manual_seed(3)
+        net = RefDTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size, cfg.num_heads,
+                      cfg.num_layers, cfg.history_len, dropout=0.0, gate=cfg.gate, identity=cfg.identity, pos=cfg.pos,
+                      discrete=cfg.discrete, vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=0)
+        st = {}
+        for k, v in net.state_dict().items():
+            f = v.double()
+            fin = f[torch.isfinite(f)]
+            st[k] = {"shape": list(v.shape), "mean": float(fin.mean()), "std": float(fin.std(unbiased=False)) if fin.numel() > 1 else 0.0,
+                     "min": float(fin.min()), "max": float(fin.max()), "requires_grad": bool(dict(net.named_parameters()).get(k, v).requires_grad)
+                     if k in dict(net.named_parameters()) else None}
+        stats[name] = {"cfg": cfg.to_json(), "tensors": st}
+    out["init_stats"] = json.dumps(stats)
+    np.savez_compressed(os.path.join(HERE, "G8_logging_init.npz"), **out)
+
+
 def time_reference():
     """the reference's own DtqnAgent.train() on CPU, cfg 1 and 2."""
     res = {"stamp": STAMP, "nproc": os.cpu_count(), "runs": []}
@@ -538,10 +595,10 @@ def time_reference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "time"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "time"]
     torch.manual_seed(0)
     for w in which:
         t0 = time.time()
         {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
-         "time": time_reference}[w]()
+         "G8": gen_G8, "time": time_reference}[w]()
         print(f"{w}: done in {time.time() - t0:.1f}s")

@@ -229,42 +229,63 @@ import numpy as np, torch, torch.distributed as td
 from dtqn_amd import _binding as B, dist as ddp
 from oracle import dtqn_oracle as O
 from helpers import make_td_case
-from emu import emu_build
-rank, world, _ = ddp.init_from_env("cpu")
-emu = B.load_library(emu_build.build())
-cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8)
-# every rank builds the same replay; rank r trains on its own half of a 2*4 batch
-net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=4, T=12, n_eps=9, mask=-5)
+on_gpu = os.environ.get("DP_DEVICE", "cpu") == "cuda"
+rank, world, local = ddp.init_from_env("cuda" if on_gpu else "cpu")
+if on_gpu:
+    from dtqn_amd import engine
+    lib, dev, kw = engine.get_lib(), f"cuda:{local}", dict(device=f"cuda:{local}", test_lib=False)
+else:
+    from emu import emu_build
+    lib, dev, kw = B.load_library(emu_build.build()), "cpu", {}
+cfg = O.NetCfg(**eval(os.environ.get("DP_CFG", "dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8)")))
+Bl, T = int(os.environ.get("DP_BATCH", "4")), int(os.environ.get("DP_T", "12"))
+# every rank builds the same replay; rank r trains on its own slice of a world*Bl batch
+net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=Bl, T=T, n_eps=9 + 2 * Bl, mask=-5, **kw)
 random.seed(77)
-eps, starts = host.sample_indices(8)
+eps, starts = host.sample_indices(world * Bl)
 dp = ddp.DataParallel(eng)
 dp.broadcast_parameters()
-eng.set_indices(eps[rank * 4:(rank + 1) * 4], starts[rank * 4:(rank + 1) * 4])
-dp.update(rep)
-np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.numpy())
+# collective votes used by DtqnAgent.train() / run.py --time-limit: every rank gets the same answer
+assert ddp.agree_all(True, dev) is True and ddp.agree_all(rank != 1, dev) is False
+assert ddp.agree_any(False, dev) is False and ddp.agree_any(rank == 1, dev) is True
+for it in range(2):
+    eng.set_indices(eps[rank * Bl:(rank + 1) * Bl], starts[rank * Bl:(rank + 1) * Bl])
+    dp.update(rep)
+if on_gpu:
+    torch.cuda.synchronize()
+np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.cpu().numpy())
 if rank == 0:
     # single learner on the union batch
-    net1, _, host1, eng1, rep1 = make_td_case(emu, cfg, seed=21, batch=8, T=12, n_eps=9, mask=-5)
-    eng1.set_indices(eps, starts)
-    eng1.update(rep1)
-    np.save(os.environ["OUT"] + ".single.npy", eng1.theta_pol.numpy())
+    net1, _, host1, eng1, rep1 = make_td_case(lib, cfg, seed=21, batch=world * Bl, T=T, n_eps=9 + 2 * Bl, mask=-5, **kw)
+    for it in range(2):
+        eng1.set_indices(eps, starts)
+        eng1.update(rep1)
+    np.save(os.environ["OUT"] + ".single.npy", eng1.theta_pol.cpu().numpy())
     np.save(os.environ["OUT"] + ".stats.npy", np.array([eng.read_stats()["grad_norm"], eng1.read_stats()["grad_norm"]]))
 td.barrier()
+td.destroy_process_group()
 '''
 
 
-def test_data_parallel_equals_single_learner_gloo(emu, tmp_path):
-    """world_size 2 on CPU (gloo): all-reduced half-batches == one learner on the union batch."""
+def run_dp_script(tmp_path, env_extra, port):
     script = tmp_path / "dp.py"
     script.write_text(DP_SCRIPT.replace("@REPO@", REPO))
     out = str(tmp_path / "out")
-    env = dict(os.environ, OUT=out, HIPEMU_THREADS="2", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, OUT=out, HIPEMU_THREADS="2", MASTER_ADDR="127.0.0.1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", str(script)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     r0, r1, single = (np.load(out + s) for s in (".rank0.npy", ".rank1.npy", ".single.npy"))
     assert np.array_equal(r0, r1)                               # replicas stay bit-identical
     norms = np.load(out + ".stats.npy")
     assert abs(norms[0] - norms[1]) <= 1e-5 * norms[1]
-    assert np.abs(r0 - single).max() <= 2e-6                    # one Adam step, same gradient up to summation order
+    # two Adam steps from the same state; gradients equal up to summation order (a noise-floor gradient may flip a step's sign)
+    assert np.abs(r0 - single).max() <= 2.01 * 2 * 3e-4
+    assert np.mean(np.abs(r0 - single) <= 2e-6) > 0.98
+
+
+def test_data_parallel_equals_single_learner_gloo(emu, tmp_path):
+    """world_size 2 on CPU (gloo): all-reduced half-batches == one learner on the union batch, over two updates, plus the
+    collective votes DtqnAgent.train() and run.py use to keep ranks in the same control flow."""
+    run_dp_script(tmp_path, {}, 29611)
