@@ -13,6 +13,16 @@
 #ifndef DTQN_SPLIT_ATTN_MFMA
 #define DTQN_SPLIT_ATTN_MFMA 1
 #endif
+// Item guard of the register-accumulated stages.  -DDTQN_BWD_FOLD_GUARD=1 folds it for full rounds of items (as the
+// forward does): see DESIGN.md section 6 for what that exposed in the <D = 128, 16-row slice> instantiation.
+#ifndef DTQN_BWD_FOLD_GUARD
+#define DTQN_BWD_FOLD_GUARD 0
+#endif
+#if DTQN_BWD_FOLD_GUARD
+#define DTQN_BWD_GUARD(w, q) Own::valid_fast(w, q)
+#else
+#define DTQN_BWD_GUARD(w, q) Own::valid(w, q)
+#endif
 
 namespace dtqn {
 
@@ -220,19 +230,19 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                              const unsigned long long w = mw[(r >> 4) % MGH][r & 3];
                              W5[r * LD5 + c] = ((w >> t.lane) & 1ull) ? v : 0.f;
                          });
-                if (Own::valid(t.wave, 0))
+                if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
-                if (Own::valid(t.wave, 0)) {
+                if (DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
                     for (int q = 0; q < NC / 4; ++q) DTQN_ASM_KEEP(w1f[0][q]);
                 }
                 tile_store<NW>(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, t, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
-                    if (q + 1 < Own::PER_WAVE && Own::valid(t.wave, q + 1))
+                    if (q + 1 < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, q + 1))
                         frag_dyw_fetch<NC>(w1f[(q + 1) & 1], W1 + (size_t)c0 * D + Own::nt(t.wave, q + 1) * 16 + t.i, D, t);
-                    if (Own::valid(t.wave, q))
+                    if (DTQN_BWD_GUARD(t.wave, q))
                         frag_dyw_mma<NC, MGX>(W5 + Own::mg(t.wave, q) * MGX * 16 * LD5, LD5, w1f[q & 1], t, xacc[q]);
                 }
                 if (c0 + NC < 4 * D) g_dh.prefetch(W2 + c0 + NC, 4 * D, t);
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             float* dst = ident ? DU : DX;
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
-                if (Own::valid(t.wave, q)) {
+                if (DTQN_BWD_GUARD(t.wave, q)) {
                     const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
                     for (int m = 0; m < MGX; ++m)
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                              if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
                          });
                 // first W_in fragment of this wave in flight during the attention passes
-                if (Own::valid(t.wave, 0))
+                if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                                            fg + pair_id(sndr, slice), t);
                 }
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
-                if (Own::valid(t.wave, 0)) {
+                if (DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
                     for (int q = 0; q < GW / 4; ++q) DTQN_ASM_KEEP(winf[0][q]);
                 }
@@ -393,9 +403,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     for (int part = 0; part < 3; ++part) {
                         const int step = q * 3 + part;
                         const int nq = part < 2 ? q : q + 1, np = part < 2 ? part + 1 : 0;
-                        if (nq < Own::PER_WAVE && Own::valid(t.wave, nq))
+                        if (nq < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, nq))
                             frag_dyw_fetch<GW>(winf[(step + 1) & 1], Win + (size_t)(np * D + g * GW) * D + Own::nt(t.wave, nq) * 16 + t.i, D, t);
-                        if (Own::valid(t.wave, q)) {
+                        if (DTQN_BWD_GUARD(t.wave, q)) {
                             const float* rows = W5r + Own::mg(t.wave, q) * MGX * 16 * LD5 + (part == 0 ? 4 * GW : part * GW);
                             frag_dyw_mma<GW, MGX>(rows, LD5, winf[step & 1], t, xacc[q]);
                         }
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             float* dst = ident ? DU : DX;
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q) {
-                if (Own::valid(t.wave, q)) {
+                if (DTQN_BWD_GUARD(t.wave, q)) {
                     const int c = Own::nt(t.wave, q) * 16 + t.i;
 #pragma unroll
                     for (int m = 0; m < MGX; ++m)

@@ -12,7 +12,8 @@ import torch  # noqa: F401
 from . import _binding
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdtqn_hip.so")
+# DTQN_HIP_LIB: an alternative BUILD of the same engine (tools/build_variant.py, A/B experiments on the GPU box)
+LIB_PATH = os.environ.get("DTQN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdtqn_hip.so")
 
 
 class EngineUnavailable(RuntimeError):
