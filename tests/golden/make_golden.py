@@ -563,19 +563,36 @@ def gen_G8():
 
 
 def time_reference():
-    """the reference's own DtqnAgent.train() on CPU, cfg 1 and 2."""
-    res = {"stamp": STAMP, "nproc": os.cpu_count(), "runs": []}
-    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
-    for B in (32, 256):
+    """the reference's OWN DtqnAgent.train() on this container's CPU cores, BASELINE
+    configs 1-5 (synthetic replay of SURVEY.md section 8d; configs 3-5 at their per-GPU batch, a handful of updates
+    each -- one update of cfg 3 is seconds of CPU), threads = 8 and 1, median + p10 / p90.  -> ref_cpu_timing.json"""
+    res = {"stamp": STAMP, "nproc": os.cpu_count(), "cpu": "", "runs": []}
+    try:
+        res["cpu"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    cases = [
+        ("config1", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50), 32, 200, -5, (10, 100)),
+        ("config2", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50), 256, 200, -5, (3, 20)),
+        ("config3", O.NetCfg(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=8), 512, 50, 7, (1, 5)),
+        ("config4", O.NetCfg(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, num_layers=2, history_len=128, discrete=True, vocab_sizes=12), 128, 250, 11, (1, 4)),
+        ("config5", O.NetCfg(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, num_layers=2, history_len=256, discrete=True, vocab_sizes=22), 32, 256, 21, (1, 4)),
+    ]
+    only = os.environ.get("REF_TIME_ONLY")
+    for name, cfg, B, T, mask, (n_warm, n) in cases:
+        if only and name not in only.split(","):
+            continue
         for threads in (8, 1):
+            if threads == 1 and name in ("config3", "config4", "config5"):
+                n_warm, n = 1, 2
             torch.set_num_threads(threads)
             random.seed(1)
             ref_random.RNG.rng = np.random.Generator(np.random.PCG64(1))
             rng = np.random.Generator(np.random.PCG64(1))
             pol = O.init_params(cfg, seed=1)
-            agent = make_ref_agent(cfg, pol, pol, B, 200, 300, -5)
-            fill_agent(agent, synth_episodes(rng, 290, 200, cfg, min_len=5))
-            n_warm, n = (5, 40) if B == 32 else (2, 8)
+            n_eps = max(B + 8, 290) if T <= 64 else 290
+            agent = make_ref_agent(cfg, pol, pol, B, T, n_eps + 10, mask)
+            fill_agent(agent, synth_episodes(rng, n_eps, T, cfg, min_len=5))
             for _ in range(n_warm):
                 agent.train()
             ts = []
@@ -584,14 +601,13 @@ def time_reference():
                 agent.train()
                 ts.append(time.perf_counter() - t0)
             ts = np.array(ts) * 1e3
-            res["runs"].append({"config": f"cfg1-shapes B={B}", "threads": threads, "updates": n,
-                                "ms_median": float(np.median(ts)), "ms_p10": float(np.percentile(ts, 10)),
-                                "ms_p90": float(np.percentile(ts, 90)),
-                                "td_updates_per_s": float(1e3 / np.median(ts))})
-            print(res["runs"][-1])
+            res["runs"].append({"config": name, "workload": f"L={cfg.history_len} D={cfg.inner_embed_size} B={B} T={T}", "threads": threads,
+                                "updates": n, "ms_median": float(np.median(ts)), "ms_p10": float(np.percentile(ts, 10)),
+                                "ms_p90": float(np.percentile(ts, 90)), "td_updates_per_s": float(1e3 / np.median(ts))})
+            print(res["runs"][-1], flush=True)
+            with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
+                json.dump(res, f, indent=1)
     torch.set_num_threads(8)
-    with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
-        json.dump(res, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ def report(key, value):
         cur = json.load(open(path))
     except Exception:
         cur = {}
-    cur[key] = value
+    cur[key] = float(value) if isinstance(value, (np.floating, float, int)) else value
     with open(path, "w") as f:
         json.dump(cur, f, indent=1, sort_keys=True)
 
