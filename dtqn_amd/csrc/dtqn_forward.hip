@@ -8,6 +8,7 @@
 // straight out of the device-resident replay arrays.
 #include "dtqn_device.hpp"
 #include "dtqn_gru.hpp"
+#include "dtqn_wl.hpp"
 
 #ifndef DTQN_SPLIT_ATTN_MFMA
 #define DTQN_SPLIT_ATTN_MFMA 1
@@ -362,28 +363,358 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     DTQN_PROF(a.prof, ps++);       // end
 }
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS>
-__global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
-    const int which = ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
-    if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true>(a);
-    else forward_body<D, MT, HD, NW, GRU, RS, false>(a);
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weights-through-LDS forward (dtqn_wl.hpp): residual gate, D <= 64.  Same stages, records and results as forward_body;
+// every GEMM stage reads its weight tile (and bias / LayerNorm vectors) from LDS, where the tile was parked one stage
+// earlier:
+//   arena region A: W_in rows [0, 2D)  ->  FFN-1 chunk 0  ->  FFN-1 chunk 1  ->  next layer's W_in (or the head's W_1)
+//   arena region B: W_in rows [2D, 3D) | W_out  ->  FFN-2 chunk 0  ->  FFN-2 chunk 1  ->  next layer's W_in
+// A tile is loaded global -> registers at the start of the stage BEFORE the one that frees its region (so the L2 round
+// trip overlaps that stage's MFMAs), written to LDS right after the barrier that frees the region, and published by the
+// next barrier.  Per-layer vectors (13 D floats) sit in one of two parameter blocks, alternating by layer parity.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int MT, int HD, int NW, int RS, bool TRAIN>
+__device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
+    static_assert(RS == 1 || RS == 2, "one or two row slices");
+    static_assert(D <= 64, "the weight arena is sized for D <= 64");
+    constexpr int NT = NW * 64;
+    constexpr int LP = MT * 16;
+    constexpr int LPF = LP * RS;
+    constexpr int LDX = D + 4, LDW = 3 * D + 4;
+    constexpr int NC = 2 * D;                      // FFN hidden columns per pass (two passes)
+    constexpr int LWD = D + 4, LWC = NC + 4;       // leading dims of [.][D] and [D][NC] weight tiles in the arena
+    constexpr int OFF_B = 2 * D * LWD, OFF_WO = 3 * D * LWD;
+    // offsets inside a layer's parameter block (dtqn_layout.cpp: ln1 w,b | ln2 w,b | b_in | b_out | b_1 | b_2)
+    constexpr int P_LN1W = 0, P_LN1B = D, P_LN2W = 2 * D, P_LN2B = 3 * D, P_INB = 4 * D, P_OUTB = 7 * D, P_F1B = 8 * D, P_F2B = 12 * D;
+    constexpr int PSN = wl_small_floats(D);
+    static_assert(PSN / 4 <= NT, "one float4 of the parameter block per thread");
+    const DtqnNet& net = a.net;
+    const Thr t = make_thr();
+    const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;
+    const int R0 = slice * LP;
+    const int which = seq / a.batch;
+    const int b = seq - which * a.batch;
+    const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
+    const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
+    const int n = nfull - R0;
+    const bool ident = RS > 1 ? false : net.identity != 0;
+    float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
+    auto rf = [&](float* base, int off, int w) -> float* { return TRAIN ? base + off + (size_t)R0 * w : nullptr; };
+    auto mf = [&](float* base, int off, int ctiles) -> float* { return TRAIN ? base + off + (size_t)(R0 / 16) * ctiles * 8 : nullptr; };
+
+    float* Xs = reinterpret_cast<float*>(dtqn_smem);   // residual stream            [LP][LDX]
+    float* Ws = Xs + LP * LDX;                         // q|k|v (GLOBAL rows), FFN hidden, staging [LPF][LDW]
+    float* Us = Ws + LPF * LDW;                        // identity only: LN output   [LP][LDX]
+    float* Ps = Us + (net.identity != 0 ? LP * LDX : 0);   // parameter blocks       [2][13 D]
+    float* Ar = Ps + 2 * PSN;                          // weight arena               [4 D (D + 4)]
+    float* AW = Ws + R0 * LDW;
+
+    // layer 0's W_in and parameter block go in flight before the window gather
+    TileRegs<NW, 3 * D, D> tw_in;
+    TileRegs<NW, D, D> tw_hd;                          // the head's first matrix takes W_in's place after the last layer
+    float4 ps_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float* __restrict__ th0 = layer_theta(net, theta, 0);
+        tw_in.load(th0 + net.lo_in_w, D, t);
+        if (t.tid < PSN / 4) ps_reg = ld4(th0 + net.lo_ln1_w + 4 * t.tid);
+    }
+
+    // ---------------- window gather + embedding (as forward_body) ----------------
+    int ep, st;
+    if (a.ep_len != nullptr) {
+        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, (uint32_t)a.step_counter[1], b, ep, st);
+        if (which == 0 && slice == 0 && t.tid == 0) { a.ep_out[b] = ep; a.start_out[b] = st; }
+    } else {
+        ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
+        st = a.start != nullptr ? a.start[b] : 0;
+    }
+    const int row0 = st + (which > 0 ? 1 : 0) + R0;
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
+    const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
+    const int KE = net.ke, KEP = net.kep;
+    const float* __restrict__ We = theta + net.off_obs_w;
+    const float* __restrict__ be = theta + net.off_obs_b;
+    const float* __restrict__ pos = theta + net.off_pos + (size_t)R0 * D;
+    if (!net.discrete && KE <= 8) {
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
+            const int r = idx / D, d = idx - r * D;
+            float v = 0.f;
+            if (r < n) {
+                if (d < adim) {
+                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else {
+                    const float* w = We + (size_t)(d - adim) * KE;
+                    const float* e = obs_rows + (size_t)r * O;
+                    float acc = be[d - adim];
+                    for (int k = 0; k < KE; ++k) acc = fmaf(e[k], w[k], acc);
+                    v = acc;
+                }
+                v += pos[r * D + d];
+            }
+            Xs[r * LDX + d] = v;
+            if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
+        }
+        if (TRAIN)
+            for (int idx = t.tid; idx < LP * KEP; idx += NT) {
+                const int r = idx / KEP, k = idx - r * KEP;
+                rf(rec, net.ao_ein, KEP)[idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
+            }
+    } else {
+        float* ein = Ws;
+        for (int idx = t.tid; idx < LP * KEP; idx += NT) {
+            const int r = idx / KEP, k = idx - r * KEP;
+            float v = 0.f;
+            if (r < n && k < KE) {
+                if (net.discrete) {
+                    const int j = k / net.embed_per_obs, c = k - j * net.embed_per_obs;
+                    int tok = (int)obs_rows[(size_t)r * O + j];
+                    tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
+                    v = theta[net.off_obs_tab + tok * net.embed_per_obs + c];
+                } else {
+                    v = obs_rows[(size_t)r * O + k];
+                }
+            }
+            ein[idx] = v;
+            if (TRAIN) rf(rec, net.ao_ein, KEP)[idx] = v;
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
+            const int r = idx / D, d = idx - r * D;
+            float v = 0.f;
+            if (r < n) {
+                if (d < adim) {
+                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else {
+                    const float* w = We + (size_t)(d - adim) * KE;
+                    const float* e = ein + r * KEP;
+                    float acc = be[d - adim];
+                    for (int k = 0; k < KE; ++k) acc = fmaf(e[k], w[k], acc);
+                    v = acc;
+                }
+                v += pos[r * D + d];
+            }
+            Xs[r * LDX + d] = v;
+            if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
+        }
+    }
+    tw_in.to_lds(Ar, LWD, t);
+    if (t.tid < PSN / 4) st4(Ps + 4 * t.tid, ps_reg);
+
+    // ---------------- transformer layers ----------------
+    constexpr int MG2 = pick_mg(D / 16, MT, NW);
+    using Own = Owned<D, MT, MG2, NW>;
+    using GQkv = StageXwL<D, MT, pick_mg(3 * D / 16, MT, NW), NW, 3 * D / 16>;
+    using GOut = StageXwL<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16>;
+    using GF1 = StageXwL<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16>;
+    for (int l = 0; l < net.num_layers; ++l) {
+        const float* __restrict__ th = layer_theta(net, theta, l);
+        float* lrec = TRAIN ? rec + net.ao_layer0 + (size_t)l * net.act_layer_stride : nullptr;
+        const float* sm = Ps + (l & 1) * PSN;            // this layer's vectors
+        const float* src = Xs;
+        TileRegs<NW, D, D> tw_o;
+        tw_o.load(th + net.lo_out_w, D, t);              // in flight during the in-projection
+        __syncthreads();                                 // (a) residual stream, W_in and the parameter block visible
+        if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+                                  nullptr, rf(lrec, net.al_u1, D));
+            __syncthreads();
+            src = Us;
+        }
+        if (TRAIN && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
+        GQkv::run(src, LDX, Ar, sm + P_INB, t, [&](int r, int c, float v) { AW[r * LDW + c] = v; });
+        tw_o.to_lds(Ar + OFF_WO, LWD, t);                // behind W_in's last row: free since the previous layer's FFN
+        TileRegs<NW, NC, D> tw_1;
+        tw_1.load(th + net.lo_f1_w, D, t);               // FFN-1 chunk 0, in flight during attention
+        __syncthreads();                                 // (b) q | k | v visible; region A free
+        if (TRAIN) {
+            tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
+            __syncthreads();
+        }
+        if (RS == 2) {
+            float* xb = a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D;
+            int32_t* flag = a.xflags + (size_t)seq * net.num_layers + l;
+            if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+            else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
+        }
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF);
+        tw_1.to_lds(Ar, LWD, t);
+        TileRegs<NW, D, NC> tw_2;
+        tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
+        __syncthreads();                                 // (c) attention output visible
+        if (TRAIN) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
+        {   // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
+            float* m_g = mf(lrec, net.al_m1, D / 16);
+            GOut::run(AW, LDW, Ar + OFF_WO, sm + P_OUTB, t, [&](int r, int c, float v) {
+                const float y = fmaxf(v, 0.f);
+                if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                Xs[r * LDX + c] += y;
+            });
+        }
+        __syncthreads();                                 // (d) stream updated; region B free
+        tw_2.to_lds(Ar + OFF_B, LWC, t);
+        tw_1.load(th + net.lo_f1_w + (size_t)NC * D, D, t);   // FFN-1 chunk 1, in flight during LayerNorm + FFN chunk 0
+        if (!ident) {  // x = LN1(x)
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
+            src = Xs;
+        } else {       // x_norm2 = LN2(x)
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
+            src = Us;
+        }
+        __syncthreads();                                 // (e) LayerNorm output and FFN-2 chunk 0 visible
+        // FFN D -> 4D -> D in two hidden-column passes of NC; the second GEMM accumulates in registers
+        f32x4 facc[Own::PER_WAVE][MG2];
+#pragma unroll
+        for (int q = 0; q < Own::PER_WAVE; ++q)
+#pragma unroll
+            for (int m = 0; m < MG2; ++m) facc[q][m] = zero4();
+        float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
+        const bool more = l + 1 < net.num_layers;
+#pragma unroll
+        for (int c0 = 0; c0 < 4 * D; c0 += NC) {
+            GF1::run(src, LDX, Ar, sm + P_F1B + c0, t, [&](int r, int c, float v) {
+                const float hv = fmaxf(v, 0.f);
+                if (TRAIN) ballot_store(mh_g, 4 * D / 16, r, c0 + c, hv > 0.f, t.lane);
+                Ws[r * LDW + c] = hv;
+            });
+            __syncthreads();                             // (f) / (h) hidden chunk visible; region A free
+            if (c0 == 0) {
+                tw_1.to_lds(Ar, LWD, t);                 // FFN-1 chunk 1
+                tw_2.load(th + net.lo_f2_w + NC, 4 * D, t);   // FFN-2 chunk 1, in flight during FFN-2 chunk 0
+            }
+            if (TRAIN) tile_store<NW>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
+#pragma unroll
+            for (int q = 0; q < Own::PER_WAVE; ++q)
+                if (Own::valid_fast(t.wave, q))
+                    frag_xwl_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW,
+                                          Ar + OFF_B + (Own::nt(t.wave, q) * 16 + t.i) * LWC, t, facc[q]);
+            if (c0 == 0) {
+                __syncthreads();                         // (g) chunk 0 of the hidden and of W_2 consumed; FFN-1 chunk 1 visible
+                tw_2.to_lds(Ar + OFF_B, LWC, t);
+                // what the stage after this layer needs goes in flight now: the next layer's W_in and vectors, or the head's
+                if (more) {
+                    const float* __restrict__ thn = layer_theta(net, theta, l + 1);
+                    tw_in.load(thn + net.lo_in_w, D, t);
+                    if (t.tid < PSN / 4) ps_reg = ld4(thn + net.lo_ln1_w + 4 * t.tid);
+                } else {
+                    tw_hd.load(theta + net.off_head1_w, D, t);
+                    if (t.tid < D / 4) ps_reg = ld4(theta + net.off_head1_b + 4 * t.tid);
+                }
+            }
+        }
+        {
+            float* m_g = mf(lrec, net.al_m2, D / 16);
+#pragma unroll
+            for (int q = 0; q < Own::PER_WAVE; ++q) {
+                if (Own::valid_fast(t.wave, q)) {
+                    const int c = Own::nt(t.wave, q) * 16 + t.i;
+                    const float b2 = sm[P_F2B + c];
+#pragma unroll
+                    for (int m = 0; m < MG2; ++m)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
+                            const float y = fmaxf(facc[q][m][r4] + b2, 0.f);
+                            if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
+                            Xs[r * LDX + c] += y;
+                        }
+                }
+            }
+        }
+        __syncthreads();                                 // (i) stream updated; the whole arena is free
+        if (more) {
+            tw_in.to_lds(Ar, LWD, t);
+            if (t.tid < PSN / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
+        } else {
+            tw_hd.to_lds(Ar, LWD, t);
+            if (t.tid < D / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
+        }
+        if (!ident) {  // x = LN2(x)
+            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s2, D), nullptr);
+        } else if (TRAIN) {
+            tile_store<NW>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
+        }
+    }
+
+    // ---------------- Q head: Linear(D,D) -> ReLU -> Linear(D,A)  (dtqn.py:149-153,216) ----------------
+    __syncthreads();
+    if (TRAIN) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
+    GOut::run(Xs, LDX, Ar, Ps + (net.num_layers & 1) * PSN, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v, 0.f); });
+    __syncthreads();
+    if (TRAIN) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
+    {
+        const float* __restrict__ W2 = theta + net.off_head2_w;
+        const float* __restrict__ b2 = theta + net.off_head2_b;
+        float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride + (size_t)R0 * a.q_row_stride;
+        for (int idx = t.tid; idx < (n < LP ? n : LP) * A; idx += NT) {
+            const int r = idx / A, ac = idx - r * A;
+            const float* hrow = Ws + r * LDW;
+            const float* w = W2 + (size_t)ac * D;
+            float acc = b2[ac];
+#pragma unroll 8
+            for (int k = 0; k < D; k += 4) {
+                const float4 hv = ld4(hrow + k), wv = ld4(w + k);
+                acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+            }
+            q[r * a.q_row_stride + ac] = acc;
+            if (a.q_last_host != nullptr && seq == 0 && R0 + r == nfull - 1) a.q_last_host[ac] = acc;
+        }
+    }
 }
 
-static size_t fwd_lds_bytes(const DtqnNet* net) {
+// WL: weights through LDS (forward_body_wl; residual gate, D <= 64, chosen by the host when the arena fits)
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL>
+__global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+    const int which = ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
+    if constexpr (WL) {
+        if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true>(a);
+        else forward_body_wl<D, MT, HD, NW, RS, false>(a);
+    } else {
+        if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true>(a);
+        else forward_body<D, MT, HD, NW, GRU, RS, false>(a);
+    }
+}
+
+// Weights through LDS: residual gate, D <= 64, parameter-block layout as dtqn_layout.cpp writes it, arena fits.
+// DTQN_WL=0 in the environment keeps the register-direct stages (A/B runs).
+static bool fwd_wl_ok(const DtqnNet* net) {
+    const int D = net->d_model;
+    if (net->tiled || net->gate != DTQN_GATE_RES || D > 64) return false;
+    const char* e = getenv("DTQN_WL");
+    if (e != nullptr && e[0] == '0') return false;
+    const int b = net->lo_ln1_w;
+    return net->lo_ln1_b - b == D && net->lo_ln2_w - b == 2 * D && net->lo_ln2_b - b == 3 * D && net->lo_in_b - b == 4 * D &&
+           net->lo_out_b - b == 7 * D && net->lo_f1_b - b == 8 * D && net->lo_f2_b - b == 12 * D;
+}
+// lp_rows: rows of the [LP][.] tiles of the launch (0 = the network's padded context)
+static size_t fwd_lds_bytes(const DtqnNet* net, bool wl = false) {
     const int LP = net->lp, D = net->d_model;
     size_t fl = (size_t)LP * (D + 4) + (size_t)LP * (3 * D + 4);
     if (net->identity) fl += (size_t)LP * (D + 4);
+    if (wl) fl += 2 * (size_t)wl_small_floats(D) + (size_t)wl_arena_floats(D);
     return fl * sizeof(float);
 }
 
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL>
+static int launch_fwd3(const FwdArgs& a, int nseq, hipStream_t stream) {
+    const size_t lds = fwd_lds_bytes(&a.net, WL);
+    static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL>), lds, attr_lds);
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 static int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
-    const size_t lds = fwd_lds_bytes(&a.net);
-    static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>), lds, attr_lds);
-    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+    if constexpr (!GRU && D <= 64) {
+        if (fwd_wl_ok(&a.net) && fwd_lds_bytes(&a.net, true) <= 160 * 1024) return launch_fwd3<D, MT, HD, NW, GRU, RS, true>(a, nseq, stream);
+    }
+    return launch_fwd3<D, MT, HD, NW, GRU, RS, false>(a, nseq, stream);
 }
 template <int D, int MT, int HD, int NW>
 static int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {

@@ -71,18 +71,20 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (pos_trainable) net->off_pos = c.take(L * D);
     {
         Cursor lc;
+        // the 13 D floats of LayerNorm affines and biases first, contiguous: the kernels that stage parameters through LDS
+        // copy them as one block per layer (dtqn_wl.hpp)
         net->lo_ln1_w = lc.take(D);
         net->lo_ln1_b = lc.take(D);
         net->lo_ln2_w = lc.take(D);
         net->lo_ln2_b = lc.take(D);
-        net->lo_in_w = lc.take(3 * D * D);
         net->lo_in_b = lc.take(3 * D);
-        net->lo_out_w = lc.take(D * D);
         net->lo_out_b = lc.take(D);
-        net->lo_f1_w = lc.take(4 * D * D);
         net->lo_f1_b = lc.take(4 * D);
-        net->lo_f2_w = lc.take(4 * D * D);
         net->lo_f2_b = lc.take(D);
+        net->lo_in_w = lc.take(3 * D * D);
+        net->lo_out_w = lc.take(D * D);
+        net->lo_f1_w = lc.take(4 * D * D);
+        net->lo_f2_w = lc.take(4 * D * D);
         net->layer_stride = lc.pos;
     }
     net->off_layer0 = c.take(net->layer_stride * NL);
