@@ -410,6 +410,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     float* Ar = Ps + 2 * PSN;                          // weight arena               [4 D (D + 4)]
     float* AW = Ws + R0 * LDW;
 
+    int ps = 0;
+    DTQN_PROF(a.prof, ps++);
     // layer 0's W_in and parameter block go in flight before the window gather
     TileRegs<NW, 3 * D, D> tw_in;
     TileRegs<NW, D, D> tw_hd;                          // the head's first matrix takes W_in's place after the last layer
@@ -502,6 +504,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     }
     tw_in.to_lds(Ar, LWD, t);
     if (t.tid < PSN / 4) st4(Ps + 4 * t.tid, ps_reg);
+    DTQN_PROF(a.prof, ps++);   // embed done
 
     // ---------------- transformer layers ----------------
     constexpr int MG2 = pick_mg(D / 16, MT, NW);
@@ -529,6 +532,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         TileRegs<NW, NC, D> tw_1;
         tw_1.load(th + net.lo_f1_w, D, t);               // FFN-1 chunk 0, in flight during attention
         __syncthreads();                                 // (b) q | k | v visible; region A free
+        DTQN_PROF(a.prof, ps++);   // qkv done
         if (TRAIN) {
             tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
@@ -544,6 +548,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         TileRegs<NW, D, NC> tw_2;
         tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
         __syncthreads();                                 // (c) attention output visible
+        DTQN_PROF(a.prof, ps++);   // attention done
         if (TRAIN) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
         {   // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
             float* m_g = mf(lrec, net.al_m1, D / 16);
@@ -554,6 +559,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             });
         }
         __syncthreads();                                 // (d) stream updated; region B free
+        DTQN_PROF(a.prof, ps++);   // out-proj done
         tw_2.to_lds(Ar + OFF_B, LWC, t);
         tw_1.load(th + net.lo_f1_w + (size_t)NC * D, D, t);   // FFN-1 chunk 1, in flight during LayerNorm + FFN chunk 0
         if (!ident) {  // x = LN1(x)
@@ -566,6 +572,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             src = Us;
         }
         __syncthreads();                                 // (e) LayerNorm output and FFN-2 chunk 0 visible
+        DTQN_PROF(a.prof, ps++);   // LN1 done
         // FFN D -> 4D -> D in two hidden-column passes of NC; the second GEMM accumulates in registers
         f32x4 facc[Own::PER_WAVE][MG2];
 #pragma unroll
@@ -626,6 +633,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             }
         }
         __syncthreads();                                 // (i) stream updated; the whole arena is free
+        DTQN_PROF(a.prof, ps++);   // FFN done
         if (more) {
             tw_in.to_lds(Ar, LWD, t);
             if (t.tid < PSN / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
@@ -643,6 +651,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
 
     // ---------------- Q head: Linear(D,D) -> ReLU -> Linear(D,A)  (dtqn.py:149-153,216) ----------------
     __syncthreads();
+    DTQN_PROF(a.prof, ps++);       // layers done
     if (TRAIN) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
     GOut::run(Xs, LDX, Ar, Ps + (net.num_layers & 1) * PSN, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v, 0.f); });
     __syncthreads();
@@ -665,6 +674,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             if (a.q_last_host != nullptr && seq == 0 && R0 + r == nfull - 1) a.q_last_host[ac] = acc;
         }
     }
+    DTQN_PROF(a.prof, ps++);       // end
 }
 
 // WL: weights through LDS (forward_body_wl; residual gate, D <= 64, chosen by the host when the arena fits)

@@ -32,6 +32,7 @@ __device__ __forceinline__ void frag_xwl_mma(const float* Xs, int lda, const flo
             for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(xp + m * 16 * lda + 4 * (s + 1));
             bf[(s + 1) & 1] = ld4(wp + 4 * (s + 1));
         }
+        DTQN_SCHED_FENCE();      // the next step's LDS reads stay AHEAD of this step's MFMAs (hipcc otherwise sinks them behind)
         const float b4[4] = {bf[s & 1].x, bf[s & 1].y, bf[s & 1].z, bf[s & 1].w};
         if (MG == 1) {
             const float a4[4] = {af[s & 1][0].x, af[s & 1][0].y, af[s & 1][0].z, af[s & 1][0].w};

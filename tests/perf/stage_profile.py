@@ -27,7 +27,7 @@ for _ in range(N):
             continue
         acc[base + 1:base + n] += np.diff(seg[:n]) / 100.0     # 100 MHz -> us
         acc[base] += (seg[n - 1] - seg[0]) / 100.0
-fw = ["total", "embed"] + [f"L{l}:{s}" for l in range(2) for s in ("qkv", "attn", "outproj", "LN1", "FFN")] + ["head+Q"]
+fw = ["total", "embed"] + [f"L{l}:{s}" for l in range(2) for s in ("qkv", "attn", "outproj", "LN1", "FFN")] + ["LN2(last)", "head+Q"]
 bw = ["total", "loss", "head"] + [f"L{l}:{s}" for l in (1, 0) for s in ("LN2b", "FFNb", "LN1b", "dO", "attnb", "dqkvWin")] + ["tail"]
 print(f"row_split = {eng.row_split}")
 for name, base, labels in (("forward", 0, fw), ("backward", 64, bw)):
