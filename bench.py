@@ -135,34 +135,47 @@ def time_kernels(agent, iters: int = 50) -> dict:
     return out
 
 
-def pmc_traffic(kernel: str, batch: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic_B32.json;
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950's wide coalesced reads).  None when no profile matches this batch."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{batch}.json")
-    if not os.path.exists(path):
-        return None
-    d = json.load(open(path))
-    for k, v in d.items():
-        if kernel in k:
-            return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+def pmc_traffic(kernel: str, batch: int, cid: int = 1):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads): this
+    round's profile of the config (profiles/r02_pmc_traffic_cfg<N>.json) when it matches the batch, else round 1's
+    cfg-1 profile.  None when no profile matches."""
+    cands = [os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg{cid}.json")] if CONFIGS[cid]["B"] == batch else []
+    cands.append(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{batch}.json"))
+    for path in cands:
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        for k, v in d.items():
+            if kernel in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     return None
+
+
+def _oracle_learner(c, batch):
+    from oracle import dtqn_oracle as O
+    from oracle.replay_oracle import ReplayOracle, synth_fill
+    disc = c["kind"] != "box"
+    vocab = c["nvec"] + 1 if disc else 0                    # tokens 0..nvec-1 plus the padding mask value
+    cfg = O.NetCfg(obs_dim=c["O"], num_actions=c["A"], inner_embed_size=c["D"], num_heads=c["H"], num_layers=c["NL"],
+                   history_len=c["L"], discrete=disc, vocab_sizes=vocab)
+    learner = O.OracleLearner(cfg, O.init_params(cfg, seed=1))
+    n_eps = max(58, batch + 8) if c["T"] <= 64 else 58
+    buf = ReplayOracle((n_eps + 2) * c["T"], c["O"], c["nvec"] if disc else -5, c["T"], c["L"])
+    synth_fill(buf, np.random.Generator(np.random.PCG64(1)), n_eps, disc, vocab, c["A"], min_len=5)
+    ot = torch.long if disc else torch.float32
+
+    def one():
+        o, a, r, no, na, d, _ = buf.sample(batch)
+        learner.update(O.Batch(torch.as_tensor(o, dtype=ot), torch.as_tensor(a, dtype=torch.long), torch.as_tensor(r),
+                               torch.as_tensor(no, dtype=ot), torch.as_tensor(na, dtype=torch.long), torch.as_tensor(d, dtype=torch.long)))
+    return one
 
 
 def cpu_baseline(c, batch: int, budget_s: float = 15.0) -> dict:
     """The oracle (un-fused PyTorch-CPU eager port of the reference's path, parity-locked to the
     reference by tests/test_oracle_golden.py) timed on this host's cores, same shapes."""
-    from oracle import dtqn_oracle as O
-    from oracle.replay_oracle import ReplayOracle, synth_fill
-    cfg = O.NetCfg(obs_dim=c["O"], num_actions=c["A"], inner_embed_size=c["D"], num_heads=c["H"], num_layers=c["NL"], history_len=c["L"])
-    learner = O.OracleLearner(cfg, O.init_params(cfg, seed=1))
-    buf = ReplayOracle(60 * c["T"], c["O"], -5, c["T"], c["L"])
-    synth_fill(buf, np.random.Generator(np.random.PCG64(1)), 58, False, 0, c["A"], min_len=5)
-
-    def one():
-        o, a, r, no, na, d, _ = buf.sample(batch)
-        learner.update(O.Batch(torch.as_tensor(o), torch.as_tensor(a, dtype=torch.long), torch.as_tensor(r), torch.as_tensor(no),
-                               torch.as_tensor(na, dtype=torch.long), torch.as_tensor(d, dtype=torch.long)))
+    one = _oracle_learner(c, batch)
     for _ in range(3):
         one()
     # tiny-op workloads do not scale to every host core: sweep a few thread counts inside the budget
@@ -182,7 +195,39 @@ def cpu_baseline(c, batch: int, budget_s: float = 15.0) -> dict:
     return {"value": trials[best], "unit": "TD-updates/s", "cores": best, "kind": "port",
             "sample": f"~{budget_s:.0f} s of TD updates of the same workload (B={batch}, L={c['L']}, D={c['D']}) on the oracle; "
                       f"updates/s by torch thread count: {json.dumps({str(k): round(v, 2) for k, v in trials.items()})} "
-                      f"on a {avail}-core host"}
+                      f"on a {avail}-core host",
+            "reference_in_build_container": reference_cpu_numbers(1)}
+
+
+def cpu_baseline_other(cid: int, budget_s: float = 6.0) -> dict:
+    """BASELINE configs 2-5: a bounded sample of oracle updates (one warm-up, then whole updates until the budget is
+    spent, at least one) at the config's own batch, 8 threads (or all cores if fewer)."""
+    c = CONFIGS[cid]
+    avail = os.cpu_count() or 1
+    threads = min(8, avail)
+    torch.set_num_threads(threads)
+    one = _oracle_learner(c, c["B"])
+    one()
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or time.perf_counter() - t0 < budget_s:
+        one()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "TD-updates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} oracle update(s) of B={c['B']}, L={c['L']}, D={c['D']} ({dt * 1e3:.0f} ms each) on a {avail}-core host",
+            "reference_in_build_container": reference_cpu_numbers(cid)}
+
+
+def reference_cpu_numbers(cid: int):
+    """The REFERENCE's own DtqnAgent.train() timed in the build container (tests/golden/make_golden.py time ->
+    tests/golden/ref_cpu_timing.json: a committed data file; the reference itself never runs on the GPU box)."""
+    path = os.path.join(ROOT, "tests", "golden", "ref_cpu_timing.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    runs = [r for r in d["runs"] if r["config"] == f"config{cid}"]
+    return {"cpu": d.get("cpu", ""), "nproc": d["nproc"], "torch": d["stamp"]["torch"],
+            "runs": [{k: r[k] for k in ("threads", "updates", "ms_median", "ms_p10", "ms_p90", "td_updates_per_s")} for r in runs]}
 
 
 def make_agent(c, batch, device, rank, sampler):
@@ -196,9 +241,38 @@ def make_agent(c, batch, device, rank, sampler):
     return agent
 
 
-def other_configs(device, steps: int = 60) -> dict:
-    """BASELINE configs 2-5 at their per-GPU batch on this GPU: TD-updates/s and the achieved algorithmic
-    FP32 FLOP rate of the whole update (5 * B * L * F_tok) against the MFMA peak."""
+def update_latency(agent, n: int = 500) -> dict:
+    """Distribution of the GPU time of single updates: one HIP event pair per update on the launch stream, n updates
+    issued back to back (no host synchronisation in between), median / p10 / p90 in microseconds."""
+    stream = torch.cuda.current_stream()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    for _ in range(20):
+        agent.train()
+    evs[0].record(stream)
+    for i in range(n):
+        agent.train()
+        evs[i + 1].record(stream)
+    evs[-1].synchronize()
+    agent._drain_stats(block=True)
+    ts = np.array([evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(n)])
+    return {"updates": n, "us_median": float(np.median(ts)), "us_p10": float(np.percentile(ts, 10)), "us_p90": float(np.percentile(ts, 90)),
+            "us_mean": float(ts.mean())}
+
+
+def mfma_counters(cid: int):
+    """Hardware MFMA utilisation from the committed rocprofv3 --pmc pass of this config (tools/profile_round.sh ->
+    profiles/r02_pmc_mfma_cfg<N>.json), per kernel: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and the MFMA op count.
+    None when the round holds no such profile."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_mfma_cfg{cid}.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path))
+
+
+def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
+    """BASELINE configs 2-5 at their per-GPU batch on this GPU: TD-updates/s (wall clock over `steps` updates), the
+    per-update latency distribution, the achieved algorithmic FP32 FLOP rate of the whole update (5 * B * L * F_tok,
+    SURVEY.md section 8d) against the MFMA peak, the measured MFMA counters of the round's profile, and the CPU baseline."""
     out = {}
     for cid in (2, 3, 4, 5):
         c = CONFIGS[cid]
@@ -215,21 +289,25 @@ def other_configs(device, steps: int = 60) -> dict:
         gflop = 5 * c["B"] * c["L"] * f_tok(c) / 1e9
         out[f"config{cid}"] = {"workload": f"{c['name']}: ctx={c['L']}, d_model={c['D']}, {c['H']} heads, {c['NL']} layers, batch {c['B']}",
                                "td_updates_per_s": 1.0 / dt, "ms_per_update": dt * 1e3, "samples_per_s": c["B"] / dt,
+                               "update_latency_us": update_latency(agent, 300),
                                "algorithmic_gflop_per_update": gflop, "achieved_tflops": gflop / dt / 1e3,
                                "frac_of_f32_mfma_peak": gflop / dt / 1e3 / MFMA_F32_PEAK_TFLOPS,
+                               "mfma_counters": mfma_counters(cid),
                                "kernel_path": "row-block tiled" if agent.engine.net.tiled else "whole-sequence (LDS-resident)"}
         del agent
         torch.cuda.empty_cache()
+        if with_cpu:
+            out[f"config{cid}"]["cpu_baseline"] = cpu_baseline_other(cid)
     return out
 
 
-def env_step_rate(agent, seconds: float = 3.0) -> dict:
+def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0") -> dict:
     """Live actor loop on the host cores: epsilon-greedy get_action (GPU forward of the rolling
-    context) + CarFlag step + observe, and the reference's coupled 1 env step : 1 update loop."""
+    context) + env step + observe, and the reference's coupled 1 env step : 1 update loop."""
     import run as runpy
     from dtqn_amd.utils.epsilon_anneal import Constant
     from dtqn_amd.utils.random import set_global_seed
-    env = dt_envs.make("DiscreteCarFlag-v0")
+    env = dt_envs.make(env_id)
     set_global_seed(1, env)
     eps = Constant(0.1)
     out = {}
@@ -294,6 +372,23 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     agent._drain_stats(block=True)
+    allreduce_us = None
+    if world > 1:
+        # the one exchange step of an update, timed by itself (every rank takes part; rank 0 reports): the flat gradient
+        # all-reduce over RCCL, HIP events on the launch stream
+        stream = torch.cuda.current_stream()
+        ts = []
+        for i in range(60):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            agent.dp.allreduce_gradient()
+            e1.record(stream)
+            e1.synchronize()
+            if i >= 10:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        allreduce_us = {"median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90)),
+                        "bytes": int(agent.engine.grad.numel() * 4)}
+        sync_all()
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
@@ -321,13 +416,17 @@ def main():
                                    f"batch {args.batch} per GPU, history {c['L']}, device-resident replay {500_000 // c['T']} episodes x {c['T']} steps",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch),
-                         "algorithmic_flops_per_launch": flops, "launch_us": kern[dom]},
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch, args.config),
+                         "algorithmic_flops_per_launch": flops, "launch_us": kern[dom],
+                         "mfma_counters": mfma_counters(args.config)},
             "hbm_view": {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
                          "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "kernels_us": kern,
+            "kernels_us": kern, "kernels_us_sum": float(sum(kern.values())),
+            "update_latency_us": update_latency(agent),
             "algorithmic_gflop_per_update": 5 * tokens * ft / 1e9,
         }
+        if world > 1:
+            line["allreduce_us"] = allreduce_us
         if tiled:
             line["roofline"]["kernel"] = dom.replace("_kernel", "") + " stage (row-block tiled: a sequence of tl_* kernels)"
         if world == 1 and args.config == 1 and not args.no_other_configs:
@@ -340,8 +439,23 @@ def main():
                                                  "step; in the coupled loops env-steps/s == TD-updates/s as in the reference "
                                                  "(1 update per env step); 'overlapped' runs the actor forward of step t+1 "
                                                  "concurrently with update t+1 (run.py --overlap)"}
+        if world == 1 and args.config == 1 and not args.no_env_rate:
+            # live Memory-5-v0 (BASELINE config 3's env) on the host cores against the cfg-3 network on the GPU
+            c3 = CONFIGS[3]
+            env = dt_envs.make("Memory-5-v0")
+            from dtqn_amd.utils.random import set_global_seed
+            set_global_seed(1, env)
+            a3 = get_agent("DTQN", [env], 8, 0, c3["D"], 500_000, device, 3e-4, c3["B"], c3["L"], -1, c3["L"], 10_000, 0.99,
+                           c3["H"], c3["NL"], 0.0, False, "res", "learned", 0, sampler="device", sample_seed=1)
+            import run as runpy
+            runpy.prepopulate(a3, 30_000, [env])
+            r3 = env_step_rate(a3, 2.0, "Memory-5-v0")
+            line["env_steps_per_sec_config3"] = {"env": "Memory-5-v0 (live, host cores)", "batch": c3["B"], "actor_only": r3["actor_only"],
+                                                 "coupled_1_update_per_env_step": r3["coupled_1to1"],
+                                                 "coupled_overlapped_two_streams": r3["coupled_1to1_overlapped"]}
+            del a3
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(c, args.batch)
+            line["cpu_baseline"] = cpu_baseline(c, args.batch) if args.config == 1 else cpu_baseline_other(args.config, 12.0)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
