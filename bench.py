@@ -301,7 +301,7 @@ def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
     return out
 
 
-def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0") -> dict:
+def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0", vector_sizes=(8, 32)) -> dict:
     """Live actor loop on the host cores: epsilon-greedy get_action (GPU forward of the rolling
     context) + env step + observe, and the reference's coupled 1 env step : 1 update loop."""
     import run as runpy
@@ -327,6 +327,25 @@ def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0
             n += 1
         torch.cuda.synchronize()
         out[mode] = n / (time.perf_counter() - t0)
+    # vectorised rollout: N host environments, ONE batched actor launch per vector step, N updates per vector step (1 : 1)
+    from dtqn_amd.agents.vector import VectorActor
+    for N in vector_sizes:
+        venvs = [dt_envs.make(env_id) for _ in range(N)]
+        for k, e in enumerate(venvs):
+            e.seed(100 + k)
+        vec = VectorActor(agent, venvs)
+        for mode in ("actor_only", "coupled_1to1"):
+            vec.reset_all()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                vec.step_all(eps.val)
+                if mode == "coupled_1to1":
+                    for _ in range(N):
+                        agent.train()
+                n += N
+            torch.cuda.synchronize()
+            out[f"vector{N}_{mode}"] = n / (time.perf_counter() - t0)
+    agent._drain_stats(block=True)
     return out
 
 
@@ -435,7 +454,12 @@ def main():
             rates = env_step_rate(agent)
             line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
                                          "coupled_overlapped_two_streams": rates["coupled_1to1_overlapped"],
-                                         "note": "single host env (CarFlag on the host cores), batch-1 actor forward on the GPU per "
+                                         **{k: v for k, v in rates.items() if k.startswith("vector")},
+                                         "standalone_td_updates_per_s": ups,
+                                         "note": "vectorN_*: N host envs, one batched actor launch per vector step (dtqn_actor_forward_batch), "
+                                                 "N updates per vector step in the coupled loop (actor : learner = 1 : 1, actions of a vector "
+                                                 "step share one parameter version).  Others: "
+                                                 "single host env (CarFlag on the host cores), batch-1 actor forward on the GPU per "
                                                  "step; in the coupled loops env-steps/s == TD-updates/s as in the reference "
                                                  "(1 update per env step); 'overlapped' runs the actor forward of step t+1 "
                                                  "concurrently with update t+1 (run.py --overlap)"}
@@ -449,10 +473,11 @@ def main():
                            c3["H"], c3["NL"], 0.0, False, "res", "learned", 0, sampler="device", sample_seed=1)
             import run as runpy
             runpy.prepopulate(a3, 30_000, [env])
-            r3 = env_step_rate(a3, 2.0, "Memory-5-v0")
+            r3 = env_step_rate(a3, 2.0, "Memory-5-v0", vector_sizes=(8,))
             line["env_steps_per_sec_config3"] = {"env": "Memory-5-v0 (live, host cores)", "batch": c3["B"], "actor_only": r3["actor_only"],
                                                  "coupled_1_update_per_env_step": r3["coupled_1to1"],
-                                                 "coupled_overlapped_two_streams": r3["coupled_1to1_overlapped"]}
+                                                 "coupled_overlapped_two_streams": r3["coupled_1to1_overlapped"],
+                                                 **{k: v for k, v in r3.items() if k.startswith("vector")}}
             del a3
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(c, args.batch) if args.config == 1 else cpu_baseline_other(args.config, 12.0)

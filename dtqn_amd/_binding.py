@@ -94,6 +94,8 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_replay_push": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, vp],
+        "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, vp],
+        "dtqn_forward_tiled_strided": [P(DtqnNet), vp, vp, vp, i32, i32, i32, vp, vp, vp],
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
         "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],

@@ -1,0 +1,127 @@
+"""Vectorised rollout: N host environments per learner, ONE batched actor launch per vector step.
+
+The reference steps one environment per network forward (run.py:356-377); at 1 env step : 1 update the actor forward
+and the Python env step sit on the critical path of every update.  `VectorActor` keeps N environments and N rolling
+contexts, stages all N prefixes through one pinned buffer, runs `dtqn_actor_forward_batch` (ragged prefixes in one
+launch: every sequence runs max n_i rows, causality keeps shorter prefixes exact) and reads the N Q-rows back from
+pinned memory.
+
+Replay semantics stay the reference's: an episode becomes sampleable when it has FINISHED (replay_buffer.py:141-145
+excludes the slot in progress).  With N episodes in progress at once, each environment collects its episode on the
+host and replays it into the buffer's producer API (store_obs, store x len, flush) when it ends, so the device arrays
+hold exactly what the single-environment loop would have written for that episode.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .. import _binding as B
+from ..utils.context import Context
+from ..utils.random import RNG
+
+
+class VectorActor:
+    def __init__(self, agent, envs: Sequence, ref_quirks: bool = False):
+        self.agent, self.envs = agent, list(envs)
+        N = self.n = len(self.envs)
+        L, O, A = agent.context_len, agent.env_obs_length, agent.num_actions
+        self.L, self.O, self.A = L, O, A
+        self.contexts: List[Context] = [Context(L, agent.obs_mask, A, O, discrete=agent.is_discrete_env, ref_quirks=ref_quirks)
+                                        for _ in range(N)]
+        self.episodes = [[] for _ in range(N)]            # per env: [first_obs, (obs, action, reward, done), ...]
+        self.returns = np.zeros(N)
+        cuda = agent.device.type == "cuda"
+        obs_bytes = N * L * O * 4
+        act_bytes = (N * L + 3) & ~3
+        total = obs_bytes + act_bytes + 4 * N
+        pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        self._ctx_h = pin(torch.zeros(total, dtype=torch.uint8))
+        self._ctx_d = torch.zeros(total, dtype=torch.uint8, device=agent.device)
+        buf = self._ctx_h.numpy()
+        self._obs_np = buf[:obs_bytes].view(np.float32).reshape(N, L, O)
+        self._act_np = buf[obs_bytes:obs_bytes + N * L].reshape(N, L)
+        self._len_np = buf[obs_bytes + act_bytes:].view(np.int32)
+        self._q_d = torch.zeros(N * L * A, device=agent.device)
+        self._q_h = pin(torch.zeros(N, A))
+        self._q_np = self._q_h.numpy()
+        eng = agent.engine
+        need = eng.lib.dtqn_forward_workspace_floats(eng._net_ref, N)
+        self._ws = torch.zeros(max(1, need), dtype=torch.float32, device=agent.device)
+        self._ws_p = ctypes.c_void_p(self._ws.data_ptr()) if need > 0 else None
+        self._p = [ctypes.c_void_p(t.data_ptr()) for t in (self._ctx_h, self._ctx_d, self._q_d, self._q_h)]
+        self.steps = 0
+        self.episodes_done = 0
+
+    # ------------------------------------------------------------------------------------------
+    def reset_all(self) -> None:
+        for i, env in enumerate(self.envs):
+            self._reset(i)
+
+    def _reset(self, i: int) -> None:
+        obs = self.envs[i].reset()
+        self.contexts[i].reset(obs)
+        self.episodes[i] = [np.array(obs, copy=True)]
+        self.returns[i] = 0.0
+
+    def q_values(self) -> np.ndarray:
+        """Q[:, -1] of every actor's current context: one launch, [N][A] (pinned host view; valid until the next call)."""
+        a, eng = self.agent, self.agent.engine
+        n_max = 1
+        for i, ctx in enumerate(self.contexts):
+            n = min(ctx.max_length, ctx.timestep + 1)
+            self._obs_np[i, :n] = ctx.obs[:n]
+            self._act_np[i, :n] = ctx.action[:n, 0]
+            self._len_np[i] = n
+            n_max = max(n_max, n)
+        stream = eng._stream()
+        rc = eng.lib.dtqn_actor_forward_batch(eng._net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
+                                              self._ws_p, stream)
+        if rc == B.DEFINES["DTQN_ERR_ARG"]:
+            raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
+        if rc != 0:
+            raise RuntimeError(f"dtqn_actor_forward_batch failed with DTQN status {rc}")
+        if a._main_stream is not None:
+            a._main_stream.synchronize()
+        return self._q_np
+
+    def act(self, epsilon: float) -> np.ndarray:
+        """Epsilon-greedy actions for all N environments (dtqn.py:76-107 per actor; draws from RNG.rng in env order)."""
+        explore = RNG.rng.random(self.n) < epsilon
+        actions = np.zeros(self.n, dtype=np.int64)
+        if not explore.all():
+            actions[:] = np.argmax(self.q_values(), axis=1)            # first max, like torch.argmax
+        if explore.any():
+            actions[explore] = RNG.rng.integers(self.A, size=int(explore.sum()))
+        return actions
+
+    def step_all(self, epsilon: float) -> int:
+        """One vector step: act, step every environment, record; finished episodes are replayed into the buffer and their
+        environments reset.  Returns the number of episodes that finished."""
+        actions = self.act(epsilon)
+        done_count = 0
+        for i, env in enumerate(self.envs):
+            a = int(actions[i])
+            obs, reward, done, info = env.step(a)
+            stored_done = False if info.get("TimeLimit.truncated", False) else done     # run.py:368-376
+            self.contexts[i].add_transition(obs, a, reward, stored_done)
+            self.episodes[i].append((np.array(obs, copy=True), a, float(reward), bool(stored_done)))
+            self.returns[i] += reward
+            if done:
+                self._commit_episode(i)
+                self._reset(i)
+                done_count += 1
+        self.steps += self.n
+        self.episodes_done += done_count
+        return done_count
+
+    def _commit_episode(self, i: int) -> None:
+        rb = self.agent.replay_buffer
+        ep = self.episodes[i]
+        rb.store_obs(ep[0])
+        for t, (obs, a, r, d) in enumerate(ep[1:]):
+            rb.store(obs, a, r, d, t + 1)
+        rb.flush()

@@ -63,8 +63,10 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
 //    pinned host memory itself.
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows);
 }
+extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                                          int batch, int n, int in_rows, float* q_out, float* workspace, void* stream);
 
 extern "C" int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, const float* obs_host, int n,
                                 void* stream) {
@@ -89,7 +91,7 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
         const bool split = workspace != nullptr && n > net->lp / 2 && dtqn_td_row_split(net, 1) >= 2;
         float* xch = split ? workspace : nullptr;
         int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, 1)) : nullptr;
-        return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags);
+        return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags, nullptr, 0);
     }
     const int rc = dtqn_forward_tiled(net, theta, obs, actions, 1, n, q_dev, workspace, stream);
     if (rc != DTQN_OK) return rc;
@@ -97,4 +99,41 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
                        hipMemcpyDeviceToHost, s) != hipSuccess)
         return DTQN_ERR_LAUNCH;
     return DTQN_OK;
+}
+
+// The same for N actors at once (vectorised rollout: N host environments per learner, one launch per vector step).
+// ctx_host is PINNED: [N][ctx_len * obs_dim f32] observations | [N][ctx_len u8] actions | [N] int32 live rows n_i (1..ctx_len),
+// copied to ctx_dev (same layout) in ONE hipMemcpyAsync.  Every sequence runs n_max = max n_i rows -- attention is causal, so
+// the rows behind a shorter prefix cannot reach its last live row -- and Q of row n_i - 1 of sequence i lands in the pinned
+// q_last_host[i][num_actions], written by the kernel (valid once `stream` has drained).  q_dev: [N][n_max][num_actions].
+// workspace as dtqn_actor_forward with batch N: dtqn_forward_workspace_floats(net, N) floats, zeroed once.
+extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n_envs,
+                                        int n_max, float* q_dev, float* q_last_host, float* workspace, void* stream) {
+    if (!net || !theta || !ctx_host || !ctx_dev || !q_dev || !q_last_host || n_envs < 1) return DTQN_ERR_ARG;
+    if (n_max < 1 || n_max > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
+    hipStream_t s = (hipStream_t)stream;
+    const int L = net->ctx_len;
+    const size_t obs_bytes = sizeof(float) * (size_t)n_envs * L * net->obs_dim;
+    const size_t act_bytes = (((size_t)n_envs * L) + 3) & ~(size_t)3;       // keeps the int32 block 4-byte aligned
+    const size_t total = obs_bytes + act_bytes + sizeof(int32_t) * (size_t)n_envs;
+    if (hipMemcpyAsync(ctx_dev, ctx_host, total, hipMemcpyHostToDevice, s) != hipSuccess) return DTQN_ERR_LAUNCH;
+    const float* obs = static_cast<const float*>(ctx_dev);
+    const uint8_t* actions = static_cast<const uint8_t*>(ctx_dev) + obs_bytes;
+    const int32_t* lens = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_dev) + obs_bytes + act_bytes);
+    if (net->tiled) {
+        // row-block tiled nets: the forward leaves Q in q_dev; the last rows come back with one small copy per actor
+        const int rc = dtqn_forward_tiled_strided(net, theta, obs, actions, n_envs, n_max, L, q_dev, workspace, stream);
+        if (rc != DTQN_OK) return rc;
+        const int32_t* lens_h = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_host) + obs_bytes + act_bytes);
+        for (int i = 0; i < n_envs; ++i)
+            if (hipMemcpyAsync(q_last_host + (size_t)i * net->num_actions, q_dev + ((size_t)i * n_max + (lens_h[i] - 1)) * net->num_actions,
+                               sizeof(float) * net->num_actions, hipMemcpyDeviceToHost, s) != hipSuccess)
+                return DTQN_ERR_LAUNCH;
+        return DTQN_OK;
+    }
+    // few actors: two workgroups per sequence once the longest prefix reaches the upper half (workspace = hand-over tiles | flags)
+    const bool split = workspace != nullptr && n_max > net->lp / 2 && dtqn_td_row_split(net, n_envs) >= 2;
+    float* xch = split ? workspace : nullptr;
+    int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, n_envs)) : nullptr;
+    return dtqn::forward_infer(net, theta, obs, actions, n_envs, n_max, q_dev, q_last_host, stream, xch, xflags, lens, L);
 }

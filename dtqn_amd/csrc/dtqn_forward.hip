@@ -31,7 +31,8 @@ struct FwdArgs {
     float* q_out;               // which-major
     long long q_which_stride, q_seq_stride;
     int q_row_stride;
-    float* q_last_host;         // optional, PINNED host memory [num_actions]: Q of the last live row of sequence 0 (actor)
+    float* q_last_host;         // optional, PINNED host memory [batch][num_actions]: Q of the last live row of every sequence (actor)
+    const int32_t* last_rows;   // optional [batch]: live rows n_i per sequence (ragged prefixes in one launch): that row is n_i - 1; nullptr = n - 1
     float* act;                 // nullptr: inference; else activation records for which == 0
     float* xch;                 // row-split hand-over buffer / flags (RS == 2 only)
     int32_t* xflags;
@@ -357,7 +358,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
             }
             q[r * a.q_row_stride + ac] = acc;
             // the actor only needs Q[:, -1] (dtqn.py:103): written straight into host memory, no copy enqueued behind the kernel
-            if (a.q_last_host != nullptr && seq == 0 && R0 + r == nfull - 1) a.q_last_host[ac] = acc;
+            if (a.q_last_host != nullptr && R0 + r == (a.last_rows != nullptr ? a.last_rows[seq] - 1 : nfull - 1)) a.q_last_host[seq * A + ac] = acc;
         }
     }
     DTQN_PROF(a.prof, ps++);       // end
@@ -671,7 +672,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
             }
             q[r * a.q_row_stride + ac] = acc;
-            if (a.q_last_host != nullptr && seq == 0 && R0 + r == nfull - 1) a.q_last_host[ac] = acc;
+            if (a.q_last_host != nullptr && R0 + r == (a.last_rows != nullptr ? a.last_rows[seq] - 1 : nfull - 1)) a.q_last_host[seq * A + ac] = acc;
         }
     }
     DTQN_PROF(a.prof, ps++);       // end
@@ -787,15 +788,16 @@ extern "C" int dtqn_lds_bytes_forward(const DtqnNet* net, int /*training*/) {
 
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows);
 }
 extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                             int batch, int n, float* q_out, void* stream) {
-    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream, nullptr, nullptr);
+    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream, nullptr, nullptr, nullptr, 0);
 }
 // xch / xflags != nullptr: latency mode, two workgroups per sequence (the caller decided it pays: dtqn_actor_forward)
 int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                        float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags) {
+                        float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows,
+                        int in_rows) {
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->tiled) return DTQN_ERR_CONFIG;                             // use dtqn_forward_tiled
@@ -804,8 +806,10 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.net = *net;
     a.theta_a = theta; a.theta_b = theta;
     a.obs = obs; a.actions = actions;
-    a.obs_ep_stride = (long long)n * net->obs_dim;
-    a.act_ep_stride = n;
+    if (in_rows <= 0) in_rows = n;              // rows per sequence in the input arrays (the batched actor packs whole contexts)
+    if (in_rows < n) return DTQN_ERR_ARG;
+    a.obs_ep_stride = (long long)in_rows * net->obs_dim;
+    a.act_ep_stride = in_rows;
     a.ep_idx = nullptr; a.start = nullptr;
     a.n = n; a.batch = batch;
     a.q_out = q_out;
@@ -813,6 +817,7 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.q_seq_stride = (long long)n * net->num_actions;
     a.q_row_stride = net->num_actions;
     a.q_last_host = q_last_host;
+    a.last_rows = last_rows;
     a.act = nullptr;
     a.xch = xch; a.xflags = xflags;
     a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
@@ -859,6 +864,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.q_seq_stride = (long long)net->lp * net->ap;
     a.q_row_stride = net->ap;
     a.q_last_host = nullptr;
+    a.last_rows = nullptr;
     a.act = td->act;
     a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());

@@ -1027,16 +1027,17 @@ extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
     return fl < 0x7fffffffLL ? (int)fl : 0;
 }
 
-extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
-                                  int batch, int n, float* q_out, float* workspace, void* stream) {
+// in_rows: rows per sequence in the obs / actions arrays (>= n; the batched actor packs whole contexts)
+extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                                          int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
     if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
-    if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
+    if (n < 1 || n > net->ctx_len || in_rows < n) return DTQN_ERR_ARG;  // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
     if (!net->tiled) return DTQN_ERR_CONFIG;
     hipStream_t s = (hipStream_t)stream;
     EmbedSrc src;
     src.obs = obs; src.actions = actions;
-    src.obs_ep_stride = (long long)n * net->obs_dim; src.act_ep_stride = n;
+    src.obs_ep_stride = (long long)in_rows * net->obs_dim; src.act_ep_stride = in_rows;
     src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
     const long long qs = (long long)n * net->num_actions;
     switch (net->d_model) {
@@ -1045,4 +1046,9 @@ extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const 
         case 256: return forward_records<256>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
         default: return DTQN_ERR_CONFIG;
     }
+}
+
+extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                                  int batch, int n, float* q_out, float* workspace, void* stream) {
+    return dtqn_forward_tiled_strided(net, theta, obs, actions, batch, n, n, q_out, workspace, stream);
 }

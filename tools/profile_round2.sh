@@ -23,7 +23,7 @@ for C in $CFGS; do
     rocprofv3 --kernel-trace --pmc $P -d $OUT/pmc_$N -- $BENCH > $OUT/bench_pmc_$N.log 2>&1
   done
   python tools/pmc_collect.py $OUT
-  rm -rf $OUT/pmc_*
+  rm -rf $OUT/pmc_*/
   head -14 $OUT/kernel_stats.md
   cat $OUT/pmc_mfma.json | head -40
 done
