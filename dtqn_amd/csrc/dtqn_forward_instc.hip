@@ -1,0 +1,6 @@
+// Explicit instantiations of the forward kernels, group C (see dtqn_forward_body.hpp).
+#include "dtqn_forward_body.hpp"
+
+namespace dtqn {
+DTQN_FWD_GROUP_C(DTQN_FWD_DEF)
+}  // namespace dtqn
