@@ -9,7 +9,6 @@
 #include "dtqn_device.hpp"
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
-#include "dtqn_backward_args.hpp"
 
 #ifndef DTQN_SPLIT_ATTN_MFMA
 #define DTQN_SPLIT_ATTN_MFMA 1
@@ -27,6 +26,27 @@
 
 namespace dtqn {
 
+struct BwdArgs {
+    DtqnNet net;
+    const float* theta;          // policy parameters
+    const float* act;            // [B][act_stride] saved by the training forward
+    float* grd;                  // [B][grd_stride]
+    float* small;                // [B][sp_stride]
+    const float* q3;             // [3][B][LP][AP]
+    float* stats_partial;        // [B][8]
+    const float* obs;            // replay arrays (actions / rewards / dones of the sampled window)
+    const uint8_t* actions;
+    const float* rewards;
+    const uint8_t* dones;
+    long long obs_ep_stride, act_ep_stride, rew_ep_stride;
+    const int32_t* ep_idx;
+    const int32_t* start;
+    int batch, history;
+    float gamma;
+    long long* prof;             // debug stage clock
+    float* xch;                  // row-split hand-over buffer / flags (RS > 1 only)
+    int32_t* xflags;
+};
 
 // RS = row slices per sequence (see dtqn_forward.hip).  RS == 2: the workgroup owns rows [R0, R0 + LP); attention is
 // the only stage that looks below R0 (keys / values of the lower rows, read from the forward's record) and the only one
@@ -534,14 +554,6 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.xch = td->xch; a.xflags = td->xflags;
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
-    {   // weights through LDS (dtqn_backward_wl.hip) where it is covered and fits; else the register-direct kernels below
-        const int rs = (td->row_split == 2 || td->row_split == 4) ? td->row_split : 1;
-        const bool sliced_ok = rs == 1 || (net->lp == 64 && a.xch && a.xflags);
-        if (sliced_ok && bwd_wl_ok(net, rs)) {
-            const int rc = launch_bwd_wl(a, D, MT / rs, HD, NW, rs, s);
-            if (rc != DTQN_ERR_CONFIG) return rc;
-        }
-    }
     if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)
         if (net->lp != 64 || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
         if (net->gate == DTQN_GATE_GRU) {

@@ -67,17 +67,11 @@ struct StageXwL {
     static constexpr int LDWL = K + 4;
     template <typename Epi>
     __device__ static __forceinline__ void run(const float* Xs, int lda, const float* Wl, const float* bl, const Thr& t, Epi epi) {
-        run(Xs, lda, Wl, bl, t, [](int, int) {}, epi);
-    }
-    // pre(nt, mg) runs before the MFMAs of each item: the place to issue the loads its epilogue needs
-    template <typename Pre, typename Epi>
-    __device__ static __forceinline__ void run(const float* Xs, int lda, const float* Wl, const float* bl, const Thr& t, Pre pre, Epi epi) {
 #pragma unroll
         for (int q = 0; q < PER_WAVE; ++q) {
             const int item = t.wave + q * NW;
             if (ITEMS >= (q + 1) * NW || item < ITEMS) {
                 const int nt = item / MGROUPS, mg = item - nt * MGROUPS;
-                pre(nt, mg);
                 const float bias = bl != nullptr ? bl[nt * 16 + t.i] : 0.f;
                 f32x4 acc[MG];
 #pragma unroll
