@@ -338,10 +338,8 @@ def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0
             vec.reset_all()
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                vec.step_all(eps.val)
-                if mode == "coupled_1to1":
-                    for _ in range(N):
-                        agent.train()
+                # coupled: the N updates are queued behind the actor forward and run while the host steps the N envs
+                vec.step_all(eps.val, updates=N if mode == "coupled_1to1" else 0)
                 n += N
             torch.cuda.synchronize()
             out[f"vector{N}_{mode}"] = n / (time.perf_counter() - t0)

@@ -53,6 +53,7 @@ class VectorActor:
         self._ws = torch.zeros(max(1, need), dtype=torch.float32, device=agent.device)
         self._ws_p = ctypes.c_void_p(self._ws.data_ptr()) if need > 0 else None
         self._p = [ctypes.c_void_p(t.data_ptr()) for t in (self._ctx_h, self._ctx_d, self._q_d, self._q_h)]
+        self._ev = torch.cuda.Event() if cuda else None      # completion of the batched actor forward alone
         self.steps = 0
         self.episodes_done = 0
 
@@ -67,8 +68,8 @@ class VectorActor:
         self.episodes[i] = [np.array(obs, copy=True)]
         self.returns[i] = 0.0
 
-    def q_values(self) -> np.ndarray:
-        """Q[:, -1] of every actor's current context: one launch, [N][A] (pinned host view; valid until the next call)."""
+    def _launch_q(self) -> None:
+        """Stage all N contexts and launch the batched actor forward on the learner's stream (no synchronisation)."""
         a, eng = self.agent, self.agent.engine
         n_max = 1
         for i, ctx in enumerate(self.contexts):
@@ -77,31 +78,53 @@ class VectorActor:
             self._act_np[i, :n] = ctx.action[:n, 0]
             self._len_np[i] = n
             n_max = max(n_max, n)
-        stream = eng._stream()
         rc = eng.lib.dtqn_actor_forward_batch(eng._net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
-                                              self._ws_p, stream)
+                                              self._ws_p, eng._stream())
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         if rc != 0:
             raise RuntimeError(f"dtqn_actor_forward_batch failed with DTQN status {rc}")
-        if a._main_stream is not None:
-            a._main_stream.synchronize()
+        if self._ev is not None:
+            self._ev.record(a._main_stream)
+
+    def _wait_q(self) -> np.ndarray:
+        if self._ev is not None:
+            self._ev.synchronize()              # the forward only: work queued behind it (TD updates) keeps running
         return self._q_np
 
-    def act(self, epsilon: float) -> np.ndarray:
-        """Epsilon-greedy actions for all N environments (dtqn.py:76-107 per actor; draws from RNG.rng in env order)."""
+    def q_values(self) -> np.ndarray:
+        """Q[:, -1] of every actor's current context: one launch, [N][A] (pinned host view; valid until the next call)."""
+        self._launch_q()
+        return self._wait_q()
+
+    def act(self, epsilon: float, between=None) -> np.ndarray:
+        """Epsilon-greedy actions for all N environments (dtqn.py:76-107 per actor; draws from RNG.rng in env order).
+        between(): called after the actor forward has been launched and before its result is awaited -- the place to
+        queue GPU work that may run while the host steps the environments."""
         explore = RNG.rng.random(self.n) < epsilon
         actions = np.zeros(self.n, dtype=np.int64)
-        if not explore.all():
-            actions[:] = np.argmax(self.q_values(), axis=1)            # first max, like torch.argmax
+        greedy = not explore.all()
+        if greedy:
+            self._launch_q()
+        if between is not None:
+            between()
+        if greedy:
+            actions[:] = np.argmax(self._wait_q(), axis=1)            # first max, like torch.argmax
         if explore.any():
             actions[explore] = RNG.rng.integers(self.A, size=int(explore.sum()))
         return actions
 
-    def step_all(self, epsilon: float) -> int:
+    def step_all(self, epsilon: float, updates: int = 0) -> int:
         """One vector step: act, step every environment, record; finished episodes are replayed into the buffer and their
-        environments reset.  Returns the number of episodes that finished."""
-        actions = self.act(epsilon)
+        environments reset.  updates > 0: that many agent.train() calls are QUEUED right behind the actor forward, so the
+        GPU runs them while the host steps the N environments (the actions of this vector step come from the parameters
+        before those updates, exactly as when train() is called after the step).  Returns the number of finished episodes."""
+        agent = self.agent
+
+        def queue_updates():
+            for _ in range(updates):
+                agent.train()
+        actions = self.act(epsilon, queue_updates if updates > 0 else None)
         done_count = 0
         for i, env in enumerate(self.envs):
             a = int(actions[i])

@@ -149,9 +149,8 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
         vector.reset_all()
     for timestep in range(agent.num_train_steps, total_steps):
         if vector is not None:
-            if timestep % vector.n == 0:
-                vector.step_all(eps.val)
-            agent.train()
+            if timestep % vector.n == 0:       # N env steps and the N updates that go with them (queued behind the actor forward)
+                vector.step_all(eps.val, updates=min(vector.n, total_steps - timestep))
         elif overlap:
             if step_overlapped(agent, env, eps):       # includes this step's train()
                 agent.replay_buffer.flush()

@@ -95,6 +95,34 @@ def make_td_case(lib, cfg, *, seed, batch, T, n_eps, mask, history=None, tuf=10_
     return net, oracle, host, eng, rep
 
 
+def engine_probe(cfg, net, eng):
+    """The engine's own ReLU activation patterns (decoded from its saved ballots / hidden record) and double-DQN argmax
+    choices, in the order oracle.td_gradients consumes them: gradients are compared CONDITIONAL on these."""
+    Bn, L, A = eng.batch, cfg.history_len, cfg.num_actions
+    q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :A].copy()
+    act = eng.act.cpu().numpy()[:Bn * net.act_stride].reshape(Bn, net.act_stride)
+    D = cfg.inner_embed_size
+    fld = lambda off, w: torch.from_numpy(act[:, off:off + net.lp * w].reshape(Bn, net.lp, w)[:, :L].copy() > 0)
+
+    def ballots(off, w):
+        """Decode the engine's ReLU ballot words (include/dtqn_hip.h, al_m1/al_mh/al_m2) into [B, L, w] booleans."""
+        ct = w // 16
+        nwords = (net.lp // 16) * ct * 4
+        words = np.ascontiguousarray(act[:, off:off + 2 * nwords]).view(np.uint64).reshape(Bn, nwords)
+        rows, cols = np.meshgrid(np.arange(L), np.arange(w), indexing="ij")
+        widx = ((rows >> 4) * ct + (cols >> 4)) * 4 + (rows & 3)
+        bit = (((rows >> 2) & 3) << 4) + (cols & 15)
+        return torch.from_numpy(((words[:, widx] >> bit.astype(np.uint64)) & np.uint64(1)).astype(bool))
+    masks = []
+    for l in range(cfg.num_layers):
+        base = net.ao_layer0 + l * net.act_layer_stride
+        m_h = ballots(base + net.al_mh, 4 * D)
+        assert torch.equal(m_h, fld(base + net.al_h, 4 * D)), "hidden ballot disagrees with the saved hidden"
+        masks += [ballots(base + net.al_m1, D), m_h, ballots(base + net.al_m2, D)]
+    masks.append(fld(net.ao_hh, D))
+    return {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
+
+
 def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False):
     """Run n_updates on both sides from identical (episode, start) draws and compare every stage:
     the three Q tensors, pre-clip gradients, statistics, parameters after the step.
@@ -118,30 +146,11 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         # engine's own activation pattern (read from its saved activations) and argmax choices, and
         # the number / size of the disagreements is bounded separately.
         q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :A].copy()
-        act = eng.act.cpu().numpy()[:Bn * net.act_stride].reshape(Bn, net.act_stride)
+        probe = engine_probe(cfg, net, eng)
         D = cfg.inner_embed_size
-        fld = lambda off, w: torch.from_numpy(act[:, off:off + net.lp * w].reshape(Bn, net.lp, w)[:, :L].copy() > 0)
-
-        def ballots(off, w):
-            """Decode the engine's ReLU ballot words (include/dtqn_hip.h, al_m1/al_mh/al_m2) into [B, L, w] booleans."""
-            ct = w // 16
-            nwords = (net.lp // 16) * ct * 4
-            words = np.ascontiguousarray(act[:, off:off + 2 * nwords]).view(np.uint64).reshape(Bn, nwords)
-            rows, cols = np.meshgrid(np.arange(L), np.arange(w), indexing="ij")
-            widx = ((rows >> 4) * ct + (cols >> 4)) * 4 + (rows & 3)
-            bit = (((rows >> 2) & 3) << 4) + (cols & 15)
-            return torch.from_numpy(((words[:, widx] >> bit.astype(np.uint64)) & np.uint64(1)).astype(bool))
-        masks = []
-        for l in range(cfg.num_layers):
-            base = net.ao_layer0 + l * net.act_layer_stride
-            m_h = ballots(base + net.al_mh, 4 * D)
-            assert torch.equal(m_h, fld(base + net.al_h, 4 * D)), "hidden ballot disagrees with the saved hidden"
-            masks += [ballots(base + net.al_m1, D), m_h, ballots(base + net.al_m2, D)]
-        masks.append(fld(net.ao_hh, D))
-        probe = {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
         grads, out = O.td_gradients(oracle.pol, oracle.tgt, cfg, batch, oracle.gamma, oracle.history, probe)
         assert not probe["masks"], "oracle consumed fewer ReLU masks than the engine saved"
-        n_relu = sum(int(np.prod(m.shape)) for m in masks) if False else Bn * L * (6 * D * cfg.num_layers + D)
+        n_relu = Bn * L * (6 * D * cfg.num_layers + D)
         assert probe.get("relu_flips", 0) <= max(2, n_relu // 20000), probe
         assert probe.get("max_flip_preact", 0.0) <= 2e-5 * max(1.0, float(out[4].detach().abs().max())), probe
         assert probe.get("argmax_flips", 0) <= max(1, Bn * L // 500), probe

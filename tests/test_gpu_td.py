@@ -161,11 +161,28 @@ def test_golden_G1_full_update(lib):
     ref_flat = flat_from_params(net, ref, keys)
     got = eng.grad.cpu().numpy()
     gerr = np.abs(got - ref_flat).max()
-    # 1.3 M ReLU decisions: a kink flip vs the reference is possible (see helpers.check_td_updates);
-    # the strict bound applies when the activation patterns agree, which the oracle can tell us
-    from helpers import oracle_batch  # noqa: F401
-    assert gerr <= 0.05 * np.abs(ref_flat).max()
+    # 1.3 M ReLU decisions and 1600 argmax choices: two correct fp32 implementations can sit on different sides of a kink
+    # whose pre-activation is ~1e-7 (helpers.check_td_updates).  So: (i) the oracle evaluated on the ENGINE's activation
+    # pattern must agree with the engine to 2e-4 of max|g| and disagree with its own pattern in at most 2 ReLUs / 1 argmax;
+    # (ii) when there is no disagreement at all, the engine must meet the reference's own gradient to the same bound.
+    from helpers import engine_probe, oracle_batch  # noqa: F401
+    from test_gpu_parity_holes import report
+    probe = engine_probe(cfg, net, eng)
+    ot = torch.float32
+    batch = O.Batch(obss=torch.as_tensor(z["batch0_obss"], dtype=ot), actions=torch.as_tensor(z["batch0_actions"], dtype=torch.long),
+                    rewards=torch.as_tensor(z["batch0_rewards"], dtype=torch.float32), next_obss=torch.as_tensor(z["batch0_next_obss"], dtype=ot),
+                    next_actions=torch.as_tensor(z["batch0_next_actions"], dtype=torch.long), dones=torch.as_tensor(z["batch0_dones"], dtype=torch.long))
+    cgrads, _ = O.td_gradients(pol, tgt, cfg, batch, float(z["gamma"]), int(z["history"]), probe)
+    cond_flat = flat_from_params(net, cgrads, keys)
+    flips = int(probe.get("relu_flips", 0)) + int(probe.get("argmax_flips", 0))
+    cerr = np.abs(got - cond_flat).max() / np.abs(cond_flat).max()
+    report("G1_gradient", {"unconditional_err_over_max": float(gerr / np.abs(ref_flat).max()), "conditional_err_over_max": float(cerr),
+                           "relu_flips": int(probe.get("relu_flips", 0)), "argmax_flips": int(probe.get("argmax_flips", 0))})
+    assert cerr <= 2e-4, cerr
+    assert probe.get("relu_flips", 0) <= 2 and probe.get("argmax_flips", 0) <= 1, probe
     strict = gerr <= 2e-4 * np.abs(ref_flat).max()
+    assert strict or flips > 0, (gerr / np.abs(ref_flat).max(), probe)
+    assert gerr <= 0.05 * np.abs(ref_flat).max()
     eng.clip_adam()
     st = eng.read_stats()
     ref_stats = json.loads(str(z["stats"]))[0]
@@ -182,7 +199,6 @@ def test_golden_G1_full_update(lib):
         solid = np.abs(ref_flat) >= 1e-3 * np.abs(ref_flat).max()
         assert d[solid].max() <= 2e-6
         assert d.max() <= 2.002 * float(z["lr"])
-    print("G1 strict gradient parity:", strict, "gerr/max", gerr / np.abs(ref_flat).max())
 
 
 @pytest.mark.parametrize("name", ["cfg4", "cfg5"])
