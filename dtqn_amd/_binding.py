@@ -93,8 +93,8 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_replay_push": [P(DtqnReplay), vp, vp, i32, vp],
-        "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, vp],
-        "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, vp],
+        "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, i32, u32, u32, vp],
+        "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_forward_tiled_strided": [P(DtqnNet), vp, vp, vp, i32, i32, i32, vp, vp, vp],
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
@@ -132,7 +132,7 @@ POS = {"learned": DEFINES["DTQN_POS_LEARNED"], "sin": DEFINES["DTQN_POS_SIN"], "
 
 def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, inner_embed_size=64, num_heads=8,
              num_layers=2, history_len=50, gate="res", identity=False, pos="learned", discrete=False,
-             vocab_sizes=0) -> DtqnNet:
+             vocab_sizes=0, dropout=0.0) -> DtqnNet:
     """Build and initialise a DtqnNet from the reference's DTQN constructor arguments
     (dtqn/networks/dtqn.py:41-59)."""
     net = DtqnNet()
@@ -142,11 +142,12 @@ def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, in
         raise ValueError("Gate must be one of `gru`, `res`")          # dtqn.py:114
     net.gate, net.identity, net.pos = GATES[gate], int(bool(identity)), POS[str(pos)]
     net.discrete, net.vocab = int(bool(discrete)), int(vocab_sizes or 0)
+    net.dropout = float(dropout)
     rc = lib.dtqn_net_init(ctypes.byref(net))
     if rc != 0:
         raise NotImplementedError(
             f"dtqn_net_init rc={rc}: this DTQN variant/shape is outside the gfx950 kernels' coverage "
-            f"(D={inner_embed_size}, H={num_heads}, L={history_len}, gate={gate}); see DESIGN.md")
+            f"(D={inner_embed_size}, H={num_heads}, L={history_len}, gate={gate}, dropout={dropout}); see DESIGN.md")
     return net
 
 

@@ -81,7 +81,7 @@ class DtqnAgent:
         if sampler not in ("reference", "device"):
             raise ValueError("sampler must be 'reference' (Python `random` stream) or 'device'")
         self.engine = TdEngine(self.policy_network.net, batch_size, lr=learning_rate, gamma=gamma, history=history,
-                               tuf=target_update_frequency, grad_norm_clip=grad_norm_clip,
+                               tuf=target_update_frequency, grad_norm_clip=grad_norm_clip, dropout_seed=int(sample_seed) + 0x5EED,
                                device=None if self._test_mode else self.device,
                                _test_lib=lib if self._test_mode else None,
                                theta_pol=self.policy_network.flat, theta_tgt=self.target_network.flat)
@@ -142,6 +142,7 @@ class DtqnAgent:
         self._ev_update_done = torch.cuda.Event() if cuda else None
         self._ev_actor_done = torch.cuda.Event() if cuda else None
         self._actor_inflight = False
+        self._actor_calls = 0
 
     # ---- mode / context (dqn.py:102-115) -------------------------------------------------------
     @property
@@ -170,8 +171,12 @@ class DtqnAgent:
             self._actor_ws = torch.zeros(max(1, need), dtype=torch.float32, device=self.device)
             self._actor_ws_p = ctypes.c_void_p(self._actor_ws.data_ptr()) if need > 0 else None
         # pinned context -> device, forward, Q of the LAST timestep -> pinned: one library call, all on `stream_ptr`
+        # the reference's policy network is in train mode during rollouts (dqn.py:102-115): with dropout > 0 the action
+        # forward drops units too; evaluation (eval_on) runs without.  Keyed by the count of actor forwards.
+        self._actor_calls += 1
         rc = eng.lib.dtqn_actor_forward(eng._net_ref, self._theta_p, self._ctx_hp, self._ctx_dp, n, self._q_p, self._q_hp,
-                                        self._actor_ws_p, stream_ptr)
+                                        self._actor_ws_p, 1 if self.train_mode == TrainMode.TRAIN else 0, eng.td.dropout_seed ^ 0xAC70,
+                                        self._actor_calls & 0xFFFFFFFF, stream_ptr)
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         if rc != 0:

@@ -78,8 +78,9 @@ class VectorActor:
             self._act_np[i, :n] = ctx.action[:n, 0]
             self._len_np[i] = n
             n_max = max(n_max, n)
+        a._actor_calls += 1
         rc = eng.lib.dtqn_actor_forward_batch(eng._net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
-                                              self._ws_p, eng._stream())
+                                              self._ws_p, 1, eng.td.dropout_seed ^ 0xAC70, a._actor_calls & 0xFFFFFFFF, eng._stream())
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         if rc != 0:

@@ -63,7 +63,8 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
 //    pinned host memory itself.
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows,
+                  uint32_t drop_seed, uint32_t drop_step, int train_mode);
 }
 extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                                           int batch, int n, int in_rows, float* q_out, float* workspace, void* stream);
@@ -77,7 +78,8 @@ extern "C" int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* re
 }
 
 extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n,
-                                  float* q_dev, float* q_last_host, float* workspace, void* stream) {
+                                  float* q_dev, float* q_last_host, float* workspace, int train_mode, uint32_t dropout_seed,
+                                  uint32_t dropout_step, void* stream) {
     if (!net || !theta || !ctx_host || !ctx_dev || !q_dev || !q_last_host) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     hipStream_t s = (hipStream_t)stream;
@@ -91,7 +93,7 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
         const bool split = workspace != nullptr && n > net->lp / 2 && dtqn_td_row_split(net, 1) >= 2;
         float* xch = split ? workspace : nullptr;
         int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, 1)) : nullptr;
-        return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags, nullptr, 0);
+        return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags, nullptr, 0, dropout_seed, dropout_step, train_mode);
     }
     const int rc = dtqn_forward_tiled(net, theta, obs, actions, 1, n, q_dev, workspace, stream);
     if (rc != DTQN_OK) return rc;
@@ -108,7 +110,8 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
 // q_last_host[i][num_actions], written by the kernel (valid once `stream` has drained).  q_dev: [N][n_max][num_actions].
 // workspace as dtqn_actor_forward with batch N: dtqn_forward_workspace_floats(net, N) floats, zeroed once.
 extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n_envs,
-                                        int n_max, float* q_dev, float* q_last_host, float* workspace, void* stream) {
+                                        int n_max, float* q_dev, float* q_last_host, float* workspace, int train_mode,
+                                        uint32_t dropout_seed, uint32_t dropout_step, void* stream) {
     if (!net || !theta || !ctx_host || !ctx_dev || !q_dev || !q_last_host || n_envs < 1) return DTQN_ERR_ARG;
     if (n_max < 1 || n_max > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     hipStream_t s = (hipStream_t)stream;
@@ -135,5 +138,5 @@ extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, 
     const bool split = workspace != nullptr && n_max > net->lp / 2 && dtqn_td_row_split(net, n_envs) >= 2;
     float* xch = split ? workspace : nullptr;
     int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, n_envs)) : nullptr;
-    return dtqn::forward_infer(net, theta, obs, actions, n_envs, n_max, q_dev, q_last_host, stream, xch, xflags, lens, L);
+    return dtqn::forward_infer(net, theta, obs, actions, n_envs, n_max, q_dev, q_last_host, stream, xch, xflags, lens, L, dropout_seed, dropout_step, train_mode);
 }

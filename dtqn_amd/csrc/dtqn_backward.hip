@@ -46,6 +46,10 @@ struct BwdArgs {
     long long* prof;             // debug stage clock
     float* xch;                  // row-split hand-over buffer / flags (RS > 1 only)
     int32_t* xflags;
+    // dropout of the training forward, recomputed here: step = step_counter[1]
+    uint32_t drop_thresh, drop_seed;
+    float drop_scale;
+    const int32_t* step_counter;
 };
 
 // RS = row slices per sequence (see dtqn_forward.hip).  RS == 2: the workgroup owns rows [R0, R0 + LP); attention is
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     float* DU = st_s + 4 * LP;                         // identity only: branch grad    [LP][LDX]
 
     const int ep = a.ep_idx[b], st0 = a.start[b] + R0;
+    const Drop dr = a.drop_thresh != 0u ? Drop{a.drop_thresh, a.drop_scale, a.drop_seed, (uint32_t)a.step_counter[1], (uint32_t)b} : drop_off();
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
@@ -199,7 +204,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
-                T2[r * LDX + c] = mask_bit(m2, D / 16, r, c) ? dy : 0.f;
+                // y2 = relu(dropout(f)): the ReLU pattern, then the keep mask of the FFN output
+                T2[r * LDX + c] = mask_bit(m2, D / 16, r, c) ? drop_apply(dr, DROP_FFN, l, (uint32_t)((R0 + r) * D + c), dy) : 0.f;
             }
         }
         __syncthreads();
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
-                attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS > 1 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF);
+                attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS > 1 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF, dr, l, g * (GW / HD));
                 __syncthreads();
                 if (RS > 1) {
                     // every slice s holds, in the k / v tiles of the rows BELOW it, its queries' share of their dK | dV: one
@@ -452,6 +458,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
 
     // ---------------- embedding: dL/dx0 -> record; table / action-embedding partials ----------------
     DTQN_PROF(a.prof, ps++);
+    if (dr.thresh != 0u) {       // x0 = dropout(embedding + position): dL/d(embedding) takes the keep mask
+        for (int idx = t.tid; idx < LP * D; idx += NT) {
+            const int r = idx / D, c = idx - r * D;
+            DX[r * LDX + c] = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + c), DX[r * LDX + c]);
+        }
+        __syncthreads();
+    }
     tile_store<NW>(DX, LDX, gf(grec, net.go_dx0, D), LP, D, t);
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
@@ -552,6 +565,9 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.batch = td->batch; a.history = td->history; a.gamma = td->gamma;
     a.prof = dtqn_debug_profile_buffer() ? static_cast<long long*>(dtqn_debug_profile_buffer()) + 64 : nullptr;
     a.xch = td->xch; a.xflags = td->xflags;
+    a.drop_thresh = net->dropout > 0.f ? (uint32_t)((double)net->dropout * 4294967296.0) : 0u;
+    a.drop_scale = net->dropout > 0.f ? 1.0f / (1.0f - net->dropout) : 1.0f;
+    a.drop_seed = td->dropout_seed; a.step_counter = td->step_counter;
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
     if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)

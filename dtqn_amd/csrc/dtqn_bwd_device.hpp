@@ -105,7 +105,10 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld, int GW, int LP, int n,
                                                               const float* delta_s, const float* lse_s, const Thr& t,
-                                                              float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
+                                                              float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
+                                                              const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+    // dr / layer / head0 (global index of the group's first head): attention-probability dropout of the forward, recomputed:
+    // o = (P * M) v with M = keep / (1 - p), so dV takes P * M, and dP = M * (dO v^T) before the softmax backward
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
     // caller cannot afford a fifth LDS tile.  Row slices as in the VALU version: queries [row0, row0 + LP)
     // (row0 a multiple of 16), keys [0, row0 + LP), global rows everywhere.
@@ -154,7 +157,8 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
                 // masked keys, and PAD query rows (t >= n: their saved lse is 0, so exp2 can overflow and inf * 0 would
                 // put a NaN into dq of a pad row, which the weight-gradient contraction over all padded rows would pick up)
                 if (s0 + t.kq * 4 + r > trow || trow >= n) p = 0.f;
-                ds[r] = p * (dp[r] - delta);
+                const float dpm = dr.thresh == 0u ? dp[r] : (drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(head0 + h, trow, s0 + t.kq * 4 + r)) ? dp[r] * dr.scale : 0.f);
+                ds[r] = p * (dpm - delta);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -216,7 +220,15 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
                 const int tr = t0 + t.kq * 4 + r;
                 p[r] = DTQN_EXP2(st[r] - lse4[r] * LOG2E);
                 if (srow > tr || tr >= n) p[r] = 0.f;
-                ds[r] = p[r] * (dp[r] - del4[r]);
+                float dpm = dp[r];
+                if (dr.thresh != 0u) {
+                    const bool keep = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(head0 + h, tr, srow));
+                    dpm = keep ? dp[r] * dr.scale : 0.f;
+                    ds[r] = p[r] * (dpm - del4[r]);
+                    p[r] = keep ? p[r] * dr.scale : 0.f;          // dV takes the dropped probabilities
+                } else {
+                    ds[r] = p[r] * (dpm - del4[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -253,7 +265,8 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
 template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
-                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
+                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
+                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
     // caller cannot afford a fifth LDS tile.
     // Row slices: queries [row0, row0 + LP) against keys [0, row0 + LP); all tile rows are GLOBAL rows, delta_s /
@@ -304,6 +317,7 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
                     sc = fmaf(q[c], k.x, sc); sc = fmaf(q[c + 1], k.y, sc); sc = fmaf(q[c + 2], k.z, sc); sc = fmaf(q[c + 3], k.w, sc);
                     dp = fmaf(dO[c], v.x, dp); dp = fmaf(dO[c + 1], v.y, dp); dp = fmaf(dO[c + 2], v.z, dp); dp = fmaf(dO[c + 3], v.w, dp);
                 }
+                if (dr.thresh != 0u) dp = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(head0 + hl, row, s)) ? dp * dr.scale : 0.f;
                 const float ds = __expf(sc - lse) * (dp - delta);
 #pragma unroll
                 for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, kk[c], dq[c]);
@@ -354,10 +368,16 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
                 }
 #pragma unroll
                 for (int c = 0; c < HD; ++c) { sc = fmaf(qq[c], k[c], sc); dp = fmaf(dd[c], v[c], dp); }
-                const float p = __expf(sc - lse_s[hl * sl_ld + row]);
+                float p = __expf(sc - lse_s[hl * sl_ld + row]);
+                float pv = p;                                   // what multiplied v in the forward
+                if (dr.thresh != 0u) {
+                    const bool keep = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(head0 + hl, row, srow));
+                    dp = keep ? dp * dr.scale : 0.f;
+                    pv = keep ? p * dr.scale : 0.f;
+                }
                 const float ds = p * (dp - delta_s[hl * sl_ld + row]);
 #pragma unroll
-                for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(p, dd[c], dv[c]); }
+                for (int c = 0; c < HD; ++c) { dk[c] = fmaf(ds, qq[c], dk[c]); dv[c] = fmaf(pv, dd[c], dv[c]); }
             }
         }
         // NOTE: other items of this pass read only q / do / lse / delta, never k or v of another row
@@ -372,9 +392,10 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
 template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
-                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0) {
-    if constexpr (MFMA) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
-    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld);
+                                                         float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
+                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+    if constexpr (MFMA) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0);
+    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0);
 }
 
 // Double-DQN target, MSE and dL/dQ of ONE sequence, executed by one wave (dtqn/agents/dtqn.py:219-253).

@@ -27,7 +27,8 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 // dtqn_forward with an optional pinned-host destination for Q of the last row of sequence 0 (dtqn_actor_forward)
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows = nullptr, int in_rows = 0);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows = nullptr, int in_rows = 0,
+                  uint32_t drop_seed = 0, uint32_t drop_step = 0, int train_mode = 0);
 
 // Raise a kernel's dynamic-LDS limit once per (instantiation, device, size): the call is a driver round trip, and the
 // attribute is per device, so a second GPU used by the same process needs its own call (`cache` = one function-static
@@ -533,6 +534,38 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dropout (train-mode forwards only; dtqn/networks/dtqn.py:105,196 on embedding + position, transformer.py:34 on the
+// attention probabilities, transformer.py:41 on the FFN output).  Keep masks are a counter-based hash of
+// (seed, update step, pass, sequence, site, layer, element): nothing is stored, the backward recomputes them.
+// torch's own Philox stream cannot be reproduced (it depends on launch geometry); the distribution is the same:
+// keep with probability 1 - p, scale kept values by 1 / (1 - p).
+// ------------------------------------------------------------------------------------------
+struct Drop {
+    uint32_t thresh;      // drop iff hash < thresh; 0 = dropout off
+    float scale;          // 1 / (1 - p)
+    uint32_t seed, step;
+    uint32_t salt;        // (pass << 20) | sequence
+};
+enum { DROP_EMB = 0, DROP_ATTN = 1, DROP_FFN = 2 };
+__device__ __forceinline__ Drop drop_off() { return Drop{0u, 1.0f, 0u, 0u, 0u}; }
+__device__ __forceinline__ bool drop_keep(const Drop& d, int site, int layer, uint32_t idx) {
+    unsigned long long z = ((unsigned long long)d.seed << 32) | (unsigned long long)d.step;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= ((unsigned long long)d.salt << 40) | ((unsigned long long)(site + 4 * layer) << 32) | (unsigned long long)idx;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32) >= d.thresh;
+}
+__device__ __forceinline__ float drop_apply(const Drop& d, int site, int layer, uint32_t idx, float v) {
+    return d.thresh == 0u ? v : (drop_keep(d, site, layer, idx) ? v * d.scale : 0.f);
+}
+// element index of an attention probability: (head, query row, key row), rows of up to 256
+__device__ __forceinline__ uint32_t drop_attn_idx(int h, int trow, int s) { return ((uint32_t)h << 16) | ((uint32_t)trow << 8) | (uint32_t)s; }
+
 // Causal attention work is triangular: the 64-item block of query rows [8g, 8g+8) costs ~8(g+1) key steps
 // (the reverse for the key-row pass of the backward).  Waves w and w + NW/2 share a SIMD (waves are dealt to
 // SIMDs cyclically), so block b of the natural order is handed to the wave that pairs the most expensive
@@ -571,7 +604,8 @@ __device__ __forceinline__ int balanced_block(int wave, int nblocks, int nlive, 
 template <int HD, int NT, bool DIAG>
 __device__ __forceinline__ void attention_forward_chunk(const float* kbase, const float* vbase, int ld, int s_first, int trow,
                                                         const float (&qf)[HD / 4], float& m, float& l,
-                                                        f32x4 (&acc)[(HD + 15) / 16][2], bool rescale, const Thr& t) {
+                                                        f32x4 (&acc)[(HD + 15) / 16][2], bool rescale, const Thr& t,
+                                                        const Drop& dr, int layer, int h) {
     constexpr int KS = HD / 4, CT = (HD + 15) / 16;
     f32x4 st[NT];
 #pragma unroll
@@ -611,6 +645,13 @@ __device__ __forceinline__ void attention_forward_chunk(const float* kbase, cons
         l = ps;
     }
     m = mn;
+    if (dr.thresh != 0u) {     // attention-probability dropout: the row sum above is of the undropped probabilities
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st[u][r] = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(h, trow, s_first + u * 16 + t.kq * 4 + r)) ? st[u][r] * dr.scale : 0.f;
+    }
     // O^T[c][t] += V^T[c][s] P^T[s][t]: A = V[s][ct*16 + i] (rows c >= HD of O^T are never stored: any in-range
     // column will do there), B = p
 #pragma unroll
@@ -628,7 +669,8 @@ __device__ __forceinline__ void attention_forward_chunk(const float* kbase, cons
 
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D, int H, int LP, int n,
-                                                       float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
+                                                       float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
+                                                       const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
     if (lse_ld == 0) lse_ld = LP;               // query rows [row0, row0 + LP), row0 a multiple of 16
     constexpr int KS = HD / 4;                  // MFMA steps of the score contraction (4 columns of q/k per step)
     constexpr int CT = (HD + 15) / 16;          // 16-row tiles of O^T (rows = head columns c)
@@ -659,12 +701,12 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
         float m = -INFINITY, l = 0.f;
         int tc0 = 0;
         for (; tc0 + 4 <= ti; tc0 += 4)
-            attention_forward_chunk<HD, 4, false>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t);
+            attention_forward_chunk<HD, 4, false>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h);
         switch (ti - tc0) {                     // the remaining 1..4 tiles end on the diagonal
-            case 0: attention_forward_chunk<HD, 1, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
-            case 1: attention_forward_chunk<HD, 2, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
-            case 2: attention_forward_chunk<HD, 3, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
-            default: attention_forward_chunk<HD, 4, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t); break;
+            case 0: attention_forward_chunk<HD, 1, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
+            case 1: attention_forward_chunk<HD, 2, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
+            case 2: attention_forward_chunk<HD, 3, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
+            default: attention_forward_chunk<HD, 4, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
         }
         // lane (i, kq) holds O^T[c = ct*16 + kq*4 + e][t = t0 + i]: four consecutive output columns of row t
         const bool live = trow < n;
@@ -690,7 +732,8 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
 // ------------------------------------------------------------------------------------------
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D, int H, int LP, int n,
-                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
+                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
     // query rows [row0, row0 + LP) of the tile (a row slice of the sequence when row0 > 0); keys 0 .. row
     if (lse_ld == 0) lse_ld = LP;
     const float scale = 1.0f / sqrtf((float)HD);
@@ -750,6 +793,11 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
 #pragma unroll
             for (int j = 0; j < KB; ++j) { p[j] = __expf(sc[j] - mn); ps += p[j]; }
             l = l * corr + ps;
+            if (dr.thresh != 0u) {     // attention-probability dropout (the row sum is of the undropped probabilities)
+#pragma unroll
+                for (int j = 0; j < KB; ++j)
+                    if (s0 + j <= row) p[j] = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(h, row, s0 + j)) ? p[j] * dr.scale : 0.f;
+            }
 #pragma unroll
             for (int c = 0; c < HD; ++c) acc[c] *= corr;
 #pragma unroll
@@ -776,9 +824,10 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
 constexpr int kAttnMfmaMinHeadDim = 16;
 template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
-                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0) {
-    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
-    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld);
+                                                  float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
+    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer);
+    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer);
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.

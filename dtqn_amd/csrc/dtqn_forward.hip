@@ -8,6 +8,13 @@ DTQN_FWD_GROUP_B(DTQN_FWD_DECL)
 DTQN_FWD_GROUP_C(DTQN_FWD_DECL)
 DTQN_FWD_GROUP_D(DTQN_FWD2_DECL)
 
+static void set_dropout(FwdArgs& a, const DtqnNet* net, int passes, uint32_t seed, uint32_t step) {
+    const bool on = net->dropout > 0.f && passes != 0;
+    a.drop_thresh = on ? (uint32_t)((double)net->dropout * 4294967296.0) : 0u;
+    a.drop_scale = on ? 1.0f / (1.0f - net->dropout) : 1.0f;
+    a.drop_seed = seed; a.drop_step = step; a.drop_passes = on ? passes : 0;
+}
+
 // mt_rows: row tiles the launch really needs (0 = the network's padded context).  Inference on a short prefix of the
 // context (the actor early in an episode) runs the instantiation with fewer row tiles when there is one.
 static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t stream, int mt_rows = 0) {
@@ -60,16 +67,17 @@ extern "C" int dtqn_lds_bytes_forward(const DtqnNet* net, int /*training*/) {
 
 namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
-                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows);
+                  float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows,
+                  uint32_t drop_seed, uint32_t drop_step, int train_mode);
 }
 extern "C" int dtqn_forward(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                             int batch, int n, float* q_out, void* stream) {
-    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream, nullptr, nullptr, nullptr, 0);
+    return forward_infer(net, theta, obs, actions, batch, n, q_out, nullptr, stream, nullptr, nullptr, nullptr, 0, 0u, 0u, 0);
 }
 // xch / xflags != nullptr: latency mode, two workgroups per sequence (the caller decided it pays: dtqn_actor_forward)
 int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                         float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows,
-                        int in_rows) {
+                        int in_rows, uint32_t drop_seed, uint32_t drop_step, int train_mode) {
     if (!net || !theta || !obs || !q_out || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len) return DTQN_ERR_ARG;                 // dtqn.py:170-173
     if (net->tiled) return DTQN_ERR_CONFIG;                             // use dtqn_forward_tiled
@@ -95,6 +103,8 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.ep_len = nullptr; a.step_counter = nullptr; a.ep_out = nullptr; a.start_out = nullptr;
     a.s_n_valid = 0; a.s_exclude = -1; a.s_seed = 0;
     a.prof = nullptr;
+    // dropout in a train-mode actor forward (the reference's policy network stays in train mode during rollouts)
+    set_dropout(a, net, train_mode ? 1 : 0, drop_seed, drop_step);
     if (xch != nullptr && xflags != nullptr) return dispatch_fwd(a, batch, 2, (hipStream_t)stream);
     // short prefix of a 64-row context: 16- or 32-row instantiation (same kernel, fewer row tiles), else the full tile
     if (net->lp == 64 && n <= 32 && net->gate == DTQN_GATE_RES) {
@@ -140,5 +150,6 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.act = td->act;
     a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
+    set_dropout(a, net, 0x3, td->dropout_seed, 0u);       // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230)
     return dispatch_fwd(a, 3 * td->batch, td->row_split >= 2 ? 2 : 1, (hipStream_t)stream);   // the forward never uses more than two slices
 }

@@ -45,6 +45,11 @@ struct FwdArgs {
     int s_n_valid, s_exclude;
     uint32_t s_seed;
     long long* prof;            // debug stage clock (see dtqn_debug_set_profile_buffer)
+    // dropout (net.dropout > 0): passes with bit `which` set in drop_passes run in train mode; step from step_counter[1]
+    // when that pointer is given (TD update), else drop_step (actor)
+    uint32_t drop_thresh, drop_seed, drop_step;
+    float drop_scale;
+    int drop_passes;
 };
 
 __device__ __forceinline__ int lds_ldx(int D) { return D + 4; }
@@ -72,6 +77,10 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const int R0 = slice * LP;
     const int which = seq / a.batch;
     const int b = seq - which * a.batch;
+    Drop dr = drop_off();
+    if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
+        dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : a.drop_step,
+                  ((uint32_t)which << 20) | (uint32_t)b};
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
@@ -126,6 +135,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
                     v = acc;
                 }
                 v += pos[r * D + d];
+                v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
             }
             Xs[r * LDX + d] = v;
             if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
@@ -170,6 +180,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
                     v = acc;
                 }
                 v += pos[r * D + d];
+                v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
             }
             Xs[r * LDX + d] = v;
             if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
@@ -220,7 +231,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
             if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
             else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
         }
-        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF);
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
         g_out.retire();
@@ -308,7 +319,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
-                            const float y = fmaxf(facc[q][m][r4] + b2v[q], 0.f);
+                            const float y = fmaxf(drop_apply(dr, DROP_FFN, l, (uint32_t)((R0 + r) * D + c), facc[q][m][r4] + b2v[q]), 0.f);
                             if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                             if (gru) Ws[r * LDW + D + c] = y;
                             else Xs[r * LDX + c] += y;
@@ -397,6 +408,10 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const int R0 = slice * LP;
     const int which = seq / a.batch;
     const int b = seq - which * a.batch;
+    Drop dr = drop_off();
+    if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
+        dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : a.drop_step,
+                  ((uint32_t)which << 20) | (uint32_t)b};
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;
@@ -456,6 +471,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                     v = acc;
                 }
                 v += pos[r * D + d];
+                v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
             }
             Xs[r * LDX + d] = v;
             if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
@@ -499,6 +515,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                     v = acc;
                 }
                 v += pos[r * D + d];
+                v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
             }
             Xs[r * LDX + d] = v;
             if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
@@ -545,7 +562,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
             else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
         }
-        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF);
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         tw_1.to_lds(Ar, LWD, t);
         TileRegs<NW, D, NC> tw_2;
         tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
@@ -627,7 +644,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) {
                             const int r = (Own::mg(t.wave, q) * MG2 + m) * 16 + t.kq * 4 + r4;
-                            const float y = fmaxf(facc[q][m][r4] + b2, 0.f);
+                            const float y = fmaxf(drop_apply(dr, DROP_FFN, l, (uint32_t)((R0 + r) * D + c), facc[q][m][r4] + b2), 0.f);
                             if (TRAIN) ballot_store(m_g, D / 16, r, c, y > 0.f, t.lane);
                             Xs[r * LDX + c] += y;
                         }

@@ -32,6 +32,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->discrete && (V < 1 || e < 1)) return DTQN_ERR_CONFIG;
     if (net->gate != DTQN_GATE_RES && net->gate != DTQN_GATE_GRU) return DTQN_ERR_CONFIG;
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
+    if (!(net->dropout >= 0.f && net->dropout < 1.f)) return DTQN_ERR_CONFIG;
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
@@ -54,6 +55,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         net->lp = (L + 63) / 64 * 64;
     }
     const int LP = net->lp;
+    if (net->tiled && net->dropout > 0.f) return DTQN_ERR_CONFIG;      // dropout: whole-sequence kernels only
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
         if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;

@@ -52,7 +52,7 @@ class DeviceReplay:
 
 class TdEngine:
     def __init__(self, net: B.DtqnNet, batch: int, *, lr=3e-4, gamma=0.99, history=None, tuf=10_000,
-                 grad_norm_clip=1.0, betas=(0.9, 0.999), eps=1e-8, n_split: Optional[int] = None,
+                 grad_norm_clip=1.0, betas=(0.9, 0.999), eps=1e-8, n_split: Optional[int] = None, dropout_seed: int = 0,
                  device=None, _test_lib=None, theta_pol: Optional[torch.Tensor] = None,
                  theta_tgt: Optional[torch.Tensor] = None):
         # `_test_lib` exists for the CPU kernel-emulation tests only (tests/emu); the product path
@@ -144,6 +144,7 @@ class TdEngine:
         td.target_update_frequency = int(tuf)
         td.gamma, td.lr, td.beta1, td.beta2, td.eps = float(gamma), float(lr), float(betas[0]), float(betas[1]), float(eps)
         td.grad_norm_clip, td.grad_scale = float(grad_norm_clip), 1.0
+        td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
 

@@ -50,17 +50,18 @@ class DTQN(nn.Module):
             raise NotImplementedError("image observations (conv embedding) are outside dtqn_amd's scope")
         if bag_size > 0:
             raise NotImplementedError("the persistent-memory bag is outside dtqn_amd's scope")
-        if dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented in the fused kernels (reference default 0.0)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")     # nn.Dropout's own check
         if pos not in B.POS:
             raise ValueError(f"{pos!r} is not a valid PosEnum")        # PosEnum(pos) in the reference (dtqn.py:101)
         self._lib = _test_lib if _test_lib is not None else engine.get_lib()
         self.obs_dim, self.discrete, self.history_len, self.bag_size = obs_dim, discrete, history_len, bag_size
+        self.dropout_p = float(dropout)
         self.num_actions = num_actions
         self.net = B.make_net(self._lib, obs_dim=obs_dim, num_actions=num_actions, embed_per_obs_dim=embed_per_obs_dim,
                               action_dim=action_dim, inner_embed_size=inner_embed_size, num_heads=num_heads,
                               num_layers=num_layers, history_len=history_len, gate=gate, identity=identity, pos=pos,
-                              discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0)
+                              discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0, dropout=dropout)
         net = self.net
         flat = np.zeros(net.n_theta, dtype=np.float32)
         self._lib.dtqn_net_fill_frozen(ctypes.byref(net), flat.ctypes.data_as(ctypes.c_void_p))

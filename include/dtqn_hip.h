@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 4
+#define DTQN_ABI_VERSION 5
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -61,6 +61,8 @@ typedef struct DtqnNet {
     int32_t pos;              /* DTQN_POS_* */
     int32_t discrete;         /* discrete observations -> Embedding(V,e)+Linear (representations.py:25-52) */
     int32_t vocab;            /* V */
+    float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
+                               * forwards only; 0 = off.  Whole-sequence kernels only (DTQN_ERR_CONFIG on the row-block tiled path) */
     /* ---- derived: geometry ---- */
     int32_t abi_version;
     int32_t lp;               /* L padded to the MFMA row tile (multiple of 16) */
@@ -243,6 +245,8 @@ typedef struct DtqnTd {
     int32_t sample_n_valid;   /* finished episode slots [0, n_valid) */
     int32_t sample_exclude;   /* slot in progress (excluded), or -1 */
     uint32_t sample_seed;
+    uint32_t dropout_seed;    /* keep masks of an update are a counter-based hash of (dropout_seed, step_counter[1], pass, sequence,
+                               * site, layer, element): recomputed by the backward, nothing stored */
     int32_t row_split;        /* workgroups per sequence in the forward / backward kernels: the value
                                * dtqn_td_row_split(net, B) returned (1 = one workgroup per sequence) */
     float gamma;
@@ -266,9 +270,12 @@ int dtqn_replay_push(const DtqnReplay* rp, const DtqnReplayRecord* recs_host, co
  * (q_dev [ctx_len][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, 1) floats, ZEROED once by the caller,
  * or NULL when that is 0: scratch of the tiled kernels, or the hand-over tiles of the two-workgroup latency mode) and
  * the Q-values of the LAST row land in the pinned q_last_host[num_actions] (written by the forward kernel itself; valid
- * once `stream` has drained).  All asynchronous on `stream`. */
+ * once `stream` has drained).  All asynchronous on `stream`.  train_mode != 0 with net->dropout > 0: the forward applies
+ * dropout (the reference keeps its policy network in train mode during rollouts, dqn.py:102-115), keyed by
+ * (dropout_seed, dropout_step). */
 int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n, float* q_dev,
-                       float* q_last_host, float* workspace, void* stream);
+                       float* q_last_host, float* workspace, int train_mode, uint32_t dropout_seed, uint32_t dropout_step,
+                       void* stream);
 
 /* The same for N actors at once (vectorised rollout: N host environments per learner, ONE launch per vector step; the
  * reference steps one environment per forward, run.py:356-377).  ctx_host is PINNED and packs
@@ -278,7 +285,8 @@ int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_h
  * q_last_host[i][num_actions], written by the kernel itself (valid once `stream` has drained); q_dev is
  * [N][n_max][num_actions]; `workspace` = dtqn_forward_workspace_floats(net, N) floats, ZEROED once, or NULL when that is 0. */
 int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n_envs, int n_max,
-                             float* q_dev, float* q_last_host, float* workspace, void* stream);
+                             float* q_dev, float* q_last_host, float* workspace, int train_mode, uint32_t dropout_seed,
+                             uint32_t dropout_step, void* stream);
 /* dtqn_forward_tiled with `in_rows` (>= n) rows per sequence in the obs / actions arrays. */
 int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                                int in_rows, float* q_out, float* workspace, void* stream);

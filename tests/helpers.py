@@ -13,7 +13,7 @@ def net_from_cfg(lib, cfg: O.NetCfg):
     return B.make_net(lib, obs_dim=cfg.obs_dim, num_actions=cfg.num_actions, embed_per_obs_dim=cfg.embed_per_obs_dim,
                       action_dim=cfg.action_dim, inner_embed_size=cfg.inner_embed_size, num_heads=cfg.num_heads,
                       num_layers=cfg.num_layers, history_len=cfg.history_len, gate=cfg.gate, identity=cfg.identity,
-                      pos=cfg.pos, discrete=cfg.discrete, vocab_sizes=cfg.vocab_sizes)
+                      pos=cfg.pos, discrete=cfg.discrete, vocab_sizes=cfg.vocab_sizes, dropout=cfg.dropout)
 
 
 def pack_theta(net, params) -> np.ndarray:
@@ -148,7 +148,9 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :A].copy()
         probe = engine_probe(cfg, net, eng)
         D = cfg.inner_embed_size
-        grads, out = O.td_gradients(oracle.pol, oracle.tgt, cfg, batch, oracle.gamma, oracle.history, probe)
+        # dropout: the engine keys its keep masks by (dropout_seed, optimizer steps so far); the oracle evaluates the same hash
+        drop = O.DropSpec(cfg.dropout, int(eng.td.dropout_seed), it) if cfg.dropout > 0 else None
+        grads, out = O.td_gradients(oracle.pol, oracle.tgt, cfg, batch, oracle.gamma, oracle.history, probe, drop)
         assert not probe["masks"], "oracle consumed fewer ReLU masks than the engine saved"
         n_relu = Bn * L * (6 * D * cfg.num_layers + D)
         assert probe.get("relu_flips", 0) <= max(2, n_relu // 20000), probe

@@ -333,3 +333,63 @@ def test_vector_actor_matches_single_actor_and_reference_buffer(emu):
             assert np.array_equal(arrays["obss"], shadow.obss) and np.array_equal(arrays["rewards"], shadow.rewards[:, :, 0])
             assert np.array_equal(arrays["actions"], shadow.actions[:, :, 0]) and np.array_equal(arrays["eplens"], shadow.episode_lengths)
     assert vec.steps == 40 * N
+
+
+def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu):
+    """--dropout p: the policy network stays in train mode during rollouts (dqn.py:102-115), so two action forwards of the
+    same context differ (fresh keep masks per call) and equal the oracle's forward with the same counter-based masks;
+    eval_on() (run.py:206) turns dropout off: repeated forwards are identical and equal the oracle without dropout."""
+    from dtqn_amd import envs
+    from dtqn_amd.agents.dtqn import DtqnAgent
+    from dtqn_amd.networks.dtqn import DTQN
+    from dtqn_amd.utils import env_processing as ep
+    from dtqn_amd.utils.random import set_global_seed
+    from oracle import dtqn_oracle as O
+    env = envs.make("DiscreteCarFlag-v0")
+    set_global_seed(2, env)
+    L, D, H, p = 20, 32, 4, 0.3
+
+    def factory():
+        m = DTQN(3, 3, 8, 0, D, H, 2, L, dropout=p, _test_lib=emu)
+        m._allow_cpu = True
+        return m
+    agent = DtqnAgent(factory, buffer_size=12 * 200, device=torch.device("cpu"), env_obs_length=3, max_env_steps=200, obs_mask=ep.get_env_obs_mask(env),
+                      num_actions=3, is_discrete_env=False, batch_size=4, context_len=L, history=L, target_update_frequency=100)
+    assert agent.policy_network.net.dropout == pytest.approx(p)
+    agent.context_reset(env.reset())
+    for _ in range(5):
+        obs, r, done, info = env.step(1)
+        agent.observe(obs, 1, r, done)
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=D, num_heads=H, num_layers=2, history_len=L, dropout=p)
+    params = {k: v.detach().clone() for k, v in agent.policy_network.state_dict().items()}
+    ctx = agent.context
+    n = ctx.timestep + 1
+    obs_t = torch.as_tensor(ctx.obs[:n], dtype=torch.float32)[None]
+    act_t = torch.as_tensor(ctx.action[:n], dtype=torch.long)[None]
+    eng = agent.engine
+    qs = []
+    for call in (1, 2):
+        agent._launch_actor_forward(eng._stream())
+        qs.append(agent._q_np.copy())
+        spec = O.DropSpec(p, int(eng.td.dropout_seed) ^ 0xAC70, agent._actor_calls, 0)
+        with torch.no_grad():
+            ref = O.forward(params, cfg, obs_t, act_t, None, spec).numpy()[0, -1]
+        assert np.abs(qs[-1] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (call, qs[-1], ref)
+    assert not np.array_equal(qs[0], qs[1])
+    agent.eval_on()
+    agent.context_reset(ctx.obs[0])
+    for t in range(1, n):
+        agent.eval_context.add_transition(ctx.obs[t], int(ctx.action[t, 0]), 0.0, False)
+    agent.eval_context.action[:n] = ctx.action[:n]
+    ev = []
+    for _ in range(2):
+        agent._launch_actor_forward(eng._stream())
+        ev.append(agent._q_np.copy())
+    with torch.no_grad():
+        ref = O.forward(params, cfg, obs_t, act_t).numpy()[0, -1]
+    assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    agent.eval_off()
+    with pytest.raises(NotImplementedError):
+        DTQN(3, 3, 8, 0, 128, 8, 2, 128, dropout=0.1, _test_lib=emu)          # row-block tiled path: dropout not covered
+    with pytest.raises(ValueError):
+        DTQN(3, 3, 8, 0, 32, 4, 2, 20, dropout=1.5, _test_lib=emu)

@@ -164,9 +164,9 @@ def test_actor_forward_one_call(emu, kw, monkeypatch):
             q_d = np.full((L, A), np.nan, dtype=np.float32)
             q_last = np.full(A, np.nan, dtype=np.float32)
             rc = emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), n, ptr(q_d), ptr(q_last),
-                                        None if workspace is None else ptr(workspace), None)
+                                        None if workspace is None else ptr(workspace), 0, 0, 0, None)
             assert rc == 0
             assert np.abs(q_last - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, workspace is None)
             assert np.array_equal(q_last, q_d[n - 1])
         assert not ws[emu.dtqn_td_xch_floats(ctypes.byref(net), 1):].any()      # hand-over flags lowered again
-    assert emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), L + 1, ptr(q_d), ptr(q_last), None, None) == B.DEFINES["DTQN_ERR_ARG"]
+    assert emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), L + 1, ptr(q_d), ptr(q_last), None, 0, 0, 0, None) == B.DEFINES["DTQN_ERR_ARG"]

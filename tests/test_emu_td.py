@@ -168,3 +168,56 @@ def test_pad_rows_with_overflowing_scores_stay_out_of_the_gradient(emu, split, h
     eng.forward_backward(rep)
     assert bool(torch.isfinite(eng.grad).all())
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+
+
+DROPOUT_CASES = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, dropout=0.1), dict(batch=4, T=12, mask=-5)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, action_dim=4, dropout=0.25), dict(batch=3, T=30, mask=-5, history=7)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, dropout=0.1), dict(batch=2, T=60, mask=-5, n_eps=10)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, gate="gru", dropout=0.2), dict(batch=4, T=12, mask=-5)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, history_len=20, identity=True, pos="sin", dropout=0.15), dict(batch=3, T=30, mask=-5)),
+]
+
+
+@pytest.mark.parametrize("kw,run", DROPOUT_CASES)
+def test_td_update_with_dropout(emu, kw, run, monkeypatch):
+    """dropout > 0 (dtqn.py:105,196; transformer.py:34,41): embedding, attention-probability and FFN-output dropout in the
+    two train-mode forwards, none in the target forward; the backward recomputes the keep masks.  The oracle evaluates the
+    same counter-based hash, so Q x3, gradients, statistics and the Adam step are compared as without dropout."""
+    if kw["inner_embed_size"] == 64:
+        monkeypatch.setenv("DTQN_ROW_SPLIT", "4")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9),
+                                               mask=run["mask"], history=run.get("history"))
+    eng.td.dropout_seed = 12345
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+def test_dropout_keep_rate_and_eval_mode(emu):
+    """The keep masks drop a fraction p of the elements and scale the rest by 1 / (1 - p) (nn.Dropout's definition); an
+    eval-mode forward (dtqn_forward, the target pass) is unaffected by the dropout setting."""
+    import ctypes
+    from helpers import net_from_cfg, pack_theta, ptr
+    sp = O.DropSpec(0.3, 99, 4, 0)
+    idx = np.arange(200_000).astype(np.uint64)
+    for site in (O.DROP_EMB, O.DROP_ATTN, O.DROP_FFN):
+        keep = O.drop_keep(sp, 3, site, 1, idx)
+        assert abs(keep.mean() - 0.7) < 4 * np.sqrt(0.21 / idx.size)
+    assert abs(sp.scale - 1 / 0.7) < 1e-6
+    # independent across passes / sequences / steps
+    a = O.drop_keep(sp, 3, 0, 0, idx[:4096]); b = O.drop_keep(O.DropSpec(0.3, 99, 5, 0), 3, 0, 0, idx[:4096])
+    assert 0.35 < (a == b).mean() < 0.8
+    kw = dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, history_len=20)
+    cfg0, cfg1 = O.NetCfg(**kw), O.NetCfg(dropout=0.5, **kw)
+    params = O.init_params(cfg0, seed=3, perturb=True)
+    rng = np.random.default_rng(1)
+    obs = rng.uniform(-1, 1, size=(2, 20, 3)).astype(np.float32)
+    act = np.zeros((2, 20), dtype=np.uint8)
+    outs = []
+    for cfg in (cfg0, cfg1):
+        net = net_from_cfg(emu, cfg)
+        theta = pack_theta(net, params)
+        q = np.full((2, 20, 3), np.nan, dtype=np.float32)
+        assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 2, 20, ptr(q), None) == 0
+        outs.append(q)
+    assert np.array_equal(outs[0], outs[1])

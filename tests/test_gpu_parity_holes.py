@@ -157,7 +157,7 @@ def _actor_forward(lib, net, theta_d, obs, act, use_workspace):
     if use_workspace and need > 0:
         ws = torch.zeros(need, device="cuda")
     rc = lib.dtqn_actor_forward(ctypes.byref(net), ptr(theta_d), ptr(ctx_h), ptr(ctx_d), n, ptr(q_d), ptr(q_last),
-                                None if ws is None else ptr(ws), engine.stream_ptr())
+                                None if ws is None else ptr(ws), 0, 0, 0, engine.stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
     if ws is not None and not net.tiled:

@@ -265,3 +265,40 @@ def test_gradient_is_bit_reproducible_in_latency_mode(lib, split, D, gate, monke
             torch.cuda.synchronize()
             assert torch.equal(eng.grad, ref) and torch.equal(eng.q3, refq), it
     assert int(eng.xflags.sum()) == 0
+
+
+DROPOUT_CASES = [
+    # cfg-1 shapes in latency mode (weights-through-LDS forward, matrix-core attention in the row slices, 4 backward slices)
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, dropout=0.1), dict(batch=32, T=200, mask=-5, n_eps=40)),
+    # one workgroup per sequence, VALU attention (head_dim 8)
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, dropout=0.2), dict(batch=48, T=200, mask=-5, n_eps=60)),
+    # matrix-core attention (head_dim 16), discrete tokens, D = 128 (register-direct stages)
+    (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9, dropout=0.1), dict(batch=8, T=50, mask=8, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, history_len=50, action_dim=8, pos="sin", dropout=0.3), dict(batch=6, T=200, mask=-5, n_eps=20, history=20)),
+    # GRU gates and identity-reordered layers
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, gate="gru", dropout=0.1), dict(batch=16, T=200, mask=-5, n_eps=30)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, identity=True, dropout=0.1), dict(batch=8, T=200, mask=-5, n_eps=30)),
+]
+
+
+@pytest.mark.parametrize("kw,run", DROPOUT_CASES)
+def test_td_update_with_dropout(lib, kw, run):
+    """dropout > 0: keep masks of the embedding, the attention probabilities and the FFN output are a counter-based hash both
+    the kernels and the oracle evaluate (the backward recomputes them); target forward in eval mode.  Same checks as without."""
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9),
+                                               mask=run["mask"], history=run.get("history"), device="cuda", test_lib=False)
+    eng.td.dropout_seed = 4242
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    # the masks matter: the same update without dropout gives different Q-values for the train-mode passes, the same for the target
+    q_drop = eng.q3.clone()
+    net0 = net_from_cfg(lib, O.NetCfg(**{**kw, "dropout": 0.0}))
+    from dtqn_amd.learner import TdEngine
+    eng0 = TdEngine(net0, run["batch"], history=eng.td.history)
+    eng0.theta_pol.copy_(eng.theta_pol); eng0.theta_tgt.copy_(eng.theta_tgt)
+    eng0.ep_idx.copy_(eng.ep_idx); eng0.start.copy_(eng.start)
+    eng.forward_backward(rep); eng0.forward_backward(rep)
+    torch.cuda.synchronize()
+    n = run["batch"] * net.lp * net.ap
+    qa, qb = eng.q3.reshape(3, -1), eng0.q3.reshape(3, -1)
+    assert not torch.equal(qa[0], qb[0]) and not torch.equal(qa[1], qb[1]) and torch.equal(qa[2], qb[2])
