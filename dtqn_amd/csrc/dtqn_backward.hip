@@ -55,7 +55,8 @@ struct BwdArgs {
 // RS = row slices per sequence (see dtqn_forward.hip).  RS == 2: the workgroup owns rows [R0, R0 + LP); attention is
 // the only stage that looks below R0 (keys / values of the lower rows, read from the forward's record) and the only one
 // that hands something over: the upper slice's contribution to dK | dV of the lower rows (slice 1 -> slice 0).
-template <int D, int MT, int HD, int NW, bool GRU, int RS>
+// DROP: the training forward ran with dropout (compile-time: the default build of a network carries no keep-mask code)
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
     constexpr int NT = NW * 64;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     float* DU = st_s + 4 * LP;                         // identity only: branch grad    [LP][LDX]
 
     const int ep = a.ep_idx[b], st0 = a.start[b] + R0;
-    const Drop dr = a.drop_thresh != 0u ? Drop{a.drop_thresh, a.drop_scale, a.drop_seed, (uint32_t)a.step_counter[1], (uint32_t)b} : drop_off();
+    Drop dr = drop_off();
+    if constexpr (DROP) dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, (uint32_t)a.step_counter[1], (uint32_t)b};
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
@@ -520,14 +522,19 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS>
-static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP>
+static int launch_bwd3(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
     static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>), lds, attr_lds);
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS>), dim3(a.batch * RS), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP>), dim3(a.batch * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+template <int D, int MT, int HD, int NW, bool GRU, int RS>
+static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
+    if (a.drop_thresh != 0u) return launch_bwd3<D, MT, HD, NW, GRU, RS, true>(a, stream);
+    return launch_bwd3<D, MT, HD, NW, GRU, RS, false>(a, stream);
 }
 template <int D, int MT, int HD, int NW>
 static int launch_bwd(const BwdArgs& a, hipStream_t stream) {

@@ -63,7 +63,9 @@ __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 // TRAIN: this workgroup saves the activation record (policy(o) pass of a TD update).  A template parameter, not a
 // pointer test: every record store is then unconditional code, and the compiler can count the stores that sit between a
 // prefetched weight fragment and its s_waitcnt instead of falling back to vmcnt(0) (measured: -6 % on the inference pass).
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool TRAIN>
+// DROP: the pass may run with dropout (net.dropout > 0; a compile-time switch: with DROP = false the keep-mask code folds away
+// and the default path carries none of it)
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool TRAIN, bool DROP>
 __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     static_assert(RS == 1 || RS == 2, "one or two row slices");
     constexpr int NT = NW * 64;                    // threads per workgroup
@@ -78,9 +80,11 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const int which = seq / a.batch;
     const int b = seq - which * a.batch;
     Drop dr = drop_off();
-    if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
-        dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : a.drop_step,
-                  ((uint32_t)which << 20) | (uint32_t)b};
+    if constexpr (DROP) {
+        if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
+            dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : a.drop_step,
+                      ((uint32_t)which << 20) | (uint32_t)b};
+    }
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
@@ -408,10 +412,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const int R0 = slice * LP;
     const int which = seq / a.batch;
     const int b = seq - which * a.batch;
-    Drop dr = drop_off();
-    if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
-        dr = Drop{a.drop_thresh, a.drop_scale, a.drop_seed, a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : a.drop_step,
-                  ((uint32_t)which << 20) | (uint32_t)b};
+    const Drop dr = drop_off();       // dropout > 0 is served by the register-direct stages (the host never picks this kernel then)
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;
@@ -696,16 +697,18 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     DTQN_PROF(a.prof, ps++);       // end
 }
 
-// WL: weights through LDS (forward_body_wl; residual gate, D <= 64, chosen by the host when the arena fits)
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL>
+// WL: weights through LDS (forward_body_wl; residual gate, D <= 64, chosen by the host when the arena fits).
+// DROP: keep-mask code compiled in (register-direct stages only).
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
+    static_assert(!(WL && DROP), "dropout runs on the register-direct stages");
     const int which = ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
     if constexpr (WL) {
         if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true>(a);
         else forward_body_wl<D, MT, HD, NW, RS, false>(a);
     } else {
-        if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true>(a);
-        else forward_body<D, MT, HD, NW, GRU, RS, false>(a);
+        if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true, DROP>(a);
+        else forward_body<D, MT, HD, NW, GRU, RS, false, DROP>(a);
     }
 }
 
@@ -729,21 +732,22 @@ inline size_t fwd_lds_bytes(const DtqnNet* net, bool wl = false) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL>
-int launch_fwd3(const FwdArgs& a, int nseq, hipStream_t stream) {
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
+int launch_fwd4(const FwdArgs& a, int nseq, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net, WL);
     static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL>), lds, attr_lds);
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
+    if (a.drop_thresh != 0u) return launch_fwd4<D, MT, HD, NW, GRU, RS, false, true>(a, nseq, stream);
     if constexpr (!GRU && D <= 64) {
-        if (fwd_wl_ok(&a.net) && fwd_lds_bytes(&a.net, true) <= 160 * 1024) return launch_fwd3<D, MT, HD, NW, GRU, RS, true>(a, nseq, stream);
+        if (fwd_wl_ok(&a.net) && fwd_lds_bytes(&a.net, true) <= 160 * 1024) return launch_fwd4<D, MT, HD, NW, GRU, RS, true, false>(a, nseq, stream);
     }
-    return launch_fwd3<D, MT, HD, NW, GRU, RS, false>(a, nseq, stream);
+    return launch_fwd4<D, MT, HD, NW, GRU, RS, false, false>(a, nseq, stream);
 }
 template <int D, int MT, int HD, int NW>
 int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
