@@ -188,16 +188,47 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
         }
     };
     auto wfrag = [&](int kc) { return kc < nch1 ? wrow + (size_t)kc * D : wrow2 + (size_t)(kc - nch1) * D; };
+    // D = 256 (one workgroup per CU: 250 registers): the operand tile of chunk kc + 1 is pulled global -> registers while chunk
+    // kc multiplies and dropped into the LDS tile once chunk kc's readers are through.  At D <= 128 two workgroups share a
+    // CU and hide each other's staging; the 16 extra registers would cost that (measured: cfg 4 603 -> 581 updates/s).
+    constexpr bool PREFETCH = D >= 256;
+    constexpr int XN = TROWS * (D / 4) / TNT;                         // float4 per thread of a [64][D] tile
+    float4 xr[PREFETCH ? XN : 1];
+    auto stage_load = [&](int kc) {
+        const float* src = kc < nch1 ? in0 + (size_t)kc * D : in20 + (size_t)(kc - nch1) * D;
+        const int ld = kc < nch1 ? a.in.ld : a.in2.ld;
+#pragma unroll
+        for (int k = 0; k < (PREFETCH ? XN : 0); ++k) {
+            const int idx = t.tid + k * TNT;
+            const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+            xr[k] = ld4(src + (size_t)r * ld + c);
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int k = 0; k < (PREFETCH ? XN : 0); ++k) {
+            const int idx = t.tid + k * TNT;
+            const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+            st4(Xt + r * LDT + c, xr[k]);
+        }
+    };
+    if (PREFETCH) stage_load(0);
     for (int kc = 0; kc < nchunks; kc += 2) {
         __syncthreads();                                              // previous chunk's tile fully consumed
-        stage(kc);
-        if (kc + 1 < nchunks) frag_xwT_fetch<D>(bf1, wfrag(kc + 1), t);
+        if (PREFETCH) stage_store(); else stage(kc);
+        if (kc + 1 < nchunks) {
+            if (PREFETCH) stage_load(kc + 1);
+            frag_xwT_fetch<D>(bf1, wfrag(kc + 1), t);
+        }
         __syncthreads();
         frag_xwT_mma<D, 4>(Xt, LDT, bf0, t, acc);
         if (kc + 1 < nchunks) {
             __syncthreads();
-            stage(kc + 1);
-            if (kc + 2 < nchunks) frag_xwT_fetch<D>(bf0, wfrag(kc + 2), t);
+            if (PREFETCH) stage_store(); else stage(kc + 1);
+            if (kc + 2 < nchunks) {
+                if (PREFETCH) stage_load(kc + 2);
+                frag_xwT_fetch<D>(bf0, wfrag(kc + 2), t);
+            }
             __syncthreads();
             frag_xwT_mma<D, 4>(Xt, LDT, bf1, t, acc);
         }
