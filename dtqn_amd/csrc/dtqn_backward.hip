@@ -65,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     constexpr int LDX = D + 4;
     constexpr int GW = D >= 64 ? 64 : D;          // attention head-group width (columns)
     constexpr int NG = D / GW;
-    constexpr int NC = D >= 128 ? D : 2 * D;      // FFN hidden columns per pass (D = 128: 2D-wide fragments would be 128 VGPRs a pair)
+    constexpr int NC = D >= 128 ? D / 2 : 2 * D;  // FFN hidden columns per pass (D = 128: 2D-wide fragments would be 128 VGPRs a pair)
     constexpr bool OST = D <= 64;                 // stage the attention output o in LDS too (sixth W5 tile) when it fits
     constexpr int W5C = ((OST ? 6 : 5) * GW > NC ? (OST ? 6 : 5) * GW : NC);
     constexpr int LD5 = W5C + 4;
@@ -221,8 +221,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             float w1f[2][NC / 4];
             const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(mf(lrec, net.al_mh, 4 * D / 16));
             constexpr int MGH = pick_mg(NC / 16, MT, NW);
-#pragma unroll
-            for (int c0 = 0; c0 < 4 * D; c0 += NC) {   // unrolled: exact s_waitcnt counts across the chunk boundary
+#pragma clang loop unroll_count(D >= 128 ? 1 : 4)
+            for (int c0 = 0; c0 < 4 * D; c0 += NC) {   // unrolled (D <= 64): exact s_waitcnt counts across the chunk boundary; at D = 128
+                                                       // the four unrolled chunks let the scheduler hoist loads until 630 bytes per lane spilled
                 g_dh.retire();
                 if (c0 == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_df, D), LP, D, t);
                 unsigned long long mw[MGH][4];         // ReLU ballots of the item's accumulator registers

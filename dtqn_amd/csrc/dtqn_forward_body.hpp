@@ -285,8 +285,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
                 b2v[q] = Own::valid_fast(t.wave, q) ? (th + net.lo_f2_b)[Own::nt(t.wave, q) * 16 + t.i] : 0.f;
             float4 w2f[2][NC / 16];                    // this wave's FFN-2 weight fragments
             float* mh_g = mf(lrec, net.al_mh, 4 * D / 16);
-#pragma unroll
-            for (int c0 = 0; c0 < 4 * D; c0 += NC) {       // unrolled: exact s_waitcnt counts across the chunk boundary
+#pragma clang loop unroll_count(D >= 128 ? 1 : 4)
+            for (int c0 = 0; c0 < 4 * D; c0 += NC) {       // unrolled (D <= 64): exact s_waitcnt counts across the chunk boundary
                 // the second GEMM's first weight fragment does not depend on the hidden: in flight during the first GEMM
                 if (Own::valid_fast(t.wave, 0))
                     frag_xwT_fetch<NC>(w2f[0], W2 + (size_t)(Own::nt(t.wave, 0) * 16 + t.i) * 4 * D + c0, t);
