@@ -421,17 +421,24 @@ struct StageXwT {
 };
 
 // Same for  dX[LP][KTILES*16] = dY W  (contraction over the NN rows of W).
-template <int NN, int MT, int MG, int NW, int KTILES>
+// KS: the contraction of an item is cut into KS parts of NN / KS rows, each with its own (double-buffered) fragment: at
+// NN = 128 a whole-contraction fragment pair is 64 registers, which (with everything else the D = 128 backward keeps live)
+// ends in scratch; two half fragments are 32.
+template <int NN, int MT, int MG, int NW, int KTILES, int KS = (NN > 64 ? 2 : 1)>
 struct StageDyW {
     static constexpr int MGROUPS = MT / MG;
     static constexpr int ITEMS = KTILES * MGROUPS;
     static constexpr int PER_WAVE = (ITEMS + NW - 1) / NW;
-    float bf[2][NN / 4];
+    static constexpr int NP = NN / KS;              // contraction rows per part
+    static constexpr int STEPS = PER_WAVE * KS;
+    float bf[2][NP / 4];
     const float* W;
     int ldw;
-    __device__ __forceinline__ void fetch(int q, const Thr& t) {
+    __device__ __forceinline__ void fetch(int st, const Thr& t) {
+        const int q = st / KS, h = st - q * KS;
         const int item = t.wave + q * NW;
-        if (ITEMS >= (q + 1) * NW || item < ITEMS) frag_dyw_fetch<NN>(bf[q & 1], W + (item / MGROUPS) * 16 + t.i, ldw, t);
+        if (ITEMS >= (q + 1) * NW || item < ITEMS)
+            frag_dyw_fetch<NP>(bf[st & 1], W + (size_t)(h * NP) * ldw + (item / MGROUPS) * 16 + t.i, ldw, t);
     }
     __device__ __forceinline__ void prefetch(const float* __restrict__ W_, int ldw_, const Thr& t) {
         W = W_;
@@ -440,7 +447,7 @@ struct StageDyW {
     }
     __device__ __forceinline__ void retire() {
 #pragma unroll
-        for (int q = 0; q < NN / 4; ++q) DTQN_ASM_KEEP(bf[0][q]);
+        for (int q = 0; q < NP / 4; ++q) DTQN_ASM_KEEP(bf[0][q]);
     }
     template <typename Epi>
     __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Epi epi) {
@@ -451,15 +458,22 @@ struct StageDyW {
     __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, Pre pre, Epi epi) {
 #pragma unroll
         for (int q = 0; q < PER_WAVE; ++q) {
-            if (q + 1 < PER_WAVE) fetch(q + 1, t);
             const int item = t.wave + q * NW;
-            if (ITEMS >= (q + 1) * NW || item < ITEMS) {
-                const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
-                pre(kt, mg);
-                f32x4 acc[MG];
+            const bool mine = ITEMS >= (q + 1) * NW || item < ITEMS;
+            const int kt = item / MGROUPS, mg = item - kt * MGROUPS;
+            f32x4 acc[MG];
 #pragma unroll
-                for (int m = 0; m < MG; ++m) acc[m] = zero4();
-                frag_dyw_mma<NN, MG>(dYs + mg * MG * 16 * lda, lda, bf[q & 1], t, acc);
+            for (int m = 0; m < MG; ++m) acc[m] = zero4();
+#pragma unroll
+            for (int h = 0; h < KS; ++h) {
+                const int st = q * KS + h;
+                if (st + 1 < STEPS) fetch(st + 1, t);
+                if (mine) {
+                    if (h == 0) pre(kt, mg);
+                    frag_dyw_mma<NP, MG>(dYs + mg * MG * 16 * lda + h * NP, lda, bf[st & 1], t, acc);
+                }
+            }
+            if (mine) {
 #pragma unroll
                 for (int m = 0; m < MG; ++m)
 #pragma unroll
