@@ -93,9 +93,11 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_replay_push": [P(DtqnReplay), vp, vp, i32, vp],
+        "dtqn_replay_gather_bag": [P(DtqnReplay), vp, vp, vp, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_forward_tiled_strided": [P(DtqnNet), vp, vp, vp, i32, i32, i32, vp, vp, vp],
+        "dtqn_forward_bag": [P(DtqnNet), vp, vp, vp, vp, vp, i32, i32, vp, vp, vp],
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
         "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],
@@ -132,7 +134,7 @@ POS = {"learned": DEFINES["DTQN_POS_LEARNED"], "sin": DEFINES["DTQN_POS_SIN"], "
 
 def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, inner_embed_size=64, num_heads=8,
              num_layers=2, history_len=50, gate="res", identity=False, pos="learned", discrete=False,
-             vocab_sizes=0, dropout=0.0) -> DtqnNet:
+             vocab_sizes=0, dropout=0.0, bag_size=0) -> DtqnNet:
     """Build and initialise a DtqnNet from the reference's DTQN constructor arguments
     (dtqn/networks/dtqn.py:41-59)."""
     net = DtqnNet()
@@ -143,11 +145,12 @@ def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, in
     net.gate, net.identity, net.pos = GATES[gate], int(bool(identity)), POS[str(pos)]
     net.discrete, net.vocab = int(bool(discrete)), int(vocab_sizes or 0)
     net.dropout = float(dropout)
+    net.bag_size = int(bag_size)
     rc = lib.dtqn_net_init(ctypes.byref(net))
     if rc != 0:
         raise NotImplementedError(
             f"dtqn_net_init rc={rc}: this DTQN variant/shape is outside the gfx950 kernels' coverage "
-            f"(D={inner_embed_size}, H={num_heads}, L={history_len}, gate={gate}, dropout={dropout}); see DESIGN.md")
+            f"(D={inner_embed_size}, H={num_heads}, L={history_len}, gate={gate}, dropout={dropout}, bag_size={bag_size}); see DESIGN.md")
     return net
 
 
@@ -189,7 +192,12 @@ def param_table(net: DtqnNet) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
             for gname, goff in (("attn_gate", net.off_gate_attn), ("mlp_gate", net.off_gate_mlp)):
                 for nm, off, shp in gate_names:
                     tab[pre + f"{gname}.{nm}"] = (goff + off, shp)
-    tab["ffn.0.weight"] = (net.off_head1_w, (D, D))
+    if net.bag_size > 0:       # dtqn.py:134-139: registered after the transformer layers, before the head
+        tab["bag_attention.in_proj_weight"] = (net.off_bag_in_w, (3 * D, D))
+        tab["bag_attention.in_proj_bias"] = (net.off_bag_in_b, (3 * D,))
+        tab["bag_attention.out_proj.weight"] = (net.off_bag_out_w, (D, D))
+        tab["bag_attention.out_proj.bias"] = (net.off_bag_out_b, (D,))
+    tab["ffn.0.weight"] = (net.off_head1_w, (D, 2 * D if net.bag_size > 0 else D))
     tab["ffn.0.bias"] = (net.off_head1_b, (D,))
     tab["ffn.2.weight"] = (net.off_head2_w, (A, D))
     tab["ffn.2.bias"] = (net.off_head2_b, (A,))

@@ -25,6 +25,7 @@ from .. import dist as ddp
 from ..buffers.replay_buffer import ReplayBuffer
 from .. import _binding as B
 from ..learner import STAT_NAMES, TdEngine
+from ..utils.bag import Bag
 from ..utils.context import Context
 from ..utils.logging_utils import DeferredRunningAverage, RunningAverage
 from ..utils.random import RNG
@@ -62,8 +63,6 @@ class DtqnAgent:
                  gamma: float = 0.99, grad_norm_clip: float = 1.0, target_update_frequency: int = 10_000,
                  history: int = 50, bag_size: int = 0, sampler: str = "reference", ref_quirks: bool = False,
                  sample_seed: int = 0, **kwargs):
-        if bag_size > 0:
-            raise NotImplementedError("the persistent-memory bag is outside dtqn_amd's scope")
         self.context_len, self.env_obs_length = context_len, env_obs_length
         self.device = torch.device(device)
         self.policy_network = network_factory()
@@ -111,6 +110,10 @@ class DtqnAgent:
         self.train_mode = TrainMode.TRAIN
         mk = lambda: Context(context_len, obs_mask, num_actions, env_obs_length, discrete=is_discrete_env, ref_quirks=ref_quirks)
         self.train_context, self.eval_context = mk(), mk()
+        mkb = lambda: Bag(bag_size, obs_mask, env_obs_length, discrete=is_discrete_env, ref_quirks=ref_quirks)
+        self.train_bag, self.eval_bag = mkb(), mkb()                   # dtqn.py:66-67
+        if bag_size > 0 and self.policy_network.bag_size != bag_size:
+            raise ValueError("the agent's bag_size must match the network's")
         # actor staging: rolling context -> pinned -> device, Q row -> pinned
         L, O, A = context_len, env_obs_length, num_actions
         pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
@@ -149,6 +152,10 @@ class DtqnAgent:
     def context(self) -> Context:
         return self.train_context if self.train_mode == TrainMode.TRAIN else self.eval_context
 
+    @property
+    def bag(self) -> Bag:                                               # dtqn.py:69-74
+        return self.train_bag if self.train_mode == TrainMode.TRAIN else self.eval_bag
+
     def eval_on(self) -> None:
         self.train_mode = TrainMode.EVAL
         self.policy_network.eval()
@@ -183,10 +190,25 @@ class DtqnAgent:
             raise RuntimeError(f"dtqn_actor_forward failed with DTQN status {rc}")
         return n
 
+    def _bag_forward(self, obs: np.ndarray, actions: np.ndarray, bag_obss: np.ndarray, bag_actions: np.ndarray) -> torch.Tensor:
+        """policy_network(obs, actions, bag_obss, bag_actions) on host arrays (batch-first); Q stays on the device."""
+        t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=self.device)
+        return self.policy_network(t(obs, self.obs_tensor_type), t(actions, torch.long), t(bag_obss, self.obs_tensor_type),
+                                   t(bag_actions, torch.long))
+
+    def _bag_action(self) -> int:
+        """get_action of a bag network (dtqn.py:79-108): the unpadded context prefix plus the WHOLE bag, padding included."""
+        ctx = self.context
+        n = min(ctx.max_length, ctx.timestep + 1)
+        q = self._bag_forward(ctx.obs[None, :n], ctx.action[None, :n], self.bag.obss[None], self.bag.actions[None])
+        return int(torch.argmax(q[:, -1, :]).item())
+
     @torch.no_grad()
     def get_action(self, epsilon: float = 0.0) -> int:
         if RNG.rng.random() < epsilon:
             return RNG.rng.integers(self.num_actions)
+        if self.bag.size > 0:
+            return self._bag_action()
         self._launch_actor_forward(self.engine._stream())
         if self._main_stream is not None:
             self._main_stream.synchronize()
@@ -199,6 +221,8 @@ class DtqnAgent:
         actor stream behind the last TD update; call train() next (it overlaps), then finish_action()."""
         if RNG.rng.random() < epsilon:
             return int(RNG.rng.integers(self.num_actions))
+        if self.bag.size > 0:                     # bag networks act through the module forward (no second stream)
+            return self._bag_action()
         if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
             return self._sync_forward_action()
         if not getattr(self, "_update_recorded", True):       # order the actor behind the last TD update (pipelined mode only)
@@ -224,9 +248,27 @@ class DtqnAgent:
         self.context.reset(obs)
         if self.train_mode == TrainMode.TRAIN:
             self.replay_buffer.store_obs(obs)
+        if self.bag.size > 0:
+            self.bag.reset()
 
+    @torch.no_grad()
     def observe(self, obs: np.ndarray, action: int, reward: float, done: bool) -> None:
-        self.context.add_transition(obs, action, reward, done)
+        """Add a transition to the context; what the context evicts goes to the bag, and when the bag is full the policy
+        network picks which of the bag_size + 1 candidate bags to keep (dtqn.py:116-160)."""
+        evicted_obs, evicted_action = self.context.add_transition(obs, action, reward, done)
+        bag = self.bag
+        if bag.size > 0 and evicted_obs is not None and not bag.add(evicted_obs, evicted_action):
+            # candidate i < bag_size: entry i replaced by the evicted pair; candidate bag_size: the bag as it is
+            k = bag.size + 1
+            cand_obss = np.tile(bag.obss, (k, 1, 1))
+            cand_actions = np.tile(bag.actions, (k, 1, 1))
+            for i in range(bag.size):
+                cand_obss[i, i] = evicted_obs
+                cand_actions[i, i] = evicted_action
+            ctx = self.context
+            q = self._bag_forward(np.tile(ctx.obs, (k, 1, 1)), np.tile(ctx.action, (k, 1, 1)), cand_obss, cand_actions)
+            keep = int(torch.argmax(torch.mean(torch.max(q, 2)[0], 1)).item())      # highest mean-over-time max-Q
+            bag.obss, bag.actions = cand_obss[keep], cand_actions[keep]
         if self.train_mode == TrainMode.TRAIN:
             self.replay_buffer.store(obs, action, reward, done, self.context.timestep)
 
@@ -246,7 +288,11 @@ class DtqnAgent:
         eng = self.engine
         sp = eng._stream()
         rb.commit(sp, self._main_stream)
-        if self.sampler == "reference":
+        if self.sampler == "reference" and self.bag.size > 0:
+            eps, starts, rows = rb.sample_bag_indices(self.batch_size, self.bag.size)       # dtqn.py:166-177
+            eng.set_indices(eps, starts)
+            eng.gather_bag(rb.dev, rows)
+        elif self.sampler == "reference":
             eng.set_indices(*rb.sample_indices(self.batch_size))
         else:
             n_valid, exclude = rb.valid_range()

@@ -26,6 +26,8 @@ from ..utils.random import RNG
 
 class VectorActor:
     def __init__(self, agent, envs: Sequence, ref_quirks: bool = False):
+        if agent.bag.size > 0:
+            raise NotImplementedError("the vectorised rollout keeps no per-environment bags; bag networks step one environment")
         self.agent, self.envs = agent, list(envs)
         N = self.n = len(self.envs)
         L, O, A = agent.context_len, agent.env_obs_length, agent.num_actions

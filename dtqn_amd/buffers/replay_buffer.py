@@ -128,6 +128,48 @@ class ReplayBuffer:
                              dtype=np.int32, count=batch_size)
         return eps, starts
 
+    def sample_bag_indices(self, batch_size: int, bag_size: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """The draws of ReplayBuffer.sample_with_bag (replay_buffer.py:171-254) from Python's `random` stream, as indices:
+        (episodes [B], starts [B], rows [B][2][bag_size]); rows[b][0] / rows[b][1] name the episode rows (all before the window)
+        whose observations / actions fill bag b, -1 = unused entry (obs_mask, action 0).  Reference behaviour kept as is:
+          * the episode list skips `i != pos[0]` WITHOUT the modulo of sample() (:183-187), so once the buffer has wrapped the
+            slot in progress can be drawn too;
+          * a window starting before row bag_size takes ALL earlier rows in order (:221-229); otherwise observation rows and
+            action rows are two INDEPENDENT random.sample draws (:232-252), so a bag entry's action need not belong to its
+            observation.  random.sample consumes the stream as a function of (population size, k) only, so sampling row
+            numbers visits the same rows as the reference's sampling of the row contents."""
+        valid = [i for i in range(min(self.pos[0], self.max_size)) if i != self.pos[0]]
+        eps = np.fromiter((random.choice(valid) for _ in range(batch_size)), dtype=np.int32, count=batch_size)
+        L = self.context_len
+        starts = np.fromiter((random.randint(0, max(0, int(self.episode_lengths[e]) - L)) for e in eps),
+                             dtype=np.int32, count=batch_size)
+        rows = np.full((batch_size, 2, bag_size), -1, dtype=np.int32)
+        for b in range(batch_size):
+            st = int(starts[b])
+            if st < bag_size:
+                rows[b, :, :st] = np.arange(st)
+            else:
+                rows[b, 0] = random.sample(range(st), k=bag_size)
+                rows[b, 1] = random.sample(range(st), k=bag_size)
+        return eps, starts, rows
+
+    def sample_with_bag(self, batch_size: int, sample_bag):
+        """Reference-shaped sample_with_bag() -> numpy arrays (compatibility / debugging path, like sample(); the TD update
+        gathers windows and bags on the device from sample_bag_indices)."""
+        self.commit()
+        eps, starts, rows = self.sample_bag_indices(batch_size, sample_bag.size)
+        e = torch.as_tensor(eps, dtype=torch.long, device=self.device).unsqueeze(1)
+        tr = torch.as_tensor(starts, dtype=torch.long, device=self.device).unsqueeze(1) + \
+            torch.arange(self.context_len, device=self.device).unsqueeze(0)
+        d = self.dev
+        out = (d.obs[e, tr], d.actions[e, tr].unsqueeze(-1), d.rewards[e, tr].unsqueeze(-1), d.obs[e, tr + 1],
+               d.actions[e, tr + 1].unsqueeze(-1), d.dones[e, tr].unsqueeze(-1).bool())
+        r = torch.as_tensor(rows, dtype=torch.long, device=self.device)
+        bo = torch.where((r[:, 0] >= 0).unsqueeze(-1), d.obs[e, r[:, 0].clamp(min=0)], torch.full((), float(self.obs_mask), device=self.device))
+        ba = torch.where(r[:, 1] >= 0, d.actions[e, r[:, 1].clamp(min=0)], torch.zeros((), dtype=d.actions.dtype, device=self.device))
+        return tuple(x.cpu().numpy() for x in out) + (self.episode_lengths[eps.reshape(-1, 1)], bo.cpu().numpy(),
+                                                      ba.unsqueeze(-1).cpu().numpy().astype(np.int64))
+
     def sample(self, batch_size: int):
         """Reference-shaped sample() -> numpy arrays (compatibility / debugging path: it gathers on
         the device and copies back; the TD update does not use it)."""

@@ -495,8 +495,10 @@ template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t,
-                                               float* __restrict__ save_in = nullptr, float* __restrict__ save_out = nullptr) {
+                                               float* __restrict__ save_in = nullptr, float* __restrict__ save_out = nullptr,
+                                               int ld_dst = 0) {                 // ld_dst: leading dim of dst when it differs from src's
     constexpr int THREADS = NW * 64;
+    if (ld_dst == 0) ld_dst = ld;
     constexpr int LPR = (THREADS / LPT) < (D / 4) ? (THREADS / LPT) : (D / 4);                  // lanes per row (4, 8 or 16)
     constexpr int NV = D / (4 * LPR);                                                           // float4 chunks per lane
     constexpr int ROWS = THREADS / LPR;
@@ -528,7 +530,7 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
         for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
         if (valid) {
-            float* dp = dst + row * ld + part * 4;
+            float* dp = dst + row * ld_dst + part * 4;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const float4 g = ld4(gamma + part * 4 + 4 * LPR * j), b = ld4(beta + part * 4 + 4 * LPR * j);

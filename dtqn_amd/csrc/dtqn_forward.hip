@@ -127,6 +127,11 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
             const int rc = dtqn_replay_sample(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed,
                                               td->step_counter, td->ep_idx, td->start, stream);
             if (rc != DTQN_OK) return rc;
+            if (net->bag_size > 0) {      // ... and the bags of those windows
+                const int rb = dtqn_replay_gather_bag(rp, td->ep_idx, td->start, nullptr, td->batch, net->bag_size, td->sample_seed,
+                                                      td->step_counter, td->bag_obs, td->bag_actions, stream);
+                if (rb != DTQN_OK) return rb;
+            }
         }
         return tiled_td_forward(net, rp, td, (hipStream_t)stream);
     }

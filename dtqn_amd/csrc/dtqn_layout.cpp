@@ -33,10 +33,11 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->gate != DTQN_GATE_RES && net->gate != DTQN_GATE_GRU) return DTQN_ERR_CONFIG;
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
     if (!(net->dropout >= 0.f && net->dropout < 1.f)) return DTQN_ERR_CONFIG;
+    if (net->bag_size < 0) return DTQN_ERR_CONFIG;
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
-    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr) {
+    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->bag_size > 0) {
         // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
         net->tiled = 1;
         net->lp = (L + 63) / 64 * 64;
@@ -56,6 +57,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     }
     const int LP = net->lp;
     if (net->tiled && net->dropout > 0.f) return DTQN_ERR_CONFIG;      // dropout: whole-sequence kernels only
+    // the bag branch is composed from the row-block kernels: post-LN layers, as many bag entries as the records have rows
+    if (net->bag_size > 0 && (net->identity || net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
         if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;
@@ -106,7 +109,12 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
             net->off_gate_attn = net->off_gate_mlp = -1;
         }
     }
-    net->off_head1_w = c.take(D * D);
+    const int bag = net->bag_size;
+    net->off_bag_in_w = bag > 0 ? c.take(3 * D * D) : -1;
+    net->off_bag_in_b = bag > 0 ? c.take(3 * D) : -1;
+    net->off_bag_out_w = bag > 0 ? c.take(D * D) : -1;
+    net->off_bag_out_b = bag > 0 ? c.take(D) : -1;
+    net->off_head1_w = c.take(D * (bag > 0 ? 2 * D : D));      // Linear(2D, D) on [working | persistent memory] with a bag (dtqn.py:140-144)
     net->off_head1_b = c.take(D);
     net->off_head2_w = c.take(A * D);
     net->off_head2_b = c.take(A);
@@ -141,6 +149,14 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->ao_layer0 = ac.take(net->act_layer_stride * NL);
     net->ao_xf = ac.take(LP * D);
     net->ao_hh = ac.take(LP * D);
+    net->bag_ld = bag > 0 ? up4(bag) : 0;
+    net->ao_bag_ein = bag > 0 ? ac.take(LP * net->kep) : -1;
+    net->ao_bag_e = bag > 0 ? ac.take(LP * D) : -1;
+    net->ao_bag_kv = bag > 0 ? ac.take(LP * 2 * D) : -1;
+    net->ao_bag_q = bag > 0 ? ac.take(LP * D) : -1;
+    net->ao_bag_p = bag > 0 ? ac.take(H * LP * net->bag_ld) : -1;
+    net->ao_bag_o = bag > 0 ? ac.take(LP * D) : -1;
+    net->ao_xcat = bag > 0 ? ac.take(LP * 2 * D) : -1;
     net->act_stride = ac.pos;
 
     // ---- gradient record ----
@@ -160,6 +176,11 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->go_dhh = gc.take(LP * D);
     net->go_dq = gc.take(LP * net->ap);
     net->go_do = net->tiled ? gc.take(LP * D) : -1;
+    net->go_dcat = bag > 0 ? gc.take(LP * 2 * D) : -1;
+    net->go_bag_do = bag > 0 ? gc.take(LP * D) : -1;
+    net->go_bag_dq = bag > 0 ? gc.take(LP * D) : -1;
+    net->go_bag_dkv = bag > 0 ? gc.take(LP * 2 * D) : -1;
+    net->go_bag_de = bag > 0 ? gc.take(LP * D) : -1;
     net->grd_stride = gc.pos;
 
     // ---- small partials ----
@@ -187,7 +208,12 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         for (int g = 0; g < 2; ++g) for (int m = 0; m < 6; ++m) count(D, D);
         if (D > 64 && !net->tiled) return DTQN_ERR_CONFIG;   // the whole-sequence GRU backward keeps five [LP][D] tiles in LDS
     }
-    count(D, D);
+    if (bag > 0) {
+        count(D, D);          // bag_attention in-projection, query rows
+        count(2 * D, D);      // ... key | value rows
+        count(D, D);          // bag_attention out-projection
+    }
+    count(D, bag > 0 ? 2 * D : D);
     count(A, D);
     net->n_wjobs = njobs;
     net->n_wtiles = ntiles;
@@ -213,6 +239,13 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
     };
     // embedding linear: dY = dx0[:, a:], X = e_in
     add(1, net->ao_ein, net->kep, net->ke, net->go_dx0 + a, D, D - a, net->off_obs_w, net->off_obs_b);
+    if (net->bag_size > 0) {
+        // the embedding linear also embeds the bag entries (dtqn.py:203-210): a second token set of the same job, summed
+        // like the layers of a shared GRU gate (records of the bag entries at a fixed distance from the context's)
+        jobs[j - 1].n_layers = 2;
+        jobs[j - 1].x_lstride = net->ao_bag_ein - net->ao_ein;
+        jobs[j - 1].dy_lstride = net->go_bag_de - net->go_dx0;
+    }
     for (int l = 0; l < NL; ++l) {
         const int ab = net->ao_layer0 + l * net->act_layer_stride;
         const int gb = net->go_layer0 + l * net->grd_layer_stride;
@@ -247,6 +280,13 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
     // the head reads the final stream: ao_xf, except for identity-reordered layers on the row-block tiled path, whose last
     // layer leaves it in its own s2 field
     const int xf_off = net->tiled && net->identity ? net->ao_layer0 + (NL - 1) * net->act_layer_stride + net->al_s2 : net->ao_xf;
+    if (net->bag_size > 0) {
+        // bag_attention (dtqn.py:134-139,211-213): q = W_q xf, k | v = W_kv E_bag, persistent memory = W_o attn + b_o
+        add(1, net->ao_xcat, 2 * D, D, net->go_bag_dq, D, D, net->off_bag_in_w, net->off_bag_in_b);
+        add(1, net->ao_bag_e, D, D, net->go_bag_dkv, 2 * D, 2 * D, net->off_bag_in_w + D * D, net->off_bag_in_b + D);
+        add(1, net->ao_bag_o, D, D, net->go_dcat + D, 2 * D, D, net->off_bag_out_w, net->off_bag_out_b);
+        add(1, net->ao_xcat, 2 * D, 2 * D, net->go_dhh, D, D, net->off_head1_w, net->off_head1_b);
+    } else
     add(1, xf_off, D, D, net->go_dhh, D, D, net->off_head1_w, net->off_head1_b);
     add(1, net->ao_hh, D, D, net->go_dq, net->ap, A, net->off_head2_w, net->off_head2_b);
     return (j == net->n_wjobs && tile == net->n_wtiles) ? DTQN_OK : DTQN_ERR_CONFIG;

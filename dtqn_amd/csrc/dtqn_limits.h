@@ -5,5 +5,6 @@
 #define DTQN_MAX_D 128          /* d_model instantiations: 64, 128 (and 16/32 for tests) */
 #define DTQN_MAX_HEAD_DIM 32
 #define DTQN_MAX_ACTIONS 64
+#define DTQN_MAX_BAG 256        /* bag entries (bag_size <= padded context <= 256, the row-block tiled path's limit) */
 #define DTQN_THREADS 256        /* 4 wave64 per workgroup */
 #define DTQN_WAVES 4

@@ -67,9 +67,62 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_sample_kernel(Sample
     a.start[b] = (int32_t)s;
 }
 
+// ---- bags of the sampled windows (ReplayBuffer.sample_with_bag, replay_buffer.py:211-254) ---------------------------------
+struct BagArgs {
+    DtqnReplay rp;
+    const int32_t *ep_idx, *start, *rows, *step_counter;
+    int bag;
+    uint32_t seed;
+    float* bag_obs;
+    uint8_t* bag_actions;
+};
+// One workgroup per window: pick the rows (host-drawn, or Floyd's sampling of `bag` distinct rows below the window), then copy
+// them out of the episode -- observation row r and the action that PRECEDED it (the replay's action row r; row 0 is the dummy).
+__global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_bag_kernel(BagArgs a) {
+    __shared__ int32_t rows[2][DTQN_MAX_BAG];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x, bag = a.bag, O = a.rp.obs_dim, T = a.rp.max_steps;
+    const int ep = a.ep_idx[b], start = a.start[b];
+    if (a.rows != nullptr) {
+        for (int k = tid; k < 2 * bag; k += DTQN_THREADS) rows[k / bag][k % bag] = a.rows[(size_t)b * 2 * bag + k];
+    } else if (tid == 0) {
+        if (start < bag) {
+            for (int j = 0; j < bag; ++j) rows[0][j] = rows[1][j] = j < start ? j : -1;
+        } else {
+            const uint32_t step = a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : 0u;
+            for (int j = 0; j < bag; ++j) {            // Floyd: the j-th pick is uniform over [0, start-bag+j], or that bound if taken
+                const int hi = start - bag + j;
+                int r = (int)(((unsigned long long)hash_u32(a.seed, step, (uint32_t)b, 2u + (uint32_t)j) * (uint32_t)(hi + 1)) >> 32);
+                for (int i = 0; i < j; ++i) if (rows[0][i] == r) { r = hi; break; }
+                rows[0][j] = rows[1][j] = r;
+            }
+        }
+    }
+    __syncthreads();
+    const float* obs = a.rp.obs + (size_t)ep * (T + 1) * O;
+    const uint8_t* act = a.rp.actions + (size_t)ep * (T + 1);
+    for (int k = tid; k < bag * O; k += DTQN_THREADS) {
+        const int r = rows[0][k / O];
+        a.bag_obs[((size_t)b * bag) * O + k] = r >= 0 ? obs[(size_t)r * O + k % O] : a.rp.obs_mask;
+    }
+    for (int k = tid; k < bag; k += DTQN_THREADS) a.bag_actions[(size_t)b * bag + k] = rows[1][k] >= 0 ? act[rows[1][k]] : (uint8_t)0;
+}
+
 }  // namespace dtqn
 
 using namespace dtqn;
+
+extern "C" int dtqn_replay_gather_bag(const DtqnReplay* rp, const int32_t* ep_idx_dev, const int32_t* start_dev, const int32_t* rows_dev,
+                                      int batch, int bag_size, uint32_t seed, const int32_t* step_counter_dev, float* bag_obs_dev,
+                                      uint8_t* bag_actions_dev, void* stream) {
+    if (!rp || !ep_idx_dev || !start_dev || !bag_obs_dev || !bag_actions_dev || batch < 1) return DTQN_ERR_ARG;
+    if (bag_size < 1 || bag_size > DTQN_MAX_BAG) return DTQN_ERR_ARG;
+    BagArgs a;
+    a.rp = *rp; a.ep_idx = ep_idx_dev; a.start = start_dev; a.rows = rows_dev; a.step_counter = step_counter_dev;
+    a.bag = bag_size; a.seed = seed; a.bag_obs = bag_obs_dev; a.bag_actions = bag_actions_dev;
+    (void)hipGetLastError();   // drop stale errors left by other users of the runtime
+    hipLaunchKernelGGL(dtqn_replay_bag_kernel, dim3(batch), dim3(DTQN_THREADS), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
 
 extern "C" int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* recs_dev, const float* obs_rows_dev,
                                  int n, void* stream) {

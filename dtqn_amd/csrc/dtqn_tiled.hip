@@ -49,6 +49,8 @@ struct TlEmbedArgs {
     int n, rpb;
     Fld x;                             // [LPB][D] embedded tokens + positions
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
+    int src_mod;                       // > 0: sequence s reads source sequence s % src_mod (one bag per window, three forwards)
+    int bag;                           // 1: bag entries (dtqn.py:203-210): no position, the action embedding is not rolled
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n;
     const int s = (int)blockIdx.x / a.rpb, rb = (int)blockIdx.x % a.rpb;
     const float* __restrict__ theta = s >= a.split ? a.theta_b : a.theta_a;
-    int ep = s, row_first = 0;
+    int ep = a.src_mod > 0 ? s % a.src_mod : s, row_first = 0;
     if (a.ep_idx != nullptr) {
         const int which = s / a.batch, b = s - which * a.batch;
         ep = a.ep_idx[b];
@@ -126,13 +128,13 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
         float v = 0.f;
         if (r < n) {
             if (d < adim) {
-                // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192)
-                if (n == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
+                if (n == 1 || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
                 else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
             } else {
                 v = acc[i] + theta[net.off_obs_b + d - adim];
             }
-            v += theta[net.off_pos + r * D + d];
+            if (!a.bag) v += theta[net.off_pos + r * D + d];
         }
         xo[(size_t)rl * a.x.ld + d] = v;
     }
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_kernel(TlLnArgs a) {
     const Thr t = make_thr();
     const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
     float* st = a.st.base != nullptr ? a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2 : nullptr;
-    layernorm_rows<D, TNW>(frow(a.src, s, row0), frow(a.dst, s, row0), D, TROWS, s >= a.split ? a.gb : a.ga,
-                           s >= a.split ? a.bb : a.ba, st, t);
+    layernorm_rows<D, TNW>(frow(a.src, s, row0), frow(a.dst, s, row0), a.src.ld, TROWS, s >= a.split ? a.gb : a.ga,
+                           s >= a.split ? a.bb : a.ba, st, t, nullptr, nullptr, a.dst.ld);
 }
 
 // backward, one workgroup per sequence walking its row blocks (the gamma / beta partial of the sequence is
@@ -620,6 +622,9 @@ struct TlEmbedBwdArgs {
     long long obs_ep_stride, act_ep_stride;
     const int32_t* ep_idx;
     const int32_t* start;
+    // bag entries (second pass over the same partials): gradient at grd + dx_off instead of go_dx0, `rows` live rows read from
+    // source sequence b of (obs, actions) directly, action embedding not rolled, partials ADDED to the context's
+    int bag, dx_off, rows;
 };
 // One workgroup per sequence, walking its 64-row blocks.  Discrete observations: d(e_in) = dx0[:, a:] W_e per block out
 // of LDS-staged tiles, then the scatter onto table rows: thread (k = j * e + c, row group) adds its rows into a private
@@ -630,10 +635,10 @@ static __host__ __device__ inline int emb_row_groups(int ke) { return ke * 4 <= 
 __global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
     const DtqnNet& net = a.net;
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const int D = net.d_model, L = net.ctx_len, A = net.num_actions, adim = net.action_dim, LP = net.lp;
-    const float* DX = a.grd + (size_t)b * net.grd_stride + net.go_dx0;
+    const int D = net.d_model, L = a.bag ? a.rows : net.ctx_len, A = net.num_actions, adim = net.action_dim, LP = net.lp;
+    const float* DX = a.grd + (size_t)b * net.grd_stride + (a.bag ? a.dx_off : net.go_dx0);
     float* srec = a.small + (size_t)b * net.sp_stride;
-    const int ep = a.ep_idx[b], st0 = a.start[b];
+    const int ep = a.bag ? b : a.ep_idx[b], st0 = a.bag ? 0 : a.start[b];
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
     if (net.discrete) {
@@ -678,14 +683,18 @@ __global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
         for (int idx = tid; idx < V * e; idx += TNT) {
             float g = 0.f;
             for (int q = 0; q < kEmbRQ * O; ++q) g += part[(size_t)q * V * e + idx];
-            srec[net.so_tab + idx] = g;
+            srec[net.so_tab + idx] = a.bag ? srec[net.so_tab + idx] + g : g;
         }
     }
     if (adim > 0) {
         for (int idx = tid; idx < A * adim; idx += TNT) {
             const int v = idx / adim, c = idx - v * adim;
             float g = 0.f;
-            if (L == 1) {
+            if (a.bag) {
+                for (int r = 0; r < L; ++r)
+                    if ((int)act_rows[r] == v) g += DX[(size_t)r * D + c];
+                g += srec[net.so_act + idx];
+            } else if (L == 1) {
                 if ((int)act_rows[0] == v) g = DX[c];
             } else {
                 for (int r = 1; r < L; ++r)
@@ -693,6 +702,119 @@ __global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
             }
             srec[net.so_act + idx] = g;
         }
+    }
+}
+
+// ---- bag attention (dtqn.py:211-213): nn.MultiheadAttention(query = working memory, key = value = bag embeddings), no mask ----
+// One workgroup per (sequence, head); the bag is at most a few dozen entries, so this is plain VALU code out of LDS.
+struct TlBagAttnArgs {
+    Fld q;                             // [LPB][D]   W_q xf + b_q
+    Fld kv;                            // [LPB][2D]  k | v of the bag entries (rows < bag)
+    Fld p;                             // [H][LPB][bag_ld] attention weights (training; base may be null)
+    Fld o;                             // [LPB][D]   attention output (before the out-projection)
+    int D, HD, n, bag, bag_ld, lpb;
+};
+__global__ __launch_bounds__(256) void tl_bag_attn_kernel(TlBagAttnArgs a) {
+    float* kl = reinterpret_cast<float*>(dtqn_smem);                   // [bag][HD] keys, then [bag][HD] values
+    const int s = (int)blockIdx.x, h = (int)blockIdx.y, tid = (int)threadIdx.x, HD = a.HD;
+    float* vl = kl + a.bag * HD;
+    for (int idx = tid; idx < a.bag * HD; idx += 256) {
+        const int j = idx / HD, c = idx - j * HD;
+        const float* row = frow(a.kv, s, j);
+        kl[idx] = row[h * HD + c];
+        vl[idx] = row[a.D + h * HD + c];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int t = tid; t < a.n; t += 256) {
+        const float* qr = frow(a.q, s, t) + h * HD;
+        float m = -INFINITY;
+        for (int j = 0; j < a.bag; ++j) {
+            float sc = 0.f;
+            for (int c = 0; c < HD; ++c) sc = fmaf(qr[c] * scale, kl[j * HD + c], sc);
+            m = fmaxf(m, sc);
+        }
+        float l = 0.f;
+        for (int j = 0; j < a.bag; ++j) {
+            float sc = 0.f;
+            for (int c = 0; c < HD; ++c) sc = fmaf(qr[c] * scale, kl[j * HD + c], sc);
+            l += __expf(sc - m);
+        }
+        float* orow = frow(a.o, s, t) + h * HD;
+        for (int c = 0; c < HD; ++c) orow[c] = 0.f;
+        float* prow = a.p.base != nullptr ? a.p.base + (size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld : nullptr;
+        for (int j = 0; j < a.bag; ++j) {
+            float sc = 0.f;
+            for (int c = 0; c < HD; ++c) sc = fmaf(qr[c] * scale, kl[j * HD + c], sc);
+            const float pj = __expf(sc - m) / l;
+            if (prow != nullptr) prow[j] = pj;
+            for (int c = 0; c < HD; ++c) orow[c] = fmaf(pj, vl[j * HD + c], orow[c]);
+        }
+    }
+}
+// backward: dP = dO v^T, dS = P (dP - sum_j P dP), dq = scale dS k, dk = scale dS^T q, dv = P^T dO
+struct TlBagAttnBwdArgs {
+    Fld q, kv, p, dO;                  // dO: [LPB][D] gradient of the attention output
+    Fld dq;                            // [LPB][D]
+    Fld dkv;                           // [LPB][2D] (rows < bag written)
+    int D, HD, n, bag, bag_ld, lpb;
+};
+__global__ __launch_bounds__(256) void tl_bag_attn_bwd_kernel(TlBagAttnBwdArgs a) {
+    float* kl = reinterpret_cast<float*>(dtqn_smem);                   // [bag][HD] k, [bag][HD] v, then [n][bag] dS
+    const int s = (int)blockIdx.x, h = (int)blockIdx.y, tid = (int)threadIdx.x, HD = a.HD;
+    float* vl = kl + a.bag * HD;
+    float* dsl = vl + a.bag * HD;
+    for (int idx = tid; idx < a.bag * HD; idx += 256) {
+        const int j = idx / HD, c = idx - j * HD;
+        const float* row = frow(a.kv, s, j);
+        kl[idx] = row[h * HD + c];
+        vl[idx] = row[a.D + h * HD + c];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int t = tid; t < a.n; t += 256) {
+        const float* dor = frow(a.dO, s, t) + h * HD;
+        const float* prow = a.p.base + (size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld;
+        float dsum = 0.f;
+        for (int j = 0; j < a.bag; ++j) {
+            float dp = 0.f;
+            for (int c = 0; c < HD; ++c) dp = fmaf(dor[c], vl[j * HD + c], dp);
+            dsl[t * a.bag + j] = dp;
+            dsum = fmaf(prow[j], dp, dsum);
+        }
+        float* dqr = frow(a.dq, s, t) + h * HD;
+        for (int c = 0; c < HD; ++c) dqr[c] = 0.f;
+        for (int j = 0; j < a.bag; ++j) {
+            const float ds = prow[j] * (dsl[t * a.bag + j] - dsum);
+            dsl[t * a.bag + j] = ds;
+            for (int c = 0; c < HD; ++c) dqr[c] = fmaf(ds * scale, kl[j * HD + c], dqr[c]);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < a.bag * HD; idx += 256) {
+        const int j = idx / HD, c = idx - j * HD;
+        float dk = 0.f, dv = 0.f;
+        for (int t = 0; t < a.n; ++t) {
+            const float pj = a.p.base[(size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld + j];
+            dk = fmaf(dsl[t * a.bag + j] * scale, frow(a.q, s, t)[h * HD + c], dk);
+            dv = fmaf(pj, frow(a.dO, s, t)[h * HD + c], dv);
+        }
+        float* row = frow(a.dkv, s, j);
+        row[h * HD + c] = dk;
+        row[a.D + h * HD + c] = dv;
+    }
+}
+// dst[rows][cols] = src[rows][cols] (any leading dims): the working-memory half of d xcat -> the stream gradient
+struct TlCopyArgs {
+    Fld src, dst;
+    int cols, rpb;
+};
+__global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int c4 = a.cols / 4;
+    for (int idx = (int)threadIdx.x; idx < TROWS * c4; idx += TNT) {
+        const int r = idx / c4, c = (idx - r * c4) * 4;
+        st4(frow(a.dst, s, row0 + r) + c, ld4(frow(a.src, s, row0 + r) + c));
     }
 }
 
@@ -753,6 +875,7 @@ struct RecMap {
     long long stride;
     int layer_stride;
     int xf, hh;
+    int bag_e = -1, bag_kv = -1, bag_q = -1, bag_o = -1, xcat = -1;
 };
 static RecMap rec_map(const DtqnNet& net, bool training) {
     RecMap m;
@@ -763,7 +886,16 @@ static RecMap rec_map(const DtqnNet& net, bool training) {
         m.xf = net.ao_layer0 + net.act_layer_stride;
         m.hh = m.xf + net.lp * net.d_model;
         m.stride = m.hh + net.lp * net.d_model;
+        if (net.bag_size > 0) {            // bag branch scratch: e | kv | q | o | xcat (no e_in, no attention weights saved)
+            m.bag_e = (int)m.stride;
+            m.bag_kv = m.bag_e + net.lp * net.d_model;
+            m.bag_q = m.bag_kv + 2 * net.lp * net.d_model;
+            m.bag_o = m.bag_q + net.lp * net.d_model;
+            m.xcat = m.bag_o + net.lp * net.d_model;
+            m.stride = m.xcat + 2 * net.lp * net.d_model;
+        }
     }
+    if (training && net.bag_size > 0) { m.bag_e = net.ao_bag_e; m.bag_kv = net.ao_bag_kv; m.bag_q = net.ao_bag_q; m.bag_o = net.ao_bag_o; m.xcat = net.ao_xcat; }
     return m;
 }
 
@@ -774,6 +906,10 @@ struct EmbedSrc {
     const int32_t* ep_idx;
     const int32_t* start;
     int batch;
+    // bag_size > 0: [bag_batch][bag_size][O] observations / [bag_batch][bag_size] actions; sequence s uses bag s % bag_batch
+    const float* bag_obs = nullptr;
+    const uint8_t* bag_actions = nullptr;
+    int bag_batch = 0;
 };
 
 // All S sequences through the network.  theta_a serves sequences [0, split), theta_b the rest.
@@ -795,6 +931,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.n = n; e.rpb = rpb;
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
+        e.src_mod = 0; e.bag = 0;
         const size_t elds = ((size_t)TROWS * (kEmbKC + 4) + (size_t)D * (kEmbKC + 1)) * sizeof(float);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
@@ -879,11 +1016,43 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         }
         if (rc != DTQN_OK) return rc;
         if (!ident) {
-            const Fld nxt = last ? F(rm.xf, D) : F(L0(l + 1) + net.al_u1, D);
+            // the working memory goes straight into the left half of xcat when there is a bag
+            const Fld nxt = last ? (net.bag_size > 0 ? F(rm.xcat, 2 * D) : F(rm.xf, D)) : F(L0(l + 1) + net.al_u1, D);
             if ((rc = lnorm(s2, nxt, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b)) != DTQN_OK) return rc;
         }
     }
     const Fld xf = ident ? F(L0(net.num_layers - 1) + net.al_s2, D) : F(rm.xf, D);
+    if (net.bag_size > 0) {
+        // ---- persistent memory (dtqn.py:201-214): embed the bag entries, attend from the working memory over them, and feed
+        //      [working memory | persistent memory] to the head
+        if (src.bag_obs == nullptr || (net.action_dim > 0 && src.bag_actions == nullptr) || src.bag_batch < 1) return DTQN_ERR_ARG;
+        const int bag = net.bag_size;
+        {
+            TlEmbedArgs e;
+            e.net = net; e.theta_a = theta_a; e.theta_b = theta_b; e.split = split;
+            e.obs = src.bag_obs; e.actions = src.bag_actions;
+            e.obs_ep_stride = (long long)bag * net.obs_dim; e.act_ep_stride = bag;
+            e.ep_idx = nullptr; e.start = nullptr; e.batch = src.bag_batch;
+            e.n = bag; e.rpb = rpb;
+            e.x = F(rm.bag_e, D);
+            e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
+            e.src_mod = src.bag_batch; e.bag = 1;
+            const size_t elds = ((size_t)TROWS * (kEmbKC + 4) + (size_t)D * (kEmbKC + 1)) * sizeof(float);
+            TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
+        }
+        const Fld xw = F(rm.xcat, 2 * D);                      // working memory = left half of xcat
+        if ((rc = linear(F(rm.bag_e, D), D, 2 * D, net.off_bag_in_w + D * D, net.off_bag_in_b + D, F(rm.bag_kv, 2 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
+        if ((rc = linear(xw, D, D, net.off_bag_in_w, net.off_bag_in_b, F(rm.bag_q, D), 0, nofld(), nofld())) != DTQN_OK) return rc;
+        {
+            TlBagAttnArgs at;
+            at.q = F(rm.bag_q, D); at.kv = F(rm.bag_kv, 2 * D); at.o = F(rm.bag_o, D);
+            at.p = training ? F(net.ao_bag_p, net.bag_ld) : nofld();
+            at.D = D; at.HD = HD; at.n = n; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb;
+            TL_LAUNCH(tl_bag_attn_kernel, dim3(S, H), dim3(256), (size_t)2 * bag * HD * sizeof(float), stream, at);
+        }
+        if ((rc = linear(F(rm.bag_o, D), D, D, net.off_bag_out_w, net.off_bag_out_b, F(rm.xcat + D, 2 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
+        if ((rc = linear(xw, 2 * D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
+    } else
     if ((rc = linear(xf, D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
     TlQArgs qa;
     qa.hh = F(rm.hh, D);
@@ -967,6 +1136,27 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         a.nsrc = 3; a.out = dst; a.mode = 1; a.mask = m;                              // dy, through the ReLU of the sub-layer output
         return launch_dx<KC>(a, B, stream);
     };
+    if (net.bag_size > 0) {
+        // d xcat = dhh W_1 ([D][2D]); its left half is dL/d(working memory) so far, its right half dL/d(persistent memory)
+        const int bag = net.bag_size;
+        if (!td.bag_obs || (net.action_dim > 0 && !td.bag_actions)) return DTQN_ERR_ARG;
+        if ((rc = dx(FG(net.go_dhh, D), D, net.off_head1_w, 2 * D, FG(net.go_dcat, 2 * D), 0, nofld())) != DTQN_OK) return rc;
+        {
+            TlCopyArgs c;
+            c.src = FG(net.go_dcat, 2 * D); c.dst = G; c.cols = D; c.rpb = rpb;
+            TL_LAUNCH(tl_copy_kernel, dim3(B * rpb), dim3(TNT), 0, stream, c);
+        }
+        if ((rc = dx(FG(net.go_dcat + D, 2 * D), D, net.off_bag_out_w, D, FG(net.go_bag_do, D), 0, nofld())) != DTQN_OK) return rc;
+        {
+            TlBagAttnBwdArgs at;
+            at.q = FA(net.ao_bag_q, D); at.kv = FA(net.ao_bag_kv, 2 * D); at.p = FA(net.ao_bag_p, net.bag_ld); at.dO = FG(net.go_bag_do, D);
+            at.dq = FG(net.go_bag_dq, D); at.dkv = FG(net.go_bag_dkv, 2 * D);
+            at.D = D; at.HD = HD; at.n = L; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb;
+            TL_LAUNCH(tl_bag_attn_bwd_kernel, dim3(B, H), dim3(256), ((size_t)2 * bag * HD + (size_t)L * bag) * sizeof(float), stream, at);
+        }
+        if ((rc = dx(FG(net.go_bag_dq, D), D, net.off_bag_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;                  // + dq W_q
+        if ((rc = dx(FG(net.go_bag_dkv, 2 * D), 2 * D, net.off_bag_in_w + D * D, D, FG(net.go_bag_de, D), 0, nofld())) != DTQN_OK) return rc;   // d E_bag
+    } else
     if ((rc = dx(FG(net.go_dhh, D), D, net.off_head1_w, D, G, 0, nofld())) != DTQN_OK) return rc;       // dL/dxf
     for (int l = net.num_layers - 1; l >= 0; --l) {
         const int tb = net.off_layer0 + l * net.layer_stride;
@@ -1014,7 +1204,14 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         const size_t lds = !net.discrete ? 0 : ((size_t)TROWS * (DO + 1) + (size_t)DO * (net.ke + 1) + (size_t)TROWS * (net.ke + 1) +
                                                 (size_t)emb_row_groups(net.ke) * net.obs_dim * net.vocab * net.embed_per_obs) * sizeof(float);
         if (lds > 150 * 1024 || net.ke > TNT) return DTQN_ERR_CONFIG;
+        a.bag = 0; a.dx_off = 0; a.rows = 0;
         TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(TNT), lds, stream, a);
+        if (net.bag_size > 0) {          // the bag entries went through the same tables: their partials are added
+            a.obs = td.bag_obs; a.actions = td.bag_actions;
+            a.obs_ep_stride = (long long)net.bag_size * net.obs_dim; a.act_ep_stride = net.bag_size;
+            a.bag = 1; a.dx_off = net.go_bag_de; a.rows = net.bag_size;
+            TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(TNT), lds, stream, a);
+        }
     }
     return DTQN_OK;
 }
@@ -1024,6 +1221,7 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
     src.obs = rp->obs; src.actions = rp->actions;
     src.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim; src.act_ep_stride = rp->max_steps + 1;
     src.ep_idx = td->ep_idx; src.start = td->start; src.batch = td->batch;
+    src.bag_obs = td->bag_obs; src.bag_actions = td->bag_actions; src.bag_batch = td->batch;
     const int S = 3 * td->batch;
     const long long qs = (long long)net->lp * net->ap;
 #define DTQN_TL_CASE(d) \
@@ -1058,18 +1256,19 @@ extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
     return fl < 0x7fffffffLL ? (int)fl : 0;
 }
 
-// in_rows: rows per sequence in the obs / actions arrays (>= n; the batched actor packs whole contexts)
-extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
-                                          int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
+static int forward_tiled_impl(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
+                              const uint8_t* bag_actions, int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
     if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len || in_rows < n) return DTQN_ERR_ARG;  // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
     if (!net->tiled) return DTQN_ERR_CONFIG;
+    if (net->bag_size > 0 && (!bag_obs || (net->action_dim > 0 && !bag_actions))) return DTQN_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     EmbedSrc src;
     src.obs = obs; src.actions = actions;
     src.obs_ep_stride = (long long)in_rows * net->obs_dim; src.act_ep_stride = in_rows;
     src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
+    src.bag_obs = bag_obs; src.bag_actions = bag_actions; src.bag_batch = batch;
     const long long qs = (long long)n * net->num_actions;
     switch (net->d_model) {
         case 64: return forward_records<64>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
@@ -1079,7 +1278,20 @@ extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta
     }
 }
 
+// in_rows: rows per sequence in the obs / actions arrays (>= n; the batched actor packs whole contexts)
+extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
+                                          int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
+    if (net && net->bag_size > 0) return DTQN_ERR_ARG;                  // bag networks: dtqn_forward_bag
+    return forward_tiled_impl(net, theta, obs, actions, nullptr, nullptr, batch, n, in_rows, q_out, workspace, stream);
+}
+
 extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                                   int batch, int n, float* q_out, float* workspace, void* stream) {
     return dtqn_forward_tiled_strided(net, theta, obs, actions, batch, n, n, q_out, workspace, stream);
+}
+
+extern "C" int dtqn_forward_bag(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
+                                const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, void* stream) {
+    if (!net || net->bag_size < 1) return DTQN_ERR_ARG;
+    return forward_tiled_impl(net, theta, obs, actions, bag_obs, bag_actions, batch, n, n, q_out, workspace, stream);
 }

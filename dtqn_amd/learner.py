@@ -144,6 +144,12 @@ class TdEngine:
         td.target_update_frequency = int(tuf)
         td.gamma, td.lr, td.beta1, td.beta2, td.eps = float(gamma), float(lr), float(betas[0]), float(betas[1]), float(eps)
         td.grad_norm_clip, td.grad_scale = float(grad_norm_clip), 1.0
+        if net.bag_size > 0:     # the sampled windows' bags (ReplayBuffer.sample_with_bag): one bag per sequence, shared by the three forwards
+            self.bag_obs = torch.zeros(Bn, net.bag_size, net.obs_dim, **f32)
+            self.bag_actions = torch.zeros(Bn, net.bag_size, dtype=torch.uint8, device=dev)
+            td.bag_obs, td.bag_actions = self.bag_obs.data_ptr(), self.bag_actions.data_ptr()
+            self._bag_rows_dev = torch.zeros(Bn, 2, net.bag_size, dtype=torch.int32, device=dev)
+            self._bag_rows_ring = []
         td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
@@ -194,6 +200,39 @@ class TdEngine:
                 self._idx_dev.copy_(slot["h"], non_blocking=True)
                 slot["event"].record()
         slot["busy"] = True
+
+    def gather_bag(self, replay: "DeviceReplay", rows) -> None:
+        """Fill the bags of the windows set_indices named from host-drawn episode rows [B][2][bag_size]
+        (ReplayBuffer.sample_bag_indices); queued on the engine's stream behind the index copy."""
+        if self.net.bag_size <= 0:
+            raise RuntimeError("this network has no bag")
+        h = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int32).reshape(self._bag_rows_dev.shape))
+        if self.device.type == "cuda":
+            # small pinned ring: the async copy must not read a buffer the next draw overwrites
+            ring = self._bag_rows_ring
+            if len(ring) < self.IDX_RING:
+                ring.append(dict(h=torch.zeros_like(h).pin_memory(), event=torch.cuda.Event(), busy=False))
+            slot = ring[self._idx_i % len(ring)]
+            if slot["busy"]:
+                slot["event"].synchronize()
+            slot["h"].copy_(h)
+            bound = self._bound_torch_stream
+            with torch.cuda.stream(bound if bound is not None else torch.cuda.current_stream(self.device)):
+                self._bag_rows_dev.copy_(slot["h"], non_blocking=True)
+                slot["event"].record()
+            slot["busy"] = True
+        else:
+            self._bag_rows_dev.copy_(h)
+        self._check(self.lib.dtqn_replay_gather_bag(replay.view_ref, _p(self.ep_idx), _p(self.start), _p(self._bag_rows_dev), self.batch,
+                                                    self.net.bag_size, 0, None, _p(self.bag_obs), _p(self.bag_actions), self._stream()),
+                    "dtqn_replay_gather_bag")
+
+    def set_bag(self, bag_obs, bag_actions) -> None:
+        """Bags of the windows set_indices named: bag_obs [B, bag_size, obs_dim], bag_actions [B, bag_size(, 1)]."""
+        if self.net.bag_size <= 0:
+            raise RuntimeError("this network has no bag")
+        self.bag_obs.copy_(torch.as_tensor(bag_obs, dtype=torch.float32).reshape(self.bag_obs.shape), non_blocking=True)
+        self.bag_actions.copy_(torch.as_tensor(bag_actions).reshape(self.bag_actions.shape).to(torch.uint8), non_blocking=True)
 
     def sample_in_forward(self, n_valid: int, exclude: int, seed: int) -> None:
         """Let the next dtqn_td_forward / dtqn_td_update draw its own windows (no sampling launch): the same draw as

@@ -48,8 +48,6 @@ class DTQN(nn.Module):
         super().__init__()
         if isinstance(obs_dim, tuple):
             raise NotImplementedError("image observations (conv embedding) are outside dtqn_amd's scope")
-        if bag_size > 0:
-            raise NotImplementedError("the persistent-memory bag is outside dtqn_amd's scope")
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")     # nn.Dropout's own check
         if pos not in B.POS:
@@ -61,7 +59,8 @@ class DTQN(nn.Module):
         self.net = B.make_net(self._lib, obs_dim=obs_dim, num_actions=num_actions, embed_per_obs_dim=embed_per_obs_dim,
                               action_dim=action_dim, inner_embed_size=inner_embed_size, num_heads=num_heads,
                               num_layers=num_layers, history_len=history_len, gate=gate, identity=identity, pos=pos,
-                              discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0, dropout=dropout)
+                              discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0, dropout=dropout,
+                              bag_size=bag_size)
         net = self.net
         flat = np.zeros(net.n_theta, dtype=np.float32)
         self._lib.dtqn_net_fill_frozen(ctypes.byref(net), flat.ctypes.data_as(ctypes.c_void_p))
@@ -131,15 +130,25 @@ class DTQN(nn.Module):
             a = actions.to(device=dev).reshape(obss.size(0), seq).to(torch.uint8).contiguous()
         q = torch.empty((obss.size(0), seq, self.num_actions), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
-        if self.net.tiled:      # contexts / widths beyond one workgroup's LDS: row-block tiled kernels + a workspace
+        if self.net.tiled:      # contexts / widths beyond one workgroup's LDS (and bag networks): row-block tiled kernels + a workspace
             need = self._lib.dtqn_forward_workspace_floats(ctypes.byref(self.net), int(obss.size(0)))
             ws = getattr(self, "_tiled_ws", None)
             if ws is None or ws.numel() < need or ws.device != dev:
                 ws = self._tiled_ws = torch.empty(need, dtype=torch.float32, device=dev)
-            rc = self._lib.dtqn_forward_tiled(ctypes.byref(self.net), ctypes.c_void_p(self.flat.data_ptr()),
-                                              ctypes.c_void_p(o.data_ptr()), None if a is None else ctypes.c_void_p(a.data_ptr()),
-                                              int(obss.size(0)), int(seq), ctypes.c_void_p(q.data_ptr()),
-                                              ctypes.c_void_p(ws.data_ptr()), stream)
+            cp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+            if self.bag_size > 0:
+                # bag_obss [B, bag_size, obs_dim], bag_actions [B, bag_size, 1] (dtqn.py:158-164,201-214)
+                assert bag_obss is not None and bag_obss.size(1) == self.bag_size, "bag_obss must be [B, bag_size, obs_dim]"
+                bo = bag_obss.to(device=dev, dtype=torch.float32).contiguous()
+                ba = None
+                if self.net.action_dim > 0:
+                    ba = bag_actions.to(device=dev).reshape(obss.size(0), self.bag_size).to(torch.uint8).contiguous()
+                rc = self._lib.dtqn_forward_bag(ctypes.byref(self.net), cp(self.flat), cp(o), cp(a), cp(bo), cp(ba), int(obss.size(0)), int(seq),
+                                                cp(q), cp(ws), stream)
+                if rc != 0:
+                    raise RuntimeError(f"dtqn_forward_bag failed with DTQN status {rc}")
+                return q
+            rc = self._lib.dtqn_forward_tiled(ctypes.byref(self.net), cp(self.flat), cp(o), cp(a), int(obss.size(0)), int(seq), cp(q), cp(ws), stream)
             if rc != 0:
                 raise RuntimeError(f"dtqn_forward_tiled failed with DTQN status {rc}")
             return q

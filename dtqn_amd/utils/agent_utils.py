@@ -24,8 +24,6 @@ def get_agent(model_str: str, envs: Sequence, embed_per_obs_dim: int, action_dim
     call sites work unchanged."""
     if model_str not in MODEL_MAP:
         raise NotImplementedError(f"model {model_str!r}: dtqn_amd implements {sorted(MODEL_MAP)} (DTQN hot path only)")
-    if bag_size > 0:
-        raise NotImplementedError("the persistent-memory bag (--bag-size > 0) is outside dtqn_amd's scope")
     env0 = envs[0]
     obs_len = env_processing.get_env_obs_length(env0)
     obs_mask = env_processing.get_env_obs_mask(env0)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 5
+#define DTQN_ABI_VERSION 6
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -61,6 +61,8 @@ typedef struct DtqnNet {
     int32_t pos;              /* DTQN_POS_* */
     int32_t discrete;         /* discrete observations -> Embedding(V,e)+Linear (representations.py:25-52) */
     int32_t vocab;            /* V */
+    int32_t bag_size;         /* persistent-memory bag (utils/bag.py, dtqn.py:134-147,201-214): 0 = none.  Bag networks run on the row-block
+                               * tiled path (post-LN layers, bag_size <= padded context) */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
                                * forwards only; 0 = off.  Whole-sequence kernels only (DTQN_ERR_CONFIG on the row-block tiled path) */
     /* ---- derived: geometry ---- */
@@ -88,7 +90,8 @@ typedef struct DtqnNet {
     int32_t off_gate_attn;    /* shared GRU gate (gates.py:5-31): w_r u_r w_z b_z u_z w_g u_g, each [D][D] ([D] for b_z) */
     int32_t off_gate_mlp;
     int32_t go_w_r, go_u_r, go_w_z, go_b_z, go_u_z, go_w_g, go_u_g;   /* offsets inside a gate block */
-    int32_t off_head1_w, off_head1_b, off_head2_w, off_head2_b;       /* ffn.0.* / ffn.2.* (Q head) */
+    int32_t off_head1_w, off_head1_b, off_head2_w, off_head2_b;       /* ffn.0.* / ffn.2.* (Q head; ffn.0.weight is [D][2D] with a bag) */
+    int32_t off_bag_in_w, off_bag_in_b, off_bag_out_w, off_bag_out_b; /* bag_attention.in_proj_* / out_proj.* (bag_size > 0) */
     int32_t n_trainable;      /* floats the optimizer updates (multiple of 4) */
     int32_t n_theta;          /* total floats of theta */
     /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
@@ -98,12 +101,17 @@ typedef struct DtqnNet {
     /* al_m1 / al_mh / al_m2: ReLU activation patterns as wave ballots, one 64-bit word per
      * (16-row tile, 16-column tile, r): bit (kq*16 + i) <-> row tile*16 + kq*4 + r, column ctile*16 + i */
     int32_t al_gate1, al_gate2;   /* GRU gate records (attention / mlp gate): z, r, h~, r*x, x, y, each [LP][D] */
+    /* bag branch (bag_size > 0), per sequence: embedding input [LP][kep] and embeddings [LP][D] of the bag entries (rows >= bag_size
+     * zero), their k | v [LP][2D], the queries [LP][D], the attention weights [H][LP][bag_ld], the attention output [LP][D], and
+     * xcat = [working memory | persistent memory] [LP][2D], the head's input */
+    int32_t ao_bag_ein, ao_bag_e, ao_bag_kv, ao_bag_q, ao_bag_p, ao_bag_o, ao_xcat, bag_ld;
     /* ---- derived: per-sequence gradient record written by the backward-data kernel ---- */
     int32_t grd_stride;
     int32_t go_dx0, go_layer0, grd_layer_stride, go_dhh, go_dq;
     int32_t gl_dqkv, gl_da, gl_dhp, gl_df;
     int32_t gl_gate1, gl_gate2;   /* GRU: d z_pre, d r_pre, d h_pre, each [LP][D] */
     int32_t go_do;                /* tiled path only: dL/d(attention output) scratch [LP][D] */
+    int32_t go_dcat, go_bag_do, go_bag_dq, go_bag_dkv, go_bag_de;   /* bag branch: d xcat [LP][2D], d attn-out, d q [LP][D], d k|v [LP][2D], d embeddings [LP][D] */
     /* ---- derived: per-sequence small partials (LayerNorm affine, embedding tables) ---- */
     int32_t sp_stride;
     int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */
@@ -181,6 +189,16 @@ int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* recs_dev, co
 /* Draws `batch` (episode, start) pairs on the device with the reference's distribution
  * (replay_buffer.py:141-158): episode uniform over finished slots [0, n_valid) minus `exclude`,
  * start uniform on {0..max(0, len-L)}.  Counter-based RNG keyed by (seed, *step_counter). */
+/* The bag half of ReplayBuffer.sample_with_bag (replay_buffer.py:211-254): for window b (episode ep_idx[b], first row start[b])
+ * fill bag_obs[b] [bag_size][O] / bag_actions[b] [bag_size] with rows of the episode BEFORE the window; unused entries hold
+ * (obs_mask, action 0).
+ *   rows_dev != NULL: int32 [batch][2][bag_size] rows chosen by the host -- observation rows, then action rows (the reference
+ *                     draws the two independently with random.sample, :232-252); -1 = unused entry.
+ *   rows_dev == NULL: drawn here, keyed by (seed, step_counter[1], b): start < bag_size -> rows 0..start-1 (:221-229), else
+ *                     bag_size distinct rows uniform over [0, start) (Floyd's sampling), the SAME rows for observations and actions. */
+int dtqn_replay_gather_bag(const DtqnReplay* rp, const int32_t* ep_idx_dev, const int32_t* start_dev, const int32_t* rows_dev,
+                           int batch, int bag_size, uint32_t seed, const int32_t* step_counter_dev, float* bag_obs_dev,
+                           uint8_t* bag_actions_dev, void* stream);
 int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed,
                        const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream);
 
@@ -232,6 +250,10 @@ typedef struct DtqnTd {
     const DtqnWJob* wjobs;    /* device copy of the job table */
     float* xch;               /* row-split exchange buffer, dtqn_td_xch_floats(net, B) floats (row_split > 1 only) */
     int32_t* xflags;          /* row-split hand-over flags, dtqn_td_xch_flags(net, B) ints, ZEROED once by the caller */
+    float* bag_obs;           /* bag_size > 0: [B][bag_size][O] f32 bag observations of the sampled windows (ReplayBuffer.sample_with_bag,
+                               * replay_buffer.py:171-264; filled by dtqn_replay_gather_bag -- by dtqn_td_forward itself when
+                               * sample_in_kernel == 1); the same bag serves all three forwards of a sequence (dtqn.py:215-230) */
+    uint8_t* bag_actions;     /* [B][bag_size] */
     /* hyper-parameters */
     int32_t batch;            /* B (local) */
     int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
@@ -287,6 +309,10 @@ int dtqn_actor_forward(const DtqnNet* net, const float* theta, const void* ctx_h
 int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void* ctx_host, void* ctx_dev, int n_envs, int n_max,
                              float* q_dev, float* q_last_host, float* workspace, int train_mode, uint32_t dropout_seed,
                              uint32_t dropout_step, void* stream);
+/* DTQN.forward with the bag arguments (dtqn.py:158-218 incl. :201-214): bag_obs [B][bag_size][O] f32, bag_actions [B][bag_size] u8
+ * (NULL when action_dim == 0).  Row-block tiled path; workspace as dtqn_forward_tiled. */
+int dtqn_forward_bag(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
+                     const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, void* stream);
 /* dtqn_forward_tiled with `in_rows` (>= n) rows per sequence in the obs / actions arrays. */
 int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                                int in_rows, float* q_out, float* workspace, void* stream);

@@ -125,7 +125,7 @@ def make_ref_net(cfg: O.NetCfg, params):
     net = RefDTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size,
                   cfg.num_heads, cfg.num_layers, cfg.history_len, dropout=0.0, gate=cfg.gate,
                   identity=cfg.identity, pos=cfg.pos, discrete=cfg.discrete,
-                  vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=0)
+                  vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=cfg.bag_size)
     assert list(net.state_dict().keys()) == O.state_dict_keys(cfg), "state_dict key order drifted"
     for k, v in net.state_dict().items():
         assert tuple(v.shape) == O.param_shapes(cfg)[k], k
@@ -157,7 +157,7 @@ def make_ref_agent(cfg: O.NetCfg, pol_params, tgt_params, B, T, buf_eps, mask, l
     agent = RefAgent(lambda: make_ref_net(cfg, next(it)), buffer_size=buf_eps * T, device=torch.device("cpu"),
                      env_obs_length=cfg.obs_dim, max_env_steps=T, obs_mask=mask, num_actions=cfg.num_actions,
                      is_discrete_env=cfg.discrete, learning_rate=lr, batch_size=B, context_len=cfg.history_len,
-                     gamma=gamma, history=history, target_update_frequency=tuf, bag_size=0)
+                     gamma=gamma, history=history, target_update_frequency=tuf, bag_size=cfg.bag_size)
     # DqnAgent.__init__ hard-copies policy -> target (dqn.py:49); restore the distinct target weights
     agent.target_network.load_state_dict({k: v.clone() for k, v in tgt_params.items()})
     agent.replay_buffer.episode_lengths = agent.replay_buffer.episode_lengths.astype(np.int64)  # quirk 1
@@ -177,14 +177,20 @@ def run_ref_updates(agent, n_updates):
     rec = {"batches": [], "grads": [], "norms": [], "stats": [], "pre": [], "post": [], "m": [], "v": []}
     tparams = [p for p in agent.policy_network.parameters() if p.requires_grad]
     flat = lambda ts: np.concatenate([t.detach().numpy().ravel() for t in ts])
-    orig_sample = agent.replay_buffer.sample
+    orig_sample, orig_sample_bag = agent.replay_buffer.sample, agent.replay_buffer.sample_with_bag
 
     def sample(bs):
         out = orig_sample(bs)
         rec["batches"].append([np.array(a) for a in out])
         return out
 
+    def sample_with_bag(bs, bag):
+        out = orig_sample_bag(bs, bag)
+        rec["batches"].append([np.array(a) for a in out])
+        return out
+
     agent.replay_buffer.sample = sample
+    agent.replay_buffer.sample_with_bag = sample_with_bag
     orig_clip = torch.nn.utils.clip_grad_norm_
 
     def clip(params, max_norm, **kw):
@@ -210,6 +216,7 @@ def run_ref_updates(agent, n_updates):
     finally:
         torch.nn.utils.clip_grad_norm_ = orig_clip
         agent.replay_buffer.sample = orig_sample
+        agent.replay_buffer.sample_with_bag = orig_sample_bag
     return rec
 
 
@@ -562,6 +569,85 @@ def gen_G8():
     np.savez_compressed(os.path.join(HERE, "G8_logging_init.npz"), **out)
 
 
+def gen_G9():
+    """Persistent-memory bag (utils/bag.py, dtqn/networks/dtqn.py:134-147,201-214, dtqn/agents/dtqn.py:116-160,166-196,
+    dtqn/buffers/replay_buffer.py:171-264), from the reference itself, for a discrete and a continuous network:
+      fwd_*   DTQN.forward with bag_obss / bag_actions at several sequence lengths;
+      td_*    DtqnAgent.train() x2 on a synthetic buffer: the nine arrays sample_with_bag returned (Python `random` stream seeded
+              right before), pre-clip gradients of update 0, statistics, parameters after update 0;
+      act_*   a greedy rollout longer than the context: per step the action taken and the bag (pos, obss, actions) after
+              observe() -- exercises Bag.add and the evict-by-Q-value choice.
+    The continuous case uses a FLOAT padding value (-5.0): with the integer mask the reference's dtype-less np.full makes
+    int64 bags / contexts that truncate the observations (utils/bag.py:42-51), a quirk pinned nowhere else."""
+    out = {"stamp": json.dumps(STAMP)}
+    cases = [("disc", O.NetCfg(obs_dim=2, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=10, discrete=True,
+                               vocab_sizes=7, action_dim=8, bag_size=4), 6, 40),
+             ("cont", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=12, bag_size=5),
+              -5.0, 40)]
+    out["names"] = json.dumps([c[0] for c in cases])
+    for name, cfg, mask, T in cases:
+        seed, B, n_eps = 50 + len(name), 6, 14
+        out[f"{name}_cfg"] = json.dumps(cfg.to_json())
+        out[f"{name}_meta"] = json.dumps({"seed": seed, "B": B, "T": T, "n_eps": n_eps, "mask": mask})
+        pol = O.init_params(cfg, seed=seed, perturb=True)
+        tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+        out[f"{name}_pol_checksum"] = checksum(pol)
+        ot = torch.long if cfg.discrete else torch.float32
+        rng = np.random.Generator(np.random.PCG64(seed + 500))
+        draw = lambda *shape: (rng.integers(0, cfg.vocab_sizes - 1, size=shape).astype(np.int64) if cfg.discrete
+                               else rng.uniform(-1, 1, size=shape).astype(np.float32))
+        # ---- forward
+        net = make_ref_net(cfg, pol)
+        for n in (1, cfg.history_len // 2, cfg.history_len):
+            obs, bag_obs = draw(3, n, cfg.obs_dim), draw(3, cfg.bag_size, cfg.obs_dim)
+            act = rng.integers(0, cfg.num_actions, size=(3, n, 1))
+            bag_act = rng.integers(0, cfg.num_actions, size=(3, cfg.bag_size, 1))
+            with torch.no_grad():
+                q = net(torch.as_tensor(obs, dtype=ot), torch.as_tensor(act), torch.as_tensor(bag_obs, dtype=ot), torch.as_tensor(bag_act)).numpy()
+            out.update({f"{name}_fwd{n}_obs": obs, f"{name}_fwd{n}_act": act, f"{name}_fwd{n}_bag_obs": bag_obs,
+                        f"{name}_fwd{n}_bag_act": bag_act, f"{name}_fwd{n}_q": q})
+        # ---- TD updates
+        ref_random.RNG.rng = np.random.Generator(np.random.PCG64(seed))
+        agent = make_ref_agent(cfg, pol, tgt, B, T, n_eps + 2, mask, tuf=10_000)
+        episodes = synth_episodes(rng, n_eps, T, cfg, min_len=cfg.history_len + 3)
+        fill_agent(agent, episodes)
+        agent.eval_off()
+        random.seed(seed + 7)
+        rec = run_ref_updates(agent, 2)
+        names9 = ["obss", "actions", "rewards", "next_obss", "next_actions", "dones", "ep_lens", "bag_obss", "bag_actions"]
+        for i, b in enumerate(rec["batches"]):
+            assert len(b) == 9
+            out.update({f"{name}_td_batch{i}_{k}": np.asarray(a) for k, a in zip(names9, b)})
+        for j, (obs, act, rew, done) in enumerate(episodes):
+            out.update({f"{name}_ep{j}_obs": obs, f"{name}_ep{j}_act": act, f"{name}_ep{j}_rew": rew})
+        keys = O.trainable_keys(cfg)
+        pnames = [n for n, p in agent.policy_network.named_parameters()]
+        gl = {n: g for n, g in zip(pnames, rec["grads"][0]) if g is not None}
+        assert sorted(gl) == sorted(keys)
+        out[f"{name}_td_grad0_flat"] = np.concatenate([gl[k].numpy().ravel() for k in keys])
+        out[f"{name}_td_post0_flat"] = rec["post"][0]
+        out[f"{name}_td_stats"] = json.dumps(rec["stats"])
+        out[f"{name}_td_grad_norms"] = np.array(rec["norms"], dtype=np.float64)
+        # ---- greedy rollout with bag evictions
+        ref_random.RNG.rng = np.random.Generator(np.random.PCG64(seed + 3))
+        agent = make_ref_agent(cfg, pol, tgt, B, T, n_eps + 2, mask)
+        agent.eval_off()
+        steps = cfg.history_len + 3 * cfg.bag_size + 2
+        traj = draw(steps + 1, cfg.obs_dim)
+        agent.context_reset(traj[0])
+        acts, poss, bobs, bacts = [], [], [], []
+        for t in range(steps):
+            a = int(agent.get_action(epsilon=0.0))
+            agent.observe(traj[t + 1], a, 0.0, False)
+            acts.append(a)
+            poss.append(agent.bag.pos)
+            bobs.append(np.array(agent.bag.obss, dtype=np.float64))
+            bacts.append(np.array(agent.bag.actions, dtype=np.int64))
+        out.update({f"{name}_act_traj": traj, f"{name}_act_actions": np.array(acts), f"{name}_act_bag_pos": np.array(poss),
+                    f"{name}_act_bag_obss": np.stack(bobs), f"{name}_act_bag_actions": np.stack(bacts)})
+    np.savez_compressed(os.path.join(HERE, "G9_bag.npz"), **out)
+
+
 def time_reference():
     """the reference's OWN DtqnAgent.train() on this container's CPU cores, BASELINE
     configs 1-5 (synthetic replay of SURVEY.md section 8d; configs 3-5 at their per-GPU batch, a handful of updates
@@ -611,10 +697,10 @@ def time_reference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "time"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "time"]
     torch.manual_seed(0)
     for w in which:
         t0 = time.time()
         {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
-         "G8": gen_G8, "time": time_reference}[w]()
+         "G8": gen_G8, "G9": gen_G9, "time": time_reference}[w]()
         print(f"{w}: done in {time.time() - t0:.1f}s")

@@ -13,7 +13,8 @@ def net_from_cfg(lib, cfg: O.NetCfg):
     return B.make_net(lib, obs_dim=cfg.obs_dim, num_actions=cfg.num_actions, embed_per_obs_dim=cfg.embed_per_obs_dim,
                       action_dim=cfg.action_dim, inner_embed_size=cfg.inner_embed_size, num_heads=cfg.num_heads,
                       num_layers=cfg.num_layers, history_len=cfg.history_len, gate=cfg.gate, identity=cfg.identity,
-                      pos=cfg.pos, discrete=cfg.discrete, vocab_sizes=cfg.vocab_sizes, dropout=cfg.dropout)
+                      pos=cfg.pos, discrete=cfg.discrete, vocab_sizes=cfg.vocab_sizes, dropout=cfg.dropout,
+                      bag_size=cfg.bag_size)
 
 
 def pack_theta(net, params) -> np.ndarray:
@@ -134,6 +135,14 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         eps, starts = host.sample_indices(Bn)
         batch = oracle_batch(host, eps, starts, cfg.discrete)
         eng.set_indices(eps, starts)
+        if cfg.bag_size > 0:       # a synthetic bag per window (the engine takes whatever the sampler hands it)
+            rng = np.random.Generator(np.random.PCG64(77 + it))
+            bo = rng.integers(0, cfg.vocab_sizes, (Bn, cfg.bag_size, cfg.obs_dim)).astype(np.float32) if cfg.discrete \
+                else rng.random((Bn, cfg.bag_size, cfg.obs_dim), dtype=np.float32)
+            ba = rng.integers(0, cfg.num_actions, (Bn, cfg.bag_size, 1))
+            eng.set_bag(bo, ba)
+            batch.bag_obss = torch.as_tensor(bo, dtype=torch.long if cfg.discrete else torch.float32)
+            batch.bag_actions = torch.as_tensor(ba, dtype=torch.long)
         pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
         if one_call:
             eng.update(rep)

@@ -170,3 +170,52 @@ def test_actor_forward_one_call(emu, kw, monkeypatch):
             assert np.array_equal(q_last, q_d[n - 1])
         assert not ws[emu.dtqn_td_xch_floats(ctypes.byref(net), 1):].any()      # hand-over flags lowered again
     assert emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), L + 1, ptr(q_d), ptr(q_last), None, 0, 0, 0, None) == B.DEFINES["DTQN_ERR_ARG"]
+
+
+BAG = [
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=20, bag_size=5),
+    dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, history_len=70, discrete=True, vocab_sizes=9, action_dim=8, bag_size=7,
+         num_layers=1),
+    dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, history_len=12, action_dim=4, bag_size=12, gate="gru", pos="sin"),
+]
+
+
+@pytest.mark.parametrize("kw", BAG)
+def test_forward_with_a_bag(emu, kw):
+    """DTQN.forward with bag_obss / bag_actions (dtqn.py:201-214): the bag entries are embedded (own actions, no roll), the final
+    hidden states cross-attend to them without a mask, and the Q head reads [hidden | attended]."""
+    cfg = O.NetCfg(**kw)
+    net = net_from_cfg(emu, cfg)
+    assert net.tiled == 1 and net.bag_size == cfg.bag_size       # bag networks always take the row-block tiled path
+    params = O.init_params(cfg, seed=4, perturb=True)
+    assert params["ffn.0.weight"].shape == (cfg.inner_embed_size, 2 * cfg.inner_embed_size)
+    theta = pack_theta(net, params)
+    rng = np.random.default_rng(6)
+    for n in sorted({1, cfg.history_len // 2 + 1, cfg.history_len}):
+        Bn = 3
+        draw = lambda m: (rng.integers(0, cfg.vocab_sizes, size=(Bn, m, cfg.obs_dim)) if cfg.discrete
+                          else rng.uniform(-1, 1, size=(Bn, m, cfg.obs_dim)).astype(np.float32))
+        obs, bag_obs = draw(n), draw(cfg.bag_size)
+        act = rng.integers(0, cfg.num_actions, size=(Bn, n, 1))
+        bag_act = rng.integers(0, cfg.num_actions, size=(Bn, cfg.bag_size, 1))
+        ot = torch.long if cfg.discrete else torch.float32
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs, dtype=ot), torch.as_tensor(act, dtype=torch.long),
+                            bag_obss=torch.as_tensor(bag_obs, dtype=ot), bag_actions=torch.as_tensor(bag_act, dtype=torch.long)).numpy()
+        q = np.full((Bn, n, cfg.num_actions), np.nan, dtype=np.float32)
+        ws = np.zeros(emu.dtqn_forward_workspace_floats(ctypes.byref(net), Bn), dtype=np.float32)
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        u8 = lambda a: np.ascontiguousarray(a.reshape(Bn, -1), dtype=np.uint8)
+        rc = emu.dtqn_forward_bag(ctypes.byref(net), ptr(theta), ptr(f32(obs)), ptr(u8(act)), ptr(f32(bag_obs)), ptr(u8(bag_act)), Bn, n,
+                                  ptr(q), ptr(ws), None)
+        assert rc == 0
+        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
+    # the bag-less entry refuses a bag network
+    assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(f32(obs)), ptr(u8(act)), Bn, n, ptr(q), ptr(ws), None) != 0
+
+
+def test_bag_configurations_outside_the_kernels_are_refused(emu):
+    for kw in (dict(identity=True), dict(bag_size=80), dict(dropout=0.1)):
+        kw = {**dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=20, bag_size=5), **kw}
+        with pytest.raises(NotImplementedError):
+            net_from_cfg(emu, O.NetCfg(**kw))

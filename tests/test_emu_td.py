@@ -221,3 +221,34 @@ def test_dropout_keep_rate_and_eval_mode(emu):
         assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 2, 20, ptr(q), None) == 0
         outs.append(q)
     assert np.array_equal(outs[0], outs[1])
+
+
+BAG_TD = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=20, bag_size=5), dict(batch=3, T=30, mask=-5, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, num_layers=1, history_len=70, discrete=True, vocab_sizes=9, action_dim=8,
+          bag_size=7), dict(batch=2, T=90, mask=8)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, num_layers=1, history_len=12, action_dim=4, bag_size=12, gate="gru"),
+     dict(batch=3, T=20, mask=-5, history=6)),
+]
+
+
+@pytest.mark.parametrize("kw,run", BAG_TD)
+def test_td_update_with_a_bag(emu, kw, run):
+    """TD update of a bag network (dtqn.py:201-214 inside DtqnAgent.train, dtqn.py:191-284): the same bag serves the three forwards;
+    gradients of the cross-attention, of the [D][2D] head and of the embeddings through BOTH the context and the bag tokens."""
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=35, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    assert net.tiled == 1
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+@pytest.mark.parametrize("kw,run", BAG_TD[:2])
+def test_td_update_with_a_bag_split_weight_gradients(emu, kw, run, monkeypatch):
+    """The same through the large-batch weight-gradient path (tiles per batch split + dtqn_td_reduce)."""
+    monkeypatch.setenv("DTQN_WGRAD_DIRECT", "0")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=36, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    assert not emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), run["batch"])
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
