@@ -189,6 +189,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->so_tab = net->discrete ? sc.take(V * e) : -1;
     net->so_act = a > 0 ? sc.take(A * a) : -1;
     net->sp_stride = sc.pos;
+    net->sp_parts = net->tiled ? LP / 64 : 1;
 
     // ---- weight-gradient jobs ----
     int njobs = 0, ntiles = 0;

@@ -54,9 +54,12 @@ struct TlEmbedArgs {
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
-// kEmbKC columns; thread (d, row group) keeps 64 / (TNT / D) row accumulators, so one W element feeds that many FMAs
-// and the e_in operand is a wave-wide LDS broadcast.
+// kEmbKC columns (padded with zeros to a multiple of 4); the product runs on the matrix cores: item = (16-column tile,
+// 16-row tile), D / 4 items dealt round-robin to the 8 waves, one v_mfma_f32_16x16x4_f32 per 4 contraction columns, both
+// operands read from LDS (leading dimensions of 4 mod 64 words: the 64 lanes of a fragment read hit 64 different banks).
 constexpr int kEmbKC = 64;
+constexpr int kEmbLD = kEmbKC + 4;
+static inline size_t tl_embed_lds(int D) { return ((size_t)TROWS + (size_t)D) * kEmbLD * sizeof(float); }
 __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const DtqnNet& net = a.net;
     const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n;
@@ -70,24 +73,23 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     }
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row_first * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
-    const int tid = (int)threadIdx.x;
-    const int KC = KE < kEmbKC ? KE : kEmbKC, LDE = kEmbKC + 4, LDWE = kEmbKC + 1;
-    float* El = reinterpret_cast<float*>(dtqn_smem);                  // [64][LDE]   e_in chunk
-    float* Wl = El + TROWS * LDE;                                      // [D][LDWE]   W_e chunk (rows >= D - adim unused)
+    const Thr t = make_thr();
+    const int tid = t.tid;
+    float* El = reinterpret_cast<float*>(dtqn_smem);                  // [64][kEmbLD]  e_in chunk
+    float* Wl = El + TROWS * kEmbLD;                                   // [D][kEmbLD]   W_e chunk, row = OUTPUT column (rows < adim: zero)
     const int DO = D - adim;                                           // outputs of the embedding linear
-    const int rpp = TNT / D, NR = TROWS / rpp;                         // rows per pass, rows per thread (D in {64, 128, 256})
-    const int d = tid % D, rg = tid / D;                               // this thread: output column d, rows rg + rpp * i
-    float acc[32];
+    const int per_wave = D / 4 / TNW;                                  // items per wave: 2 / 4 / 8 at D = 64 / 128 / 256
+    f32x4 acc[8];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    for (int q = 0; q < 8; ++q) acc[q] = zero4();
     float* eo = a.ein.base != nullptr ? frow(a.ein, s, rb * TROWS) : nullptr;
-    for (int k0 = 0; k0 < KE; k0 += KC) {
-        const int kc = KE - k0 < KC ? KE - k0 : KC;
+    for (int k0 = 0; k0 < KE; k0 += kEmbKC) {
+        const int kc = KE - k0 < kEmbKC ? KE - k0 : kEmbKC, kc4 = (kc + 3) & ~3;
         __syncthreads();                                               // previous chunk consumed
-        for (int idx = tid; idx < TROWS * kc; idx += TNT) {
-            const int rl = idx / kc, k = k0 + (idx - rl * kc), r = rb * TROWS + rl;
+        for (int idx = tid; idx < TROWS * kc4; idx += TNT) {
+            const int rl = idx / kc4, kl = idx - rl * kc4, k = k0 + kl, r = rb * TROWS + rl;
             float v = 0.f;
-            if (r < n) {
+            if (r < n && kl < kc) {
                 if (net.discrete) {
                     const int jj = k / net.embed_per_obs, cdim = k - jj * net.embed_per_obs;
                     int tok = (int)obs_rows[(size_t)r * O + jj];
@@ -97,24 +99,24 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
                     v = obs_rows[(size_t)r * O + k];
                 }
             }
-            El[rl * LDE + (k - k0)] = v;
-            if (eo != nullptr) eo[(size_t)rl * KEP + k] = v;
+            El[rl * kEmbLD + kl] = v;
+            if (eo != nullptr && kl < kc) eo[(size_t)rl * KEP + k] = v;
         }
-        for (int idx = tid; idx < DO * kc; idx += TNT) {
-            const int dd = idx / kc, k = idx - dd * kc;
-            Wl[dd * LDWE + k] = theta[net.off_obs_w + (size_t)dd * KE + k0 + k];
+        for (int idx = tid; idx < D * kc4; idx += TNT) {
+            const int d = idx / kc4, kl = idx - d * kc4;
+            Wl[d * kEmbLD + kl] = (d >= adim && kl < kc) ? theta[net.off_obs_w + (size_t)(d - adim) * KE + k0 + kl] : 0.f;
         }
         __syncthreads();
-        if (d >= adim) {
-            const float* wr = Wl + (d - adim) * LDWE;
-            for (int k = 0; k < kc; ++k) {
-                const float wv = wr[k];
 #pragma unroll
-                for (int i = 0; i < 32; ++i)
-                    if (i < NR) acc[i] = fmaf(El[(rg + rpp * i) * LDE + k], wv, acc[i]);
-            }
+        for (int q = 0; q < 8; ++q) {
+            if (q >= per_wave) break;
+            const int item = t.wave + q * TNW, nt = item >> 2, mt = item & 3;
+            const float* ap = El + (mt * 16 + t.i) * kEmbLD + t.kq;
+            const float* bp = Wl + (nt * 16 + t.i) * kEmbLD + t.kq;
+            for (int k = 0; k < kc4; k += 4) acc[q] = mfma16(ap[k], bp[k], acc[q]);
         }
     }
+    (void)DO;
     if (eo != nullptr)                                                 // zero the padding columns [KE, KEP) of the saved input
         for (int idx = tid; idx < TROWS * (KEP - KE); idx += TNT) {
             const int rl = idx / (KEP - KE), k = KE + idx - rl * (KEP - KE);
@@ -122,21 +124,25 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
         }
     float* xo = frow(a.x, s, rb * TROWS);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if (i >= NR) break;
-        const int rl = rg + rpp * i, r = rb * TROWS + rl;
-        float v = 0.f;
-        if (r < n) {
-            if (d < adim) {
-                // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
-                if (n == 1 || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
-                else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
-            } else {
-                v = acc[i] + theta[net.off_obs_b + d - adim];
+    for (int q = 0; q < 8; ++q) {
+        if (q >= per_wave) break;
+        const int item = t.wave + q * TNW, nt = item >> 2, mt = item & 3, d = nt * 16 + t.i;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int rl = mt * 16 + t.kq * 4 + r4, r = rb * TROWS + rl;
+            float v = 0.f;
+            if (r < n) {
+                if (d < adim) {
+                    // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
+                    if (n == 1 || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
+                    else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else {
+                    v = acc[q][r4] + theta[net.off_obs_b + d - adim];
+                }
+                if (!a.bag) v += theta[net.off_pos + r * D + d];
             }
-            if (!a.bag) v += theta[net.off_pos + r * D + d];
+            xo[(size_t)rl * a.x.ld + d] = v;
         }
-        xo[(size_t)rl * a.x.ld + d] = v;
     }
 }
 
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     };
     if (PREFETCH) stage_load(0);
     for (int kc = 0; kc < nchunks; kc += 2) {
-        __syncthreads();                                              // previous chunk's tile fully consumed
+        if (kc > 0) __syncthreads();                                  // previous chunk's tile fully consumed
         if (PREFETCH) stage_store(); else stage(kc);
         if (kc + 1 < nchunks) {
             if (PREFETCH) stage_load(kc + 1);
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     };
     frag_dyw_fetch<KC>(bf0, wchunk(0), a.KOUT, t);
     for (int kc = 0; kc < nchunks; kc += 2) {
-        __syncthreads();
+        if (kc > 0) __syncthreads();                                  // previous chunk's tile fully consumed
         stage(kc);
         if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf1, wchunk(kc + 1), a.KOUT, t);
         __syncthreads();
@@ -439,13 +445,16 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_kernel(TlLnArgs a) {
                            s >= a.split ? a.bb : a.ba, st, t, nullptr, nullptr, a.dst.ld);
 }
 
-// backward, one workgroup per sequence walking its row blocks (the gamma / beta partial of the sequence is
-// accumulated across the blocks); dst may alias dy; accumulate: dst += dL/d(LN input) (identity-reordered layers, where
-// the LayerNorm sits on the branch and the residual stream gradient passes by it)
+// backward, one workgroup per (sequence, 64-row block): 8 lanes per row, each with D / 32 float4 of the row in registers.
+// The row statistics meet in a butterfly over the 8 lanes; the column sums (d gamma = sum_r dy * xhat, d beta = sum_r dy)
+// over the 8 rows of a wave in a butterfly over the lane bits 3..5, then over the 8 waves through LDS, and go to the
+// small-partial record of THIS row block (DtqnNet.sp_parts records per sequence; the reducers of dtqn_wgrad.hip add them
+// up in a fixed order).  dst may alias dy (every element is read and written by the same lane); accumulate: dst +=
+// dL/d(LN input) (identity-reordered layers, where the LayerNorm sits on the branch and the stream gradient passes by it).
 struct TlLnBwdArgs {
     Fld dy, xin, st, dst;
     const float* gamma;
-    float* small;                      // per-sequence partial record
+    float* small;                      // per-(sequence, row block) partial records
     long long small_stride;
     int dgb_off;
     int rpb;
@@ -453,15 +462,67 @@ struct TlLnBwdArgs {
 };
 template <int D>
 __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
-    float* red = reinterpret_cast<float*>(dtqn_smem);
+    constexpr int NV = D / 32;                                         // float4 per lane: columns part * 4 + 32 * j
+    float* red = reinterpret_cast<float*>(dtqn_smem);                  // [TNW][2][D]
     const Thr t = make_thr();
-    const int s = (int)blockIdx.x;
-    float* dgb = a.small + (size_t)s * a.small_stride + a.dgb_off;
-    for (int rb = 0; rb < a.rpb; ++rb) {
-        const int row0 = rb * TROWS;
-        layernorm_backward<D, TNW>(frow(a.dy, s, row0), frow(a.xin, s, row0), frow(a.dst, s, row0), a.accumulate != 0, D, TROWS,
-                                   a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2, a.gamma, dgb, red, t, rb > 0);
-        __syncthreads();
+    const int s = (int)blockIdx.x / a.rpb, rb = (int)blockIdx.x % a.rpb, row = rb * TROWS + (t.tid >> 3), part = t.tid & 7;
+    const float* stp = a.st.base + (size_t)s * a.st.stride + (size_t)row * 2;
+    const float mean = stp[0], rstd = stp[1];
+    const float* yp = frow(a.dy, s, row) + part * 4;
+    const float* xp = frow(a.xin, s, row) + part * 4;
+    float4 y[NV], xh[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { y[j] = ld4(yp + 32 * j); xh[j] = ld4(xp + 32 * j); }
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 gm = ld4(a.gamma + part * 4 + 32 * j);
+        xh[j] = make_float4((xh[j].x - mean) * rstd, (xh[j].y - mean) * rstd, (xh[j].z - mean) * rstd, (xh[j].w - mean) * rstd);
+        const float4 g = make_float4(y[j].x * gm.x, y[j].y * gm.y, y[j].z * gm.z, y[j].w * gm.w);
+        c1 += (g.x + g.y) + (g.z + g.w);
+        c2 += (g.x * xh[j].x + g.y * xh[j].y) + (g.z * xh[j].z + g.w * xh[j].w);
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
+    c1 *= (1.0f / D);
+    c2 *= (1.0f / D);
+    // column sums over the 8 rows of this wave
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        float sg[4] = {y[j].x * xh[j].x, y[j].y * xh[j].y, y[j].z * xh[j].z, y[j].w * xh[j].w};
+        float sb[4] = {y[j].x, y[j].y, y[j].z, y[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) { sg[c] += __shfl_xor(sg[c], m); sb[c] += __shfl_xor(sb[c], m); }
+        }
+        if (t.lane < 8) {
+            st4(red + (t.wave * 2 + 0) * D + part * 4 + 32 * j, make_float4(sg[0], sg[1], sg[2], sg[3]));
+            st4(red + (t.wave * 2 + 1) * D + part * 4 + 32 * j, make_float4(sb[0], sb[1], sb[2], sb[3]));
+        }
+    }
+    float* dp = frow(a.dst, s, row) + part * 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 gm = ld4(a.gamma + part * 4 + 32 * j);
+        float4 o;
+        o.x = rstd * (y[j].x * gm.x - c1 - xh[j].x * c2);
+        o.y = rstd * (y[j].y * gm.y - c1 - xh[j].y * c2);
+        o.z = rstd * (y[j].z * gm.z - c1 - xh[j].z * c2);
+        o.w = rstd * (y[j].w * gm.w - c1 - xh[j].w * c2);
+        if (a.accumulate) {
+            const float4 p = ld4(dp + 32 * j);
+            o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
+        }
+        st4(dp + 32 * j, o);
+    }
+    __syncthreads();
+    float* dgb = a.small + ((size_t)s * a.rpb + rb) * a.small_stride + a.dgb_off;
+    for (int idx = t.tid; idx < 2 * D; idx += TNT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) v += red[w * 2 * D + idx];
+        dgb[idx] = v;
     }
 }
 
@@ -540,18 +601,32 @@ struct TlQArgs {
     int q_row_stride;
     int D, A, n, S;
 };
+// 16 lanes per token row: lane c holds columns 4c + 64j of the hidden row (one coalesced read of the row per 16 lanes), multiplies
+// them with the same columns of every action's weight row (a few KB, cache resident) and the 16 partials meet in a butterfly.
 __global__ __launch_bounds__(256) void tl_qhead_kernel(TlQArgs a) {
-    const int total = a.S * a.n * a.A;
-    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < total; idx += (int)gridDim.x * 256) {
-        const int ac = idx % a.A, r = (idx / a.A) % a.n, s = idx / (a.A * a.n);
-        const float* hrow = frow(a.hh, s, r);
-        const float* w = (s >= a.split ? a.W2b : a.W2a) + (size_t)ac * a.D;
-        float acc = (s >= a.split ? a.b2b : a.b2a)[ac];
-        for (int k = 0; k < a.D; k += 4) {
-            const float4 hv = ld4(hrow + k), wv = ld4(w + k);
-            acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+    const int rows = a.S * a.n, c = (int)threadIdx.x & 15, nj = a.D / 64;
+    for (int g = (int)(blockIdx.x * 16 + (threadIdx.x >> 4)); g < (rows + 15) / 16 * 16; g += (int)gridDim.x * 16) {
+        const bool live = g < rows;                                   // dead row groups still take part in the shuffles
+        const int gs = live ? g : 0, s = gs / a.n, r = gs - s * a.n;
+        const float* hrow = frow(a.hh, s, r) + 4 * c;
+        float4 hv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[j] = j < nj ? ld4(hrow + 64 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* W = (s >= a.split ? a.W2b : a.W2a) + 4 * c;
+        const float* bias = s >= a.split ? a.b2b : a.b2a;
+        float* qrow = a.q + (size_t)s * a.q_seq_stride + (size_t)r * a.q_row_stride;
+        for (int ac = 0; ac < a.A; ++ac) {
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nj) {
+                    const float4 wv = ld4(W + (size_t)ac * a.D + 64 * j);
+                    p = fmaf(hv[j].x, wv.x, p); p = fmaf(hv[j].y, wv.y, p); p = fmaf(hv[j].z, wv.z, p); p = fmaf(hv[j].w, wv.w, p);
+                }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) p += __shfl_xor(p, m);
+            if (live && c == (ac & 15)) qrow[ac] = p + bias[ac];
         }
-        a.q[(size_t)s * a.q_seq_stride + (size_t)r * a.q_row_stride + ac] = acc;
     }
 }
 
@@ -626,58 +701,119 @@ struct TlEmbedBwdArgs {
     // source sequence b of (obs, actions) directly, action embedding not rolled, partials ADDED to the context's
     int bag, dx_off, rows;
 };
-// One workgroup per sequence, walking its 64-row blocks.  Discrete observations: d(e_in) = dx0[:, a:] W_e per block out
-// of LDS-staged tiles, then the scatter onto table rows: thread (k = j * e + c, row group) adds its rows into a private
-// [token][c] column of an LDS table (no two threads share an address), and the O * (row groups) private tables are summed
-// in a fixed order at the end -- deterministic, no atomics.
+// One workgroup per (sequence, 64-row block); its partials go to the small-partial record of that row block.
+// Discrete observations: d(e_in) [64][KE] = dx0[:, a:] [64][DO] * W_e [DO][KE] on the matrix cores (contraction in chunks of 64
+// columns through LDS, zero padded to multiples of 4 / 16), then the scatter onto table rows: thread (k = j * e + c, row
+// group) adds its rows into a private [token][c] column of an LDS table (no two threads share an address), and the
+// O * (row groups) private tables are summed in a fixed order at the end -- deterministic, no atomics.  The tokens and
+// actions of the block are staged in LDS once (no global load inside the scatter loops).
 // row groups of a 64-row block walked by different threads of the scatter: 4 if the thread count allows, else 2 or 1
 static __host__ __device__ inline int emb_row_groups(int ke) { return ke * 4 <= TNT ? 4 : ke * 2 <= TNT ? 2 : 1; }
+constexpr int kEbKC = 64, kEbLDT = kEbKC + 4;
+static __host__ __device__ inline int emb_bwd_ldk(int ke) {            // leading dim of the W_e chunk / d(e_in): >= KE16, == 16 mod 64
+    const int ke16 = (ke + 15) & ~15;
+    return ((ke16 - 16 + 63) / 64) * 64 + 16;
+}
+static inline size_t tl_embed_bwd_lds(const DtqnNet& net) {
+    const int ldk = emb_bwd_ldk(net.ke);
+    size_t f = (size_t)TROWS * (net.action_dim + 1) + TROWS + 4;                           // action columns of dx0, actions
+    if (net.discrete)
+        f += (size_t)TROWS * kEbLDT + (size_t)kEbKC * ldk + (size_t)TROWS * ldk + (size_t)TROWS * net.obs_dim +
+             (size_t)emb_row_groups(net.ke) * net.obs_dim * net.vocab * net.embed_per_obs;
+    return f * sizeof(float);
+}
 __global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
     const DtqnNet& net = a.net;
-    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const int D = net.d_model, L = a.bag ? a.rows : net.ctx_len, A = net.num_actions, adim = net.action_dim, LP = net.lp;
-    const float* DX = a.grd + (size_t)b * net.grd_stride + (a.bag ? a.dx_off : net.go_dx0);
-    float* srec = a.small + (size_t)b * net.sp_stride;
+    const Thr t = make_thr();
+    const int tid = t.tid;
+    const int rpb = net.lp / TROWS, b = (int)blockIdx.x / rpb, rb = (int)blockIdx.x % rpb, row0 = rb * TROWS;
+    const int D = net.d_model, L = a.bag ? a.rows : net.ctx_len, A = net.num_actions, adim = net.action_dim;
+    if (a.bag && row0 >= L) return;                                    // bag pass: nothing of the bag in this row block
+    const float* DX = a.grd + (size_t)b * net.grd_stride + (a.bag ? a.dx_off : net.go_dx0) + (size_t)row0 * D;
+    float* srec = a.small + ((size_t)b * rpb + rb) * net.sp_stride;
     const int ep = a.bag ? b : a.ep_idx[b], st0 = a.bag ? 0 : a.start[b];
-    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)(st0 + row0) * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
+    const int nrows = L - row0 < TROWS ? L - row0 : TROWS;             // live rows of this block
+    float* Al = reinterpret_cast<float*>(dtqn_smem);                   // [64][adim + 1]  action columns of dx0
+    int* actl = reinterpret_cast<int*>(Al + TROWS * (adim + 1));       // [64 + 1] the action that pairs with row r (see below)
+    float* rest = reinterpret_cast<float*>(actl + TROWS + 4);
+    if (adim > 0) {
+        for (int idx = tid; idx < TROWS * adim; idx += TNT) {
+            const int rl = idx / adim, c = idx - rl * adim;
+            Al[rl * (adim + 1) + c] = rl < nrows ? DX[(size_t)rl * D + c] : 0.f;
+        }
+        // row r carries the embedding of: its own action (bag entries), the action of row 0 (a single-row forward), else the
+        // action of row r - 1 with nothing at r = 0 (the roll of dtqn.py:184-192)
+        for (int rl = tid; rl < TROWS; rl += TNT) {
+            const int r = row0 + rl;
+            int v = -1;
+            if (rl < nrows) {
+                if (a.bag) v = (int)act_rows[r];
+                else if (L == 1) v = (int)act_rows[0];
+                else if (r > 0) v = (int)act_rows[r - 1];
+            }
+            actl[rl] = v;
+        }
+    }
     if (net.discrete) {
         const int KE = net.ke, e = net.embed_per_obs, V = net.vocab, O = net.obs_dim, DO = D - adim;
-        const int LDT = DO + 1, LDK = KE + 1, kEmbRQ = emb_row_groups(KE);
-        float* Tl = reinterpret_cast<float*>(dtqn_smem);       // [64][LDT]  dx0[:, a:] of the current row block
-        float* Wl = Tl + TROWS * LDT;                          // [DO][LDK]  W_e
-        float* dein = Wl + (size_t)DO * LDK;                   // [64][LDK]  dL/d(gathered table rows)
-        float* part = dein + TROWS * LDK;                      // [kEmbRQ][O][V][e] private scatter tables
+        const int LDK = emb_bwd_ldk(KE), kEmbRQ = emb_row_groups(KE), NT16 = (KE + 15) / 16;
+        float* Tl = rest;                                      // [64][kEbLDT]  chunk of dx0[:, a:]
+        float* Wl = Tl + TROWS * kEbLDT;                       // [64][LDK]     chunk of W_e (row = contraction index)
+        float* dein = Wl + (size_t)kEbKC * LDK;                // [64][LDK]     dL/d(gathered table rows)
+        int* tokl = reinterpret_cast<int*>(dein + (size_t)TROWS * LDK);   // [64][O]
+        float* part = reinterpret_cast<float*>(tokl + TROWS * O);         // [kEmbRQ][O][V][e] private scatter tables
         const float* __restrict__ We = a.theta + net.off_obs_w;
-        for (int idx = tid; idx < DO * KE; idx += TNT) Wl[(idx / KE) * LDK + idx % KE] = We[idx];
         for (int idx = tid; idx < kEmbRQ * O * V * e; idx += TNT) part[idx] = 0.f;
-        for (int rb = 0; rb < LP / TROWS; ++rb) {
-            __syncthreads();                                   // previous block's tiles consumed (and Wl / part initialised)
-            for (int idx = tid; idx < TROWS * DO; idx += TNT) {
-                const int rl = idx / DO, dd = idx - rl * DO, r = rb * TROWS + rl;
-                Tl[rl * LDT + dd] = r < L ? DX[(size_t)r * D + adim + dd] : 0.f;
+        for (int idx = tid; idx < TROWS * O; idx += TNT) {
+            const int rl = idx / O;
+            int tok = rl < nrows ? (int)obs_rows[idx] : 0;
+            tokl[idx] = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+        }
+        // items (16-row tile mt, 16-column tile nt) dealt to the waves; at most 2 per wave for KE <= 64, else serial loops
+        const int items = 4 * NT16;
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = zero4();
+        for (int k0 = 0; k0 < DO; k0 += kEbKC) {
+            const int kc = DO - k0 < kEbKC ? DO - k0 : kEbKC, kc4 = (kc + 3) & ~3;
+            __syncthreads();                                   // previous chunk consumed
+            for (int idx = tid; idx < TROWS * kc4; idx += TNT) {
+                const int rl = idx / kc4, kl = idx - rl * kc4;
+                Tl[rl * kEbLDT + kl] = (rl < nrows && kl < kc) ? DX[(size_t)rl * D + adim + k0 + kl] : 0.f;
+            }
+            for (int idx = tid; idx < kc4 * NT16 * 16; idx += TNT) {
+                const int kl = idx / (NT16 * 16), k = idx - kl * (NT16 * 16);
+                Wl[kl * LDK + k] = (kl < kc && k < KE) ? We[(size_t)(k0 + kl) * KE + k] : 0.f;
             }
             __syncthreads();
-            for (int idx = tid; idx < TROWS * KE; idx += TNT) {
-                const int rl = idx / KE, k = idx - rl * KE;
-                const float* tr = Tl + rl * LDT;
-                float g = 0.f;
-                for (int dd = 0; dd < DO; ++dd) g = fmaf(tr[dd], Wl[dd * LDK + k], g);
-                dein[rl * LDK + k] = g;
-            }
-            __syncthreads();
-            if (tid < KE * kEmbRQ) {
-                const int k = tid % KE, rq = tid / KE, jj = k / e, c = k - jj * e;
-                float* mine = part + ((size_t)(rq * O + jj) * V) * e + c;
-                for (int rl = rq * (TROWS / kEmbRQ); rl < (rq + 1) * (TROWS / kEmbRQ); ++rl) {
-                    const int r = rb * TROWS + rl;
-                    if (r < L) {
-                        int tok = (int)obs_rows[(size_t)r * O + jj];
-                        tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-                        mine[tok * e] += dein[rl * LDK + k];
-                    }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int item = t.wave + q * TNW;
+                if (item < items) {
+                    const int nt = item >> 2, mt = item & 3;
+                    const float* ap = Tl + (mt * 16 + t.i) * kEbLDT + t.kq;
+                    const float* bp = Wl + t.kq * LDK + nt * 16 + t.i;
+                    for (int k = 0; k < kc4; k += 4) acc[q] = mfma16(ap[k], bp[(size_t)k * LDK], acc[q]);
                 }
             }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int item = t.wave + q * TNW;
+            if (item < items) {
+                const int nt = item >> 2, mt = item & 3;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) dein[(mt * 16 + t.kq * 4 + r4) * LDK + nt * 16 + t.i] = acc[q][r4];
+            }
+        }
+        __syncthreads();
+        if (tid < KE * kEmbRQ) {
+            const int k = tid % KE, rq = tid / KE, jj = k / e, c = k - jj * e;
+            float* mine = part + ((size_t)(rq * O + jj) * V) * e + c;
+            for (int rl = rq * (TROWS / kEmbRQ); rl < (rq + 1) * (TROWS / kEmbRQ); ++rl)
+                if (rl < nrows) mine[tokl[rl * O + jj] * e] += dein[rl * LDK + k];
         }
         __syncthreads();
         for (int idx = tid; idx < V * e; idx += TNT) {
@@ -685,22 +821,16 @@ __global__ __launch_bounds__(TNT) void tl_embed_bwd_kernel(TlEmbedBwdArgs a) {
             for (int q = 0; q < kEmbRQ * O; ++q) g += part[(size_t)q * V * e + idx];
             srec[net.so_tab + idx] = a.bag ? srec[net.so_tab + idx] + g : g;
         }
+    } else {
+        __syncthreads();
     }
     if (adim > 0) {
         for (int idx = tid; idx < A * adim; idx += TNT) {
             const int v = idx / adim, c = idx - v * adim;
             float g = 0.f;
-            if (a.bag) {
-                for (int r = 0; r < L; ++r)
-                    if ((int)act_rows[r] == v) g += DX[(size_t)r * D + c];
-                g += srec[net.so_act + idx];
-            } else if (L == 1) {
-                if ((int)act_rows[0] == v) g = DX[c];
-            } else {
-                for (int r = 1; r < L; ++r)
-                    if ((int)act_rows[r - 1] == v) g += DX[(size_t)r * D + c];
-            }
-            srec[net.so_act + idx] = g;
+            for (int rl = 0; rl < nrows; ++rl)
+                if (actl[rl] == v) g += Al[rl * (adim + 1) + c];
+            srec[net.so_act + idx] = a.bag ? srec[net.so_act + idx] + g : g;
         }
     }
 }
@@ -847,9 +977,8 @@ static int launch_ln(const TlLnArgs& a, int S, hipStream_t stream) {
 }
 template <int D>
 static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
-    constexpr int PARTS = TNT / D >= 1 ? TNT / D : 1;
-    const size_t lds = (size_t)PARTS * 2 * D * sizeof(float);
-    TL_LAUNCH((tl_layernorm_bwd_kernel<D>), dim3(S), dim3(TNT), lds, stream, a);
+    const size_t lds = (size_t)TNW * 2 * D * sizeof(float);
+    TL_LAUNCH((tl_layernorm_bwd_kernel<D>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
 static int launch_attn(const TlAttnArgs& a, int S, int H, int HD, hipStream_t stream) {
@@ -932,7 +1061,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
         e.src_mod = 0; e.bag = 0;
-        const size_t elds = ((size_t)TROWS * (kEmbKC + 4) + (size_t)D * (kEmbKC + 1)) * sizeof(float);
+        const size_t elds = tl_embed_lds(D);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
     auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
@@ -1037,7 +1166,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
             e.src_mod = src.bag_batch; e.bag = 1;
-            const size_t elds = ((size_t)TROWS * (kEmbKC + 4) + (size_t)D * (kEmbKC + 1)) * sizeof(float);
+            const size_t elds = tl_embed_lds(D);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
         const Fld xw = F(rm.xcat, 2 * D);                      // working memory = left half of xcat
@@ -1060,8 +1189,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     qa.b2a = theta_a + net.off_head2_b; qa.b2b = theta_b + net.off_head2_b;
     qa.split = split; qa.q = q_out; qa.q_seq_stride = q_seq_stride; qa.q_row_stride = q_row_stride;
     qa.D = D; qa.A = net.num_actions; qa.n = n; qa.S = S;
-    const int total = S * n * net.num_actions;
-    TL_LAUNCH(tl_qhead_kernel, dim3((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048), dim3(256), 0, stream, qa);
+    const int qgroups = (S * n + 15) / 16;
+    TL_LAUNCH(tl_qhead_kernel, dim3(qgroups < 4096 ? qgroups : 4096), dim3(256), 0, stream, qa);
     return DTQN_OK;
 }
 
@@ -1200,17 +1329,16 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         a.net = net; a.theta = theta; a.grd = grd; a.small = td.small;
         a.obs = rp.obs; a.actions = rp.actions; a.obs_ep_stride = obs_ep_stride; a.act_ep_stride = act_ep_stride;
         a.ep_idx = td.ep_idx; a.start = td.start;
-        const int DO = D - net.action_dim;
-        const size_t lds = !net.discrete ? 0 : ((size_t)TROWS * (DO + 1) + (size_t)DO * (net.ke + 1) + (size_t)TROWS * (net.ke + 1) +
-                                                (size_t)emb_row_groups(net.ke) * net.obs_dim * net.vocab * net.embed_per_obs) * sizeof(float);
-        if (lds > 150 * 1024 || net.ke > TNT) return DTQN_ERR_CONFIG;
+        const size_t lds = tl_embed_bwd_lds(net);
+        // (KE <= 256: at most 4 x 16 column tiles x 4 row tiles = the 4 items a wave keeps accumulators for)
+        if (lds > 150 * 1024 || net.ke > 128) return DTQN_ERR_CONFIG;
         a.bag = 0; a.dx_off = 0; a.rows = 0;
-        TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(TNT), lds, stream, a);
+        TL_LAUNCH(tl_embed_bwd_kernel, dim3(B * rpb), dim3(TNT), lds, stream, a);
         if (net.bag_size > 0) {          // the bag entries went through the same tables: their partials are added
             a.obs = td.bag_obs; a.actions = td.bag_actions;
             a.obs_ep_stride = (long long)net.bag_size * net.obs_dim; a.act_ep_stride = net.bag_size;
             a.bag = 1; a.dx_off = net.go_bag_de; a.rows = net.bag_size;
-            TL_LAUNCH(tl_embed_bwd_kernel, dim3(B), dim3(TNT), lds, stream, a);
+            TL_LAUNCH(tl_embed_bwd_kernel, dim3(B * rpb), dim3(TNT), lds, stream, a);
         }
     }
     return DTQN_OK;

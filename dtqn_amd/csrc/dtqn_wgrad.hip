@@ -61,7 +61,7 @@ __device__ __forceinline__ void small_partials_block(const WgradArgs& a, int sb,
             stride = (size_t)net.grd_stride;
         }
         float v = 0.f;
-        const int per = base == a.small ? a.row_split : 1;    // the grd record is per sequence, the small record per workgroup
+        const int per = base == a.small ? a.row_split * net.sp_parts : 1;    // the grd record is per sequence, the small records per workgroup
         for (int b = b_lo * per; b < b_hi * per; ++b) v += base[(size_t)b * stride + src];
         out[dst] = v;
     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
                     base = a.grd;
                     stride = (size_t)net.grd_stride;
                 }
-                const int cnt = a.batch * (base == a.small ? a.row_split : 1);
+                const int cnt = a.batch * (base == a.small ? a.row_split * net.sp_parts : 1);
 #pragma unroll 8
                 for (int q = t.wave; q < cnt; q += kDirectWaves) v += base[(size_t)q * stride + src];
             }

@@ -98,7 +98,7 @@ class TdEngine:
         # latency mode for small batches: two workgroups per sequence (include/dtqn_hip.h, dtqn_td_row_split)
         self.row_split = int(self.lib.dtqn_td_row_split(ctypes.byref(net), Bn))
         RS = self.row_split
-        self.small = torch.zeros(Bn * RS * net.sp_stride, **f32)
+        self.small = torch.zeros(Bn * RS * net.sp_parts * net.sp_stride, **f32)
         self.q3 = torch.zeros(3 * Bn * net.lp * net.ap, **f32)
         self.gsplit = torch.zeros(self.n_split * nt, **f32)
         self.norm_partial = torch.zeros(max(self.n_norm_blocks, int(self.lib.dtqn_td_norm_partials(ctypes.byref(net)))), **f32)

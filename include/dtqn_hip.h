@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 6
+#define DTQN_ABI_VERSION 7
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -115,6 +115,8 @@ typedef struct DtqnNet {
     /* ---- derived: per-sequence small partials (LayerNorm affine, embedding tables) ---- */
     int32_t sp_stride;
     int32_t so_ln, so_tab, so_act;      /* [NL][4][D], [V][e], [A][a] */
+    int32_t sp_parts;                   /* small-partial records per sequence and backward workgroup slice: 1, or padded context / 64 on the
+                                         * row-block tiled path (one per 64-row block) */
     /* ---- derived: weight-gradient job table ---- */
     int32_t n_wjobs;
     int32_t n_wtiles;         /* total 64x64 output blocks over all jobs */
@@ -236,7 +238,7 @@ typedef struct DtqnTd {
     /* workspaces */
     float* act;               /* [B][act_stride] */
     float* grd;               /* [B][grd_stride] */
-    float* small;             /* [B * row_split][sp_stride] */
+    float* small;             /* [B * row_split * net.sp_parts][sp_stride] */
     float* q3;                /* [3][B][LP][AP]: Q_pol(o), Q_pol(o'), Q_tgt(o') */
     float* gsplit;            /* [n_split][n_trainable] split-K partials of the weight gradients */
     float* norm_partial;      /* [dtqn_td_norm_partials()] per-workgroup sums of squares of grad */

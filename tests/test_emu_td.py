@@ -1,5 +1,7 @@
 """Kernel-logic tests on the CPU for the full TD update (forward x3, loss, backward, weight
 gradients, reduce, clip + Adam) on the test-only HIP emulation, against the oracle."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
