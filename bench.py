@@ -135,12 +135,19 @@ def time_kernels(agent, iters: int = 50) -> dict:
     return out
 
 
+def _round_profiles(kind: str, cid: int):
+    """profiles/r02<suffix>_<kind>_cfg<N>.json of this round, newest suffix first ('' < 'b' < 'c' ...)."""
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", f"r02*_{kind}_cfg{cid}.json")), reverse=True)
+
+
 def pmc_traffic(kernel: str, batch: int, cid: int = 1):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
     separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads): this
     round's profile of the config (profiles/r02_pmc_traffic_cfg<N>.json) when it matches the batch, else round 1's
     cfg-1 profile.  None when no profile matches."""
-    cands = [os.path.join(ROOT, "profiles", f"r02_pmc_traffic_cfg{cid}.json")] if CONFIGS[cid]["B"] == batch else []
+    # (r02b / r02c ...: re-profiles of a config after later kernel changes of the round; the newest one wins)
+    cands = _round_profiles("pmc_traffic", cid) if CONFIGS[cid]["B"] == batch else []
     cands.append(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{batch}.json"))
     for path in cands:
         if not os.path.exists(path):
@@ -263,10 +270,11 @@ def mfma_counters(cid: int):
     """Hardware MFMA utilisation from the committed rocprofv3 --pmc pass of this config (tools/profile_round.sh ->
     profiles/r02_pmc_mfma_cfg<N>.json), per kernel: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and the MFMA op count.
     None when the round holds no such profile."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_mfma_cfg{cid}.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path))
+    for path in _round_profiles("pmc_mfma", cid):
+        d = json.load(open(path))
+        if d:
+            return d
+    return None
 
 
 def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
