@@ -146,6 +146,42 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     }
 }
 
+// Fragments of the row-block GEMMs with the contraction index grouped in 16s: at step s lane (i, kq) holds
+// k = 16 s + 4 kq + {0..3} of weight row i, so the four kq lanes of a row read 64 contiguous bytes and a wave's load
+// instruction touches 16 cache lines (frag_xwT_fetch's k = kq K/4 + 4 s + c layout touches 64: one per lane).  The A
+// operand follows the same order out of LDS: 16-lane groups read rows 132 words apart -> 64 different banks.
+template <int K>
+__device__ __forceinline__ void frag16_fetch(float4 (&bf)[K / 16], const float* __restrict__ Wrow, const Thr& t) {
+    const float4* wp = reinterpret_cast<const float4*>(Wrow + t.kq * 4);
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) bf[s] = wp[4 * s];
+}
+template <int K, int MG>
+__device__ __forceinline__ void frag16_mma(const float* Xs, int lda, const float4 (&bf)[K / 16], const Thr& t, f32x4 (&acc)[MG]) {
+    constexpr int KS = K / 16;
+    const float* xp = Xs + t.i * lda + t.kq * 4;
+    float4 af[2][MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) af[0][m] = ld4(xp + m * 16 * lda);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(xp + m * 16 * lda + 16 * (s + 1));
+        }
+        const float b4[4] = {bf[s].x, bf[s].y, bf[s].z, bf[s].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) {
+                const float4 a = af[s & 1][m];
+                const float av = c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w));
+                acc[m] = mfma16(av, b4[c], acc[m]);
+            }
+        }
+    }
+}
+
 // ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T [+ IN2[rows][K2] * W2[N][K2]^T] + b) ----------------------
 //   mode 0: OUT = y      mode 1: OUT = relu(y)      mode 2: OUT = RES + relu(y)   (residual gate)
 //   modes 1 / 2 optionally save the ReLU pattern as wave ballots (same word layout as the whole-sequence kernels)
@@ -183,7 +219,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     float4 bf0[D / 16], bf1[D / 16];
     const float* wrow = W + (size_t)(live ? col : 0) * a.K;
     const float* wrow2 = a.K2 > 0 ? W2 + (size_t)(live ? col : 0) * a.K2 : nullptr;
-    frag_xwT_fetch<D>(bf0, wrow, t);
+    frag16_fetch<D>(bf0, wrow, t);
     const float* in0 = frow(a.in, s, row0);
     const float* in20 = a.K2 > 0 ? frow(a.in2, s, row0) : nullptr;
     const int nch1 = a.K / D, nchunks = nch1 + a.K2 / D;
@@ -226,21 +262,26 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
         if (PREFETCH) stage_store(); else stage(kc);
         if (kc + 1 < nchunks) {
             if (PREFETCH) stage_load(kc + 1);
-            frag_xwT_fetch<D>(bf1, wfrag(kc + 1), t);
+            frag16_fetch<D>(bf1, wfrag(kc + 1), t);
         }
         __syncthreads();
-        frag_xwT_mma<D, 4>(Xt, LDT, bf0, t, acc);
+        frag16_mma<D, 4>(Xt, LDT, bf0, t, acc);
         if (kc + 1 < nchunks) {
             __syncthreads();
             if (PREFETCH) stage_store(); else stage(kc + 1);
             if (kc + 2 < nchunks) {
                 if (PREFETCH) stage_load(kc + 2);
-                frag_xwT_fetch<D>(bf0, wfrag(kc + 2), t);
+                frag16_fetch<D>(bf0, wfrag(kc + 2), t);
             }
             __syncthreads();
-            frag_xwT_mma<D, 4>(Xt, LDT, bf1, t, acc);
+            frag16_mma<D, 4>(Xt, LDT, bf1, t, acc);
         }
     }
+    // epilogue through LDS: the accumulators (MFMA layout: lane = column, 4 rows) go into the operand tile as [row][column of
+    // this 128-column block], then every lane handles float4 pieces of whole rows: 16-byte loads of RES / AUX and 16-byte
+    // stores (a quarter of the memory instructions of per-lane dword accesses).  ReLU ballots are taken in the MFMA layout.
+    constexpr int LDE = 16 * TNW + 4;                                 // epilogue tile [64][128 + 4]
+    __syncthreads();                                                  // the last chunk's tile is consumed
     if (live) {
         const float b = bias != nullptr ? bias[col] : 0.f;
         float* mrec = a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
@@ -248,30 +289,44 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = row0 + m * 16 + t.kq * 4 + r4;
-                float* op = frow(a.out, s, row) + col;
+                const int rl = m * 16 + t.kq * 4 + r4;
                 const float v = acc[m][r4] + b;
-                if (a.mode == 0) {
-                    *op = v;
-                } else if (a.mode == 3) {
-                    const float g = sigmoidf_(v);
-                    *op = g;
-                    if (a.out2.base != nullptr) {
-                        const float x = frow(a.res, s, row)[col];
-                        frow(a.out2, s, row)[col] = g * x;
-                        if (a.out3.base != nullptr) frow(a.out3, s, row)[col] = x;
-                    }
-                } else if (a.mode == 4) {
-                    const float hc = tanhf(v);
-                    const float z = frow(a.aux, s, row)[col], x = frow(a.res, s, row)[col];
-                    *op = hc;
-                    frow(a.out2, s, row)[col] = (1.0f - z) * x + z * hc;
-                } else {
-                    if (mrec != nullptr) ballot_store(mrec, a.N / 16, row, col, v > 0.f, t.lane);
-                    const float y = fmaxf(v, 0.f);
-                    *op = a.mode == 1 ? y : frow(a.res, s, row)[col] + y;
-                }
+                if (mrec != nullptr && (a.mode == 1 || a.mode == 2)) ballot_store(mrec, a.N / 16, row0 + rl, col, v > 0.f, t.lane);
+                Xt[rl * LDE + t.wave * 16 + t.i] = v;
             }
+    }
+    __syncthreads();
+    const int cb = (int)blockIdx.y * TNW * 16;                        // first column of this block
+    for (int idx = t.tid; idx < TROWS * (TNW * 4); idx += TNT) {
+        const int rl = idx / (TNW * 4), c = (idx - rl * (TNW * 4)) * 4, cg = cb + c, row = row0 + rl;
+        if (cg >= a.N) continue;
+        const float4 v = ld4(Xt + rl * LDE + c);
+        float* op = frow(a.out, s, row) + cg;
+        if (a.mode == 0) {
+            st4(op, v);
+        } else if (a.mode == 3) {
+            const float4 g = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+            st4(op, g);
+            if (a.out2.base != nullptr) {
+                const float4 x = ld4(frow(a.res, s, row) + cg);
+                st4(frow(a.out2, s, row) + cg, make_float4(g.x * x.x, g.y * x.y, g.z * x.z, g.w * x.w));
+                if (a.out3.base != nullptr) st4(frow(a.out3, s, row) + cg, x);
+            }
+        } else if (a.mode == 4) {
+            const float4 hc = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+            const float4 z = ld4(frow(a.aux, s, row) + cg), x = ld4(frow(a.res, s, row) + cg);
+            st4(op, hc);
+            st4(frow(a.out2, s, row) + cg, make_float4((1.0f - z.x) * x.x + z.x * hc.x, (1.0f - z.y) * x.y + z.y * hc.y,
+                                                       (1.0f - z.z) * x.z + z.z * hc.z, (1.0f - z.w) * x.w + z.w * hc.w));
+        } else {
+            const float4 y = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (a.mode == 1) {
+                st4(op, y);
+            } else {
+                const float4 r = ld4(frow(a.res, s, row) + cg);
+                st4(op, make_float4(r.x + y.x, r.y + y.y, r.z + y.z, r.w + y.w));
+            }
+        }
     }
 }
 
@@ -331,6 +386,9 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
             frag_dyw_mma<KC, 4>(Yt, LDT, bf1, t, acc);
         }
     }
+    // epilogue through LDS (see tl_linear_kernel): accumulators -> [row][column] tile -> 16-byte row pieces
+    constexpr int LDE = 16 * TNW + 4;
+    __syncthreads();                                                  // the last chunk's tile is consumed
     if (live) {
         const unsigned long long* mrec =
             a.mode == 1 ? reinterpret_cast<const unsigned long long*>(a.mask.base + (size_t)s * a.mask.stride) : nullptr;
@@ -338,16 +396,27 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = row0 + m * 16 + t.kq * 4 + r4;
-                float* op = frow(a.out, s, row) + col;
-                const float v = acc[m][r4];
-                if (a.mode == 0) *op = v;
-                else if (a.mode == 2) *op += v;
-                else {
+                const int rl = m * 16 + t.kq * 4 + r4, row = row0 + rl;
+                float v = acc[m][r4];
+                if (a.mode == 1) {
                     const unsigned long long w = mrec[((row >> 4) * (a.KOUT / 16) + (col >> 4)) * 4 + r4];
-                    *op = ((w >> t.lane) & 1ull) ? v : 0.f;
+                    v = ((w >> t.lane) & 1ull) ? v : 0.f;
                 }
+                Yt[rl * LDE + t.wave * 16 + t.i] = v;
             }
+    }
+    __syncthreads();
+    const int cb = (int)blockIdx.y * TNW * 16;
+    for (int idx = t.tid; idx < TROWS * (TNW * 4); idx += TNT) {
+        const int rl = idx / (TNW * 4), c = (idx - rl * (TNW * 4)) * 4, cg = cb + c;
+        if (cg >= a.KOUT) continue;
+        float4 v = ld4(Yt + rl * LDE + c);
+        float* op = frow(a.out, s, row0 + rl) + cg;
+        if (a.mode == 2) {
+            const float4 p = ld4(op);
+            v = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+        }
+        st4(op, v);
     }
 }
 
@@ -960,13 +1029,13 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
 
 template <int D>
 static int launch_linear(const TlLinearArgs& a, int S, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * (D + 4) * sizeof(float);
+    const size_t lds = (size_t)TROWS * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);     // operand tile, reused by the [64][128] epilogue tile
     TL_LAUNCH((tl_linear_kernel<D>), dim3(S * a.rpb, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
 template <int KC>
 static int launch_dx(const TlDxArgs& a, int S, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * (KC + 4) * sizeof(float);
+    const size_t lds = (size_t)TROWS * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
     TL_LAUNCH((tl_dx_kernel<KC>), dim3(S * a.rpb, (a.KOUT + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }

@@ -46,9 +46,10 @@ CASES = [
      dict(batch=3, T=140, mask=11, n_eps=8, history=40)),
     # (GRU + identity + discrete tokens at D = 128, L = 128 with the perturbed test weights is ill-conditioned: the fp32
     #  oracle itself sits 9e-4 from its fp64 evaluation there, as does the HIP path -- so that combination is tested on
-    #  continuous observations at L = 50)
+    #  continuous observations at L = 50; its gradient sits at 2.3e-4 of the largest entry with the 16-grouped contraction order
+    #  of the row-block GEMMs and within 2e-4 with the previous order: summation-order noise, so this one case gets 4e-4)
     (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, gate="gru", identity=True, pos="sin"),
-     dict(batch=4, T=200, mask=-5, n_eps=12, tuf=2)),
+     dict(batch=4, T=200, mask=-5, n_eps=12, tuf=2, grad_rtol=4e-4)),
     (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=100, discrete=True, vocab_sizes=22, gate="gru", num_layers=1),
      dict(batch=2, T=120, mask=21, n_eps=5)),
 ]
@@ -60,7 +61,7 @@ def test_td_update_vs_oracle(lib, kw, run):
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9),
                                                mask=run["mask"], history=run.get("history"), tuf=run.get("tuf", 10_000),
                                                device="cuda", test_lib=False)
-    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3, grad_rtol=run.get("grad_rtol", 2e-4))
     assert int(eng.xflags.sum()) == 0          # latency mode: every hand-over flag was lowered again
 
 
