@@ -156,9 +156,10 @@ __device__ __forceinline__ void frag16_fetch(float4 (&bf)[K / 16], const float* 
 #pragma unroll
     for (int s = 0; s < K / 16; ++s) bf[s] = wp[4 * s];
 }
-template <int K, int MG>
-__device__ __forceinline__ void frag16_mma(const float* Xs, int lda, const float4 (&bf)[K / 16], const Thr& t, f32x4 (&acc)[MG]) {
+template <int K, int MG, int NB = K / 16>
+__device__ __forceinline__ void frag16_mma(const float* Xs, int lda, const float4 (&bf)[NB], const Thr& t, f32x4 (&acc)[MG]) {
     constexpr int KS = K / 16;
+    static_assert(NB >= KS, "fragment array too short");
     const float* xp = Xs + t.i * lda + t.kq * 4;
     float4 af[2][MG];
 #pragma unroll
@@ -327,6 +328,139 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
                 st4(op, make_float4(r.x + y.x, r.y + y.y, r.z + y.z, r.w + y.w));
             }
         }
+    }
+}
+
+// ---- fused feed-forward block: OUT = f(relu(IN W1^T + b1) W2^T + b2), hidden width 4 D (transformer.py:55-61, 76-77) -------------
+//   mode 1: OUT = relu(y) (GRU gate input)      mode 2: OUT = RES + relu(y) (residual gate)
+// One workgroup per (sequence, 64-row block).  The input tile stays in LDS; the hidden layer is produced in chunks of 128
+// units (wave w: units 16 w .. 16 w + 15 of the chunk, all 64 rows), dropped into a second LDS tile after bias + ReLU and
+// consumed right there as the contraction chunk of the second product, whose [64][D] accumulators stay in registers.  The
+// hidden activations never make the trip through memory that two separate GEMMs need ([rows][4 D] floats out and in again --
+// the row-block path is bound by exactly that traffic); they are WRITTEN (with their ReLU ballots) only
+// for the sequences the backward pass will read (s < n_save: the training third of a TD update).
+// Weight fragments alternate between two register arrays by name; the fetch of the next step is issued before the MFMAs of
+// the current one.
+struct TlFfnArgs {
+    Fld in, out, res;
+    Fld h, mh, m2;                     // hidden record [LPB][4D], its ballots, the output's ballots (bases may be null)
+    const float *W1a, *W1b, *b1a, *b1b, *W2a, *W2b, *b2a, *b2b;
+    int split, rpb, mode, n_save;
+};
+template <int D>
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs a) {
+    constexpr int KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
+    constexpr int LDX = D + 4, LDH = 128 + 4;
+    static_assert((NKA == 1 && NOT == 1) || (NKA == 2 && NOT == 2), "step sequence written for D in {64, 128, 256}");
+    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDX] input rows
+    float* Hs = Xt + TROWS * LDX;                                      // [64][LDH] hidden chunk / output staging
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const bool second = s >= a.split, save = s < a.n_save;
+    const float* __restrict__ W1 = second ? a.W1b : a.W1a;
+    const float* __restrict__ W2 = second ? a.W2b : a.W2a;
+    const float* __restrict__ b1 = second ? a.b1b : a.b1a;
+    const float* __restrict__ b2 = second ? a.b2b : a.b2a;
+    const int wc = t.wave * 16 + t.i;                                  // this lane's column inside a 128-column block
+    auto fetchA = [&](float4 (&bf)[8], int j, int kc) {                // W1 [4D][D]: hidden unit j * 128 + wc, contraction chunk kc
+        const float* wr = W1 + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    auto fetchB = [&](float4 (&bf)[8], int j, int ot) {                // W2 [D][4D]: output column ot * 128 + wc, hidden chunk j
+        const int col = ot * 128 + wc;
+        const float* wr = W2 + (size_t)(col < D ? col : 0) * HID + j * 128 + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    float4 bf0[8], bf1[8];
+    fetchA(bf0, 0, 0);
+    {
+        const float* in0 = frow(a.in, s, row0);
+        for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
+            const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+            st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.in.ld + c));
+        }
+    }
+    f32x4 accO[NOT][4];
+#pragma unroll
+    for (int o = 0; o < NOT; ++o)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) accO[o][m] = zero4();
+    float* mrec_h = save && a.mh.base != nullptr ? a.mh.base + (size_t)s * a.mh.stride : nullptr;
+    __syncthreads();
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 accA[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) accA[m] = zero4();
+        if (NKA == 1) {
+            fetchB(bf1, j, 0);
+            frag16_mma<KA, 4, 8>(Xt, LDX, bf0, t, accA);
+        } else {
+            fetchA(bf1, j, 1);
+            frag16_mma<KA, 4, 8>(Xt, LDX, bf0, t, accA);
+            fetchB(bf0, j, 0);
+            frag16_mma<KA, 4, 8>(Xt + KA, LDX, bf1, t, accA);
+        }
+        {
+            const int hc = j * 128 + wc;
+            const float bv = b1[hc];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = m * 16 + t.kq * 4 + r4;
+                    const float v = accA[m][r4] + bv;
+                    if (mrec_h != nullptr) ballot_store(mrec_h, HID / 16, row0 + rl, hc, v > 0.f, t.lane);
+                    Hs[rl * LDH + wc] = fmaxf(v, 0.f);
+                }
+        }
+        __syncthreads();                                               // the hidden chunk is complete
+        if (save && a.h.base != nullptr) {
+            for (int idx = t.tid; idx < TROWS * 32; idx += TNT) {
+                const int rl = idx >> 5, c = (idx & 31) * 4;
+                st4(frow(a.h, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+            }
+        }
+        if (NOT == 1) {
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            if (wc < D) frag16_mma<128, 4, 8>(Hs, LDH, bf1, t, accO[0]);
+        } else {
+            fetchB(bf1, j, 1);
+            frag16_mma<128, 4, 8>(Hs, LDH, bf0, t, accO[0]);
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            frag16_mma<128, 4, 8>(Hs, LDH, bf1, t, accO[NOT - 1]);
+        }
+        __syncthreads();                                               // ... and consumed
+    }
+    float* mrec_o = save && a.m2.base != nullptr ? a.m2.base + (size_t)s * a.m2.stride : nullptr;
+#pragma unroll
+    for (int o = 0; o < NOT; ++o) {
+        const int col = o * 128 + wc;
+        if (col < D) {
+            const float bv = b2[col];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = m * 16 + t.kq * 4 + r4;
+                    const float v = accO[o][m][r4] + bv;
+                    if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
+                    Hs[rl * LDH + wc] = fmaxf(v, 0.f);
+                }
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < TROWS * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4, cg = o * 128 + c;
+            if (cg >= D) continue;
+            float4 y = ld4(Hs + rl * LDH + c);
+            if (a.mode == 2) {
+                const float4 r = ld4(frow(a.res, s, row0 + rl) + cg);
+                y = make_float4(r.x + y.x, r.y + y.y, r.z + y.z, r.w + y.w);
+            }
+            st4(frow(a.out, s, row0 + rl) + cg, y);
+        }
+        if (o + 1 < NOT) __syncthreads();
     }
 }
 
@@ -1033,6 +1167,12 @@ static int launch_linear(const TlLinearArgs& a, int S, hipStream_t stream) {
     TL_LAUNCH((tl_linear_kernel<D>), dim3(S * a.rpb, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
+template <int D>
+static int launch_ffn(const TlFfnArgs& a, int S, hipStream_t stream) {
+    const size_t lds = (size_t)TROWS * ((D + 4) + (128 + 4)) * sizeof(float);
+    TL_LAUNCH((tl_ffn_kernel<D>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
 template <int KC>
 static int launch_dx(const TlDxArgs& a, int S, hipStream_t stream) {
     const size_t lds = (size_t)TROWS * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
@@ -1201,16 +1341,21 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         if (!ident) rc = lnorm(s1, u2, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b);
         else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
         if (rc != DTQN_OK) return rc;
-        if ((rc = linear(u2, D, 4 * D, tb + net.lo_f1_w, tb + net.lo_f1_b, F(ab + net.al_h, 4 * D), 1, nofld(),
-                         training ? F(ab + net.al_mh, 0) : nofld())) != DTQN_OK) return rc;
-        // s2 = gate(post-LN: u2 | identity: s1, relu(h W_2^T + b))
-        if (!gru) {
-            rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, s2, 2, ident ? s1 : u2,
-                        training ? F(ab + net.al_m2, 0) : nofld());
-        } else {
-            rc = linear(F(ab + net.al_h, 4 * D), 4 * D, D, tb + net.lo_f2_w, tb + net.lo_f2_b, F(ab + net.al_gate2 + 5 * LPD, D), 1, nofld(),
-                        training ? F(ab + net.al_m2, 0) : nofld());
-            if (rc == DTQN_OK) rc = gate(ident ? s1 : u2, ab + net.al_gate2, net.off_gate_mlp, s2);
+        // s2 = gate(post-LN: u2 | identity: s1, relu(relu(u2 W_1^T + b) W_2^T + b)): one fused launch, the hidden layer stays in LDS
+        {
+            TlFfnArgs fa = {};
+            fa.in = u2;
+            fa.W1a = theta_a + tb + net.lo_f1_w; fa.W1b = theta_b + tb + net.lo_f1_w; fa.b1a = theta_a + tb + net.lo_f1_b; fa.b1b = theta_b + tb + net.lo_f1_b;
+            fa.W2a = theta_a + tb + net.lo_f2_w; fa.W2b = theta_b + tb + net.lo_f2_w; fa.b2a = theta_a + tb + net.lo_f2_b; fa.b2b = theta_b + tb + net.lo_f2_b;
+            fa.split = split; fa.rpb = rpb;
+            fa.n_save = training ? src.batch : 0;                     // only the training third of a TD update is read again
+            fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
+            fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
+            fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
+            if (!gru) { fa.mode = 2; fa.out = s2; fa.res = ident ? s1 : u2; }
+            else { fa.mode = 1; fa.out = F(ab + net.al_gate2 + 5 * LPD, D); fa.res = nofld(); }
+            rc = launch_ffn<D>(fa, S, stream);
+            if (rc == DTQN_OK && gru) rc = gate(ident ? s1 : u2, ab + net.al_gate2, net.off_gate_mlp, s2);
         }
         if (rc != DTQN_OK) return rc;
         if (!ident) {
