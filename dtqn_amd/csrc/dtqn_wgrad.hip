@@ -26,6 +26,8 @@ struct WgradArgs {
     int batch, n_split, n_jobs;
     int n_small;            // elements of the small-partials index space (LN affine, tables, learned pos table)
     int row_split;          // small-partial records per sequence (one per workgroup of the backward kernel)
+    int small_blocks;       // blocks per split that sum the small partials
+    int xcd_map;            // 1: (split, tile) pairs dealt to the XCDs in contiguous runs (see the kernel); 0: pair = block (A/B timing)
 };
 
 // Extra blocks of the same launch: sum the backward kernel's per-sequence partials (LayerNorm gamma/beta,
@@ -71,12 +73,19 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     const Thr t = make_thr();
     const DtqnNet& net = a.net;
     const int LP = net.lp;
-    if ((int)blockIdx.x >= net.n_wtiles) {
-        small_partials_block(a, (int)blockIdx.x - net.n_wtiles, (int)blockIdx.y);
+    // (split, tile) pairs in split-major order, P of them.  Workgroup b runs on XCD b % 8 (round-robin dispatch); it takes
+    // pair (b % 8) * ceil(P / 8) + b / 8, so every XCD works through a contiguous run of pairs: the tiles of one weight
+    // matrix and one token range one after the other, which share their dY / X columns -- re-reads of the records then hit
+    // that XCD's L2 instead of each of the eight L2s pulling its own copy out of MALL / HBM.
+    const int P = net.n_wtiles * a.n_split, per = (P + 7) / 8, tile_blocks = per * 8, id = (int)blockIdx.x;
+    if (id >= tile_blocks) {
+        small_partials_block(a, (id - tile_blocks) % a.small_blocks, (id - tile_blocks) / a.small_blocks);
         return;
     }
+    const int pair = a.xcd_map ? (id % 8) * per + id / 8 : id;
+    if (pair >= P) return;
     // locate the job of this block
-    const int tile = (int)blockIdx.x, split = (int)blockIdx.y;
+    const int split = pair / net.n_wtiles, tile = pair - split * net.n_wtiles;
     int j = 0;
     for (int k = 1; k < a.n_jobs; ++k)
         if (a.jobs[k].tile0 <= tile) j = k;
@@ -101,15 +110,15 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
 
     const int b_lo = (int)((long long)a.batch * split / a.n_split);
     const int b_hi = (int)((long long)a.batch * (split + 1) / a.n_split);
-    // work unit = (sequence of this split, quarter of its LP/4 token steps); units are dealt to the 4 waves,
-    // so even a one-sequence split keeps every wave busy
-    constexpr int NSUB = 4;
-    const int steps_per_sub = (LP / 4 + NSUB - 1) / NSUB;
+    // work unit = (sequence of this split, 16 of its tokens = four 4-token MFMA steps); units are dealt to the 4 waves, so
+    // even a one-sequence split keeps every wave busy.  The eight operand loads of a unit go in flight at once and units are
+    // fetched ahead of the one that multiplies -- two ahead for the long contexts of the row-block path (three register buffers, alternating by name): the records come out of
+    // MALL / HBM (memory-side latency of microseconds), a unit's 64 MFMAs last about one.  Padded contexts that are not a
+    // multiple of 16 rows (none today) take the step-wise loop below.
+    const bool fast = LP % 16 == 0;
+    const int NSUB = fast ? LP / 16 : 4;
+    const int steps_per_sub = fast ? 4 : (LP / 4 + NSUB - 1) / NSUB;
     const int units = (b_hi - b_lo) * NSUB * job.n_layers;
-    // the common shape (64-row records: four 4-token steps per unit): the eight operand loads of a unit go in flight at
-    // once, and the NEXT unit's loads are issued before this unit's MFMAs -- the records come from other XCDs' kernels
-    // (memory-side latency), the MFMAs are short
-    const bool fast = LP == 64;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto unit_ptrs = [&](int u, const float*& yp, const float*& xp, int& s_lo, int& s_hi) {
         const int lyr = u / ((b_hi - b_lo) * NSUB), ul = u - lyr * (b_hi - b_lo) * NSUB;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
         xp = xbase + (size_t)b * xstride + (size_t)lyr * job.x_lstride + (size_t)t.kq * job.ldx + xcol;
     };
     if (fast) {
-        float4 av[2][4], bv[2][4];
+        float4 av[3][4], bv[3][4];
         auto unit_load = [&](int u, float4 (&a4)[4], float4 (&b4)[4]) {
             const float *yp, *xp;
             int s_lo, s_hi;
@@ -143,15 +152,32 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
                     for (int ck = 0; ck < 4; ++ck) acc[cn][ck] = mfma16(aa[cn], bb[ck], acc[cn][ck]);
             }
         };
+        constexpr int W = DTQN_WAVES;
         int u = t.wave;
         if (u < units) unit_load(u, av[0], bv[0]);
-        for (; u < units; u += 2 * DTQN_WAVES) {           // two units per trip: buffers alternate without dynamic indexing
-            const int u1 = u + DTQN_WAVES, u2 = u + 2 * DTQN_WAVES;
-            if (u1 < units) unit_load(u1, av[1], bv[1]);
-            unit_mma(av[0], bv[0]);
-            if (u1 < units) {
-                if (u2 < units) unit_load(u2, av[0], bv[0]);
-                unit_mma(av[1], bv[1]);
+        if (LP <= 64) {
+            // 64-row records (whole-sequence kernels): one unit ahead is enough (measured: two ahead costs cfg 2 / 3 about 1 %)
+            for (; u < units; u += 2 * W) {
+                if (u + W < units) unit_load(u + W, av[1], bv[1]);
+                unit_mma(av[0], bv[0]);
+                if (u + W < units) {
+                    if (u + 2 * W < units) unit_load(u + 2 * W, av[0], bv[0]);
+                    unit_mma(av[1], bv[1]);
+                }
+            }
+        } else {
+            if (u + W < units) unit_load(u + W, av[1], bv[1]);
+            for (; u < units; u += 3 * W) {                // three units per trip: the buffers rotate without dynamic indexing
+                if (u + 2 * W < units) unit_load(u + 2 * W, av[2], bv[2]);
+                unit_mma(av[0], bv[0]);
+                if (u + W < units) {
+                    if (u + 3 * W < units) unit_load(u + 3 * W, av[0], bv[0]);
+                    unit_mma(av[1], bv[1]);
+                    if (u + 2 * W < units) {
+                        if (u + 4 * W < units) unit_load(u + 4 * W, av[1], bv[1]);
+                        unit_mma(av[2], bv[2]);
+                    }
+                }
             }
         }
     }
@@ -561,10 +587,14 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
                 (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
                 (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);
     const int small_blocks = (a.n_small + 1023) / 1024;
+    a.small_blocks = small_blocks;
+    const char* xm = getenv("DTQN_WGRAD_XCD");
+    a.xcd_map = xm != nullptr ? atoi(xm) : 1;
+    const int tile_blocks = (net->n_wtiles * td->n_split + 7) / 8 * 8;
     const size_t lds = (size_t)DTQN_WAVES * 65 * 68 * sizeof(float);
     static size_t attr_lds[kMaxDevices] = {};    // per device
     raise_lds_limit(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(net->n_wtiles + small_blocks, td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(tile_blocks + small_blocks * td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
