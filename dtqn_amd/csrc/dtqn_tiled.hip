@@ -347,15 +347,17 @@ struct TlFfnArgs {
     const float *W1a, *W1b, *b1a, *b1b, *W2a, *W2b, *b2a, *b2b;
     int split, rpb, mode, n_save;
 };
-template <int D>
+// MR rows per workgroup (64, or 32 when the launch would otherwise be a round and a half of workgroups: launch_ffn)
+template <int D, int MR>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs a) {
+    constexpr int MT = MR / 16;
     constexpr int KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
     constexpr int LDX = D + 4, LDH = 128 + 4;
     static_assert((NKA == 1 && NOT == 1) || (NKA == 2 && NOT == 2), "step sequence written for D in {64, 128, 256}");
-    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDX] input rows
-    float* Hs = Xt + TROWS * LDX;                                      // [64][LDH] hidden chunk / output staging
+    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
+    float* Hs = Xt + MR * LDX;                                         // [MR][LDH] hidden chunk / output staging
     const Thr t = make_thr();
-    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;      // a.rpb: MR-row blocks per sequence
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W1 = second ? a.W1b : a.W1a;
     const float* __restrict__ W2 = second ? a.W2b : a.W2a;
@@ -377,36 +379,36 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
     fetchA(bf0, 0, 0);
     {
         const float* in0 = frow(a.in, s, row0);
-        for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
+        for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
             st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.in.ld + c));
         }
     }
-    f32x4 accO[NOT][4];
+    f32x4 accO[NOT][MT];
 #pragma unroll
     for (int o = 0; o < NOT; ++o)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) accO[o][m] = zero4();
+        for (int m = 0; m < MT; ++m) accO[o][m] = zero4();
     float* mrec_h = save && a.mh.base != nullptr ? a.mh.base + (size_t)s * a.mh.stride : nullptr;
     __syncthreads();
     for (int j = 0; j < NJ; ++j) {
-        f32x4 accA[4];
+        f32x4 accA[MT];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) accA[m] = zero4();
+        for (int m = 0; m < MT; ++m) accA[m] = zero4();
         if (NKA == 1) {
             fetchB(bf1, j, 0);
-            frag16_mma<KA, 4, 8>(Xt, LDX, bf0, t, accA);
+            frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, accA);
         } else {
             fetchA(bf1, j, 1);
-            frag16_mma<KA, 4, 8>(Xt, LDX, bf0, t, accA);
+            frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, accA);
             fetchB(bf0, j, 0);
-            frag16_mma<KA, 4, 8>(Xt + KA, LDX, bf1, t, accA);
+            frag16_mma<KA, MT, 8>(Xt + KA, LDX, bf1, t, accA);
         }
         {
             const int hc = j * 128 + wc;
             const float bv = b1[hc];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int rl = m * 16 + t.kq * 4 + r4;
@@ -417,19 +419,19 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
         }
         __syncthreads();                                               // the hidden chunk is complete
         if (save && a.h.base != nullptr) {
-            for (int idx = t.tid; idx < TROWS * 32; idx += TNT) {
+            for (int idx = t.tid; idx < MR * 32; idx += TNT) {
                 const int rl = idx >> 5, c = (idx & 31) * 4;
                 st4(frow(a.h, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
             }
         }
         if (NOT == 1) {
             if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
-            if (wc < D) frag16_mma<128, 4, 8>(Hs, LDH, bf1, t, accO[0]);
+            if (wc < D) frag16_mma<128, MT, 8>(Hs, LDH, bf1, t, accO[0]);
         } else {
             fetchB(bf1, j, 1);
-            frag16_mma<128, 4, 8>(Hs, LDH, bf0, t, accO[0]);
+            frag16_mma<128, MT, 8>(Hs, LDH, bf0, t, accO[0]);
             if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
-            frag16_mma<128, 4, 8>(Hs, LDH, bf1, t, accO[NOT - 1]);
+            frag16_mma<128, MT, 8>(Hs, LDH, bf1, t, accO[NOT - 1]);
         }
         __syncthreads();                                               // ... and consumed
     }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
         if (col < D) {
             const float bv = b2[col];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int rl = m * 16 + t.kq * 4 + r4;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
                 }
         }
         __syncthreads();
-        for (int idx = t.tid; idx < TROWS * 32; idx += TNT) {
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
             const int rl = idx >> 5, c = (idx & 31) * 4, cg = o * 128 + c;
             if (cg >= D) continue;
             float4 y = ld4(Hs + rl * LDH + c);
@@ -1167,10 +1169,22 @@ static int launch_linear(const TlLinearArgs& a, int S, hipStream_t stream) {
     TL_LAUNCH((tl_linear_kernel<D>), dim3(S * a.rpb, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
+// a.rpb on entry: 64-row blocks per sequence.  64-row workgroups when there are many of them; when the launch is only a few
+// rounds of the chip's resident workgroups (two per CU at D <= 128, one at D = 256), 32-row workgroups even the rounds out
+// (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3; cfg 5: 384 on 256 -> 768 = 3).  DTQN_FFN_ROWS=32|64 forces one.
 template <int D>
-static int launch_ffn(const TlFfnArgs& a, int S, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * ((D + 4) + (128 + 4)) * sizeof(float);
-    TL_LAUNCH((tl_ffn_kernel<D>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
+    const int blocks64 = S * a.rpb, slots = 256 * (D <= 128 ? 2 : 1);
+    const char* e = getenv("DTQN_FFN_ROWS");
+    const bool half = e != nullptr ? atoi(e) == 32 : blocks64 < 4 * slots;
+    if (half) {
+        a.rpb *= 2;
+        const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_ffn_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_ffn_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    }
     return DTQN_OK;
 }
 template <int KC>
