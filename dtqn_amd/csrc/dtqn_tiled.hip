@@ -200,21 +200,23 @@ struct TlLinearArgs {
     Fld aux, out2, out3;
 };
 // (second launch bound = waves per SIMD the register budget must allow: two resident workgroups up to D = 128)
-template <int D>
+// MR rows per workgroup: 64, or 32 when the launch would be only a few rounds of resident workgroups (launch_linear)
+template <int D, int MR>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLinearArgs a) {
+    constexpr int MT = MR / 16;
     constexpr int LDT = D + 4;
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDT] input tile of the current K chunk
     const Thr t = make_thr();
-    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;       // a.rpb: MR-row blocks per sequence
     const int ntile = (int)blockIdx.y * TNW + t.wave;                 // this wave's 16-column output tile
     const int col = ntile * 16 + t.i;
     const bool live = col < a.N;                                      // N is a multiple of 16: wave-uniform
     const float* __restrict__ W = s >= a.split ? a.Wb : a.Wa;
     const float* __restrict__ W2 = s >= a.split ? a.W2b : a.W2a;
     const float* __restrict__ bias = s >= a.split ? a.bb : a.ba;
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = zero4();
+    for (int m = 0; m < MT; ++m) acc[m] = zero4();
     // two weight fragments that alternate by NAME: indexing them with the chunk counter would put the array into
     // scratch memory (dynamic register indexing does not exist) -- 272 / 528 bytes per lane before this was unrolled
     float4 bf0[D / 16], bf1[D / 16];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     auto stage = [&](int kc) {                                        // chunk kc of the operand(s) -> LDS
         const float* src = kc < nch1 ? in0 + (size_t)kc * D : in20 + (size_t)(kc - nch1) * D;
         const int ld = kc < nch1 ? a.in.ld : a.in2.ld;
-        for (int idx = t.tid; idx < TROWS * (D / 4); idx += TNT) {
+        for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
             st4(Xt + r * LDT + c, ld4(src + (size_t)r * ld + c));
         }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     // kc multiplies and dropped into the LDS tile once chunk kc's readers are through.  At D <= 128 two workgroups share a
     // CU and hide each other's staging; the 16 extra registers would cost that (measured: cfg 4 603 -> 581 updates/s).
     constexpr bool PREFETCH = D >= 256;
-    constexpr int XN = TROWS * (D / 4) / TNT;                         // float4 per thread of a [64][D] tile
+    constexpr int XN = MR * (D / 4) / TNT;                         // float4 per thread of a [64][D] tile
     float4 xr[PREFETCH ? XN : 1];
     auto stage_load = [&](int kc) {
         const float* src = kc < nch1 ? in0 + (size_t)kc * D : in20 + (size_t)(kc - nch1) * D;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
             frag16_fetch<D>(bf1, wfrag(kc + 1), t);
         }
         __syncthreads();
-        frag16_mma<D, 4>(Xt, LDT, bf0, t, acc);
+        frag16_mma<D, MT>(Xt, LDT, bf0, t, acc);
         if (kc + 1 < nchunks) {
             __syncthreads();
             if (PREFETCH) stage_store(); else stage(kc + 1);
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
                 frag16_fetch<D>(bf0, wfrag(kc + 2), t);
             }
             __syncthreads();
-            frag16_mma<D, 4>(Xt, LDT, bf1, t, acc);
+            frag16_mma<D, MT>(Xt, LDT, bf1, t, acc);
         }
     }
     // epilogue through LDS: the accumulators (MFMA layout: lane = column, 4 rows) go into the operand tile as [row][column of
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
         const float b = bias != nullptr ? bias[col] : 0.f;
         float* mrec = a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rl = m * 16 + t.kq * 4 + r4;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     }
     __syncthreads();
     const int cb = (int)blockIdx.y * TNW * 16;                        // first column of this block
-    for (int idx = t.tid; idx < TROWS * (TNW * 4); idx += TNT) {
+    for (int idx = t.tid; idx < MR * (TNW * 4); idx += TNT) {
         const int rl = idx / (TNW * 4), c = (idx - rl * (TNW * 4)) * 4, cg = cb + c, row = row0 + rl;
         if (cg >= a.N) continue;
         const float4 v = ld4(Xt + rl * LDE + c);
@@ -478,18 +480,19 @@ struct TlDxArgs {
     Fld dy2, dy3;
     const float *W2, *W3;
 };
-template <int KC>
+template <int KC, int MR>
 __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
+    constexpr int MT = MR / 16;
     constexpr int LDT = KC + 4;
     float* Yt = reinterpret_cast<float*>(dtqn_smem);                   // [64][LDT] dY tile of the current chunk
     const Thr t = make_thr();
-    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;       // a.rpb: MR-row blocks per sequence
     const int ntile = (int)blockIdx.y * TNW + t.wave;
     const int col = ntile * 16 + t.i;
     const bool live = col < a.KOUT;
-    f32x4 acc[4];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = zero4();
+    for (int m = 0; m < MT; ++m) acc[m] = zero4();
     float bf0[KC / 4], bf1[KC / 4];                                    // alternate by name (see tl_linear_kernel)
     const int cl = live ? col : 0;
     const int per = a.N / KC, nchunks = per * a.nsrc;
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
         const int p = kc / per, j = kc - p * per;
         const Fld& dyf = p == 0 ? a.dy : p == 1 ? a.dy2 : a.dy3;
         const float* dy0 = frow(dyf, s, row0) + (size_t)j * KC;
-        for (int idx = t.tid; idx < TROWS * (KC / 4); idx += TNT) {
+        for (int idx = t.tid; idx < MR * (KC / 4); idx += TNT) {
             const int r = idx / (KC / 4), c = (idx - r * (KC / 4)) * 4;
             st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * dyf.ld + c));
         }
@@ -513,13 +516,13 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
         stage(kc);
         if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf1, wchunk(kc + 1), a.KOUT, t);
         __syncthreads();
-        frag_dyw_mma<KC, 4>(Yt, LDT, bf0, t, acc);
+        frag_dyw_mma<KC, MT>(Yt, LDT, bf0, t, acc);
         if (kc + 1 < nchunks) {
             __syncthreads();
             stage(kc + 1);
             if (kc + 2 < nchunks) frag_dyw_fetch<KC>(bf0, wchunk(kc + 2), a.KOUT, t);
             __syncthreads();
-            frag_dyw_mma<KC, 4>(Yt, LDT, bf1, t, acc);
+            frag_dyw_mma<KC, MT>(Yt, LDT, bf1, t, acc);
         }
     }
     // epilogue through LDS (see tl_linear_kernel): accumulators -> [row][column] tile -> 16-byte row pieces
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
         const unsigned long long* mrec =
             a.mode == 1 ? reinterpret_cast<const unsigned long long*>(a.mask.base + (size_t)s * a.mask.stride) : nullptr;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int rl = m * 16 + t.kq * 4 + r4, row = row0 + rl;
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     }
     __syncthreads();
     const int cb = (int)blockIdx.y * TNW * 16;
-    for (int idx = t.tid; idx < TROWS * (TNW * 4); idx += TNT) {
+    for (int idx = t.tid; idx < MR * (TNW * 4); idx += TNT) {
         const int rl = idx / (TNW * 4), c = (idx - rl * (TNW * 4)) * 4, cg = cb + c;
         if (cg >= a.KOUT) continue;
         float4 v = ld4(Yt + rl * LDE + c);
@@ -1163,10 +1166,26 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
         if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;                                                 \
     } while (0)
 
+// Rows per workgroup of the linear / dY W kernels: 64.  The 32-row instantiations (DTQN_GEMM_ROWS=32) even out short launches
+// (768 workgroups on 512 slots; 256 for the backward products into a D-wide output) but fetch every weight fragment for half
+// the MFMAs: measured cfg 4 787 -> 748, cfg 5 445 -> 408 updates/s, so they stay an experiment switch.  (The fused feed-forward
+// kernel, whose workgroups run 8-16 weight fragments deep, gains from 32 rows: launch_ffn.)
+static bool tl_half_rows(int blocks64, int slots) {
+    (void)blocks64; (void)slots;
+    const char* e = getenv("DTQN_GEMM_ROWS");
+    return e != nullptr && atoi(e) == 32;
+}
 template <int D>
-static int launch_linear(const TlLinearArgs& a, int S, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);     // operand tile, reused by the [64][128] epilogue tile
-    TL_LAUNCH((tl_linear_kernel<D>), dim3(S * a.rpb, (a.N + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
+static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
+    const int cb = (a.N + 16 * TNW - 1) / (16 * TNW);
+    if (tl_half_rows(S * a.rpb * cb, 256 * (D <= 128 ? 2 : 1))) {
+        a.rpb *= 2;
+        const size_t lds = (size_t)32 * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
+        TL_LAUNCH((tl_linear_kernel<D, 32>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)64 * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);
+        TL_LAUNCH((tl_linear_kernel<D, 64>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+    }
     return DTQN_OK;
 }
 // a.rpb on entry: 64-row blocks per sequence.  64-row workgroups when there are many of them; when the launch is only a few
@@ -1188,9 +1207,16 @@ static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     return DTQN_OK;
 }
 template <int KC>
-static int launch_dx(const TlDxArgs& a, int S, hipStream_t stream) {
-    const size_t lds = (size_t)TROWS * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
-    TL_LAUNCH((tl_dx_kernel<KC>), dim3(S * a.rpb, (a.KOUT + 16 * TNW - 1) / (16 * TNW)), dim3(TNT), lds, stream, a);
+static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
+    const int cb = (a.KOUT + 16 * TNW - 1) / (16 * TNW);
+    if (tl_half_rows(S * a.rpb * cb, 512)) {
+        a.rpb *= 2;
+        const size_t lds = (size_t)32 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
+        TL_LAUNCH((tl_dx_kernel<KC, 32>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)64 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);
+        TL_LAUNCH((tl_dx_kernel<KC, 64>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+    }
     return DTQN_OK;
 }
 template <int D>

@@ -258,10 +258,12 @@ def test_td_update_with_a_bag_split_weight_gradients(emu, kw, run, monkeypatch):
 
 @pytest.mark.parametrize("rows", ["32", "64"])
 @pytest.mark.parametrize("kw,run", [TILED[0], TILED[4], BAG_TD[1]])
-def test_td_update_tiled_ffn_rows_per_workgroup(emu, kw, run, rows, monkeypatch):
-    """The fused feed-forward kernel of the row-block path with 32- and with 64-row workgroups (launch_ffn picks by launch size)."""
+def test_td_update_tiled_rows_per_workgroup(emu, kw, run, rows, monkeypatch):
+    """The GEMM kernels of the row-block path (linear, dY W, fused feed-forward) with 32- and with 64-row workgroups (the launchers
+    pick by launch size: small test shapes would always take 32)."""
     monkeypatch.setenv("DTQN_FORCE_TILED", "1")
     monkeypatch.setenv("DTQN_FFN_ROWS", rows)
+    monkeypatch.setenv("DTQN_GEMM_ROWS", rows)
     cfg = O.NetCfg(**kw)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=37, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
                                                history=run.get("history"), tuf=run.get("tuf", 10_000))

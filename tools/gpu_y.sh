@@ -1,10 +1,10 @@
 #!/bin/bash
-# fused feed-forward kernel: 64- vs 32-row workgroups at cfg 4 / 5 (DTQN_FFN_ROWS), then parity of the tiled path
+# linear and dY W kernels: 64- vs 32-row workgroups at cfg 4 / 5 (DTQN_GEMM_ROWS), default policy last, then parity of the tiled path
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 for c in 4 5; do
-  for r in 64 32; do
-    export DTQN_FFN_ROWS=$r
+  for r in 64 32 auto; do
+    if [ $r = auto ]; then unset DTQN_GEMM_ROWS; else export DTQN_GEMM_ROWS=$r; fi
     timeout 200 python bench.py --config $c --steps 200 --warmup 20 --no-other-configs --no-env-rate --no-cpu-baseline > gpurun_out/y_cfg${c}_$r.json 2> gpurun_out/y_cfg${c}_$r.err
     python - <<PY
 import json
@@ -16,5 +16,5 @@ except Exception as e:
 PY
   done
 done
-unset DTQN_FFN_ROWS
+unset DTQN_GEMM_ROWS
 timeout 900 python -m pytest tests/test_gpu_td.py tests/test_gpu_bag.py tests/test_gpu_forward.py -x -q -m gpu 2>&1 | tail -3
