@@ -1188,14 +1188,16 @@ static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
     }
     return DTQN_OK;
 }
-// a.rpb on entry: 64-row blocks per sequence.  64-row workgroups when there are many of them; when the launch is only a few
-// rounds of the chip's resident workgroups (two per CU at D <= 128, one at D = 256), 32-row workgroups even the rounds out
-// (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3; cfg 5: 384 on 256 -> 768 = 3).  DTQN_FFN_ROWS=32|64 forces one.
+// a.rpb on entry: 64-row blocks per sequence.  64-row workgroups by default; when the last round of 64-row workgroups would
+// leave more than 15 % of the launch's slots idle (resident workgroups: two per CU at D <= 128, one at D = 256), 32-row
+// workgroups even the rounds out (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3, 764 -> 788 updates/s; cfg 5: 384
+// on 256 -> 768 = 3, 437 -> 445).  DTQN_FFN_ROWS=32|64 forces one.
 template <int D>
 static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     const int blocks64 = S * a.rpb, slots = 256 * (D <= 128 ? 2 : 1);
     const char* e = getenv("DTQN_FFN_ROWS");
-    const bool half = e != nullptr ? atoi(e) == 32 : blocks64 < 4 * slots;
+    const int rounds = (blocks64 + slots - 1) / slots;
+    const bool half = e != nullptr ? atoi(e) == 32 : (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
     if (half) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
