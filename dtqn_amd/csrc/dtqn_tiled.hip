@@ -348,6 +348,10 @@ struct TlFfnArgs {
     Fld h, mh, m2;                     // hidden record [LPB][4D], its ballots, the output's ballots (bases may be null)
     const float *W1a, *W1b, *b1a, *b1b, *W2a, *W2b, *b2a, *b2b;
     int split, rpb, mode, n_save;
+    // mode 2 with the LayerNorm that follows the block in a post-LN layer (transformer.py:78) folded in: ln_out = LN(OUT), the
+    // row statistics to ln_st and OUT itself are stored only for the sequences the backward pass reads (s < n_save)
+    Fld ln_out, ln_st;                 // ln_out.base == nullptr: no LayerNorm
+    const float *lga, *lgb, *lba, *lbb;
 };
 // MR rows per workgroup (64, or 32 when the launch would otherwise be a round and a half of workgroups: launch_ffn)
 template <int D, int MR>
@@ -438,6 +442,67 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
         __syncthreads();                                               // ... and consumed
     }
     float* mrec_o = save && a.m2.base != nullptr ? a.m2.base + (size_t)s * a.m2.stride : nullptr;
+    if (a.ln_out.base != nullptr) {
+        // relu(y) of all D columns into the (spent) input tile, then rows: LPR lanes per row hold the row in registers, add the
+        // residual, take mean / variance in a butterfly (same two-pass arithmetic as layernorm_rows) and write LN(OUT)
+#pragma unroll
+        for (int o = 0; o < NOT; ++o) {
+            const int col = o * 128 + wc;
+            if (col < D) {
+                const float bv = b2[col];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int rl = m * 16 + t.kq * 4 + r4;
+                        const float v = accO[o][m][r4] + bv;
+                        if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
+                        Xt[rl * LDX + col] = fmaxf(v, 0.f);
+                    }
+            }
+        }
+        __syncthreads();
+        constexpr int LPR = TNT / MR, NV = D / (4 * LPR);              // lanes per row (8 / 16), float4 per lane
+        static_assert(NV >= 1, "row pass needs at least one float4 per lane");
+        const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
+        const float* gamma = second ? a.lgb : a.lga;
+        const float* beta = second ? a.lbb : a.lba;
+        float4 y[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            const float4 v = ld4(Xt + rl * LDX + c), r = ld4(frow(a.res, s, row) + c);
+            y[j] = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+            sum += (y[j].x + y[j].y) + (y[j].z + y[j].w);
+            if (save) st4(frow(a.out, s, row) + c, y[j]);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float p = y[j].x - mean, q = y[j].y - mean, u = y[j].z - mean, w = y[j].w - mean;
+            sq += (p * p + q * q) + (u * u + w * w);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            const float4 g = ld4(gamma + c), bb = ld4(beta + c);
+            st4(frow(a.ln_out, s, row) + c, make_float4((y[j].x - mean) * rstd * g.x + bb.x, (y[j].y - mean) * rstd * g.y + bb.y,
+                                                        (y[j].z - mean) * rstd * g.z + bb.z, (y[j].w - mean) * rstd * g.w + bb.w));
+        }
+        if (save && a.ln_st.base != nullptr && part == 0) {
+            float* stp = a.ln_st.base + (size_t)s * a.ln_st.stride + (size_t)row * 2;
+            stp[0] = mean;
+            stp[1] = rstd;
+        }
+        return;
+    }
 #pragma unroll
     for (int o = 0; o < NOT; ++o) {
         const int col = o * 128 + wc;
@@ -1384,6 +1449,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
         if (rc != DTQN_OK) return rc;
         // s2 = gate(post-LN: u2 | identity: s1, relu(relu(u2 W_1^T + b) W_2^T + b)): one fused launch, the hidden layer stays in LDS
+        bool ln2_folded = false;
         {
             TlFfnArgs fa = {};
             fa.in = u2;
@@ -1396,11 +1462,18 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
             if (!gru) { fa.mode = 2; fa.out = s2; fa.res = ident ? s1 : u2; }
             else { fa.mode = 1; fa.out = F(ab + net.al_gate2 + 5 * LPD, D); fa.res = nofld(); }
+            ln2_folded = !gru && !ident;
+            if (ln2_folded) {            // post-LN residual layer: the LayerNorm that closes it rides in the kernel's epilogue
+                fa.ln_out = last ? (net.bag_size > 0 ? F(rm.xcat, 2 * D) : F(rm.xf, D)) : F(L0(l + 1) + net.al_u1, D);
+                fa.ln_st = st2;
+                fa.lga = theta_a + tb + net.lo_ln2_w; fa.lgb = theta_b + tb + net.lo_ln2_w;
+                fa.lba = theta_a + tb + net.lo_ln2_b; fa.lbb = theta_b + tb + net.lo_ln2_b;
+            }
             rc = launch_ffn<D>(fa, S, stream);
             if (rc == DTQN_OK && gru) rc = gate(ident ? s1 : u2, ab + net.al_gate2, net.off_gate_mlp, s2);
         }
         if (rc != DTQN_OK) return rc;
-        if (!ident) {
+        if (!ident && !ln2_folded) {
             // the working memory goes straight into the left half of xcat when there is a bag
             const Fld nxt = last ? (net.bag_size > 0 ? F(rm.xcat, 2 * D) : F(rm.xf, D)) : F(L0(l + 1) + net.al_u1, D);
             if ((rc = lnorm(s2, nxt, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b)) != DTQN_OK) return rc;
