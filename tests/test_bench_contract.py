@@ -24,12 +24,13 @@ def test_algorithmic_flops_match_the_survey():
 def test_pmc_traffic_reads_the_committed_profile():
     import bench
     t = bench.pmc_traffic("dtqn_forward_kernel", 32, 1)
-    d = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic_cfg1.json")))       # this round's --pmc passes of cfg 1
+    d = json.load(open(bench._round_profiles("pmc_traffic", 1)[0]))                 # this round's newest --pmc passes of cfg 1
     key = [k for k in d if "dtqn_forward_kernel" in k][0]
     assert t == int((2 * d[key]["FETCH_SIZE"] + d[key]["WRITE_SIZE"]) * 1024)       # gfx950: FETCH_SIZE doubled, KB units
     assert bench.pmc_traffic("dtqn_forward_kernel", 7, 1) is None                   # no profile for that batch
     t3 = bench.pmc_traffic("dtqn_backward_kernel", 512, 3)                          # every BASELINE config has its own file
-    d3 = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_traffic_cfg3.json")))
+    d3 = json.load(open(bench._round_profiles("pmc_traffic", 3)[0]))
+    assert os.path.basename(bench._round_profiles("pmc_traffic", 3)[0]) >= "r02e_pmc_traffic_cfg3.json"      # newest suffix first
     key3 = [k for k in d3 if "dtqn_backward_kernel" in k][0]
     assert t3 == int((2 * d3[key3]["FETCH_SIZE"] + d3[key3]["WRITE_SIZE"]) * 1024)
     m = bench.mfma_counters(1)
