@@ -333,6 +333,75 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     }
 }
 
+// ---- wide linear: OUT[rows][N] = IN[rows][D] W[N][D]^T + b for N a multiple of 128 (the packed q | k | v projection) -----------
+// One workgroup per (sequence, MR-row block) walks ALL column blocks of 128: the input tile is staged once (tl_linear_kernel stages
+// it once per column block), weight fragments are fetched one step ahead of the MFMAs that use them, and each block of
+// accumulators leaves through a second LDS tile as 16-byte row pieces.  Same structure as the first product of tl_ffn_kernel.
+struct TlWideArgs {
+    Fld in, out;
+    const float *Wa, *Wb, *ba, *bb;    // sequences >= split use Wb / bb
+    int split, rpb, N;
+};
+template <int D, int MR>
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideArgs a) {
+    constexpr int MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, LDX = D + 4, LDH = 128 + 4;
+    static_assert(NKA == 1 || NKA == 2, "step sequence written for D in {64, 128, 256}");
+    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
+    float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;
+    const bool second = s >= a.split;
+    const float* __restrict__ W = second ? a.Wb : a.Wa;
+    const float* __restrict__ bias = second ? a.bb : a.ba;
+    const int wc = t.wave * 16 + t.i, NB = a.N / 128;
+    auto fetch = [&](float4 (&bf)[8], int j, int kc) {                 // W [N][D]: output column j * 128 + wc, contraction chunk kc
+        const float* wr = W + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    float4 bf0[8], bf1[8];
+    fetch(bf0, 0, 0);
+    {
+        const float* in0 = frow(a.in, s, row0);
+        for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
+            const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+            st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.in.ld + c));
+        }
+    }
+    __syncthreads();
+    // one column block: `cur` holds its first fragment on entry; on exit the first fragment of block j + 1 sits in `nxt`
+    // (NKA == 1: the buffers swap roles from block to block) or in `cur` again (NKA == 2)
+    auto block = [&](float4 (&cur)[8], float4 (&nxt)[8], int j) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero4();
+        if (NKA == 1) {
+            if (j + 1 < NB) fetch(nxt, j + 1, 0);
+            frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+        } else {
+            fetch(nxt, j, 1);
+            frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+            if (j + 1 < NB) fetch(cur, j + 1, 0);
+            frag16_mma<KA, MT, 8>(Xt + KA, LDX, nxt, t, acc);
+        }
+        const float bv = bias != nullptr ? bias[j * 128 + wc] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) Hs[(m * 16 + t.kq * 4 + r4) * LDH + wc] = acc[m][r4] + bv;
+        __syncthreads();
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4;
+            st4(frow(a.out, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+        }
+        __syncthreads();                                               // staging tile free for the next block
+    };
+    for (int j = 0; j < NB; ++j) {
+        if (NKA == 2 || (j & 1) == 0) block(bf0, bf1, j);
+        else block(bf1, bf0, j);
+    }
+}
+
 // ---- fused feed-forward block: OUT = f(relu(IN W1^T + b1) W2^T + b2), hidden width 4 D (transformer.py:55-61, 76-77) -------------
 //   mode 1: OUT = relu(y) (GRU gate input)      mode 2: OUT = RES + relu(y) (residual gate)
 // One workgroup per (sequence, 64-row block).  The input tile stays in LDS; the hidden layer is produced in chunks of 128
@@ -1253,6 +1322,24 @@ static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
     }
     return DTQN_OK;
 }
+// a.rpb on entry: 64-row blocks per sequence; rows per workgroup chosen like launch_ffn's (DTQN_FFN_ROWS forces)
+static bool tl_rows32(int blocks64, int slots) {
+    const char* e = getenv("DTQN_FFN_ROWS");
+    const int rounds = (blocks64 + slots - 1) / slots;
+    return e != nullptr ? atoi(e) == 32 : (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
+}
+template <int D>
+static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
+    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1))) {
+        a.rpb *= 2;
+        const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_wide_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_wide_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    }
+    return DTQN_OK;
+}
 // a.rpb on entry: 64-row blocks per sequence.  64-row workgroups by default; when the last round of 64-row workgroups would
 // leave more than 15 % of the launch's slots idle (resident workgroups: two per CU at D <= 128, one at D = 256), 32-row
 // workgroups even the rounds out (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3, 764 -> 788 updates/s; cfg 5: 384
@@ -1261,9 +1348,8 @@ template <int D>
 static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     const int blocks64 = S * a.rpb, slots = 256 * (D <= 128 ? 2 : 1);
     const char* e = getenv("DTQN_FFN_ROWS");
-    const int rounds = (blocks64 + slots - 1) / slots;
-    const bool half = e != nullptr ? atoi(e) == 32 : (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
-    if (half) {
+    (void)e;
+    if (tl_rows32(blocks64, slots)) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
         TL_LAUNCH((tl_ffn_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
@@ -1427,7 +1513,16 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         // the residual stream entering the layer: post-LN keeps it in u1 itself; identity in x0 / the previous s2
         const Fld stream_in = !ident ? u1 : (l == 0 ? F(net.ao_x0, D) : F(L0(l - 1) + net.al_s2, D));
         if (ident && (rc = lnorm(stream_in, u1, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b)) != DTQN_OK) return rc;
-        if ((rc = linear(u1, D, 3 * D, tb + net.lo_in_w, tb + net.lo_in_b, F(ab + net.al_qkv, 3 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
+        if ((3 * D) % 128 == 0 && getenv("DTQN_NO_WIDE") == nullptr) {        // packed q | k | v projection: one workgroup per row block walks the column blocks
+            TlWideArgs wa = {};
+            wa.in = u1; wa.out = F(ab + net.al_qkv, 3 * D);
+            wa.Wa = theta_a + tb + net.lo_in_w; wa.Wb = theta_b + tb + net.lo_in_w; wa.ba = theta_a + tb + net.lo_in_b; wa.bb = theta_b + tb + net.lo_in_b;
+            wa.split = split; wa.rpb = rpb; wa.N = 3 * D;
+            rc = launch_wide<D>(wa, S, stream);
+        } else {
+            rc = linear(u1, D, 3 * D, tb + net.lo_in_w, tb + net.lo_in_b, F(ab + net.al_qkv, 3 * D), 0, nofld(), nofld());
+        }
+        if (rc != DTQN_OK) return rc;
         {
             TlAttnArgs at;
             at.qkv = F(ab + net.al_qkv, 3 * D); at.o = F(ab + net.al_o, D);
