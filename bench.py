@@ -443,6 +443,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch, args.config),
                          "algorithmic_flops_per_launch": flops, "launch_us": kern[dom],
+                         # the other stage of the pair and the whole update, priced the same way (the backward is the
+                         # data-gradient half only: 1x the forward FLOPs of one pass; weight gradients are their own kernel)
+                         "per_stage": {k: {"launch_us": kern[k], "algorithmic_flops": f,
+                                           "frac": f / (kern[k] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS}
+                                       for k, f in (("dtqn_forward_kernel", 3 * tokens * ft), ("dtqn_backward_kernel", tokens * ft))},
+                         "whole_update_frac": 5 * tokens * ft / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "mfma_counters": mfma_counters(args.config)},
             "hbm_view": {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
                          "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
