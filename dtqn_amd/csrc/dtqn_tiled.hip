@@ -183,6 +183,33 @@ __device__ __forceinline__ void frag16_mma(const float* Xs, int lda, const float
     }
 }
 
+// frag_dyw_mma (dtqn_device.hpp) over the first NN / 4 entries of a 32-entry fragment array
+template <int NN, int MG>
+__device__ __forceinline__ void frag_dyw_mma_n(const float* dYs, int lda, const float (&bf)[32], const Thr& t, f32x4 (&acc)[MG]) {
+    constexpr int KS = NN / 16;
+    static_assert(NN <= 128 && MG >= 2, "fragment array holds 32 entries; MG == 1 uses frag_dyw_mma's two-accumulator form");
+    const float* yp = dYs + t.i * lda + t.kq * (NN / 4);
+    float4 af[2][MG];
+#pragma unroll
+    for (int m = 0; m < MG; ++m) af[0][m] = ld4(yp + m * 16 * lda);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(yp + m * 16 * lda + 4 * (s + 1));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 0; m < MG; ++m) {
+                const float4 a = af[s & 1][m];
+                const float av = c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w));
+                acc[m] = mfma16(av, bf[4 * s + c], acc[m]);
+            }
+        }
+    }
+}
+
 // ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T [+ IN2[rows][K2] * W2[N][K2]^T] + b) ----------------------
 //   mode 0: OUT = y      mode 1: OUT = relu(y)      mode 2: OUT = RES + relu(y)   (residual gate)
 //   modes 1 / 2 optionally save the ReLU pattern as wave ballots (same word layout as the whole-sequence kernels)
@@ -690,6 +717,134 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
             v = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
         }
         st4(op, v);
+    }
+}
+
+// ---- fused feed-forward backward: dh' = (df W2) * [h > 0] -> du = dh' W1 (the mirror of tl_ffn_kernel) ------------------------
+//   df = dL/d(output of the block before its gate's ReLU mask is applied) * [f > 0] when m2 is given (residual gate: the
+//   mask stage of the gate backward rides in this kernel's staging and df is stored for the weight gradients), else dy is df.
+//   OUT (op)= du:  out_mode 2: OUT += du (post-LN: the stream IS the block's input)   out_mode 0: OUT = du (identity layers)
+// One workgroup per (sequence, MR-row block): the df tile stays in LDS; the hidden gradient is produced in chunks of 128 units
+// (contraction over the D outputs of the block), masked with the saved ballots of the hidden ReLU, written out once (the
+// weight gradients need it) and consumed from a second LDS tile as the contraction chunk of the product with W1, whose
+// [MR][D] accumulators stay in registers.  Weight fragments (dword columns of W2 / W1) are fetched one step ahead.
+struct TlFfnBwdArgs {
+    Fld dy, m2, df;                    // m2.base == nullptr: dy is df itself (no mask, df not stored)
+    Fld dhp, mh;                       // dh' record [LPB][4D] (out), ballots of the hidden ReLU
+    Fld out;
+    const float *W1, *W2;              // W1 [4D][D], W2 [D][4D]
+    int rpb, out_mode;
+};
+template <int D, int MR>
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfnBwdArgs a) {
+    constexpr int MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
+    constexpr int LDX = D + 4, LDH = 128 + 4;
+    static_assert((NKA == 1 && NOT == 1) || (NKA == 2 && NOT == 2), "step sequence written for D in {64, 128, 256}");
+    float* Yt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] df rows
+    float* Hs = Yt + MR * LDX;                                         // [MR][LDH] dh' chunk / output staging
+    const Thr t = make_thr();
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;
+    const int wc = t.wave * 16 + t.i;
+    // phase A fragment: W2[n][j * 128 + wc], n over contraction chunk kc (KA rows); phase B: W1[j * 128 + k][ot * 128 + wc], k < 128
+    auto fetchA = [&](float (&bf)[32], int j, int kc) {
+        const float* wp = a.W2 + (size_t)(kc * KA + t.kq * (KA / 4)) * HID + j * 128 + wc;
+#pragma unroll
+        for (int q = 0; q < KA / 4; ++q) bf[q] = wp[(size_t)q * HID];
+    };
+    auto fetchB = [&](float (&bf)[32], int j, int ot) {
+        const int col = ot * 128 + wc;
+        const float* wp = a.W1 + (size_t)(j * 128 + t.kq * 32) * D + (col < D ? col : 0);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) bf[q] = wp[(size_t)q * D];
+    };
+    float bf0[32], bf1[32];
+    fetchA(bf0, 0, 0);
+    {
+        const unsigned long long* mrec =
+            a.m2.base != nullptr ? reinterpret_cast<const unsigned long long*>(a.m2.base + (size_t)s * a.m2.stride) : nullptr;
+        for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
+            const int rl = idx / (D / 4), c = (idx - rl * (D / 4)) * 4, row = row0 + rl;
+            float4 v = ld4(frow(a.dy, s, row) + c);
+            if (mrec != nullptr) {
+                const unsigned long long w = mrec[((row >> 4) * (D / 16) + (c >> 4)) * 4 + (row & 3)];
+                const int b0 = (((row >> 2) & 3) << 4) + (c & 15);
+                v.x = ((w >> b0) & 1ull) ? v.x : 0.f;
+                v.y = ((w >> (b0 + 1)) & 1ull) ? v.y : 0.f;
+                v.z = ((w >> (b0 + 2)) & 1ull) ? v.z : 0.f;
+                v.w = ((w >> (b0 + 3)) & 1ull) ? v.w : 0.f;
+                st4(frow(a.df, s, row) + c, v);
+            }
+            st4(Yt + rl * LDX + c, v);
+        }
+    }
+    f32x4 accO[NOT][MT];
+#pragma unroll
+    for (int o = 0; o < NOT; ++o)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accO[o][m] = zero4();
+    const unsigned long long* mrec_h = reinterpret_cast<const unsigned long long*>(a.mh.base + (size_t)s * a.mh.stride);
+    __syncthreads();
+    for (int j = 0; j < NJ; ++j) {
+        f32x4 accA[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accA[m] = zero4();
+        if (NKA == 1) {
+            fetchB(bf1, j, 0);
+            frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, accA);
+        } else {
+            fetchA(bf1, j, 1);
+            frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, accA);
+            fetchB(bf0, j, 0);
+            frag_dyw_mma_n<KA, MT>(Yt + KA, LDX, bf1, t, accA);
+        }
+        {
+            const int hc = j * 128 + wc;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = m * 16 + t.kq * 4 + r4, row = row0 + rl;
+                    const unsigned long long w = mrec_h[((row >> 4) * (HID / 16) + (hc >> 4)) * 4 + r4];
+                    Hs[rl * LDH + wc] = ((w >> t.lane) & 1ull) ? accA[m][r4] : 0.f;
+                }
+        }
+        __syncthreads();                                               // the dh' chunk is complete
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4;
+            st4(frow(a.dhp, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+        }
+        if (NOT == 1) {
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            if (wc < D) frag_dyw_mma_n<128, MT>(Hs, LDH, bf1, t, accO[0]);
+        } else {
+            fetchB(bf1, j, 1);
+            frag_dyw_mma_n<128, MT>(Hs, LDH, bf0, t, accO[0]);
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            frag_dyw_mma_n<128, MT>(Hs, LDH, bf1, t, accO[NOT - 1]);
+        }
+        __syncthreads();                                               // ... and consumed
+    }
+#pragma unroll
+    for (int o = 0; o < NOT; ++o) {
+        if (o * 128 + wc < D) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Hs[(m * 16 + t.kq * 4 + r4) * LDH + wc] = accO[o][m][r4];
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4, cg = o * 128 + c;
+            if (cg >= D) continue;
+            float4 v = ld4(Hs + rl * LDH + c);
+            float* op = frow(a.out, s, row0 + rl) + cg;
+            if (a.out_mode == 2) {
+                const float4 p = ld4(op);
+                v = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+            }
+            st4(op, v);
+        }
+        if (o + 1 < NOT) __syncthreads();
     }
 }
 
@@ -1322,11 +1477,25 @@ static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
     }
     return DTQN_OK;
 }
+template <int D>
+static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream);
 // a.rpb on entry: 64-row blocks per sequence; rows per workgroup chosen like launch_ffn's (DTQN_FFN_ROWS forces)
 static bool tl_rows32(int blocks64, int slots) {
     const char* e = getenv("DTQN_FFN_ROWS");
     const int rounds = (blocks64 + slots - 1) / slots;
     return e != nullptr ? atoi(e) == 32 : (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
+}
+template <int D>
+static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream) {
+    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1))) {
+        a.rpb *= 2;
+        const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_ffn_bwd_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
+        TL_LAUNCH((tl_ffn_bwd_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    }
+    return DTQN_OK;
 }
 template <int D>
 static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
@@ -1718,16 +1887,37 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         // post-LN: x_out = LN2(s2)
         if (!ident && (rc = ln_bwd(G, FA(ab + net.al_s2, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, false)) != DTQN_OK) return rc;
         // s2 = (u2 | s1) + relu(f):  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  du2 = dh' W1
-        if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
-        if ((rc = dx(FG(gb + net.gl_df, D), D, tb + net.lo_f2_w, 4 * D, FG(gb + net.gl_dhp, 4 * D), 1, FA(ab + net.al_mh, 0))) != DTQN_OK) return rc;
-        if (!ident) {
-            // the stream IS u2: ds2 + du2, then u2 = LN1(s1)
-            if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, G, 2, nofld())) != DTQN_OK) return rc;
-            if ((rc = ln_bwd(G, FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, false)) != DTQN_OK) return rc;
-        } else {
-            // u2 = LN2(s1) sits on the branch: ds1 = ds2 + LN2'(du2)
-            if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, T, 0, nofld())) != DTQN_OK) return rc;
-            if ((rc = ln_bwd(T, FA(ab + net.al_s1, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, true)) != DTQN_OK) return rc;
+        // one fused launch: the gate's ReLU mask (residual gate) rides in its staging, dh' is written once and never read back.
+        // D <= 128 only: measured cfg 4 825 -> 838 updates/s, but cfg 5 (D = 256: 172 registers, one workgroup per CU) 461 -> 458
+        const char* ffb = getenv("DTQN_FFN_BWD");
+        if (ffb != nullptr ? atoi(ffb) != 0 : D <= 128) {
+            TlFfnBwdArgs fb = {};
+            if (!gru) { fb.dy = G; fb.m2 = FA(ab + net.al_m2, 0); fb.df = FG(gb + net.gl_df, D); }
+            else {
+                if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
+                fb.dy = FG(gb + net.gl_df, D); fb.m2 = nofld(); fb.df = nofld();
+            }
+            fb.dhp = FG(gb + net.gl_dhp, 4 * D); fb.mh = FA(ab + net.al_mh, 0);
+            fb.W1 = theta + tb + net.lo_f1_w; fb.W2 = theta + tb + net.lo_f2_w; fb.rpb = rpb;
+            if (!ident) { fb.out = G; fb.out_mode = 2; } else { fb.out = T; fb.out_mode = 0; }
+            if ((rc = launch_ffn_bwd<D>(fb, B, stream)) != DTQN_OK) return rc;
+            if (!ident) {
+                if ((rc = ln_bwd(G, FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, false)) != DTQN_OK) return rc;
+            } else {
+                if ((rc = ln_bwd(T, FA(ab + net.al_s1, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, true)) != DTQN_OK) return rc;
+            }
+        } else {                                                       // the separate launches (A/B timing)
+            if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
+            if ((rc = dx(FG(gb + net.gl_df, D), D, tb + net.lo_f2_w, 4 * D, FG(gb + net.gl_dhp, 4 * D), 1, FA(ab + net.al_mh, 0))) != DTQN_OK) return rc;
+            if (!ident) {
+                // the stream IS u2: ds2 + du2, then u2 = LN1(s1)
+                if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, G, 2, nofld())) != DTQN_OK) return rc;
+                if ((rc = ln_bwd(G, FA(ab + net.al_s1, D), FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, false)) != DTQN_OK) return rc;
+            } else {
+                // u2 = LN2(s1) sits on the branch: ds1 = ds2 + LN2'(du2)
+                if ((rc = dx(FG(gb + net.gl_dhp, 4 * D), 4 * D, tb + net.lo_f1_w, D, T, 0, nofld())) != DTQN_OK) return rc;
+                if ((rc = ln_bwd(T, FA(ab + net.al_s1, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, true)) != DTQN_OK) return rc;
+            }
         }
         // s1 = x + relu(a):  da = ds1 * [a > 0];  dO = da W_o;  attention backward;  du1 = dqkv W_in
         if ((rc = gate_bwd(ab + net.al_gate1, gb + net.gl_gate1, net.off_gate_attn, FA(ab + net.al_m1, 0), FG(gb + net.gl_da, D))) != DTQN_OK) return rc;
