@@ -368,21 +368,28 @@ struct TlWideArgs {
     Fld in, out;
     const float *Wa, *Wb, *ba, *bb;    // sequences >= split use Wb / bb
     int split, rpb, N;
+    // LN instantiation (N == D): OUT = RES + relu(y) followed by the LayerNorm that closes the attention half of a post-LN layer
+    // (transformer.py:70-72): ln_out = LN(OUT).  OUT, its ReLU ballots and the row statistics are stored only for the sequences
+    // the backward pass reads (s < n_save)
+    Fld res, mask, ln_out, ln_st;
+    const float *lga, *lgb, *lba, *lbb;
+    int n_save;
 };
-template <int D, int MR>
+template <int D, int MR, bool LN>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideArgs a) {
     constexpr int MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, LDX = D + 4, LDH = 128 + 4;
     static_assert(NKA == 1 || NKA == 2, "step sequence written for D in {64, 128, 256}");
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
-    float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging
+    float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging (plain) | [MR][LDX] all columns (LN)
     const Thr t = make_thr();
     const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;
-    const bool second = s >= a.split;
+    const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W = second ? a.Wb : a.Wa;
     const float* __restrict__ bias = second ? a.bb : a.ba;
-    const int wc = t.wave * 16 + t.i, NB = a.N / 128;
+    const int wc = t.wave * 16 + t.i, NB = LN ? (D + 127) / 128 : a.N / 128;
     auto fetch = [&](float4 (&bf)[8], int j, int kc) {                 // W [N][D]: output column j * 128 + wc, contraction chunk kc
-        const float* wr = W + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
+        const int col = j * 128 + wc;
+        const float* wr = W + (size_t)((!LN || col < D) ? col : 0) * D + kc * KA + t.kq * 4;
 #pragma unroll
         for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
     };
@@ -395,6 +402,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
             st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.in.ld + c));
         }
     }
+    float* mrec = LN && save && a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
     __syncthreads();
     // one column block: `cur` holds its first fragment on entry; on exit the first fragment of block j + 1 sits in `nxt`
     // (NKA == 1: the buffers swap roles from block to block) or in `cur` again (NKA == 2)
@@ -402,16 +410,32 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         f32x4 acc[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[m] = zero4();
+        const bool live = !LN || j * 128 + wc < D;                     // D = 64: waves 4..7 have no column
         if (NKA == 1) {
             if (j + 1 < NB) fetch(nxt, j + 1, 0);
-            frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+            if (live) frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
         } else {
             fetch(nxt, j, 1);
             frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
             if (j + 1 < NB) fetch(cur, j + 1, 0);
             frag16_mma<KA, MT, 8>(Xt + KA, LDX, nxt, t, acc);
         }
-        const float bv = bias != nullptr ? bias[j * 128 + wc] : 0.f;
+        const int col = j * 128 + wc;
+        const float bv = bias != nullptr && live ? bias[col] : 0.f;
+        if (LN) {
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int rl = m * 16 + t.kq * 4 + r4;
+                        const float v = acc[m][r4] + bv;
+                        if (mrec != nullptr) ballot_store(mrec, D / 16, row0 + rl, col, v > 0.f, t.lane);
+                        Hs[rl * LDX + col] = fmaxf(v, 0.f);
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -426,6 +450,50 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
     for (int j = 0; j < NB; ++j) {
         if (NKA == 2 || (j & 1) == 0) block(bf0, bf1, j);
         else block(bf1, bf0, j);
+    }
+    if (LN) {
+        // rows: LPR lanes per row hold the row in registers, add the residual, take mean / variance in a butterfly (the two-pass
+        // arithmetic of layernorm_rows) and write LN(OUT)
+        __syncthreads();
+        constexpr int LPR = TNT / MR, NV = D / (4 * LPR);
+        static_assert(NV >= 1, "row pass needs at least one float4 per lane");
+        const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
+        const float* gamma = second ? a.lgb : a.lga;
+        const float* beta = second ? a.lbb : a.lba;
+        float4 y[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            const float4 v = ld4(Hs + rl * LDX + c), r = ld4(frow(a.res, s, row) + c);
+            y[j] = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+            sum += (y[j].x + y[j].y) + (y[j].z + y[j].w);
+            if (save) st4(frow(a.out, s, row) + c, y[j]);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float p = y[j].x - mean, q = y[j].y - mean, u = y[j].z - mean, w = y[j].w - mean;
+            sq += (p * p + q * q) + (u * u + w * w);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            const float4 g = ld4(gamma + c), bb = ld4(beta + c);
+            st4(frow(a.ln_out, s, row) + c, make_float4((y[j].x - mean) * rstd * g.x + bb.x, (y[j].y - mean) * rstd * g.y + bb.y,
+                                                        (y[j].z - mean) * rstd * g.z + bb.z, (y[j].w - mean) * rstd * g.w + bb.w));
+        }
+        if (save && a.ln_st.base != nullptr && part == 0) {
+            float* stp = a.ln_st.base + (size_t)s * a.ln_st.stride + (size_t)row * 2;
+            stp[0] = mean;
+            stp[1] = rstd;
+        }
     }
 }
 
@@ -1499,13 +1567,17 @@ static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream) {
 }
 template <int D>
 static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
+    const bool ln = a.ln_out.base != nullptr;
+    const size_t cols = ln ? (size_t)2 * (D + 4) : (size_t)(D + 4) + (128 + 4);
     if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1))) {
         a.rpb *= 2;
-        const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_wide_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        const size_t lds = 32 * cols * sizeof(float);
+        if (ln) TL_LAUNCH((tl_wide_kernel<D, 32, true>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_wide_kernel<D, 32, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     } else {
-        const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_wide_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        const size_t lds = 64 * cols * sizeof(float);
+        if (ln) TL_LAUNCH((tl_wide_kernel<D, 64, true>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_wide_kernel<D, 64, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     }
     return DTQN_OK;
 }
@@ -1699,19 +1771,32 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             at.D = D; at.lpb = lpb; at.n = n;
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
-        // s1 = gate(stream, relu(o W_o^T + b))
-        if (!gru) {
-            rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, s1, 2, stream_in,
-                        training ? F(ab + net.al_m1, 0) : nofld());
+        // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
+        if (!gru && !ident && getenv("DTQN_NO_WIDE") == nullptr) {
+            // post-LN residual layer: out-projection, residual add and LayerNorm-1 in one launch (s1 kept for the backward only)
+            TlWideArgs wa = {};
+            wa.in = F(ab + net.al_o, D); wa.out = s1; wa.N = D;
+            wa.Wa = theta_a + tb + net.lo_out_w; wa.Wb = theta_b + tb + net.lo_out_w; wa.ba = theta_a + tb + net.lo_out_b; wa.bb = theta_b + tb + net.lo_out_b;
+            wa.split = split; wa.rpb = rpb;
+            wa.res = stream_in; wa.mask = training ? F(ab + net.al_m1, 0) : nofld();
+            wa.ln_out = u2; wa.ln_st = st1;
+            wa.lga = theta_a + tb + net.lo_ln1_w; wa.lgb = theta_b + tb + net.lo_ln1_w; wa.lba = theta_a + tb + net.lo_ln1_b; wa.lbb = theta_b + tb + net.lo_ln1_b;
+            wa.n_save = training ? src.batch : 0;
+            if ((rc = launch_wide<D>(wa, S, stream)) != DTQN_OK) return rc;
         } else {
-            rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, F(ab + net.al_gate1 + 5 * LPD, D), 1, nofld(),
-                        training ? F(ab + net.al_m1, 0) : nofld());
-            if (rc == DTQN_OK) rc = gate(stream_in, ab + net.al_gate1, net.off_gate_attn, s1);
+            if (!gru) {
+                rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, s1, 2, stream_in,
+                            training ? F(ab + net.al_m1, 0) : nofld());
+            } else {
+                rc = linear(F(ab + net.al_o, D), D, D, tb + net.lo_out_w, tb + net.lo_out_b, F(ab + net.al_gate1 + 5 * LPD, D), 1, nofld(),
+                            training ? F(ab + net.al_m1, 0) : nofld());
+                if (rc == DTQN_OK) rc = gate(stream_in, ab + net.al_gate1, net.off_gate_attn, s1);
+            }
+            if (rc != DTQN_OK) return rc;
+            if (!ident) rc = lnorm(s1, u2, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b);
+            else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
+            if (rc != DTQN_OK) return rc;
         }
-        if (rc != DTQN_OK) return rc;
-        if (!ident) rc = lnorm(s1, u2, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b);
-        else rc = lnorm(s1, u2, st2, tb + net.lo_ln2_w, tb + net.lo_ln2_b);
-        if (rc != DTQN_OK) return rc;
         // s2 = gate(post-LN: u2 | identity: s1, relu(relu(u2 W_1^T + b) W_2^T + b)): one fused launch, the hidden layer stays in LDS
         bool ln2_folded = false;
         {
