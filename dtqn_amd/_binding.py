@@ -93,6 +93,8 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_replay_push": [P(DtqnReplay), vp, vp, i32, vp],
+        "dtqn_td_prefers_tiled": [P(DtqnNet), i32],
+        "dtqn_net_tiled_twin": [P(DtqnNet), P(DtqnNet)],
         "dtqn_replay_gather_bag": [P(DtqnReplay), vp, vp, vp, i32, i32, u32, vp, vp, vp, vp],
         "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, i32, u32, u32, vp],

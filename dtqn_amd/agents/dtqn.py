@@ -174,14 +174,14 @@ class DtqnAgent:
         self._ctx_act_np[:n] = ctx.action[:n, 0]
         eng = self.engine
         if self._actor_ws is None:       # tiled kernels' scratch, or the hand-over tiles of the two-workgroup latency mode
-            need = eng.lib.dtqn_forward_workspace_floats(eng._net_ref, 1)
+            need = eng.lib.dtqn_forward_workspace_floats(eng._actor_net_ref, 1)
             self._actor_ws = torch.zeros(max(1, need), dtype=torch.float32, device=self.device)
             self._actor_ws_p = ctypes.c_void_p(self._actor_ws.data_ptr()) if need > 0 else None
         # pinned context -> device, forward, Q of the LAST timestep -> pinned: one library call, all on `stream_ptr`
         # the reference's policy network is in train mode during rollouts (dqn.py:102-115): with dropout > 0 the action
         # forward drops units too; evaluation (eval_on) runs without.  Keyed by the count of actor forwards.
         self._actor_calls += 1
-        rc = eng.lib.dtqn_actor_forward(eng._net_ref, self._theta_p, self._ctx_hp, self._ctx_dp, n, self._q_p, self._q_hp,
+        rc = eng.lib.dtqn_actor_forward(eng._actor_net_ref, self._theta_p, self._ctx_hp, self._ctx_dp, n, self._q_p, self._q_hp,
                                         self._actor_ws_p, 1 if self.train_mode == TrainMode.TRAIN else 0, eng.td.dropout_seed ^ 0xAC70,
                                         self._actor_calls & 0xFFFFFFFF, stream_ptr)
         if rc == B.DEFINES["DTQN_ERR_ARG"]:

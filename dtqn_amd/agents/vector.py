@@ -51,7 +51,7 @@ class VectorActor:
         self._q_h = pin(torch.zeros(N, A))
         self._q_np = self._q_h.numpy()
         eng = agent.engine
-        need = eng.lib.dtqn_forward_workspace_floats(eng._net_ref, N)
+        need = eng.lib.dtqn_forward_workspace_floats(eng._actor_net_ref, N)
         self._ws = torch.zeros(max(1, need), dtype=torch.float32, device=agent.device)
         self._ws_p = ctypes.c_void_p(self._ws.data_ptr()) if need > 0 else None
         self._p = [ctypes.c_void_p(t.data_ptr()) for t in (self._ctx_h, self._ctx_d, self._q_d, self._q_h)]
@@ -81,7 +81,7 @@ class VectorActor:
             self._len_np[i] = n
             n_max = max(n_max, n)
         a._actor_calls += 1
-        rc = eng.lib.dtqn_actor_forward_batch(eng._net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
+        rc = eng.lib.dtqn_actor_forward_batch(eng._actor_net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
                                               self._ws_p, 1, eng.td.dropout_seed ^ 0xAC70, a._actor_calls & 0xFFFFFFFF, eng._stream())
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173

@@ -35,6 +35,19 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
     // of the BACKWARD kernel (4 x 16 rows); the forward kernel never uses more than two (2 x 32 rows).
     return 3 * batch * 2 <= 256 ? 4 : 1;
 }
+// Both kernel families cover D = 128 / residual gate / post-LN / 64-row contexts.  Measured at BASELINE config 3 shapes (updates/s,
+// whole-sequence | row-block): B = 64 1681 | 1880, B = 128 1244 | 1391, B = 256 895 | 863, B = 512 459 | 499 -- the row-block
+// kernels win wherever latency mode is out of reach, except around B = 256 (a round and a half of workgroups in several of their
+// launches).  D = 64 stays whole-sequence (cfg 2: 2898 | 1697).
+extern "C" int dtqn_td_prefers_tiled(const DtqnNet* net, int batch) {
+    if (!net || batch < 1 || net->tiled) return 0;
+    const bool covered = net->d_model == 128 && net->gate == DTQN_GATE_RES && !net->identity && net->lp == 64 && net->dropout == 0.f &&
+                         net->bag_size == 0;
+    if (!covered) return 0;
+    const char* e = getenv("DTQN_TRAIN_TILED");
+    if (e != nullptr) return atoi(e) != 0 ? 1 : 0;
+    return dtqn_td_row_split(net, batch) == 1 ? 1 : 0;
+}
 extern "C" int dtqn_td_xch_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
     return 3 * batch * net->num_layers * (net->lp / 2) * 2 * net->d_model;   // K | V (or dK | dV) of the lower half rows

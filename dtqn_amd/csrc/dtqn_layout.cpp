@@ -23,6 +23,13 @@ struct Cursor {
 
 extern "C" int dtqn_abi_version(void) { return DTQN_ABI_VERSION; }
 
+extern "C" int dtqn_net_tiled_twin(const DtqnNet* src, DtqnNet* dst) {
+    if (!src || !dst) return DTQN_ERR_ARG;
+    *dst = *src;                      // the input fields; dtqn_net_init recomputes everything derived
+    dst->force_tiled = 1;
+    return dtqn_net_init(dst);
+}
+
 extern "C" int dtqn_net_init(DtqnNet* net) {
     if (!net) return DTQN_ERR_ARG;
     const int O = net->obs_dim, A = net->num_actions, e = net->embed_per_obs, a = net->action_dim;
@@ -37,7 +44,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
-    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->bag_size > 0) {
+    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0) {
         // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
         net->tiled = 1;
         net->lp = (L + 63) / 64 * 64;

@@ -455,8 +455,9 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         // rows: LPR lanes per row hold the row in registers, add the residual, take mean / variance in a butterfly (the two-pass
         // arithmetic of layernorm_rows) and write LN(OUT)
         __syncthreads();
-        constexpr int LPR = TNT / MR, NV = D / (4 * LPR);
-        static_assert(NV >= 1, "row pass needs at least one float4 per lane");
+        // 8 lanes per row whatever MR is: see tl_ffn_kernel
+        constexpr int LPR = 8, NV = D / (4 * LPR);
+        if (t.tid >= MR * LPR) return;
         const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
         const float* gamma = second ? a.lgb : a.lga;
         const float* beta = second ? a.lbb : a.lba;
@@ -626,8 +627,11 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
             }
         }
         __syncthreads();
-        constexpr int LPR = TNT / MR, NV = D / (4 * LPR);              // lanes per row (8 / 16), float4 per lane
-        static_assert(NV >= 1, "row pass needs at least one float4 per lane");
+        // 8 lanes per row whatever MR is (at MR = 32 the upper four waves sit this out): the reduction order of a row must not
+        // depend on the rows-per-workgroup variant the launcher picked from the batch size, or Q of a sequence would
+        // depend on how many sequences share its batch
+        constexpr int LPR = 8, NV = D / (4 * LPR);
+        if (t.tid >= MR * LPR) return;                                 // wave-uniform (MR * 8 is a multiple of 64)
         const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
         const float* gamma = second ? a.lgb : a.lga;
         const float* beta = second ? a.lbb : a.lba;

@@ -65,9 +65,18 @@ class TdEngine:
         else:
             self.lib = _test_lib
             self.device = torch.device("cpu")
+        # `actor_net`: the net of the caller's modules (what acting / inference forwards use).  `net`: what the TD update runs on --
+        # the same, or its row-block twin where the library's policy says that family is faster for this batch (same theta
+        # layout, records laid out for the tiled kernels; include/dtqn_hip.h, dtqn_td_prefers_tiled)
+        self.actor_net = net
+        self.batch = int(batch)
+        if self.lib.dtqn_td_prefers_tiled(ctypes.byref(net), self.batch):
+            twin = B.DtqnNet()
+            if (self.lib.dtqn_net_tiled_twin(ctypes.byref(net), ctypes.byref(twin)) == 0 and twin.n_theta == net.n_theta
+                    and twin.n_trainable == net.n_trainable and twin.off_pos == net.off_pos and B.param_table(twin) == B.param_table(net)):
+                net = twin
         self.net = net
         self._bound_stream = None
-        self.batch = int(batch)
         dev = self.device
         nt, nth = net.n_trainable, net.n_theta
         f32 = dict(dtype=torch.float32, device=dev)
@@ -153,6 +162,7 @@ class TdEngine:
         td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
+        self._actor_net_ref = ctypes.byref(self.actor_net)
 
     # -- helpers ------------------------------------------------------------------------------
     def _stream(self):
@@ -272,9 +282,9 @@ class TdEngine:
     def forward(self, obs: torch.Tensor, actions: Optional[torch.Tensor], target: bool = False) -> torch.Tensor:
         """DTQN.forward on [B, n, O] float32 observations (inference; no autograd graph)."""
         Bn, n = int(obs.shape[0]), int(obs.shape[1])
-        q = torch.empty((Bn, n, self.net.num_actions), dtype=torch.float32, device=self.device)
+        q = torch.empty((Bn, n, self.actor_net.num_actions), dtype=torch.float32, device=self.device)
         theta = self.theta_tgt if target else self.theta_pol
-        rc = self.lib.dtqn_forward(ctypes.byref(self.net), _p(theta), _p(obs), _p(actions), Bn, n, _p(q), self._stream())
+        rc = self.lib.dtqn_forward(self._actor_net_ref, _p(theta), _p(obs), _p(actions), Bn, n, _p(q), self._stream())
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         self._check(rc, "dtqn_forward")

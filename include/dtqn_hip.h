@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 7
+#define DTQN_ABI_VERSION 8
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -61,6 +61,8 @@ typedef struct DtqnNet {
     int32_t pos;              /* DTQN_POS_* */
     int32_t discrete;         /* discrete observations -> Embedding(V,e)+Linear (representations.py:25-52) */
     int32_t vocab;            /* V */
+    int32_t force_tiled;      /* input: 1 = lay the records out for the row-block tiled kernels even where the whole-sequence kernels
+                               * cover the shape (dtqn_net_tiled_twin) */
     int32_t bag_size;         /* persistent-memory bag (utils/bag.py, dtqn.py:134-147,201-214): 0 = none.  Bag networks run on the row-block
                                * tiled path (post-LN layers, bag_size <= padded context) */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
@@ -328,6 +330,13 @@ int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const flo
  * the slices below it) and two in the forward.  Returns 1 when the shape / variant / batch does not profit (the chip
  * is already full) or is not covered. */
 int dtqn_td_row_split(const DtqnNet* net, int batch);
+/* Training-path policy for shapes both kernel families cover: 1 when the TD update of `batch` sequences is faster on the
+ * row-block tiled kernels than on the whole-sequence ones (D = 128, residual gate, post-LN, 64-row contexts, no dropout, batches
+ * beyond latency mode: measured 460 -> 499 updates/s at BASELINE config 3).  The caller then trains with the twin of the net --
+ * dtqn_net_tiled_twin: same parameters and theta layout, records laid out for the tiled kernels -- and keeps the original for the
+ * actor's forwards.  DTQN_TRAIN_TILED=0|1 overrides. */
+int dtqn_td_prefers_tiled(const DtqnNet* net, int batch);
+int dtqn_net_tiled_twin(const DtqnNet* src, DtqnNet* dst);
 int dtqn_td_xch_floats(const DtqnNet* net, int batch);
 int dtqn_td_xch_flags(const DtqnNet* net, int batch);
 

@@ -131,6 +131,7 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
     everything compared is still left behind by that call."""
     keys = O.trainable_keys(cfg)
     Bn, L, A = eng.batch, cfg.history_len, cfg.num_actions
+    net = eng.net                  # the net the update runs on: the caller's, or its row-block twin (dtqn_td_prefers_tiled)
     for it in range(n_updates):
         eps, starts = host.sample_indices(Bn)
         batch = oracle_batch(host, eps, starts, cfg.discrete)

@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 FULL = {
     "cfg2": (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50), 256, 200, -5),
     "cfg3": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=8), 512, 50, 7),
+    # the same on the whole-sequence kernels (DTQN_TRAIN_TILED=0): the library's policy trains cfg 3 on the row-block twin of the net
+    "cfg3_whole_sequence": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=8), 512, 50, 7),
     "cfg4": (dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, num_layers=2, history_len=128, discrete=True, vocab_sizes=12), 128, 250, 11),
     "cfg5": (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, num_layers=2, history_len=256, discrete=True, vocab_sizes=22), 32, 256, 21),
 }
@@ -47,7 +49,9 @@ def _engine(lib, cfg, batch, T, mask, params, replay_arrays):
 
 
 @pytest.mark.parametrize("name", sorted(FULL))
-def test_full_size_update_properties(lib, name):
+def test_full_size_update_properties(lib, name, monkeypatch):
+    if name.endswith("_whole_sequence"):
+        monkeypatch.setenv("DTQN_TRAIN_TILED", "0")
     kw, Bn, T, mask = FULL[name]
     cfg = O.NetCfg(**kw)
     L, A = cfg.history_len, cfg.num_actions
@@ -111,7 +115,10 @@ def test_full_size_update_properties(lib, name):
         eng8.forward_backward(rep8)
         torch.cuda.synchronize()
         q_8 = eng8.q3.cpu().numpy().reshape(3, 8, net.lp, net.ap)[:, :, :L, :A]
-        assert np.abs(q_8 - q_full[:, sl]).max() <= 1e-5 * scale, (name, start)
+        # (cfg 3: the 8-sequence engine runs the whole-sequence kernels in latency mode, the full batch the row-block ones --
+        #  two kernel families, two summation orders)
+        same_family = eng8.net.tiled == eng.net.tiled
+        assert np.abs(q_8 - q_full[:, sl]).max() <= (1e-5 if same_family else 5e-5) * scale, (name, start)
     # and those 8 sequences against the CPU oracle (one subset: the oracle needs seconds per forward at these widths)
     sl = slice(0, 8)
     ot = torch.long if cfg.discrete else torch.float32

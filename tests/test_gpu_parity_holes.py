@@ -55,14 +55,32 @@ def report(key, value):
 CFG3 = dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9)
 
 
-def test_cfg3_whole_sequence_kernels_at_batch_128(lib):
-    """Memory-5 shapes at a batch that dispatches what the bench times for cfg 3: row_split 1, <128, 4, 16, 8> forward /
-    backward, 64 x 64-tile weight gradients + reduce."""
+def test_cfg3_whole_sequence_kernels_at_batch_128(lib, monkeypatch):
+    """Memory-5 shapes at a large batch on the whole-sequence kernels (DTQN_TRAIN_TILED=0: the library's policy would train this
+    shape on the row-block kernels): row_split 1, <128, 4, 16, 8> forward / backward, 64 x 64-tile weight gradients + reduce."""
+    monkeypatch.setenv("DTQN_TRAIN_TILED", "0")
     cfg = O.NetCfg(**CFG3)
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=5, batch=128, T=50, n_eps=200, mask=8, device="cuda", test_lib=False)
-    assert eng.row_split == 1 and net.tiled == 0
+    assert eng.row_split == 1 and net.tiled == 0 and eng.net.tiled == 0
     assert lib.dtqn_td_wgrad_is_direct(ctypes.byref(net), 128) == 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+def test_cfg3_training_is_routed_to_the_row_block_kernels(lib):
+    """What the bench times for cfg 3: D = 128 / residual gate / post-LN / 64-row contexts beyond latency mode train on the
+    row-block twin of the net (dtqn_td_prefers_tiled: same theta layout, records of the tiled kernels), while acting and
+    inference forwards keep the whole-sequence kernels."""
+    cfg = O.NetCfg(**CFG3)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=5, batch=128, T=50, n_eps=200, mask=8, device="cuda", test_lib=False)
+    assert net.tiled == 0 and eng.net.tiled == 1 and eng.actor_net.tiled == 0
+    assert eng.net.n_theta == net.n_theta and B.param_table(eng.net) == B.param_table(net)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    # inference through the engine's forward entry still takes the caller's (whole-sequence) net
+    obs = torch.zeros(2, cfg.history_len, cfg.obs_dim, device="cuda")
+    assert eng.forward(obs, None).shape == (2, cfg.history_len, cfg.num_actions)
+    # below the threshold (latency mode reaches batch 42) the same shape trains on the whole-sequence kernels
+    _, _, _, eng8, _ = make_td_case(lib, cfg, seed=5, batch=8, T=50, n_eps=20, mask=8, device="cuda", test_lib=False)
+    assert eng8.net.tiled == 0
 
 
 @pytest.mark.parametrize("kw,batch", [
@@ -75,6 +93,7 @@ def test_one_workgroup_per_sequence_forced_at_small_batch(lib, kw, batch, monkey
     """DTQN_ROW_SPLIT=0: the small-batch shapes of the latency-mode tests through the one-workgroup-per-sequence
     instantiations (what every batch > 42 runs)."""
     monkeypatch.setenv("DTQN_ROW_SPLIT", "0")
+    monkeypatch.setenv("DTQN_TRAIN_TILED", "0")          # (D = 128 without row slices would otherwise train on the row-block twin)
     cfg = O.NetCfg(**kw)
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=23, batch=batch, T=120, n_eps=40, mask=8 if cfg.discrete else -5,
                                                device="cuda", test_lib=False)
