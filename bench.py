@@ -441,7 +441,9 @@ def main():
                                    f"batch {args.batch} per GPU, history {c['L']}, device-resident replay {500_000 // c['T']} episodes x {c['T']} steps",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, args.batch, args.config),
+                         "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                         # (row-block path: the "kernel" is a stage of many tl_* launches; their counters are in the profile files)
+                         "traffic": None if tiled else pmc_traffic(dom, args.batch, args.config),
                          "algorithmic_flops_per_launch": flops, "launch_us": kern[dom],
                          # the other stage of the pair and the whole update, priced the same way (the backward is the
                          # data-gradient half only: 1x the forward FLOPs of one pass; weight gradients are their own kernel)
