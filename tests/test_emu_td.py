@@ -269,3 +269,26 @@ def test_td_update_tiled_rows_per_workgroup(emu, kw, run, rows, monkeypatch):
                                                history=run.get("history"), tuf=run.get("tuf", 10_000))
     assert net.tiled == 1
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+def test_training_on_the_row_block_twin(emu, monkeypatch):
+    """dtqn_td_prefers_tiled / dtqn_net_tiled_twin: a D = 128 residual post-LN net with 64-row contexts trains on the row-block twin
+    of the caller's net (same theta layout, tiled records) while inference keeps the caller's net.  The policy asks for it beyond
+    latency mode (batch > 42); DTQN_TRAIN_TILED=1 forces it at a batch the emulation finishes quickly."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, action_dim=8)
+    net = B.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, action_dim=8)
+    assert net.tiled == 0 and emu.dtqn_td_prefers_tiled(ctypes.byref(net), 2) == 0 and emu.dtqn_td_prefers_tiled(ctypes.byref(net), 64) == 1
+    for kw in (dict(inner_embed_size=64), dict(gate="gru"), dict(identity=True), dict(history_len=20)):     # shapes the policy leaves alone
+        other = B.make_net(emu, **{**dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50), **kw})
+        assert emu.dtqn_td_prefers_tiled(ctypes.byref(other), 64) == 0, kw
+    monkeypatch.setenv("DTQN_TRAIN_TILED", "1")
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=41, batch=2, T=60, n_eps=5, mask=-5, tuf=2)
+    assert net.tiled == 0 and eng.net.tiled == 1 and eng.actor_net.tiled == 0
+    assert eng.net.n_theta == net.n_theta and B.param_table(eng.net) == B.param_table(net)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    obs = torch.zeros(1, 7, cfg.obs_dim)
+    q = eng.forward(obs, torch.zeros(1, 7, 1, dtype=torch.uint8))            # whole-sequence inference entry on the caller's net
+    assert q.shape == (1, 7, cfg.num_actions) and torch.isfinite(q).all()
+    monkeypatch.setenv("DTQN_TRAIN_TILED", "0")
+    _, _, _, eng0, _ = make_td_case(emu, cfg, seed=41, batch=2, T=60, n_eps=5, mask=-5)
+    assert eng0.net.tiled == 0
