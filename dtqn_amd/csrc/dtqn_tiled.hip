@@ -1520,8 +1520,10 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
 // ---- launch helpers --------------------------------------------------------------------------------------------------------
 #define TL_LAUNCH(kernel, grid, block, lds, stream, args)                                                            \
     do {                                                                                                             \
-        if ((lds) > 0)                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds)); \
+        if ((lds) > 48 * 1024) {            /* beyond the default dynamic-LDS limit: raise it once per kernel and device */   \
+            static size_t tl_attr_lds_[kMaxDevices] = {};                                                            \
+            raise_lds_limit(reinterpret_cast<const void*>(&kernel), (lds), tl_attr_lds_);                               \
+        }                                                                                                            \
         (void)hipGetLastError();                                                                                     \
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, args);                                                  \
         if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;                                                 \
