@@ -1,25 +1,25 @@
 #!/bin/bash
-# stall attribution of the tiled GEMM kernels at cfg 4: a few --pmc passes (kernel trace only), summarised per kernel
+# Stall attribution with a few --pmc passes (kernel trace only), summarised per kernel:
+#   bash tools/counters_tiled_gemm.sh <config> "<kernel substrings>"   ->  gpurun_out/counters_cfg<N>.txt
+# SQ wait / active / instruction-mix / LDS counters (per shader engine: 8 CUs x 4 SIMDs; *_CYCLES of waves in quad-cycles).
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out/s
+C=${1:-4}
+KERNELS=${2:-"tl_ffn tl_wide tl_dx wgrad tl_attn"}
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCP|TCC|TA|TD)_[A-Z0-9_]+" | sort -u > gpurun_out/s/counters.txt
-wc -l gpurun_out/s/counters.txt
-BENCH="python bench.py --config 4 --steps 40 --warmup 10 --no-cpu-baseline --no-env-rate --no-other-configs"
+OUT=gpurun_out/counters_cfg$C.txt
+: > $OUT
+BENCH="python bench.py --config $C --steps 60 --warmup 10 --no-cpu-baseline --no-env-rate --no-other-configs"
 i=0
 for P in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
-         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" \
          "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-         "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
-         "SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU" \
-         "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
-         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+         "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$i
-  timeout 240 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc_$i -- $BENCH > gpurun_out/s/pass_$i.log 2>&1
-  echo "pass $i rc=$? : $P"
+  timeout 240 rocprofv3 --kernel-trace --pmc $P -d /tmp/pmc_$i -- $BENCH > /tmp/pass_$i.log 2>&1
+  echo "# pass $i rc=$? : $P" >> $OUT
   DB=$(find /tmp/pmc_$i -name '*results.db' | head -1)
-  if [ -n "$DB" ]; then python tools/pmc_summary.py "$DB" "tl_linear" > gpurun_out/s/pass_${i}_linear.txt 2>&1; python tools/pmc_summary.py "$DB" "tl_dx" > gpurun_out/s/pass_${i}_dx.txt 2>&1; python tools/pmc_summary.py "$DB" "wgrad" > gpurun_out/s/pass_${i}_wgrad.txt 2>&1; fi
-  grep -v "^    @" gpurun_out/s/pass_$i.log | tail -3 > gpurun_out/s/pass_$i.tail; rm gpurun_out/s/pass_$i.log
+  if [ -n "$DB" ]; then for K in $KERNELS; do python tools/pmc_summary.py "$DB" "$K" >> $OUT 2>&1; done; fi
 done
-cat gpurun_out/s/pass_*_linear.txt
+tail -40 $OUT
