@@ -28,11 +28,14 @@ def test_pmc_traffic_reads_the_committed_profile():
     key = [k for k in d if "dtqn_forward_kernel" in k][0]
     assert t == int((2 * d[key]["FETCH_SIZE"] + d[key]["WRITE_SIZE"]) * 1024)       # gfx950: FETCH_SIZE doubled, KB units
     assert bench.pmc_traffic("dtqn_forward_kernel", 7, 1) is None                   # no profile for that batch
-    t3 = bench.pmc_traffic("dtqn_backward_kernel", 512, 3)                          # every BASELINE config has its own file
-    d3 = json.load(open(bench._round_profiles("pmc_traffic", 3)[0]))
-    assert os.path.basename(bench._round_profiles("pmc_traffic", 3)[0]) >= "r02e_pmc_traffic_cfg3.json"      # newest suffix first
-    key3 = [k for k in d3 if "dtqn_backward_kernel" in k][0]
-    assert t3 == int((2 * d3[key3]["FETCH_SIZE"] + d3[key3]["WRITE_SIZE"]) * 1024)
+    t2 = bench.pmc_traffic("dtqn_backward_kernel", 256, 2)                          # every BASELINE config has its own files
+    d2 = json.load(open(bench._round_profiles("pmc_traffic", 2)[0]))
+    key2 = [k for k in d2 if "dtqn_backward_kernel" in k][0]
+    assert t2 == int((2 * d2[key2]["FETCH_SIZE"] + d2[key2]["WRITE_SIZE"]) * 1024)
+    names3 = [os.path.basename(p) for p in bench._round_profiles("pmc_traffic", 3)]   # newest suffix of the round first
+    assert names3 == sorted(names3, reverse=True) and names3[0] >= "r02f_pmc_traffic_cfg3.json"
+    # cfg 3 trains on the row-block kernels since r02f: the whole-sequence kernel is found in the older profile of the config
+    assert bench.pmc_traffic("dtqn_backward_kernel", 512, 3) is not None
     m = bench.mfma_counters(1)
     fk = [k for k in m if "dtqn_forward_kernel" in k][0]
     assert 0.0 < m[fk]["mfma_util_vs_launch"] < 1.0 and m[fk]["SQ_VALU_MFMA_BUSY_CYCLES"] > 0
