@@ -292,3 +292,14 @@ def test_training_on_the_row_block_twin(emu, monkeypatch):
     monkeypatch.setenv("DTQN_TRAIN_TILED", "0")
     _, _, _, eng0, _ = make_td_case(emu, cfg, seed=41, batch=2, T=60, n_eps=5, mask=-5)
     assert eng0.net.tiled == 0
+
+
+@pytest.mark.parametrize("ffn_bwd", ["0", "1"])
+def test_td_update_tiled_path_width_256(emu, ffn_bwd, monkeypatch):
+    """D = 256 takes the two-chunk / two-column-block step sequences of the fused row-block kernels (tl_wide, tl_ffn, and with
+    DTQN_FFN_BWD=1 the fused feed-forward backward that is off by default at this width); everything else in this file runs D = 64."""
+    monkeypatch.setenv("DTQN_FFN_BWD", ffn_bwd)
+    cfg = O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=256, num_heads=8, num_layers=1, history_len=12, action_dim=8)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=43, batch=2, T=20, n_eps=5, mask=-5)
+    assert net.tiled == 1
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
