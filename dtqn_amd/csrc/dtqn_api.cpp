@@ -78,6 +78,8 @@ namespace dtqn {
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows,
                   uint32_t drop_seed, uint32_t drop_step, int train_mode);
+int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream);
 }
 extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                                           int batch, int n, int in_rows, float* q_out, float* workspace, void* stream);
@@ -108,7 +110,7 @@ extern "C" int dtqn_actor_forward(const DtqnNet* net, const float* theta, const 
         int32_t* xflags = split ? reinterpret_cast<int32_t*>(workspace + dtqn_td_xch_floats(net, 1)) : nullptr;
         return dtqn::forward_infer(net, theta, obs, actions, 1, n, q_dev, q_last_host, stream, xch, xflags, nullptr, 0, dropout_seed, dropout_step, train_mode);
     }
-    const int rc = dtqn_forward_tiled(net, theta, obs, actions, 1, n, q_dev, workspace, stream);
+    const int rc = dtqn::tiled_forward_actor(net, theta, obs, actions, 1, n, n, q_dev, workspace, train_mode, dropout_seed, dropout_step, s);
     if (rc != DTQN_OK) return rc;
     if (hipMemcpyAsync(q_last_host, q_dev + (size_t)(n - 1) * net->num_actions, sizeof(float) * net->num_actions,
                        hipMemcpyDeviceToHost, s) != hipSuccess)
@@ -138,7 +140,8 @@ extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, 
     const int32_t* lens = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_dev) + obs_bytes + act_bytes);
     if (net->tiled) {
         // row-block tiled nets: the forward leaves Q in q_dev; the last rows come back with one small copy per actor
-        const int rc = dtqn_forward_tiled_strided(net, theta, obs, actions, n_envs, n_max, L, q_dev, workspace, stream);
+        const int rc = dtqn::tiled_forward_actor(net, theta, obs, actions, n_envs, n_max, L, q_dev, workspace, train_mode, dropout_seed,
+                                                 dropout_step, (hipStream_t)stream);
         if (rc != DTQN_OK) return rc;
         const int32_t* lens_h = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_host) + obs_bytes + act_bytes);
         for (int i = 0; i < n_envs; ++i)

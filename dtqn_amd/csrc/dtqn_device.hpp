@@ -25,6 +25,8 @@ namespace dtqn {
 // row-block tiled TD passes (dtqn_tiled.hip), dispatched to by dtqn_td_forward / dtqn_td_backward when net->tiled
 int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
+int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream);
 // dtqn_forward with an optional pinned-host destination for Q of the last row of sequence 0 (dtqn_actor_forward)
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows = nullptr, int in_rows = 0,
@@ -686,7 +688,7 @@ __device__ __forceinline__ void attention_forward_chunk(const float* kbase, cons
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D, int H, int LP, int n,
                                                        float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                       const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
+                                                       const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
     if (lse_ld == 0) lse_ld = LP;               // query rows [row0, row0 + LP), row0 a multiple of 16
     constexpr int KS = HD / 4;                  // MFMA steps of the score contraction (4 columns of q/k per step)
     constexpr int CT = (HD + 15) / 16;          // 16-row tiles of O^T (rows = head columns c)
@@ -717,12 +719,12 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
         float m = -INFINITY, l = 0.f;
         int tc0 = 0;
         for (; tc0 + 4 <= ti; tc0 += 4)
-            attention_forward_chunk<HD, 4, false>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h);
+            attention_forward_chunk<HD, 4, false>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, head0 + h);
         switch (ti - tc0) {                     // the remaining 1..4 tiles end on the diagonal
-            case 0: attention_forward_chunk<HD, 1, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
-            case 1: attention_forward_chunk<HD, 2, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
-            case 2: attention_forward_chunk<HD, 3, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
-            default: attention_forward_chunk<HD, 4, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, h); break;
+            case 0: attention_forward_chunk<HD, 1, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, head0 + h); break;
+            case 1: attention_forward_chunk<HD, 2, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, head0 + h); break;
+            case 2: attention_forward_chunk<HD, 3, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, head0 + h); break;
+            default: attention_forward_chunk<HD, 4, true>(kbase, vbase, ld, tc0 * 16, trow, qf, m, l, acc, tc0 > 0, t, dr, layer, head0 + h); break;
         }
         // lane (i, kq) holds O^T[c = ct*16 + kq*4 + e][t = t0 + i]: four consecutive output columns of row t
         const bool live = trow < n;
@@ -749,7 +751,7 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
     // query rows [row0, row0 + LP) of the tile (a row slice of the sequence when row0 > 0); keys 0 .. row
     if (lse_ld == 0) lse_ld = LP;
     const float scale = 1.0f / sqrtf((float)HD);
@@ -812,7 +814,7 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
             if (dr.thresh != 0u) {     // attention-probability dropout (the row sum is of the undropped probabilities)
 #pragma unroll
                 for (int j = 0; j < KB; ++j)
-                    if (s0 + j <= row) p[j] = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(h, row, s0 + j)) ? p[j] * dr.scale : 0.f;
+                    if (s0 + j <= row) p[j] = drop_keep(dr, DROP_ATTN, layer, drop_attn_idx(head0 + h, row, s0 + j)) ? p[j] * dr.scale : 0.f;
             }
 #pragma unroll
             for (int c = 0; c < HD; ++c) acc[c] *= corr;
@@ -841,9 +843,11 @@ constexpr int kAttnMfmaMinHeadDim = 16;
 template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0) {
-    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer);
-    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer);
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+    // head0: global index of the tile's first head (the row-block kernels hold one head per workgroup): the keep masks of
+    // the attention-probability dropout are keyed by the global head
+    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0);
+    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0);
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.

@@ -63,7 +63,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         net->lp = (L + 63) / 64 * 64;
     }
     const int LP = net->lp;
-    if (net->tiled && net->dropout > 0.f) return DTQN_ERR_CONFIG;      // dropout: whole-sequence kernels only
+    if (net->bag_size > 0 && net->dropout > 0.f) return DTQN_ERR_CONFIG;    // (the bag attention has its own dropout: not built)
     // the bag branch is composed from the row-block kernels: post-LN layers, as many bag entries as the records have rows
     if (net->bag_size > 0 && (net->identity || net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
     if (net->tiled) {

@@ -34,6 +34,34 @@ static inline Fld fld(float* rec, long long stride, int off, int ld) { return Fl
 static inline Fld nofld() { return Fld{nullptr, 0, 0}; }
 __device__ __forceinline__ float* frow(const Fld& f, int s, int row) { return f.base + (size_t)s * f.stride + (size_t)row * f.ld; }
 
+// Dropout on the row-block path (net.dropout > 0): the keep-mask hash of the whole-sequence kernels (dtqn_device.hpp drop_keep),
+// keyed by (seed, step, pass, sequence, site, layer, element).  Sequence s of a launch belongs to pass s / batch; bit p of
+// `passes` says whether pass p runs in train mode (TD update: policy(o) and policy(o') do, the target net does not).
+struct TlDrop {
+    uint32_t thresh;                   // 0: dropout off
+    float scale;
+    uint32_t seed, step;
+    const int32_t* step_counter;       // TD update: step = step_counter[1]; else `step`
+    int batch, passes;
+};
+static inline TlDrop tl_drop_none() { TlDrop d = {}; d.scale = 1.0f; d.batch = 1; return d; }
+static inline TlDrop tl_drop_make(const DtqnNet& net, uint32_t seed, uint32_t step, const int32_t* step_counter, int batch, int passes) {
+    TlDrop d = tl_drop_none();
+    if (net.dropout > 0.f && passes != 0) {
+        d.thresh = (uint32_t)((double)net.dropout * 4294967296.0);
+        d.scale = 1.0f / (1.0f - net.dropout);
+        d.seed = seed; d.step = step; d.step_counter = step_counter; d.batch = batch > 0 ? batch : 1; d.passes = passes;
+    }
+    return d;
+}
+__device__ __forceinline__ Drop tl_drop(const TlDrop& d, int s) {
+    if (d.thresh == 0u) return drop_off();
+    const int which = s / d.batch;
+    if (!((d.passes >> which) & 1)) return drop_off();
+    return Drop{d.thresh, d.scale, d.seed, d.step_counter != nullptr ? (uint32_t)d.step_counter[1] : d.step,
+                ((uint32_t)which << 20) | (uint32_t)(s - which * d.batch)};
+}
+
 // ---- embedding + position ---------------------------------------------------------------------------
 struct TlEmbedArgs {
     DtqnNet net;
@@ -51,6 +79,7 @@ struct TlEmbedArgs {
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
     int src_mod;                       // > 0: sequence s reads source sequence s % src_mod (one bag per window, three forwards)
     int bag;                           // 1: bag entries (dtqn.py:203-210): no position, the action embedding is not rolled
+    TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
@@ -123,6 +152,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
             eo[(size_t)rl * KEP + k] = 0.f;
         }
     float* xo = frow(a.x, s, rb * TROWS);
+    const Drop edr = tl_drop(a.drop, s);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (q >= per_wave) break;
@@ -140,6 +170,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
                     v = acc[q][r4] + theta[net.off_obs_b + d - adim];
                 }
                 if (!a.bag) v += theta[net.off_pos + r * D + d];
+                v = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d), v);
             }
             xo[(size_t)rl * a.x.ld + d] = v;
         }
@@ -517,6 +548,8 @@ struct TlFfnArgs {
     // row statistics to ln_st and OUT itself are stored only for the sequences the backward pass reads (s < n_save)
     Fld ln_out, ln_st;                 // ln_out.base == nullptr: no LayerNorm
     const float *lga, *lgb, *lba, *lbb;
+    TlDrop drop;                       // dropout on the block's output, before the gate's ReLU (transformer.py:38-42)
+    int layer;
 };
 // MR rows per workgroup (64, or 32 when the launch would otherwise be a round and a half of workgroups: launch_ffn)
 template <int D, int MR>
@@ -607,6 +640,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
         __syncthreads();                                               // ... and consumed
     }
     float* mrec_o = save && a.m2.base != nullptr ? a.m2.base + (size_t)s * a.m2.stride : nullptr;
+    const Drop fdr = tl_drop(a.drop, s);
     if (a.ln_out.base != nullptr) {
         // relu(y) of all D columns into the (spent) input tile, then rows: LPR lanes per row hold the row in registers, add the
         // residual, take mean / variance in a butterfly (same two-pass arithmetic as layernorm_rows) and write LN(OUT)
@@ -620,7 +654,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const int rl = m * 16 + t.kq * 4 + r4;
-                        const float v = accO[o][m][r4] + bv;
+                        const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * D + col), accO[o][m][r4] + bv);
                         if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
                         Xt[rl * LDX + col] = fmaxf(v, 0.f);
                     }
@@ -681,7 +715,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int rl = m * 16 + t.kq * 4 + r4;
-                    const float v = accO[o][m][r4] + bv;
+                    const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * D + col), accO[o][m][r4] + bv);
                     if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
                     Hs[rl * LDH + wc] = fmaxf(v, 0.f);
                 }
@@ -806,6 +840,8 @@ struct TlFfnBwdArgs {
     Fld out;
     const float *W1, *W2;              // W1 [4D][D], W2 [D][4D]
     int rpb, out_mode;
+    TlDrop drop;                       // the forward's dropout on the block's output: df also takes its keep mask (and is stored
+    int layer;                         // to `df` when that is given, masked or not)
 };
 template <int D, int MR>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfnBwdArgs a) {
@@ -834,6 +870,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfn
     {
         const unsigned long long* mrec =
             a.m2.base != nullptr ? reinterpret_cast<const unsigned long long*>(a.m2.base + (size_t)s * a.m2.stride) : nullptr;
+        const Drop bdr = tl_drop(a.drop, s);
         for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
             const int rl = idx / (D / 4), c = (idx - rl * (D / 4)) * 4, row = row0 + rl;
             float4 v = ld4(frow(a.dy, s, row) + c);
@@ -844,8 +881,15 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfn
                 v.y = ((w >> (b0 + 1)) & 1ull) ? v.y : 0.f;
                 v.z = ((w >> (b0 + 2)) & 1ull) ? v.z : 0.f;
                 v.w = ((w >> (b0 + 3)) & 1ull) ? v.w : 0.f;
-                st4(frow(a.df, s, row) + c, v);
             }
+            if (bdr.thresh != 0u) {
+                const uint32_t e0 = (uint32_t)(row * D + c);
+                v.x = drop_apply(bdr, DROP_FFN, a.layer, e0, v.x);
+                v.y = drop_apply(bdr, DROP_FFN, a.layer, e0 + 1, v.y);
+                v.z = drop_apply(bdr, DROP_FFN, a.layer, e0 + 2, v.z);
+                v.w = drop_apply(bdr, DROP_FFN, a.layer, e0 + 3, v.w);
+            }
+            if (a.df.base != nullptr) st4(frow(a.df, s, row) + c, v);
             st4(Yt + rl * LDX + c, v);
         }
     }
@@ -926,8 +970,11 @@ struct TlAttnArgs {
     Fld o;                             // [LPB][D]
     Fld lse;                           // [H][LPB] (base may be null)
     int D, lpb, n;
+    TlDrop drop;                       // dropout on the attention probabilities (MultiheadAttention(dropout=p), transformer.py:34)
+    int layer;
 };
-template <int HD>
+// DROP: compile-time, so that the default build of the kernel carries no keep-mask code
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void tl_attn_kernel(TlAttnArgs a) {
     constexpr int LDH = 3 * HD + 4;
     float* T = reinterpret_cast<float*>(dtqn_smem);                    // [lpb][q | k | v] of this head
@@ -941,7 +988,9 @@ __global__ __launch_bounds__(256) void tl_attn_kernel(TlAttnArgs a) {
     }
     __syncthreads();
     float* lse = a.lse.base != nullptr ? a.lse.base + (size_t)s * a.lse.stride + (size_t)h * a.lpb : nullptr;
-    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, lse, t);       // one head: "D" = HD, H = 1
+    Drop dr = drop_off();
+    if constexpr (DROP) dr = tl_drop(a.drop, s);
+    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, lse, t, 0, 0, dr, a.layer, h);       // one head: "D" = HD, H = 1
     __syncthreads();
     float* dst = frow(a.o, s, 0) + h * HD;
     for (int idx = t.tid; idx < a.lpb * (HD / 4); idx += 256) {
@@ -956,8 +1005,10 @@ struct TlAttnBwdArgs {
     Fld dO;                            // [LPB][D] dL/d(attention output)
     Fld dqkv;                          // [LPB][3D] out
     int D, lpb, n;
+    TlDrop drop;                       // the forward's attention-probability dropout, recomputed
+    int layer;
 };
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void tl_attn_bwd_kernel(TlAttnBwdArgs a) {
     constexpr int LDH = 4 * HD + 4;
     float* T = reinterpret_cast<float*>(dtqn_smem);
@@ -990,7 +1041,9 @@ __global__ __launch_bounds__(256) void tl_attn_bwd_kernel(TlAttnBwdArgs a) {
     }
     __syncthreads();
     float* dq = frow(a.dqkv, s, 0) + h * HD;
-    attention_backward_group<HD, 4>(T, LDH, HD, a.lpb, a.n, delta_s, lse_s, t, dq, a.dqkv.ld);
+    Drop dr = drop_off();
+    if constexpr (DROP) dr = tl_drop(a.drop, s);
+    attention_backward_group<HD, 4>(T, LDH, HD, a.lpb, a.n, delta_s, lse_s, t, dq, a.dqkv.ld, 0, 0, dr, a.layer, h);
     __syncthreads();
     for (int idx = t.tid; idx < a.lpb * 2 * (HD / 4); idx += 256) {
         const int r = idx / (2 * (HD / 4)), rem = idx - r * (2 * (HD / 4));
@@ -1113,6 +1166,31 @@ __global__ __launch_bounds__(TNT) void tl_mask_kernel(TlMaskArgs a) {
         o.z = mask_bit(mrec, a.D / 16, r, c + 2) ? v.z : 0.f;
         o.w = mask_bit(mrec, a.D / 16, r, c + 3) ? v.w : 0.f;
         st4(frow(a.dst, s, r) + c, o);
+    }
+}
+
+// ---- x *= keep mask of a dropout site, in place (backward: gradients of x0 / of the feed-forward output where no GEMM kernel
+//      carries the mask in its staging) -------------------------------------------------------------------------------------
+struct TlDropRowsArgs {
+    Fld x;
+    int D, rpb, site, layer;
+    TlDrop drop;
+};
+__global__ __launch_bounds__(TNT) void tl_drop_rows_kernel(TlDropRowsArgs a) {
+    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
+    const Drop dr = tl_drop(a.drop, s);
+    if (dr.thresh == 0u) return;
+    const int c4 = a.D / 4;
+    for (int idx = (int)threadIdx.x; idx < TROWS * c4; idx += TNT) {
+        const int r = row0 + idx / c4, c = (idx % c4) * 4;
+        float* p = frow(a.x, s, r) + c;
+        float4 v = ld4(p);
+        const uint32_t e0 = (uint32_t)(r * a.D + c);
+        v.x = drop_apply(dr, a.site, a.layer, e0, v.x);
+        v.y = drop_apply(dr, a.site, a.layer, e0 + 1, v.y);
+        v.z = drop_apply(dr, a.site, a.layer, e0 + 2, v.z);
+        v.w = drop_apply(dr, a.site, a.layer, e0 + 3, v.w);
+        st4(p, v);
     }
 }
 
@@ -1632,17 +1710,31 @@ static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
 }
 static int launch_attn(const TlAttnArgs& a, int S, int H, int HD, hipStream_t stream) {
     const size_t lds = (size_t)a.lpb * (3 * HD + 4) * sizeof(float);
-    if (HD == 8) TL_LAUNCH((tl_attn_kernel<8>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32>), dim3(S, H), dim3(256), lds, stream, a);
+    if (a.drop.thresh != 0u) {
+        if (HD == 8) TL_LAUNCH((tl_attn_kernel<8, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else return DTQN_ERR_CONFIG;
+        return DTQN_OK;
+    }
+    if (HD == 8) TL_LAUNCH((tl_attn_kernel<8, false>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16, false>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32, false>), dim3(S, H), dim3(256), lds, stream, a);
     else return DTQN_ERR_CONFIG;
     return DTQN_OK;
 }
 static int launch_attn_bwd(const TlAttnBwdArgs& a, int S, int H, int HD, hipStream_t stream) {
     const size_t lds = ((size_t)a.lpb * (4 * HD + 4) + 2 * (size_t)a.lpb) * sizeof(float);
-    if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32>), dim3(S, H), dim3(256), lds, stream, a);
+    if (a.drop.thresh != 0u) {
+        if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32, true>), dim3(S, H), dim3(256), lds, stream, a);
+        else return DTQN_ERR_CONFIG;
+        return DTQN_OK;
+    }
+    if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8, false>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16, false>), dim3(S, H), dim3(256), lds, stream, a);
+    else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32, false>), dim3(S, H), dim3(256), lds, stream, a);
     else return DTQN_ERR_CONFIG;
     return DTQN_OK;
 }
@@ -1694,7 +1786,7 @@ struct EmbedSrc {
 template <int D>
 static int forward_records(const DtqnNet& net, const float* theta_a, const float* theta_b, int split, const EmbedSrc& src,
                            int S, int n, float* rec, bool training, float* q_out, long long q_seq_stride, int q_row_stride,
-                           hipStream_t stream) {
+                           hipStream_t stream, const TlDrop& drop) {
     const int lpb = net.lp, H = net.num_heads, HD = net.head_dim, rpb = lpb / TROWS;
     const RecMap rm = rec_map(net, training);
     const bool ident = net.identity != 0;
@@ -1709,7 +1801,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.n = n; e.rpb = rpb;
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
-        e.src_mod = 0; e.bag = 0;
+        e.src_mod = 0; e.bag = 0; e.drop = drop;
         const size_t elds = tl_embed_lds(D);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
@@ -1774,7 +1866,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             TlAttnArgs at;
             at.qkv = F(ab + net.al_qkv, 3 * D); at.o = F(ab + net.al_o, D);
             at.lse = training ? F(ab + net.al_lse, lpb) : nofld();
-            at.D = D; at.lpb = lpb; at.n = n;
+            at.D = D; at.lpb = lpb; at.n = n; at.drop = drop; at.layer = l;
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
@@ -1810,7 +1902,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.in = u2;
             fa.W1a = theta_a + tb + net.lo_f1_w; fa.W1b = theta_b + tb + net.lo_f1_w; fa.b1a = theta_a + tb + net.lo_f1_b; fa.b1b = theta_b + tb + net.lo_f1_b;
             fa.W2a = theta_a + tb + net.lo_f2_w; fa.W2b = theta_b + tb + net.lo_f2_w; fa.b2a = theta_a + tb + net.lo_f2_b; fa.b2b = theta_b + tb + net.lo_f2_b;
-            fa.split = split; fa.rpb = rpb;
+            fa.split = split; fa.rpb = rpb; fa.drop = drop; fa.layer = l;
             fa.n_save = training ? src.batch : 0;                     // only the training third of a TD update is read again
             fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
             fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
@@ -1849,7 +1941,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.n = bag; e.rpb = rpb;
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
-            e.src_mod = src.bag_batch; e.bag = 1;
+            e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none();
             const size_t elds = tl_embed_lds(D);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
@@ -1925,6 +2017,14 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         return DTQN_OK;
     };
     const bool ident = net.identity != 0, gru = net.gate == DTQN_GATE_GRU;
+    // the training forward's dropout (pass 0 of the TD update), recomputed: step = step_counter[1], not yet advanced
+    const TlDrop drop = tl_drop_make(net, td.dropout_seed, 0u, td.step_counter, B, 0x1);
+    auto drop_rows = [&](Fld x, int site, int layer) -> int {
+        TlDropRowsArgs a;
+        a.x = x; a.D = D; a.rpb = rpb; a.site = site; a.layer = layer; a.drop = drop;
+        TL_LAUNCH(tl_drop_rows_kernel, dim3(B * rpb), dim3(TNT), 0, stream, a);
+        return DTQN_OK;
+    };
     const Fld T = FG(net.go_do, D);                       // branch-gradient scratch (dO of the attention; LN inputs' gradients)
     const int LPD = lpb * D;
     // dL/d(gate output) in G  ->  G = the part that flows on along the stream (dL/dx), dst = dL/d(sub-layer output):
@@ -1986,10 +2086,11 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             if (!gru) { fb.dy = G; fb.m2 = FA(ab + net.al_m2, 0); fb.df = FG(gb + net.gl_df, D); }
             else {
                 if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
-                fb.dy = FG(gb + net.gl_df, D); fb.m2 = nofld(); fb.df = nofld();
+                fb.dy = FG(gb + net.gl_df, D); fb.m2 = nofld();
+                fb.df = drop.thresh != 0u ? FG(gb + net.gl_df, D) : nofld();          // dropout: the keep mask goes into df in place
             }
             fb.dhp = FG(gb + net.gl_dhp, 4 * D); fb.mh = FA(ab + net.al_mh, 0);
-            fb.W1 = theta + tb + net.lo_f1_w; fb.W2 = theta + tb + net.lo_f2_w; fb.rpb = rpb;
+            fb.W1 = theta + tb + net.lo_f1_w; fb.W2 = theta + tb + net.lo_f2_w; fb.rpb = rpb; fb.drop = drop; fb.layer = l;
             if (!ident) { fb.out = G; fb.out_mode = 2; } else { fb.out = T; fb.out_mode = 0; }
             if ((rc = launch_ffn_bwd<D>(fb, B, stream)) != DTQN_OK) return rc;
             if (!ident) {
@@ -1999,6 +2100,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             }
         } else {                                                       // the separate launches (A/B timing)
             if ((rc = gate_bwd(ab + net.al_gate2, gb + net.gl_gate2, net.off_gate_mlp, FA(ab + net.al_m2, 0), FG(gb + net.gl_df, D))) != DTQN_OK) return rc;
+            if (drop.thresh != 0u && (rc = drop_rows(FG(gb + net.gl_df, D), DROP_FFN, l)) != DTQN_OK) return rc;
             if ((rc = dx(FG(gb + net.gl_df, D), D, tb + net.lo_f2_w, 4 * D, FG(gb + net.gl_dhp, 4 * D), 1, FA(ab + net.al_mh, 0))) != DTQN_OK) return rc;
             if (!ident) {
                 // the stream IS u2: ds2 + du2, then u2 = LN1(s1)
@@ -2017,7 +2119,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             TlAttnBwdArgs a;
             a.qkv = FA(ab + net.al_qkv, 3 * D); a.o = FA(ab + net.al_o, D); a.lse = FA(ab + net.al_lse, lpb);
             a.dO = FG(net.go_do, D); a.dqkv = FG(gb + net.gl_dqkv, 3 * D);
-            a.D = D; a.lpb = lpb; a.n = L;
+            a.D = D; a.lpb = lpb; a.n = L; a.drop = drop; a.layer = l;
             if ((rc = launch_attn_bwd(a, B, H, HD, stream)) != DTQN_OK) return rc;
         }
         if (!ident) {
@@ -2029,6 +2131,8 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             if ((rc = ln_bwd(T, stream_in, FA(ab + net.al_st1, 2), tb + net.lo_ln1_w, sm, true)) != DTQN_OK) return rc;
         }
     }
+    // x0 = dropout(embedding + position): dL/d(embedding) and the position gradient take the keep mask
+    if (drop.thresh != 0u && (rc = drop_rows(G, DROP_EMB, 0)) != DTQN_OK) return rc;
     if (net.discrete || net.action_dim > 0) {
         TlEmbedBwdArgs a;
         a.net = net; a.theta = theta; a.grd = grd; a.small = td.small;
@@ -2057,8 +2161,10 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
     src.bag_obs = td->bag_obs; src.bag_actions = td->bag_actions; src.bag_batch = td->batch;
     const int S = 3 * td->batch;
     const long long qs = (long long)net->lp * net->ap;
+    // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230); step = optimizer steps so far
+    const TlDrop drop = tl_drop_make(*net, td->dropout_seed, 0u, td->step_counter, td->batch, 0x3);
 #define DTQN_TL_CASE(d) \
-    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, 2 * td->batch, src, S, net->ctx_len, td->act, true, td->q3, qs, net->ap, stream);
+    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, 2 * td->batch, src, S, net->ctx_len, td->act, true, td->q3, qs, net->ap, stream, drop);
     switch (net->d_model) {
         DTQN_TL_CASE(64)
         DTQN_TL_CASE(128)
@@ -2090,7 +2196,8 @@ extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
 }
 
 static int forward_tiled_impl(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
-                              const uint8_t* bag_actions, int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
+                              const uint8_t* bag_actions, int batch, int n, int in_rows, float* q_out, float* workspace, void* stream,
+                              int train_mode = 0, uint32_t drop_seed = 0u, uint32_t drop_step = 0u) {
     if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len || in_rows < n) return DTQN_ERR_ARG;  // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
@@ -2103,13 +2210,25 @@ static int forward_tiled_impl(const DtqnNet* net, const float* theta, const floa
     src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
     src.bag_obs = bag_obs; src.bag_actions = bag_actions; src.bag_batch = batch;
     const long long qs = (long long)n * net->num_actions;
+    // a train-mode forward of the actor (the reference's policy network stays in train mode during rollouts): one pass, sequence = salt
+    const TlDrop drop = tl_drop_make(*net, drop_seed, drop_step, nullptr, batch, train_mode ? 0x1 : 0);
     switch (net->d_model) {
-        case 64: return forward_records<64>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
-        case 128: return forward_records<128>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
-        case 256: return forward_records<256>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s);
+        case 64: return forward_records<64>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s, drop);
+        case 128: return forward_records<128>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s, drop);
+        case 256: return forward_records<256>(*net, theta, theta, batch, src, batch, n, workspace, false, q_out, qs, net->num_actions, s, drop);
         default: return DTQN_ERR_CONFIG;
     }
 }
+
+namespace dtqn {
+// dtqn_actor_forward / dtqn_actor_forward_batch on a row-block net: the strided forward with the actor's train-mode dropout
+int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream) {
+    if (net && net->bag_size > 0) return DTQN_ERR_ARG;
+    return forward_tiled_impl(net, theta, obs, actions, nullptr, nullptr, batch, n, in_rows, q_out, workspace, stream, train_mode, drop_seed,
+                              drop_step);
+}
+}  // namespace dtqn
 
 // in_rows: rows per sequence in the obs / actions arrays (>= n; the batched actor packs whole contexts)
 extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,

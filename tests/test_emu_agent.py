@@ -335,8 +335,10 @@ def test_vector_actor_matches_single_actor_and_reference_buffer(emu):
     assert vec.steps == 40 * N
 
 
-def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu):
-    """--dropout p: the policy network stays in train mode during rollouts (dqn.py:102-115), so two action forwards of the
+@pytest.mark.parametrize("tiled", [False, True])
+def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu, tiled, monkeypatch):
+    """(whole-sequence kernels, and the row-block kernels forced on the same small shape)
+    --dropout p: the policy network stays in train mode during rollouts (dqn.py:102-115), so two action forwards of the
     same context differ (fresh keep masks per call) and equal the oracle's forward with the same counter-based masks;
     eval_on() (run.py:206) turns dropout off: repeated forwards are identical and equal the oracle without dropout."""
     from dtqn_amd import envs
@@ -347,7 +349,9 @@ def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu):
     from oracle import dtqn_oracle as O
     env = envs.make("DiscreteCarFlag-v0")
     set_global_seed(2, env)
-    L, D, H, p = 20, 32, 4, 0.3
+    L, D, H, p = (20, 64, 4, 0.3) if tiled else (20, 32, 4, 0.3)
+    if tiled:
+        monkeypatch.setenv("DTQN_FORCE_TILED", "1")
 
     def factory():
         m = DTQN(3, 3, 8, 0, D, H, 2, L, dropout=p, _test_lib=emu)
@@ -355,7 +359,7 @@ def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu):
         return m
     agent = DtqnAgent(factory, buffer_size=12 * 200, device=torch.device("cpu"), env_obs_length=3, max_env_steps=200, obs_mask=ep.get_env_obs_mask(env),
                       num_actions=3, is_discrete_env=False, batch_size=4, context_len=L, history=L, target_update_frequency=100)
-    assert agent.policy_network.net.dropout == pytest.approx(p)
+    assert agent.policy_network.net.dropout == pytest.approx(p) and agent.policy_network.net.tiled == int(tiled)
     agent.context_reset(env.reset())
     for _ in range(5):
         obs, r, done, info = env.step(1)
@@ -389,7 +393,8 @@ def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu):
         ref = O.forward(params, cfg, obs_t, act_t).numpy()[0, -1]
     assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
     agent.eval_off()
+    assert DTQN(3, 3, 8, 0, 128, 8, 2, 128, dropout=0.1, _test_lib=emu).net.tiled == 1       # long contexts: row-block kernels, with dropout
     with pytest.raises(NotImplementedError):
-        DTQN(3, 3, 8, 0, 128, 8, 2, 128, dropout=0.1, _test_lib=emu)          # row-block tiled path: dropout not covered
+        DTQN(3, 3, 8, 0, 64, 8, 2, 20, dropout=0.1, bag_size=4, _test_lib=emu)          # bag networks: dropout not covered
     with pytest.raises(ValueError):
         DTQN(3, 3, 8, 0, 32, 4, 2, 20, dropout=1.5, _test_lib=emu)

@@ -195,6 +195,33 @@ def test_td_update_with_dropout(emu, kw, run, monkeypatch):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
 
 
+TILED_DROPOUT = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=20, dropout=0.1), dict(batch=3, T=30, mask=-5, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, num_layers=1, history_len=70, discrete=True, vocab_sizes=9, action_dim=8,
+          dropout=0.25), dict(batch=2, T=90, mask=8, history=30)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, num_layers=2, history_len=12, gate="gru", dropout=0.2), dict(batch=3, T=20, mask=-5)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, num_layers=1, history_len=20, identity=True, pos="sin", dropout=0.15),
+     dict(batch=3, T=30, mask=-5)),
+]
+
+
+@pytest.mark.parametrize("ffn_bwd", ["1", "0"])
+@pytest.mark.parametrize("kw,run", TILED_DROPOUT)
+def test_td_update_with_dropout_on_the_row_block_path(emu, kw, run, ffn_bwd, monkeypatch):
+    """The same on the row-block tiled kernels: the embedding epilogue, the attention kernels (one head per workgroup: global
+    head index in the mask key), the fused feed-forward epilogue; in the backward the keep masks ride in the staging of the
+    fused feed-forward backward (DTQN_FFN_BWD=1) or in a row kernel in front of the separate products (=0), and dL/dx0 takes the
+    embedding mask before the table / position gradients."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_FFN_BWD", ffn_bwd)
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=23, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    assert net.tiled == 1 and net.dropout > 0
+    eng.td.dropout_seed = 4321
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
 def test_dropout_keep_rate_and_eval_mode(emu):
     """The keep masks drop a fraction p of the elements and scale the rest by 1 / (1 - p) (nn.Dropout's definition); an
     eval-mode forward (dtqn_forward, the target pass) is unaffected by the dropout setting."""

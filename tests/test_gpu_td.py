@@ -279,6 +279,12 @@ DROPOUT_CASES = [
     # GRU gates and identity-reordered layers
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, gate="gru", dropout=0.1), dict(batch=16, T=200, mask=-5, n_eps=30)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, identity=True, dropout=0.1), dict(batch=8, T=200, mask=-5, n_eps=30)),
+    # row-block tiled kernels: BASELINE config 4 / 5 shapes, a GRU-gated D = 128 net and an identity-reordered one
+    (dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, history_len=128, discrete=True, vocab_sizes=12, dropout=0.1), dict(batch=4, T=140, mask=11, n_eps=8)),
+    (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=256, discrete=True, vocab_sizes=22, dropout=0.1), dict(batch=2, T=260, mask=21, n_eps=5)),
+    (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9, gate="gru", dropout=0.2),
+     dict(batch=8, T=50, mask=8, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, identity=True, action_dim=8, dropout=0.1), dict(batch=8, T=200, mask=-5, n_eps=20)),
 ]
 
 
