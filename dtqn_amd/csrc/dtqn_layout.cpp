@@ -64,8 +64,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     }
     const int LP = net->lp;
     if (net->bag_size > 0 && net->dropout > 0.f) return DTQN_ERR_CONFIG;    // (the bag attention has its own dropout: not built)
-    // the bag branch is composed from the row-block kernels: post-LN layers, as many bag entries as the records have rows
-    if (net->bag_size > 0 && (net->identity || net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
+    // the bag branch is composed from the row-block kernels: as many bag entries as the records have rows
+    if (net->bag_size > 0 && (net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
         if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;

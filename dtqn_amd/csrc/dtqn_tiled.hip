@@ -1932,6 +1932,11 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         //      [working memory | persistent memory] to the head
         if (src.bag_obs == nullptr || (net.action_dim > 0 && src.bag_actions == nullptr) || src.bag_batch < 1) return DTQN_ERR_ARG;
         const int bag = net.bag_size;
+        if (ident) {        // no closing LayerNorm wrote the working memory into xcat: identity layers end in s2 of the last layer
+            TlCopyArgs c;
+            c.src = xf; c.dst = F(rm.xcat, 2 * D); c.cols = D; c.rpb = rpb;
+            TL_LAUNCH(tl_copy_kernel, dim3(S * rpb), dim3(TNT), 0, stream, c);
+        }
         {
             TlEmbedArgs e;
             e.net = net; e.theta_a = theta_a; e.theta_b = theta_b; e.split = split;

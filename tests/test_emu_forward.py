@@ -177,6 +177,7 @@ BAG = [
     dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, history_len=70, discrete=True, vocab_sizes=9, action_dim=8, bag_size=7,
          num_layers=1),
     dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, history_len=12, action_dim=4, bag_size=12, gate="gru", pos="sin"),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, history_len=20, bag_size=6, identity=True),
 ]
 
 
@@ -215,7 +216,7 @@ def test_forward_with_a_bag(emu, kw):
 
 
 def test_bag_configurations_outside_the_kernels_are_refused(emu):
-    for kw in (dict(identity=True), dict(bag_size=80), dict(dropout=0.1)):
+    for kw in (dict(bag_size=80), dict(dropout=0.1)):
         kw = {**dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=20, bag_size=5), **kw}
         with pytest.raises(NotImplementedError):
             net_from_cfg(emu, O.NetCfg(**kw))
