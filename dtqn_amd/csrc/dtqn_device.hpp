@@ -565,7 +565,7 @@ struct Drop {
     uint32_t seed, step;
     uint32_t salt;        // (pass << 20) | sequence
 };
-enum { DROP_EMB = 0, DROP_ATTN = 1, DROP_FFN = 2 };
+enum { DROP_EMB = 0, DROP_ATTN = 1, DROP_FFN = 2, DROP_BAG = 3 };    // (the tag of a mask key is site + 4 * layer; DROP_BAG has no layer)
 __device__ __forceinline__ Drop drop_off() { return Drop{0u, 1.0f, 0u, 0u, 0u}; }
 __device__ __forceinline__ bool drop_keep(const Drop& d, int site, int layer, uint32_t idx) {
     unsigned long long z = ((unsigned long long)d.seed << 32) | (unsigned long long)d.step;

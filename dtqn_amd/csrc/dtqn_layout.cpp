@@ -63,7 +63,6 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         net->lp = (L + 63) / 64 * 64;
     }
     const int LP = net->lp;
-    if (net->bag_size > 0 && net->dropout > 0.f) return DTQN_ERR_CONFIG;    // (the bag attention has its own dropout: not built)
     // the bag branch is composed from the row-block kernels: as many bag entries as the records have rows
     if (net->bag_size > 0 && (net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
     if (net->tiled) {

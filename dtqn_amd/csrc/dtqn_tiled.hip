@@ -1490,6 +1490,7 @@ struct TlBagAttnArgs {
     Fld p;                             // [H][LPB][bag_ld] attention weights (training; base may be null)
     Fld o;                             // [LPB][D]   attention output (before the out-projection)
     int D, HD, n, bag, bag_ld, lpb;
+    TlDrop drop;                       // dropout on the attention weights (nn.MultiheadAttention(dropout=p), dtqn.py:136-141): site DROP_BAG
 };
 __global__ __launch_bounds__(256) void tl_bag_attn_kernel(TlBagAttnArgs a) {
     float* kl = reinterpret_cast<float*>(dtqn_smem);                   // [bag][HD] keys, then [bag][HD] values
@@ -1503,6 +1504,7 @@ __global__ __launch_bounds__(256) void tl_bag_attn_kernel(TlBagAttnArgs a) {
     }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD);
+    const Drop dr = tl_drop(a.drop, s);
     for (int t = tid; t < a.n; t += 256) {
         const float* qr = frow(a.q, s, t) + h * HD;
         float m = -INFINITY;
@@ -1524,8 +1526,9 @@ __global__ __launch_bounds__(256) void tl_bag_attn_kernel(TlBagAttnArgs a) {
             float sc = 0.f;
             for (int c = 0; c < HD; ++c) sc = fmaf(qr[c] * scale, kl[j * HD + c], sc);
             const float pj = __expf(sc - m) / l;
-            if (prow != nullptr) prow[j] = pj;
-            for (int c = 0; c < HD; ++c) orow[c] = fmaf(pj, vl[j * HD + c], orow[c]);
+            if (prow != nullptr) prow[j] = pj;                         // the backward wants the weights BEFORE dropout
+            const float pd = drop_apply(dr, DROP_BAG, 0, drop_attn_idx(h, t, j), pj);
+            for (int c = 0; c < HD; ++c) orow[c] = fmaf(pd, vl[j * HD + c], orow[c]);
         }
     }
 }
@@ -1535,6 +1538,7 @@ struct TlBagAttnBwdArgs {
     Fld dq;                            // [LPB][D]
     Fld dkv;                           // [LPB][2D] (rows < bag written)
     int D, HD, n, bag, bag_ld, lpb;
+    TlDrop drop;
 };
 __global__ __launch_bounds__(256) void tl_bag_attn_bwd_kernel(TlBagAttnBwdArgs a) {
     float* kl = reinterpret_cast<float*>(dtqn_smem);                   // [bag][HD] k, [bag][HD] v, then [n][bag] dS
@@ -1549,6 +1553,7 @@ __global__ __launch_bounds__(256) void tl_bag_attn_bwd_kernel(TlBagAttnBwdArgs a
     }
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)HD);
+    const Drop dr = tl_drop(a.drop, s);
     for (int t = tid; t < a.n; t += 256) {
         const float* dor = frow(a.dO, s, t) + h * HD;
         const float* prow = a.p.base + (size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld;
@@ -1556,6 +1561,7 @@ __global__ __launch_bounds__(256) void tl_bag_attn_bwd_kernel(TlBagAttnBwdArgs a
         for (int j = 0; j < a.bag; ++j) {
             float dp = 0.f;
             for (int c = 0; c < HD; ++c) dp = fmaf(dor[c], vl[j * HD + c], dp);
+            dp = drop_apply(dr, DROP_BAG, 0, drop_attn_idx(h, t, j), dp);     // d(weights) = keep mask * d(dropped weights)
             dsl[t * a.bag + j] = dp;
             dsum = fmaf(prow[j], dp, dsum);
         }
@@ -1572,7 +1578,8 @@ __global__ __launch_bounds__(256) void tl_bag_attn_bwd_kernel(TlBagAttnBwdArgs a
         const int j = idx / HD, c = idx - j * HD;
         float dk = 0.f, dv = 0.f;
         for (int t = 0; t < a.n; ++t) {
-            const float pj = a.p.base[(size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld + j];
+            const float pj = drop_apply(dr, DROP_BAG, 0, drop_attn_idx(h, t, j),
+                                        a.p.base[(size_t)s * a.p.stride + ((size_t)h * a.lpb + t) * a.bag_ld + j]);    // dv takes the dropped weights
             dk = fmaf(dsl[t * a.bag + j] * scale, frow(a.q, s, t)[h * HD + c], dk);
             dv = fmaf(pj, frow(a.dO, s, t)[h * HD + c], dv);
         }
@@ -1957,7 +1964,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             TlBagAttnArgs at;
             at.q = F(rm.bag_q, D); at.kv = F(rm.bag_kv, 2 * D); at.o = F(rm.bag_o, D);
             at.p = training ? F(net.ao_bag_p, net.bag_ld) : nofld();
-            at.D = D; at.HD = HD; at.n = n; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb;
+            at.D = D; at.HD = HD; at.n = n; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb; at.drop = drop;
             TL_LAUNCH(tl_bag_attn_kernel, dim3(S, H), dim3(256), (size_t)2 * bag * HD * sizeof(float), stream, at);
         }
         if ((rc = linear(F(rm.bag_o, D), D, D, net.off_bag_out_w, net.off_bag_out_b, F(rm.xcat + D, 2 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
@@ -2069,7 +2076,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             TlBagAttnBwdArgs at;
             at.q = FA(net.ao_bag_q, D); at.kv = FA(net.ao_bag_kv, 2 * D); at.p = FA(net.ao_bag_p, net.bag_ld); at.dO = FG(net.go_bag_do, D);
             at.dq = FG(net.go_bag_dq, D); at.dkv = FG(net.go_bag_dkv, 2 * D);
-            at.D = D; at.HD = HD; at.n = L; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb;
+            at.D = D; at.HD = HD; at.n = L; at.bag = bag; at.bag_ld = net.bag_ld; at.lpb = lpb; at.drop = drop;
             TL_LAUNCH(tl_bag_attn_bwd_kernel, dim3(B, H), dim3(256), ((size_t)2 * bag * HD + (size_t)L * bag) * sizeof(float), stream, at);
         }
         if ((rc = dx(FG(net.go_bag_dq, D), D, net.off_bag_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;                  // + dq W_q

@@ -64,7 +64,7 @@ typedef struct DtqnNet {
     int32_t force_tiled;      /* input: 1 = lay the records out for the row-block tiled kernels even where the whole-sequence kernels
                                * cover the shape (dtqn_net_tiled_twin) */
     int32_t bag_size;         /* persistent-memory bag (utils/bag.py, dtqn.py:134-147,201-214): 0 = none.  Bag networks run on the row-block
-                               * tiled path (bag_size <= padded context, no dropout) */
+                               * tiled path (bag_size <= padded context) */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
                                * forwards only; 0 = off.  Whole-sequence kernels only (DTQN_ERR_CONFIG on the row-block tiled path) */
     /* ---- derived: geometry ---- */

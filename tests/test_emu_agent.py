@@ -394,7 +394,6 @@ def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu, tiled,
     assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
     agent.eval_off()
     assert DTQN(3, 3, 8, 0, 128, 8, 2, 128, dropout=0.1, _test_lib=emu).net.tiled == 1       # long contexts: row-block kernels, with dropout
-    with pytest.raises(NotImplementedError):
-        DTQN(3, 3, 8, 0, 64, 8, 2, 20, dropout=0.1, bag_size=4, _test_lib=emu)          # bag networks: dropout not covered
+    assert DTQN(3, 3, 8, 0, 64, 8, 2, 20, dropout=0.1, bag_size=4, _test_lib=emu).net.tiled == 1
     with pytest.raises(ValueError):
         DTQN(3, 3, 8, 0, 32, 4, 2, 20, dropout=1.5, _test_lib=emu)

@@ -216,7 +216,7 @@ def test_forward_with_a_bag(emu, kw):
 
 
 def test_bag_configurations_outside_the_kernels_are_refused(emu):
-    for kw in (dict(bag_size=80), dict(dropout=0.1)):
+    for kw in (dict(bag_size=80), dict(inner_embed_size=32, num_heads=4)):
         kw = {**dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=20, bag_size=5), **kw}
         with pytest.raises(NotImplementedError):
             net_from_cfg(emu, O.NetCfg(**kw))

@@ -258,6 +258,9 @@ BAG_TD = [
           bag_size=7), dict(batch=2, T=90, mask=8)),
     (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, num_layers=1, history_len=12, action_dim=4, bag_size=12, gate="gru"),
      dict(batch=3, T=20, mask=-5, history=6)),
+    # dropout: the bag attention drops attention weights too (its own site of the mask key); bag embeddings are not dropped
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, num_layers=1, history_len=20, bag_size=6, dropout=0.2, action_dim=4),
+     dict(batch=3, T=30, mask=-5)),
     # identity-reordered layers: no closing LayerNorm, the working memory is the last layer's stream
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, num_layers=2, history_len=20, bag_size=6, identity=True, pos="sin"),
      dict(batch=3, T=30, mask=-5, tuf=2)),
