@@ -30,6 +30,10 @@ BAG_TD = [
      dict(batch=3, T=140, mask=11, n_eps=8, history=40)),
     (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=100, discrete=True, vocab_sizes=22, num_layers=1, bag_size=64),
      dict(batch=2, T=120, mask=21, n_eps=5)),
+    # identity-reordered layers; dropout (incl. the bag attention's own)
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, bag_size=8, identity=True, pos="sin"), dict(batch=6, T=80, mask=-5, n_eps=12)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, history_len=70, discrete=True, vocab_sizes=9, action_dim=8, bag_size=7, dropout=0.2),
+     dict(batch=4, T=90, mask=8, tuf=2)),
 ]
 
 
@@ -39,6 +43,7 @@ def test_td_update_with_a_bag_vs_oracle(lib, kw, run):
     net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=35, batch=run["batch"], T=run["T"], n_eps=run.get("n_eps", 9), mask=run["mask"],
                                                history=run.get("history"), tuf=run.get("tuf", 10_000), device="cuda", test_lib=False)
     assert net.tiled == 1 and net.bag_size == cfg.bag_size
+    eng.td.dropout_seed = 777
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
 
 
