@@ -252,23 +252,29 @@ class DtqnAgent:
             self.bag.reset()
 
     @torch.no_grad()
+    def _bag_insert(self, bag: Bag, ctx: Context, evicted_obs, evicted_action) -> None:
+        """What the context evicted goes to the bag; a full bag keeps the best of its bag_size + 1 candidate contents by the
+        policy network's mean-over-time max-Q (dtqn.py:125-157).  Shared by observe() and the vectorised rollout."""
+        if bag.add(evicted_obs, evicted_action):
+            return
+        # candidate i < bag_size: entry i replaced by the evicted pair; candidate bag_size: the bag as it is
+        k = bag.size + 1
+        cand_obss = np.tile(bag.obss, (k, 1, 1))
+        cand_actions = np.tile(bag.actions, (k, 1, 1))
+        for i in range(bag.size):
+            cand_obss[i, i] = evicted_obs
+            cand_actions[i, i] = evicted_action
+        q = self._bag_forward(np.tile(ctx.obs, (k, 1, 1)), np.tile(ctx.action, (k, 1, 1)), cand_obss, cand_actions)
+        keep = int(torch.argmax(torch.mean(torch.max(q, 2)[0], 1)).item())      # highest mean-over-time max-Q
+        bag.obss, bag.actions = cand_obss[keep], cand_actions[keep]
+
+    @torch.no_grad()
     def observe(self, obs: np.ndarray, action: int, reward: float, done: bool) -> None:
         """Add a transition to the context; what the context evicts goes to the bag, and when the bag is full the policy
         network picks which of the bag_size + 1 candidate bags to keep (dtqn.py:116-160)."""
         evicted_obs, evicted_action = self.context.add_transition(obs, action, reward, done)
-        bag = self.bag
-        if bag.size > 0 and evicted_obs is not None and not bag.add(evicted_obs, evicted_action):
-            # candidate i < bag_size: entry i replaced by the evicted pair; candidate bag_size: the bag as it is
-            k = bag.size + 1
-            cand_obss = np.tile(bag.obss, (k, 1, 1))
-            cand_actions = np.tile(bag.actions, (k, 1, 1))
-            for i in range(bag.size):
-                cand_obss[i, i] = evicted_obs
-                cand_actions[i, i] = evicted_action
-            ctx = self.context
-            q = self._bag_forward(np.tile(ctx.obs, (k, 1, 1)), np.tile(ctx.action, (k, 1, 1)), cand_obss, cand_actions)
-            keep = int(torch.argmax(torch.mean(torch.max(q, 2)[0], 1)).item())      # highest mean-over-time max-Q
-            bag.obss, bag.actions = cand_obss[keep], cand_actions[keep]
+        if self.bag.size > 0 and evicted_obs is not None:
+            self._bag_insert(self.bag, self.context, evicted_obs, evicted_action)
         if self.train_mode == TrainMode.TRAIN:
             self.replay_buffer.store(obs, action, reward, done, self.context.timestep)
 

@@ -20,20 +20,23 @@ import numpy as np
 import torch
 
 from .. import _binding as B
+from ..utils.bag import Bag
 from ..utils.context import Context
 from ..utils.random import RNG
 
 
 class VectorActor:
     def __init__(self, agent, envs: Sequence, ref_quirks: bool = False):
-        if agent.bag.size > 0:
-            raise NotImplementedError("the vectorised rollout keeps no per-environment bags; bag networks step one environment")
         self.agent, self.envs = agent, list(envs)
         N = self.n = len(self.envs)
         L, O, A = agent.context_len, agent.env_obs_length, agent.num_actions
         self.L, self.O, self.A = L, O, A
         self.contexts: List[Context] = [Context(L, agent.obs_mask, A, O, discrete=agent.is_discrete_env, ref_quirks=ref_quirks)
                                         for _ in range(N)]
+        # bag networks: one bag per environment (utils/bag.py; dtqn.py:66-74 keeps one per agent because it steps one environment)
+        self.bags = [Bag(agent.bag.size, agent.obs_mask, O, discrete=agent.is_discrete_env, ref_quirks=ref_quirks)
+                     for _ in range(N)] if agent.bag.size > 0 else None
+        self._q_pending = None
         self.episodes = [[] for _ in range(N)]            # per env: [first_obs, (obs, action, reward, done), ...]
         self.returns = np.zeros(N)
         cuda = agent.device.type == "cuda"
@@ -67,12 +70,24 @@ class VectorActor:
     def _reset(self, i: int) -> None:
         obs = self.envs[i].reset()
         self.contexts[i].reset(obs)
+        if self.bags is not None:
+            self.bags[i].reset()
         self.episodes[i] = [np.array(obs, copy=True)]
         self.returns[i] = 0.0
 
     def _launch_q(self) -> None:
         """Stage all N contexts and launch the batched actor forward on the learner's stream (no synchronisation)."""
         a, eng = self.agent, self.agent.engine
+        if self.bags is not None:
+            # bag networks: the module forward with the N bags (dtqn_forward_bag); every sequence runs the longest prefix, the
+            # rows behind a shorter one cannot reach its last live row (causal), its own bag attends row by row
+            lens = [min(c.max_length, c.timestep + 1) for c in self.contexts]
+            n_max = max(lens)
+            obs = np.stack([c.obs[:n_max] for c in self.contexts])
+            act = np.stack([c.action[:n_max] for c in self.contexts])
+            q = a._bag_forward(obs, act, np.stack([b.obss for b in self.bags]), np.stack([b.actions for b in self.bags]))
+            self._q_pending = (q, lens)
+            return
         n_max = 1
         for i, ctx in enumerate(self.contexts):
             n = min(ctx.max_length, ctx.timestep + 1)
@@ -91,6 +106,12 @@ class VectorActor:
             self._ev.record(a._main_stream)
 
     def _wait_q(self) -> np.ndarray:
+        if self._q_pending is not None:
+            q, lens = self._q_pending
+            self._q_pending = None
+            qh = q.cpu().numpy()
+            self._q_np[:] = np.stack([qh[i, n - 1] for i, n in enumerate(lens)])
+            return self._q_np
         if self._ev is not None:
             self._ev.synchronize()              # the forward only: work queued behind it (TD updates) keeps running
         return self._q_np
@@ -133,7 +154,9 @@ class VectorActor:
             a = int(actions[i])
             obs, reward, done, info = env.step(a)
             stored_done = False if info.get("TimeLimit.truncated", False) else done     # run.py:368-376
-            self.contexts[i].add_transition(obs, a, reward, stored_done)
+            evicted_obs, evicted_action = self.contexts[i].add_transition(obs, a, reward, stored_done)
+            if self.bags is not None and evicted_obs is not None:
+                agent._bag_insert(self.bags[i], self.contexts[i], evicted_obs, evicted_action)
             self.episodes[i].append((np.array(obs, copy=True), a, float(reward), bool(stored_done)))
             self.returns[i] += reward
             if done:

@@ -7,8 +7,7 @@ running the DTQN hot path on the MI355X engine (dtqn_amd).
 Differences from the reference, all at the edges of the hot path:
   * `--envs` defaults to the LIST ["DiscreteCarFlag-v0"] (the reference's string default iterates
     over characters, SURVEY.md section 4 quirk 7);
-  * `--model` accepts DTQN only; `--render` and image domains are out of scope; `--bag-size > 0` works with one
-    environment per process (no `--num-envs`);
+  * `--model` accepts DTQN only; `--render` and image domains are out of scope;
   * new flags: `--sampler {reference,device}` (replay index draw on the host with Python's `random`
     stream like the reference, or on the GPU), `--ref-quirks` (reproduce the reference's
     int-truncated actor context), `--prepopulate N` (the reference hard-codes 50 000);

@@ -232,3 +232,90 @@ def test_bag_class_matches_the_reference_semantics():
     q.add(np.array([0.9, -0.9]), 1)
     assert q.obss.dtype == np.int64 and q.obss[0].tolist() == [0, 0]
     assert Bag(2, 7, 1, discrete=True).obss.dtype == np.int64
+
+
+class _ScriptedEnv:
+    """Replays a fixed observation sequence (the golden rollout's) behind the env surface the vectorised rollout uses."""
+
+    def __init__(self, traj):
+        self.traj, self.t = traj, 0
+
+    def reset(self):
+        self.t = 0
+        return self.traj[0]
+
+    def step(self, action):
+        self.t += 1
+        return self.traj[self.t], 0.0, False, {}
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_vectorised_rollout_keeps_one_bag_per_environment(emu, name):
+    """VectorActor with a bag network: N environments, N bags, one batched forward per vector step.  Fed the golden rollout's
+    observations in two environments (one of them a step behind, so the prefixes are ragged), every environment reproduces the
+    reference's greedy actions and bag contents step by step."""
+    import dtqn_amd.utils.random as rnd
+    from dtqn_amd.agents.vector import VectorActor
+    z, cfg, meta, pol, tgt = load_case(name)
+    rnd.RNG.rng = np.random.Generator(np.random.PCG64(meta["seed"] + 3))
+    agent = make_bag_agent(emu, cfg, meta, pol, tgt)
+    agent.eval_off()
+    traj = z[f"{name}_act_traj"]
+    vec = VectorActor(agent, [_ScriptedEnv(traj), _ScriptedEnv(traj)])
+    assert vec.bags is not None and len(vec.bags) == 2
+    vec.reset_all()
+    # the padding actions of a fresh context are random draws (utils/context.py:50): give both contexts the golden agent's
+    rnd.RNG.rng = np.random.Generator(np.random.PCG64(meta["seed"] + 3))
+    ref_ctx_actions = rnd.RNG.rng.integers(cfg.num_actions, size=(cfg.history_len, 1))
+    for c in vec.contexts:
+        c.action[:] = ref_ctx_actions
+    # environment 1 runs one step behind: advance environment 0 alone first
+    q0 = vec.q_values()
+    a0 = int(np.argmax(q0[0]))
+    assert a0 == int(z[f"{name}_act_actions"][0])
+    obs, r, d, info = vec.envs[0].step(a0)
+    ev = vec.contexts[0].add_transition(obs, a0, r, d)
+    assert ev[0] is None
+    steps = len(traj) - 2
+    for t in range(steps):
+        q = vec.q_values()
+        acts = np.argmax(q, axis=1)
+        assert int(acts[0]) == int(z[f"{name}_act_actions"][t + 1]) and int(acts[1]) == int(z[f"{name}_act_actions"][t]), t
+        for i, env in enumerate(vec.envs):
+            obs, r, d, info = env.step(int(acts[i]))
+            eo, ea = vec.contexts[i].add_transition(obs, int(acts[i]), r, d)
+            if eo is not None:
+                agent._bag_insert(vec.bags[i], vec.contexts[i], eo, ea)
+        for i, tt in ((0, t + 1), (1, t)):
+            assert vec.bags[i].pos == int(z[f"{name}_act_bag_pos"][tt]), (t, i)
+            assert np.array_equal(np.asarray(vec.bags[i].obss, dtype=np.float64), z[f"{name}_act_bag_obss"][tt]), (t, i)
+            assert np.array_equal(np.asarray(vec.bags[i].actions, dtype=np.int64), z[f"{name}_act_bag_actions"][tt]), (t, i)
+    assert vec.bags[0].is_full and vec.bags[1].is_full
+    # and the public loop: one vector step through step_all keeps going from here without error, bags reset with their envs
+    vec._reset(1)
+    assert vec.bags[1].pos == 0
+
+
+def test_vectorised_rollout_with_bags_runs_the_public_loop(emu):
+    """step_all() on live environments with a bag network: contexts overflow into the per-environment bags, finished episodes are
+    replayed into the buffer, and train() samples bags for them."""
+    import dtqn_amd.utils.random as rnd
+    from dtqn_amd import envs
+    from dtqn_amd.agents.vector import VectorActor
+    z, cfg, meta, pol, tgt = load_case("cont")
+    rnd.RNG.rng = np.random.Generator(np.random.PCG64(9))
+    meta = {**meta, "T": 200, "n_eps": 30, "B": 2}
+    agent = make_bag_agent(emu, cfg, meta, pol, tgt)
+    agent.eval_off()
+    es = [envs.make("DiscreteCarFlag-v0") for _ in range(3)]
+    for i, e in enumerate(es):
+        e.seed(i)
+    vec = VectorActor(agent, es)
+    vec.reset_all()
+    done = 0
+    for _ in range(260):
+        done += vec.step_all(0.3)
+    assert done >= 3 and any(b.pos > 0 for b in vec.bags)
+    assert agent.replay_buffer.can_sample(agent.batch_size)
+    agent.train()
+    assert agent.num_train_steps == 1 and agent.td_errors.mean() >= 0
