@@ -99,7 +99,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_actor_forward": [P(DtqnNet), vp, vp, vp, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_actor_forward_batch": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp, i32, u32, u32, vp],
         "dtqn_forward_tiled_strided": [P(DtqnNet), vp, vp, vp, i32, i32, i32, vp, vp, vp],
-        "dtqn_forward_bag": [P(DtqnNet), vp, vp, vp, vp, vp, i32, i32, vp, vp, vp],
+        "dtqn_forward_bag": [P(DtqnNet), vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, u32, u32, vp],
         "dtqn_forward": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp],
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
         "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],

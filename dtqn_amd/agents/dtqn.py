@@ -193,8 +193,14 @@ class DtqnAgent:
     def _bag_forward(self, obs: np.ndarray, actions: np.ndarray, bag_obss: np.ndarray, bag_actions: np.ndarray) -> torch.Tensor:
         """policy_network(obs, actions, bag_obss, bag_actions) on host arrays (batch-first); Q stays on the device."""
         t = lambda a, dt: torch.as_tensor(a, dtype=dt, device=self.device)
+        drop = None
+        if self.train_mode == TrainMode.TRAIN and self.policy_network.dropout_p > 0.0:
+            # the reference's policy network is in train mode here (dqn.py:102-115): fresh keep masks per forward, keyed like
+            # the plain actor's (seed ^ 0xAC70, count of actor forwards)
+            self._actor_calls += 1
+            drop = (int(self.engine.td.dropout_seed) ^ 0xAC70, self._actor_calls)
         return self.policy_network(t(obs, self.obs_tensor_type), t(actions, torch.long), t(bag_obss, self.obs_tensor_type),
-                                   t(bag_actions, torch.long))
+                                   t(bag_actions, torch.long), _train_dropout=drop)
 
     def _bag_action(self) -> int:
         """get_action of a bag network (dtqn.py:79-108): the unpadded context prefix plus the WHOLE bag, padding included."""

@@ -2255,7 +2255,9 @@ extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const 
 }
 
 extern "C" int dtqn_forward_bag(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
-                                const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, void* stream) {
+                                const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, int train_mode,
+                                uint32_t dropout_seed, uint32_t dropout_step, void* stream) {
     if (!net || net->bag_size < 1) return DTQN_ERR_ARG;
-    return forward_tiled_impl(net, theta, obs, actions, bag_obs, bag_actions, batch, n, n, q_out, workspace, stream);
+    return forward_tiled_impl(net, theta, obs, actions, bag_obs, bag_actions, batch, n, n, q_out, workspace, stream, train_mode, dropout_seed,
+                              dropout_step);
 }

@@ -114,7 +114,8 @@ class DTQN(nn.Module):
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, obss: torch.Tensor, actions: Optional[torch.Tensor] = None,
-                bag_obss: Optional[torch.Tensor] = None, bag_actions: Optional[torch.Tensor] = None) -> torch.Tensor:
+                bag_obss: Optional[torch.Tensor] = None, bag_actions: Optional[torch.Tensor] = None,
+                _train_dropout: Optional[tuple] = None) -> torch.Tensor:
         """obss [B, seq, obs_dim] (float, or integer tokens for discrete envs), actions [B, seq, 1]
         -> Q [B, seq, num_actions].  Inference only (no autograd graph)."""
         seq = obss.size(1)
@@ -143,8 +144,11 @@ class DTQN(nn.Module):
                 ba = None
                 if self.net.action_dim > 0:
                     ba = bag_actions.to(device=dev).reshape(obss.size(0), self.bag_size).to(torch.uint8).contiguous()
+                # _train_dropout = (seed, step): a train-mode forward of the agent (acting, bag eviction) with dropout > 0
+                td_ = _train_dropout if (_train_dropout is not None and self.dropout_p > 0.0) else None
                 rc = self._lib.dtqn_forward_bag(ctypes.byref(self.net), cp(self.flat), cp(o), cp(a), cp(bo), cp(ba), int(obss.size(0)), int(seq),
-                                                cp(q), cp(ws), stream)
+                                                cp(q), cp(ws), 1 if td_ else 0, int(td_[0]) & 0xFFFFFFFF if td_ else 0,
+                                                int(td_[1]) & 0xFFFFFFFF if td_ else 0, stream)
                 if rc != 0:
                     raise RuntimeError(f"dtqn_forward_bag failed with DTQN status {rc}")
                 return q

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 8
+#define DTQN_ABI_VERSION 9
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -314,9 +314,12 @@ int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, const void*
                              float* q_dev, float* q_last_host, float* workspace, int train_mode, uint32_t dropout_seed,
                              uint32_t dropout_step, void* stream);
 /* DTQN.forward with the bag arguments (dtqn.py:158-218 incl. :201-214): bag_obs [B][bag_size][O] f32, bag_actions [B][bag_size] u8
- * (NULL when action_dim == 0).  Row-block tiled path; workspace as dtqn_forward_tiled. */
+ * (NULL when action_dim == 0).  Row-block tiled path; workspace as dtqn_forward_tiled.
+ * train_mode != 0 with net->dropout > 0: a train-mode forward (the reference's policy network stays in train mode while the agent
+ * acts and while it chooses what the bag keeps, dqn.py:102-115): keep masks keyed by (dropout_seed, dropout_step, sequence). */
 int dtqn_forward_bag(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
-                     const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, void* stream);
+                     const uint8_t* bag_actions, int batch, int n, float* q_out, float* workspace, int train_mode,
+                     uint32_t dropout_seed, uint32_t dropout_step, void* stream);
 /* dtqn_forward_tiled with `in_rows` (>= n) rows per sequence in the obs / actions arrays. */
 int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                                int in_rows, float* q_out, float* workspace, void* stream);

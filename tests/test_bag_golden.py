@@ -319,3 +319,49 @@ def test_vectorised_rollout_with_bags_runs_the_public_loop(emu):
     assert agent.replay_buffer.can_sample(agent.batch_size)
     agent.train()
     assert agent.num_train_steps == 1 and agent.td_errors.mean() >= 0
+
+
+def test_bag_agent_with_dropout_acts_in_train_mode(emu):
+    """--bag-size N --dropout p: the action forward of a bag network runs in train mode like the reference's (dqn.py:102-115):
+    fresh keep masks per call -- context tokens, attention weights of the layers and of the bag attention -- equal to the oracle's
+    forward with the same counter-based masks; under eval_on() repeated forwards are identical and equal the oracle without dropout."""
+    import dtqn_amd.utils.random as rnd
+    z, cfg0, meta, pol, tgt = load_case("cont")
+    cfg = O.NetCfg(**{**cfg0.to_json(), "dropout": 0.25})
+    rnd.RNG.rng = np.random.Generator(np.random.PCG64(2))
+    from dtqn_amd.agents.dtqn import DtqnAgent
+    from dtqn_amd.networks.dtqn import DTQN
+
+    def factory():
+        m = DTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size, cfg.num_heads, cfg.num_layers,
+                 cfg.history_len, bag_size=cfg.bag_size, dropout=cfg.dropout, _test_lib=emu)
+        m._allow_cpu = True
+        m.load_state_dict({k: (pol[k] if k in pol else v) for k, v in m.state_dict().items()})
+        return m
+    agent = DtqnAgent(factory, buffer_size=600, device=torch.device("cpu"), env_obs_length=cfg.obs_dim, max_env_steps=40, obs_mask=meta["mask"],
+                      num_actions=cfg.num_actions, is_discrete_env=False, batch_size=2, context_len=cfg.history_len, history=cfg.history_len,
+                      bag_size=cfg.bag_size)
+    agent.eval_off()
+    traj = z["cont_act_traj"]
+    agent.context_reset(traj[0])
+    for t in range(cfg.history_len + 3):                        # a full context and a partly filled bag
+        agent.observe(traj[t + 1], int(t % cfg.num_actions), 0.0, False)
+    assert 0 < agent.bag.pos < agent.bag.size           # padding entries stay in the bag forward, like the reference
+    ctx, bag, eng = agent.context, agent.bag, agent.engine
+    ot = torch.float32
+    args = (torch.as_tensor(ctx.obs[None], dtype=ot), torch.as_tensor(ctx.action[None], dtype=torch.long))
+    bargs = dict(bag_obss=torch.as_tensor(bag.obss[None], dtype=ot), bag_actions=torch.as_tensor(bag.actions[None], dtype=torch.long))
+    qs = []
+    for _ in range(2):
+        q = agent._bag_forward(ctx.obs[None], ctx.action[None], bag.obss[None], bag.actions[None]).numpy()[0]
+        spec = O.DropSpec(cfg.dropout, int(eng.td.dropout_seed) ^ 0xAC70, agent._actor_calls, 0)
+        with torch.no_grad():
+            ref = O.forward(pol, cfg, *args, None, spec, **bargs).numpy()[0]
+        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        qs.append(q)
+    assert not np.array_equal(qs[0], qs[1])
+    agent.eval_on()
+    ev = [agent._bag_forward(ctx.obs[None], ctx.action[None], bag.obss[None], bag.actions[None]).numpy()[0] for _ in range(2)]
+    with torch.no_grad():
+        ref = O.forward(pol, cfg, *args, **bargs).numpy()[0]
+    assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

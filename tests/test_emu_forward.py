@@ -208,7 +208,7 @@ def test_forward_with_a_bag(emu, kw):
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         u8 = lambda a: np.ascontiguousarray(a.reshape(Bn, -1), dtype=np.uint8)
         rc = emu.dtqn_forward_bag(ctypes.byref(net), ptr(theta), ptr(f32(obs)), ptr(u8(act)), ptr(f32(bag_obs)), ptr(u8(bag_act)), Bn, n,
-                                  ptr(q), ptr(ws), None)
+                                  ptr(q), ptr(ws), 0, 0, 0, None)
         assert rc == 0
         assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
     # the bag-less entry refuses a bag network
