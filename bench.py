@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the DTQN TD-update hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: under torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is one rank; started plainly, bench.py
+re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 (one rank per GPU over RCCL).
 
 One "step" = one DtqnAgent.train() = one TD update (sample windows -> 3 forwards -> double-DQN loss
 -> backward -> clip -> Adam; four launches at batch 32, the window draw is part of the forward kernel) on a device-resident
 synthetic replay of the shape SURVEY.md section 8d prescribes.  Workload at every N: BASELINE.json's metric configuration, DiscreteCarFlag-v0 shapes,
 context 50, d_model 64, 8 heads, 2 layers, batch 32 PER GPU (weak scaling: each rank owns its
 replay shard and batch; the only exchange is the flat-gradient all-reduce over RCCL).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line (kept under 4 KB: the contract keys first, then `roofline` and `cpu_baseline`, then one-number
+summaries) and writes everything else it measured -- per-update latency distributions, per-config details, counter dumps --
+to gpurun_out/bench_detail.json.
 """
 from __future__ import annotations
 
@@ -132,43 +137,58 @@ def time_kernels(agent, iters: int = 50) -> dict:
             e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         out[name] = float(np.mean(ts))          # us
+    agent._calls_issued += 3 + iters            # the statistics ring counts optimizer launches: keep the host's count in step
+    agent._drain_stats(block=True)
     return out
 
 
 def _round_profiles(kind: str, cid: int):
-    """profiles/r02<suffix>_<kind>_cfg<N>.json of this round, newest suffix first ('' < 'b' < 'c' ...)."""
+    """profiles/r<NN><suffix>_<kind>_cfg<N>.json, newest round and suffix first ('r02' < 'r02b' < 'r03' ...)."""
     import glob
-    return sorted(glob.glob(os.path.join(ROOT, "profiles", f"r02*_{kind}_cfg{cid}.json")), reverse=True)
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]*_{kind}_cfg{cid}.json")), reverse=True)
+
+
+def build_digest() -> str:
+    """Source digest of the engine that is loaded (dtqn_build_info: 'dtqn_hip gfx950 src=<digest>')."""
+    from dtqn_amd import engine
+    info = engine.get_lib().dtqn_build_info().decode()
+    return info.split("src=")[-1].split()[0] if "src=" in info else info
 
 
 def pmc_traffic(kernel: str, batch: int, cid: int = 1):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's wide coalesced reads): this
-    round's profile of the config (profiles/r02_pmc_traffic_cfg<N>.json) when it matches the batch, else round 1's
-    cfg-1 profile.  None when no profile matches."""
-    # (r02b / r02c ...: re-profiles of a config after later kernel changes of the round; the newest one wins)
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc passes of this config (FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, in KB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    tools/profile_round3.sh is the only writer of those files and stamps them with the engine's source digest and the git
+    commit (`_meta`).  Returns (bytes, source) -- source names the file, its stamp and whether the stamp equals the engine
+    loaded now (false: the counters were taken on other kernels than the ones being timed) -- or (None, None)."""
     cands = _round_profiles("pmc_traffic", cid) if CONFIGS[cid]["B"] == batch else []
     cands.append(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_B{batch}.json"))
     for path in cands:
         if not os.path.exists(path):
             continue
         d = json.load(open(path))
+        meta = d.get("_meta", {})
         for k, v in d.items():
-            if kernel in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
-    return None
+            if k != "_meta" and kernel in k and v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None:
+                src = {"file": os.path.relpath(path, ROOT), "src": meta.get("src"), "git": meta.get("git"),
+                       "matches_build": meta.get("src") == build_digest()}
+                return int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), src
+    return None, None
 
 
 def _oracle_learner(c, batch):
     from oracle import dtqn_oracle as O
     from oracle.replay_oracle import ReplayOracle, synth_fill
     disc = c["kind"] != "box"
-    vocab = c["nvec"] + 1 if disc else 0                    # tokens 0..nvec-1 plus the padding mask value
+    # reference mask / vocabulary (utils/env_processing.py:100-112, agent_utils.py:92-95): Discrete(n): mask n, V = n + 1;
+    # MultiDiscrete(nvec): mask max(nvec) + 1, V = max(nvec) + 2 (cfg 3: mask 8, V = 9)
+    mask = (c["nvec"] + 1 if c["kind"] == "multidiscrete" else c["nvec"]) if disc else -5
+    vocab = mask + 1 if disc else 0
     cfg = O.NetCfg(obs_dim=c["O"], num_actions=c["A"], inner_embed_size=c["D"], num_heads=c["H"], num_layers=c["NL"],
                    history_len=c["L"], discrete=disc, vocab_sizes=vocab)
     learner = O.OracleLearner(cfg, O.init_params(cfg, seed=1))
     n_eps = max(58, batch + 8) if c["T"] <= 64 else 58
-    buf = ReplayOracle((n_eps + 2) * c["T"], c["O"], c["nvec"] if disc else -5, c["T"], c["L"])
+    buf = ReplayOracle((n_eps + 2) * c["T"], c["O"], mask, c["T"], c["L"])
     synth_fill(buf, np.random.Generator(np.random.PCG64(1)), n_eps, disc, vocab, c["A"], min_len=5)
     ot = torch.long if disc else torch.float32
 
@@ -248,6 +268,77 @@ def make_agent(c, batch, device, rank, sampler):
     return agent
 
 
+def time_hbm_kernels(agent, c, kern: dict, iters: int = 50) -> dict:
+    """The HBM-bound launches of the path, each priced as algorithmic bytes per launch / average
+    launch duration (HIP events on the launch stream) / 8 TB/s:
+      dtqn_clip_adam_kernel      28 * P_t bytes (read p, g, m, v; write p, m, v)
+      dtqn_replay_sample_kernel  B draws: episode length read + (episode, start) written = 12 * B bytes
+      dtqn_replay_apply_kernel   256 producer records of an env-step stream: 32-byte record + observation row read from pinned
+                                 staging, obs row + action + reward + done + episode length written (a cleanse of a slot,
+                                 (T + 1) * (4 * O + 1) + 5 * T bytes, once per episode start)
+    At these sizes (0.4 - 7 MB, a few KB for the replay kernels) a launch is a few microseconds of launch floor; the fractions
+    are small by construction and reported because north_star asks for them."""
+    eng, rb = agent.engine, agent.replay_buffer
+    lib, rep = eng.lib, rb.dev
+    stream = torch.cuda.current_stream()
+    s = ctypes.c_void_p(stream.cuda_stream)
+    p_t = eng.net.n_trainable
+    out = {"dtqn_clip_adam_kernel": {"bytes": 28 * p_t, "us": kern["dtqn_clip_adam_kernel"]}}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        stream.synchronize()
+        ts = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        return float(np.mean(ts))
+
+    n_valid, exclude = rb.valid_range()
+    out["dtqn_replay_sample_kernel"] = {"bytes": 12 * eng.batch,
+                                        "us": timed(lambda: eng.sample_on_device(rep, n_valid, exclude, 1, stream=s))}
+    # producer: commits of 256 records (the staging capacity) written into the slot in progress; the slot is restored afterwards
+    E, T, O = rb.max_size, c["T"], c["O"]
+    slot = exclude
+    keep = {k: getattr(rep, k)[slot].clone() for k in ("obs", "actions", "rewards", "dones")}
+    keep_len, keep_pos = int(rb.episode_lengths[slot]), list(rb.pos)
+    n_rec = rb.STAGE_CAPACITY
+    obs_rows = np.random.Generator(np.random.PCG64(3)).uniform(-1, 1, size=(n_rec, O)).astype(np.float32)
+    ts = []
+    for i in range(8 + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rb.pos = [keep_pos[0], 0]
+        rb.store_obs(obs_rows[0])
+        for j in range(1, n_rec):
+            t = (j - 1) % T
+            rb.store(obs_rows[j], 1, 0.5, False, t + 1)
+            if t == T - 1:
+                rb.pos = [keep_pos[0], 0]
+        e0.record(stream)
+        rb.commit(stream_ptr=s)
+        e1.record(stream)
+        e1.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1) * 1e3)
+    apply_bytes = n_rec * (32 + 4 * O) + (n_rec - 1) * (4 * O + 1 + 4 + 1 + 4) + ((T + 1) * (4 * O + 1) + 5 * T)
+    out["dtqn_replay_apply_kernel"] = {"bytes": apply_bytes, "us": float(np.mean(ts)), "records": n_rec}
+    for k in ("obs", "actions", "rewards", "dones"):
+        getattr(rep, k)[slot].copy_(keep[k])
+    rb.episode_lengths[slot] = keep_len
+    rep.ep_len.copy_(torch.from_numpy(rb.episode_lengths))
+    rb.pos = keep_pos
+    torch.cuda.synchronize()
+    for v in out.values():
+        v["GBs"] = v["bytes"] / (v["us"] * 1e-6) / 1e9
+        v["frac"] = v["GBs"] / HBM_PEAK_GBS
+    return out
+
+
 def update_latency(agent, n: int = 500) -> dict:
     """Distribution of the GPU time of single updates: one HIP event pair per update on the launch stream, n updates
     issued back to back (no host synchronisation in between), median / p10 / p90 in microseconds."""
@@ -267,20 +358,19 @@ def update_latency(agent, n: int = 500) -> dict:
 
 
 def mfma_counters(cid: int):
-    """Hardware MFMA utilisation from the committed rocprofv3 --pmc pass of this config (tools/profile_round.sh ->
-    profiles/r02_pmc_mfma_cfg<N>.json), per kernel: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and the MFMA op count.
-    None when the round holds no such profile."""
+    """Hardware MFMA utilisation from the newest committed rocprofv3 --pmc pass of this config (per kernel:
+    SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and the MFMA op count).  Goes to the detail file, never into the line."""
     for path in _round_profiles("pmc_mfma", cid):
         d = json.load(open(path))
         if d:
-            return d
+            return {"file": os.path.relpath(path, ROOT), "counters": d}
     return None
 
 
 def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
     """BASELINE configs 2-5 at their per-GPU batch on this GPU: TD-updates/s (wall clock over `steps` updates), the
     per-update latency distribution, the achieved algorithmic FP32 FLOP rate of the whole update (5 * B * L * F_tok,
-    SURVEY.md section 8d) against the MFMA peak, the measured MFMA counters of the round's profile, and the CPU baseline."""
+    SURVEY.md section 8d) against the MFMA peak, and the CPU baseline."""
     out = {}
     for cid in (2, 3, 4, 5):
         c = CONFIGS[cid]
@@ -295,18 +385,46 @@ def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
         dt = (time.perf_counter() - t0) / steps
         agent._drain_stats(block=True)
         gflop = 5 * c["B"] * c["L"] * f_tok(c) / 1e9
+        kern = time_kernels(agent, 20) if not agent.engine.net.tiled else {}
         out[f"config{cid}"] = {"workload": f"{c['name']}: ctx={c['L']}, d_model={c['D']}, {c['H']} heads, {c['NL']} layers, batch {c['B']}",
                                "td_updates_per_s": 1.0 / dt, "ms_per_update": dt * 1e3, "samples_per_s": c["B"] / dt,
                                "update_latency_us": update_latency(agent, 300),
                                "algorithmic_gflop_per_update": gflop, "achieved_tflops": gflop / dt / 1e3,
                                "frac_of_f32_mfma_peak": gflop / dt / 1e3 / MFMA_F32_PEAK_TFLOPS,
-                               "mfma_counters": mfma_counters(cid),
+                               "kernels_us": kern,
+                               "clip_adam_hbm": ({"bytes": 28 * agent.engine.net.n_trainable, "us": kern["dtqn_clip_adam_kernel"],
+                                                  "frac": 28 * agent.engine.net.n_trainable / (kern["dtqn_clip_adam_kernel"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                                                 if kern else time_clip_adam(agent)),
                                "kernel_path": "row-block tiled" if agent.engine.net.tiled else "whole-sequence (LDS-resident)"}
         del agent
         torch.cuda.empty_cache()
         if with_cpu:
             out[f"config{cid}"]["cpu_baseline"] = cpu_baseline_other(cid)
     return out
+
+
+def time_clip_adam(agent, iters: int = 20) -> dict:
+    """The optimizer launch by itself (HIP events), priced against HBM: 28 * P_t bytes per launch."""
+    eng = agent.engine
+    stream = torch.cuda.current_stream()
+    s = ctypes.c_void_p(stream.cuda_stream)
+    n, t = ctypes.byref(eng.net), ctypes.byref(eng.td)
+    for _ in range(3):
+        eng.lib.dtqn_td_clip_adam(n, t, s)
+    stream.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.lib.dtqn_td_clip_adam(n, t, s)
+        e1.record(stream)
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    us = float(np.mean(ts))
+    agent._calls_issued += 3 + iters          # the statistics ring counts optimizer launches
+    agent._drain_stats(block=True)
+    b = 28 * eng.net.n_trainable
+    return {"bytes": b, "us": us, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0", vector_sizes=(8, 32)) -> dict:
@@ -355,6 +473,37 @@ def env_step_rate(agent, seconds: float = 3.0, env_id: str = "DiscreteCarFlag-v0
     return out
 
 
+def _self_launch(args) -> None:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (same interpreter, one rank per
+    GPU, rendezvous on 127.0.0.1) and hand the process over to the launcher; rank 0 of the job prints the line."""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def _r(x, nd=4):
+    """Round floats for the line (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+LINE_LIMIT = 4000      # bytes: the driver keeps an 8 KB stdout tail; round 2's 37 KB line was cut and never parsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,11 +515,15 @@ def main():
     ap.add_argument("--sampler", default="device", choices=["device", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-rate", action="store_true", help="skip the live env-steps/s loops (cleaner rocprofv3 traces)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the full measurement record goes (the printed line only carries summaries)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)                                # does not return
     rank, world, local = ddp.init_from_env("cuda")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     c = CONFIGS[args.config]
@@ -397,10 +550,10 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     agent._drain_stats(block=True)
-    allreduce_us = None
+    exchange_us = None
     if world > 1:
-        # the one exchange step of an update, timed by itself (every rank takes part; rank 0 reports): the flat gradient
-        # all-reduce over RCCL, HIP events on the launch stream
+        # the one exchange step of an update, timed by itself (every rank takes part; rank 0 reports), HIP events on the
+        # launch stream
         stream = torch.cuda.current_stream()
         ts = []
         for i in range(60):
@@ -411,8 +564,8 @@ def main():
             e1.synchronize()
             if i >= 10:
                 ts.append(e0.elapsed_time(e1) * 1e3)
-        allreduce_us = {"median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90)),
-                        "bytes": int(agent.engine.grad.numel() * 4)}
+        exchange_us = {"kind": agent.dp.exchange_kind(), "median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)),
+                       "p90": float(np.percentile(ts, 90)), "bytes": int(agent.engine.grad.numel() * 4)}
         sync_all()
 
     if rank == 0:
@@ -425,58 +578,68 @@ def main():
         dom = max(("dtqn_forward_kernel", "dtqn_backward_kernel"), key=lambda k: kern[k])
         # algorithmic FLOPs per launch: forward kernel = 3 forwards; backward kernel = data-gradient half
         # of the backward (~ 1x forward; the weight-gradient half runs in dtqn_wgrad_kernel)
-        flops = {"dtqn_forward_kernel": 3 * tokens * ft, "dtqn_backward_kernel": 1 * tokens * ft}[dom]
+        stage_flops = {"dtqn_forward_kernel": 3 * tokens * ft, "dtqn_backward_kernel": 1 * tokens * ft}
+        flops = stage_flops[dom]
         ach = flops / (kern[dom] * 1e-6) / 1e12
         p_t = agent.engine.net.n_trainable
         p_all = agent.engine.net.n_theta
         gather_bytes = args.batch * ((c["L"] + 1) * 4 * c["O"] + (c["L"] + 1) + c["L"] * 4 + c["L"])
         alg_bytes = gather_bytes + 4 * 2 * p_all + 4 * p_t + 28 * p_t
+        traffic, traffic_src = (None, None) if tiled else pmc_traffic(dom, args.batch, args.config)
+        whole_frac = 5 * tokens * ft / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
+        detail = {"build": build_digest(), "kernels_us": kern, "kernels_us_sum": float(sum(kern.values()))}
+        # -------- the line: contract keys first, then roofline and cpu_baseline, then one-number summaries ---------------
         line = {
             "metric": "env-steps/sec + TD-updates/sec, DiscreteCarFlag-v0 ctx=50 b=32, 1/2/4/8 GPU",
             "value": ups, "unit": "TD-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic replay (SURVEY.md section 8d shapes), random-init weights",
+            "data": "synthetic replay (SURVEY.md 8d shapes), random-init weights",
             "config": {"workload": f"{c['name']} shapes (BASELINE config {args.config}): ctx={c['L']}, d_model={c['D']}, {c['H']} heads, "
                                    f"{c['NL']} layers, obs {c['O']} {'f32' if c['kind'] == 'box' else 'tokens'}, {c['A']} actions, "
-                                   f"batch {args.batch} per GPU, history {c['L']}, device-resident replay {500_000 // c['T']} episodes x {c['T']} steps",
+                                   f"batch {args.batch} per GPU, history {c['L']}, device replay {500_000 // c['T']} x {c['T']} steps",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "sampler": args.sampler},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                         # (row-block path: the "kernel" is a stage of many tl_* launches; their counters are in the profile files)
-                         "traffic": None if tiled else pmc_traffic(dom, args.batch, args.config),
-                         "algorithmic_flops_per_launch": flops, "launch_us": kern[dom],
-                         # the other stage of the pair and the whole update, priced the same way (the backward is the
-                         # data-gradient half only: 1x the forward FLOPs of one pass; weight gradients are their own kernel)
-                         "per_stage": {k: {"launch_us": kern[k], "algorithmic_flops": f,
-                                           "frac": f / (kern[k] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS}
-                                       for k, f in (("dtqn_forward_kernel", 3 * tokens * ft), ("dtqn_backward_kernel", tokens * ft))},
-                         "whole_update_frac": 5 * tokens * ft / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         "mfma_counters": mfma_counters(args.config)},
-            "hbm_view": {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
-                         "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "kernels_us": kern, "kernels_us_sum": float(sum(kern.values())),
-            "update_latency_us": update_latency(agent),
-            "algorithmic_gflop_per_update": 5 * tokens * ft / 1e9,
+            "roofline": {"bound": "mfma", "kernel": dom if not tiled else dom.replace("_kernel", "") + " stage (row-block tl_* kernels)",
+                         "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_src": traffic_src, "launch_us": kern[dom], "flops_per_launch": flops,
+                         # both stages and the whole update priced the same way (backward = data-gradient half: 1x one
+                         # forward pass; weight gradients are their own kernel)
+                         "stage_frac": {k.replace("dtqn_", "").replace("_kernel", ""): f / (kern[k] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS
+                                        for k, f in stage_flops.items()},
+                         "whole_update_frac": whole_frac},
         }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(c, args.batch) if args.config == 1 else cpu_baseline_other(args.config, 12.0)
+            detail["cpu_baseline"] = cb
+            ref = cb.get("reference_in_build_container") or {}
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": cb["sample"],
+                                    "reference_train_in_build_container_updates_per_s":
+                                        {str(r["threads"]): r["td_updates_per_s"] for r in ref.get("runs", [])}}
+        line["kernels_us"] = {k.replace("dtqn_", "").replace("_kernel", ""): v for k, v in kern.items()}
+        line["hbm_view"] = {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
+                            "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if not tiled:
+            hb = time_hbm_kernels(agent, c, kern)
+            detail["hbm_kernels"] = hb
+            line["hbm_kernels"] = {k.replace("dtqn_", "").replace("_kernel", ""): {"bytes": v["bytes"], "us": v["us"], "frac_of_8TBs": v["frac"]}
+                                   for k, v in hb.items()}
+        lat = update_latency(agent)
+        detail["update_latency_us"] = lat
+        line["update_us_median"] = lat["us_median"]
         if world > 1:
-            line["allreduce_us"] = allreduce_us
-        if tiled:
-            line["roofline"]["kernel"] = dom.replace("_kernel", "") + " stage (row-block tiled: a sequence of tl_* kernels)"
+            line["exchange_us"] = exchange_us
         if world == 1 and args.config == 1 and not args.no_other_configs:
-            line["other_configs"] = other_configs(device)
+            oc = other_configs(device, with_cpu=not args.no_cpu_baseline)
+            detail["other_configs"] = {k: dict(v, mfma_counters=mfma_counters(int(k[-1]))) for k, v in oc.items()}
+            line["other_configs"] = {k[-1]: {"B": CONFIGS[int(k[-1])]["B"], "updates_per_s": v["td_updates_per_s"],
+                                             "frac_mfma": v["frac_of_f32_mfma_peak"], "clip_adam_frac_hbm": v["clip_adam_hbm"]["frac"],
+                                             "cpu_updates_per_s": v.get("cpu_baseline", {}).get("value")} for k, v in oc.items()}
         if world == 1 and c["kind"] == "box" and not args.no_env_rate:
             rates = env_step_rate(agent)
-            line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1_update_per_env_step": rates["coupled_1to1"],
-                                         "coupled_overlapped_two_streams": rates["coupled_1to1_overlapped"],
-                                         **{k: v for k, v in rates.items() if k.startswith("vector")},
-                                         "standalone_td_updates_per_s": ups,
-                                         "note": "vectorN_*: N host envs, one batched actor launch per vector step (dtqn_actor_forward_batch), "
-                                                 "N updates per vector step in the coupled loop (actor : learner = 1 : 1, actions of a vector "
-                                                 "step share one parameter version).  Others: "
-                                                 "single host env (CarFlag on the host cores), batch-1 actor forward on the GPU per "
-                                                 "step; in the coupled loops env-steps/s == TD-updates/s as in the reference "
-                                                 "(1 update per env step); 'overlapped' runs the actor forward of step t+1 "
-                                                 "concurrently with update t+1 (run.py --overlap)"}
+            detail["env_steps_per_sec"] = rates
+            line["env_steps_per_sec"] = {"actor_only": rates["actor_only"], "coupled_1to1": rates["coupled_1to1"],
+                                         "coupled_1to1_overlap": rates["coupled_1to1_overlapped"],
+                                         **{k: v for k, v in rates.items() if k.startswith("vector")}}
         if world == 1 and args.config == 1 and not args.no_env_rate:
             # live Memory-5-v0 (BASELINE config 3's env) on the host cores against the cfg-3 network on the GPU
             c3 = CONFIGS[3]
@@ -488,14 +651,26 @@ def main():
             import run as runpy
             runpy.prepopulate(a3, 30_000, [env])
             r3 = env_step_rate(a3, 2.0, "Memory-5-v0", vector_sizes=(8,))
-            line["env_steps_per_sec_config3"] = {"env": "Memory-5-v0 (live, host cores)", "batch": c3["B"], "actor_only": r3["actor_only"],
-                                                 "coupled_1_update_per_env_step": r3["coupled_1to1"],
-                                                 "coupled_overlapped_two_streams": r3["coupled_1to1_overlapped"],
-                                                 **{k: v for k, v in r3.items() if k.startswith("vector")}}
+            detail["env_steps_per_sec_config3"] = dict(r3, env="Memory-5-v0 (live, host cores)", batch=c3["B"])
+            line["env_steps_per_sec_cfg3"] = {"actor_only": r3["actor_only"], "coupled_1to1": r3["coupled_1to1"]}
             del a3
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(c, args.batch) if args.config == 1 else cpu_baseline_other(args.config, 12.0)
-        print(json.dumps(line), flush=True)
+        detail["mfma_counters"] = mfma_counters(args.config)
+        line["detail_file"] = os.path.relpath(args.detail, ROOT)
+        line = _r(line)
+        line["value"], line["ms_per_step"] = ups, ms              # the two the driver cross-checks: full precision
+        text = json.dumps(line, separators=(",", ":"))
+        for k in ("env_steps_per_sec_cfg3", "hbm_view", "kernels_us", "hbm_kernels", "other_configs", "env_steps_per_sec"):
+            if len(text) <= LINE_LIMIT:
+                break
+            line.pop(k, None)                                     # never reached with today's keys; the contract keys always stay
+            text = json.dumps(line, separators=(",", ":"))
+        try:
+            os.makedirs(os.path.dirname(args.detail), exist_ok=True)
+            with open(args.detail, "w") as f:
+                json.dump(dict(detail, line=line), f, indent=1)
+        except OSError:
+            pass
+        print(text, flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -72,6 +72,9 @@ class DataParallel:
         for t in (e.theta_pol, e.theta_tgt, e.adam_m, e.adam_v, e.step_counter):
             td.broadcast(t, src=src, group=self.group)
 
+    def exchange_kind(self) -> str:
+        return "rccl all_reduce"
+
     def allreduce_gradient(self) -> None:
         td.all_reduce(self.engine.grad, op=td.ReduceOp.SUM, group=self.group)
 

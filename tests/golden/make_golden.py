@@ -123,7 +123,7 @@ def checksum(params):
 
 def make_ref_net(cfg: O.NetCfg, params):
     net = RefDTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size,
-                  cfg.num_heads, cfg.num_layers, cfg.history_len, dropout=0.0, gate=cfg.gate,
+                  cfg.num_heads, cfg.num_layers, cfg.history_len, dropout=cfg.dropout, gate=cfg.gate,
                   identity=cfg.identity, pos=cfg.pos, discrete=cfg.discrete,
                   vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=cfg.bag_size)
     assert list(net.state_dict().keys()) == O.state_dict_keys(cfg), "state_dict key order drifted"
@@ -648,6 +648,140 @@ def gen_G9():
     np.savez_compressed(os.path.join(HERE, "G9_bag.npz"), **out)
 
 
+class RefDropoutHash:
+    """Stands in for torch.nn.functional.dropout while THE REFERENCE runs (gen_G10).  torch's Philox stream cannot be matched
+    by another implementation, but everything else about the reference's dropout can be pinned: WHICH tensors are dropped (the
+    call sites), in which forward passes (train / eval mode, i.e. whether `training` arrives True), and how survivors are scaled.
+    Each call the reference makes with training=True is answered with the keep mask of oracle.dtqn_oracle.drop_keep for
+    (seed, step, pass, sequence, site, layer, element); the site is identified by the ORDER and SHAPE of the reference's own
+    calls inside one DTQN.forward (dtqn/networks/dtqn.py:196 -> [B, n, D]; per layer transformer.py:34 attention weights
+    [B*H, n, n] then transformer.py:41 [B, n, D]; dtqn.py:136-141 bag attention weights [B*H, n, bag]).  A call the restatement
+    does not expect (wrong shape, wrong order, an extra site) raises, so the fixture cannot be written from a different
+    site structure than the one oracle / kernels implement."""
+
+    def __init__(self, cfg: O.NetCfg, seed: int):
+        self.cfg, self.seed, self.step, self.which, self.calls, self.log = cfg, seed, 0, None, 0, []
+
+    def begin_pass(self, which):
+        self.which, self.calls = which, 0
+
+    def __call__(self, input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            self.log.append(("eval", self.which, tuple(input.shape)))
+            return input
+        cfg = self.cfg
+        assert self.which is not None, "train-mode dropout outside a tracked policy forward"
+        spec = O.DropSpec(float(p), self.seed, self.step, self.which)
+        k = self.calls
+        self.calls += 1
+        H, D, NL = cfg.num_heads, cfg.inner_embed_size, cfg.num_layers
+        if k == 0:
+            assert input.dim() == 3 and input.shape[-1] == D, input.shape
+            self.log.append(("emb", self.which, tuple(input.shape)))
+            return O.drop_rows(spec, input, O.DROP_EMB, 0)
+        j, layer = (k - 1) % 2, (k - 1) // 2
+        if layer < NL and j == 0:
+            BH, n, m = input.shape
+            assert BH % H == 0 and n == m, input.shape
+            self.log.append(("attn", self.which, layer, tuple(input.shape)))
+            return O.drop_attn(spec, input.reshape(BH // H, H, n, m), layer).reshape(BH, n, m)
+        if layer < NL:
+            assert input.dim() == 3 and input.shape[-1] == D, input.shape
+            self.log.append(("ffn", self.which, layer, tuple(input.shape)))
+            return O.drop_rows(spec, input, O.DROP_FFN, layer)
+        assert cfg.bag_size > 0 and k == 1 + 2 * NL, ("unexpected dropout call", k, tuple(input.shape))
+        BH, n, m = input.shape
+        assert m == cfg.bag_size and BH % H == 0, input.shape
+        self.log.append(("bag", self.which, tuple(input.shape)))
+        Bn = BH // H
+        idx = ((np.arange(H)[:, None, None] << 16) | (np.arange(n)[None, :, None] << 8) | np.arange(m)[None, None, :]).astype(np.uint64)
+        keep = np.stack([O.drop_keep(spec, b, O.DROP_BAG, 0, idx) for b in range(Bn)])
+        return input * torch.from_numpy(keep.astype(np.float32) * np.float32(spec.scale)).reshape(BH, n, m)
+
+
+def gen_G10():
+    """Dropout pinned to the reference.  THE REFERENCE's DtqnAgent.train() runs with --dropout p on
+    res / GRU / identity / bag networks while torch.nn.functional.dropout is replaced by RefDropoutHash: the reference decides
+    where and when dropout applies, the hash only supplies reproducible keep masks.  Stored per case and update: the sampled
+    batch, the Q-values of the three forwards AS train() COMPUTED THEM (policy(o) and policy(o') in train mode with independent
+    masks, target(o') in eval mode), pre-clip gradients, statistics, parameters after the step, and the log of the reference's
+    dropout calls (site order, shapes, and which calls arrived with training=False)."""
+    import torch.nn.functional as F
+    cases = [
+        ("res", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50, dropout=0.1), 8, 120, -5),
+        ("gru", O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, num_layers=2, history_len=20, gate="gru", action_dim=4,
+                         dropout=0.2), 4, 40, -5),
+        ("ident", O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=32, num_heads=2, num_layers=2, history_len=24, identity=True, pos="sin",
+                           discrete=True, vocab_sizes=9, dropout=0.15), 4, 40, 8),
+        ("bag", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=12, bag_size=5, dropout=0.1),
+         6, 40, -5.0),
+    ]
+    out = {"stamp": json.dumps(STAMP), "names": json.dumps([c[0] for c in cases]), "n_updates": 2}
+    orig_dropout = F.dropout
+    for name, cfg, B, T, mask in cases:
+        seed, drop_seed, n_eps = 300 + len(name), 4242, 14
+        random.seed(seed)
+        ref_random.RNG.rng = np.random.Generator(np.random.PCG64(seed))
+        rng = np.random.Generator(np.random.PCG64(seed + 1000))
+        pol = O.init_params(cfg, seed=seed, perturb=True)
+        tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+        agent = make_ref_agent(cfg, pol, tgt, B, T, n_eps + 2, mask)
+        fill_agent(agent, synth_episodes(rng, n_eps, T, cfg, min_len=cfg.history_len + 3 if cfg.bag_size else 3))
+        hasher = RefDropoutHash(cfg, drop_seed)
+        qs = []
+        n_pol = [0]
+
+        def pol_pre(mod, args):
+            hasher.begin_pass(n_pol[0] % 2)          # train(): policy(o) is pass 0, policy(o') pass 1 (dtqn.py:215,226)
+            n_pol[0] += 1
+
+        def tgt_pre(mod, args):
+            hasher.begin_pass(None)                  # eval mode: a training=True call here would trip the assert
+
+        keep_q = lambda mod, args, outp: qs.append(outp.detach().numpy().copy())
+        hooks = [agent.policy_network.register_forward_pre_hook(pol_pre), agent.target_network.register_forward_pre_hook(tgt_pre),
+                 agent.policy_network.register_forward_hook(keep_q), agent.target_network.register_forward_hook(keep_q)]
+        F.dropout = hasher
+        try:
+            agent.eval_off()
+            random.seed(seed + 7)
+            recs = []
+            for it in range(2):
+                hasher.step = it
+                recs.append(run_ref_updates(agent, 1))
+        finally:
+            F.dropout = orig_dropout
+            for h in hooks:
+                h.remove()
+        assert len(qs) == 6 and n_pol[0] == 4
+        assert agent.policy_network.training and not agent.target_network.training
+        out[f"{name}_cfg"] = json.dumps(cfg.to_json())
+        out[f"{name}_meta"] = json.dumps({"seed": seed, "drop_seed": drop_seed, "B": B, "T": T, "n_eps": n_eps, "mask": mask})
+        out[f"{name}_pol_checksum"] = checksum(pol)
+        out[f"{name}_drop_calls"] = json.dumps(hasher.log)
+        keys = O.trainable_keys(cfg)
+        pnames = [n for n, p in agent.policy_network.named_parameters()]
+        names9 = ["obss", "actions", "rewards", "next_obss", "next_actions", "dones", "ep_lens", "bag_obss", "bag_actions"]
+        for it, rec in enumerate(recs):
+            out.update({f"{name}_u{it}_{k}": np.asarray(a) for k, a in zip(names9, rec["batches"][0])})
+            out[f"{name}_u{it}_q_all"], out[f"{name}_u{it}_q_next_pol"], out[f"{name}_u{it}_q_next_tgt"] = qs[3 * it:3 * it + 3]
+            gl = {n: g for n, g in zip(pnames, rec["grads"][0]) if g is not None}
+            assert sorted(gl) == sorted(keys)
+            out[f"{name}_u{it}_grad_flat"] = np.concatenate([gl[k].numpy().ravel() for k in keys])
+            if it == 0:      # update 1 starts from these (pre of update 0 = the seeded parameters)
+                out[f"{name}_u{it}_post_flat"] = rec["post"][0]
+            out[f"{name}_u{it}_stats"] = json.dumps(rec["stats"][0])
+            out[f"{name}_u{it}_grad_norm"] = rec["norms"][0]
+        # the episodes, so that a device replay can be filled with the same content (bag sampling reads rows before the window)
+        out[f"{name}_replay_obss"] = np.asarray(agent.replay_buffer.obss)
+        out[f"{name}_replay_actions"] = np.asarray(agent.replay_buffer.actions)
+        out[f"{name}_replay_rewards"] = np.asarray(agent.replay_buffer.rewards)
+        out[f"{name}_replay_dones"] = np.asarray(agent.replay_buffer.dones)
+        out[f"{name}_replay_lens"] = np.asarray(agent.replay_buffer.episode_lengths)
+        print(name, "dropout calls:", len(hasher.log), "eval-mode calls:", sum(1 for c in hasher.log if c[0] == "eval"))
+    np.savez_compressed(os.path.join(HERE, "G10_dropout.npz"), **out)
+
+
 def time_reference():
     """the reference's OWN DtqnAgent.train() on this container's CPU cores, BASELINE
     configs 1-5 (synthetic replay of SURVEY.md section 8d; configs 3-5 at their per-GPU batch, a handful of updates
@@ -697,10 +831,10 @@ def time_reference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "time"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "time"]
     torch.manual_seed(0)
     for w in which:
         t0 = time.time()
         {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
-         "G8": gen_G8, "G9": gen_G9, "time": time_reference}[w]()
+         "G8": gen_G8, "G9": gen_G9, "G10": gen_G10, "time": time_reference}[w]()
         print(f"{w}: done in {time.time() - t0:.1f}s")

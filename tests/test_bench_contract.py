@@ -21,26 +21,52 @@ def test_algorithmic_flops_match_the_survey():
     assert bench.MFMA_F32_PEAK_TFLOPS == pytest.approx(157.3) and bench.HBM_PEAK_GBS == 8000.0
 
 
-def test_pmc_traffic_reads_the_committed_profile():
+def test_pmc_traffic_reads_the_committed_profile(monkeypatch):
     import bench
-    t = bench.pmc_traffic("dtqn_forward_kernel", 32, 1)
-    d = json.load(open(bench._round_profiles("pmc_traffic", 1)[0]))                 # this round's newest --pmc passes of cfg 1
+    monkeypatch.setattr(bench, "build_digest", lambda: "0" * 16)                    # no engine needed for the lookup itself
+    t, src = bench.pmc_traffic("dtqn_forward_kernel", 32, 1)
+    path = bench._round_profiles("pmc_traffic", 1)[0]                               # the newest --pmc passes of cfg 1
+    d = json.load(open(path))
     key = [k for k in d if "dtqn_forward_kernel" in k][0]
     assert t == int((2 * d[key]["FETCH_SIZE"] + d[key]["WRITE_SIZE"]) * 1024)       # gfx950: FETCH_SIZE doubled, KB units
-    assert bench.pmc_traffic("dtqn_forward_kernel", 7, 1) is None                   # no profile for that batch
-    t2 = bench.pmc_traffic("dtqn_backward_kernel", 256, 2)                          # every BASELINE config has its own files
-    d2 = json.load(open(bench._round_profiles("pmc_traffic", 2)[0]))
-    key2 = [k for k in d2 if "dtqn_backward_kernel" in k][0]
-    assert t2 == int((2 * d2[key2]["FETCH_SIZE"] + d2[key2]["WRITE_SIZE"]) * 1024)
-    names3 = [os.path.basename(p) for p in bench._round_profiles("pmc_traffic", 3)]   # newest suffix of the round first
+    assert src["file"] == os.path.relpath(path, REPO) and src["matches_build"] is False   # stamped with where it came from
+    assert bench.pmc_traffic("dtqn_forward_kernel", 7, 1) == (None, None)           # no profile for that batch
+    t2, _ = bench.pmc_traffic("dtqn_backward_kernel", 256, 2)                       # every BASELINE config has its own files
+    assert t2 is not None and t2 > 0
+    names3 = [os.path.basename(p) for p in bench._round_profiles("pmc_traffic", 3)]   # newest round / suffix first
     assert names3 == sorted(names3, reverse=True) and names3[0] >= "r02f_pmc_traffic_cfg3.json"
-    # cfg 3 trains on the row-block kernels since r02f: the whole-sequence kernel is found in the older profile of the config
-    assert bench.pmc_traffic("dtqn_backward_kernel", 512, 3) is not None
-    m = bench.mfma_counters(1)
+    m = bench.mfma_counters(1)["counters"]
     fk = [k for k in m if "dtqn_forward_kernel" in k][0]
     assert 0.0 < m[fk]["mfma_util_vs_launch"] < 1.0 and m[fk]["SQ_VALU_MFMA_BUSY_CYCLES"] > 0
     ref = bench.reference_cpu_numbers(1)
     assert ref["runs"] and {r["threads"] for r in ref["runs"]} == {1, 8} and all(r["td_updates_per_s"] > 0 for r in ref["runs"])
+
+
+def test_gpus_n_outside_torchrun_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 2` with no WORLD_SIZE re-executes under torch.distributed.run on 127.0.0.1."""
+    import argparse
+    import bench
+    import torch
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(os, "execvpe", lambda exe, cmd, env: seen.update(exe=exe, cmd=cmd, env=env))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "7", "--warmup", "3"])
+    bench._self_launch(argparse.Namespace(gpus=2))
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "7", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench._self_launch(argparse.Namespace(gpus=2))
+
+
+def test_line_rounding_keeps_the_line_small():
+    import bench
+    big = {"a": 1.23456789012345, "b": {"c": [0.000123456789, 3]}, "s": "x"}
+    assert bench._r(big) == {"a": 1.235, "b": {"c": [0.0001235, 3]}, "s": "x"}
+    assert bench.LINE_LIMIT <= 4096
 
 
 @pytest.mark.gpu
@@ -51,6 +77,8 @@ def test_bench_line_contract():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    assert len(lines[0]) <= 4096                        # the driver keeps an 8 KB stdout tail: the whole line must fit
+    assert lines[0].startswith('{"metric":')            # contract keys lead the line
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
@@ -59,6 +87,11 @@ def test_bench_line_contract():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
     assert "workload" in d["config"] and "batch 32" in d["config"]["workload"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert r["bound"] in ("hbm", "mfma") and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=2e-3)
+    assert "traffic" in r and "traffic_src" in r
+    hk = d["hbm_kernels"]                               # the HBM-bound launches priced against 8 TB/s
+    assert {"clip_adam", "replay_sample", "replay_apply"} <= set(hk) and all(0 < v["frac_of_8TBs"] < 1 for v in hk.values())
+    det = json.load(open(os.path.join(REPO, d["detail_file"])))
+    assert det["line"]["value"] == d["value"] and "update_latency_us" in det
     assert d["value"] == pytest.approx(1000.0 / d["ms_per_step"], rel=1e-6)
     assert d["value"] > 2000            # an order of magnitude above the CPU oracle; the tuned kernels do ~8.9k

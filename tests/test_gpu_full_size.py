@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 
 FULL = {
     "cfg2": (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50), 256, 200, -5),
-    "cfg3": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=8), 512, 50, 7),
+    "cfg3": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=9), 512, 50, 8),
     # the same on the whole-sequence kernels (DTQN_TRAIN_TILED=0): the library's policy trains cfg 3 on the row-block twin of the net
-    "cfg3_whole_sequence": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=8), 512, 50, 7),
+    "cfg3_whole_sequence": (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, num_layers=2, history_len=50, discrete=True, vocab_sizes=9), 512, 50, 8),
     "cfg4": (dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, num_layers=2, history_len=128, discrete=True, vocab_sizes=12), 128, 250, 11),
     "cfg5": (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, num_layers=2, history_len=256, discrete=True, vocab_sizes=22), 32, 256, 21),
 }
@@ -59,7 +59,7 @@ def test_full_size_update_properties(lib, name, monkeypatch):
     E = Bn + 40
     lens = rng.integers(5, T + 1, size=E).astype(np.int32)
     if cfg.discrete:
-        obs = rng.integers(0, cfg.vocab_sizes - 1, size=(E, T + 1, cfg.obs_dim)).astype(np.float32)
+        obs = rng.integers(0, cfg.vocab_sizes - 1, size=(E, T + 1, cfg.obs_dim)).astype(np.float32)   # tokens below the mask value (cfg 3: SURVEY.md section 8, V = 9, mask 8)
     else:
         obs = rng.uniform(-1, 1, size=(E, T + 1, cfg.obs_dim)).astype(np.float32)
     obs[np.arange(T + 1)[None, :] > lens[:, None]] = mask

@@ -3,8 +3,18 @@ pmc_traffic.json {kernel: {FETCH_SIZE, WRITE_SIZE}} (KB per launch, as reported)
 mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES}}.   python tools/pmc_collect.py <dir with pmc_*/>"""
 import glob
 import json
+import os
 import sqlite3
 import sys
+
+
+def stamp():
+    """What the counters were taken on: the source digest of the engine that is loaded (dtqn_build_info) and the commit the
+    caller names in GIT_HEAD (the GPU box has no .git).  bench.py compares `src` with the engine it is timing."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dtqn_amd import engine
+    info = engine.get_lib().dtqn_build_info().decode()
+    return {"src": info.split("src=")[-1].split()[0], "git": os.environ.get("GIT_HEAD"), "tool": "tools/profile_round3.sh"}
 
 
 def per_kernel(db):
@@ -36,6 +46,7 @@ def main(out):
             busy, tot = v.get("SQ_VALU_MFMA_BUSY_CYCLES"), v.get("SQ_BUSY_CYCLES")
             v["mfma_busy_frac"] = (busy / tot) if busy is not None and tot else None
             mfma[k] = v
+    traffic["_meta"] = stamp()
     json.dump(traffic, open(f"{out}/pmc_traffic.json", "w"), indent=1, sort_keys=True)
     json.dump(mfma, open(f"{out}/pmc_mfma.json", "w"), indent=1, sort_keys=True)
 
