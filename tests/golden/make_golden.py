@@ -711,7 +711,7 @@ def gen_G10():
         ("res", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50, dropout=0.1), 8, 120, -5),
         ("gru", O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, num_layers=2, history_len=20, gate="gru", action_dim=4,
                          dropout=0.2), 4, 40, -5),
-        ("ident", O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=32, num_heads=2, num_layers=2, history_len=24, identity=True, pos="sin",
+        ("ident", O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=32, num_heads=4, num_layers=2, history_len=24, identity=True, pos="sin",
                            discrete=True, vocab_sizes=9, dropout=0.15), 4, 40, 8),
         ("bag", O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=12, bag_size=5, dropout=0.1),
          6, 40, -5.0),
@@ -745,10 +745,19 @@ def gen_G10():
         try:
             agent.eval_off()
             random.seed(seed + 7)
-            recs = []
+            recs, draws = [], []
+            orig_choice, orig_randint = random.choice, random.randint
             for it in range(2):
                 hasher.step = it
-                recs.append(run_ref_updates(agent, 1))
+                log = {"choice": [], "randint": []}
+                # the sampler's draws (replay_buffer.py:146-157 / :186-205): B episode choices, then B window starts
+                random.choice = lambda seq, _l=log: (_l["choice"].append(orig_choice(seq)) or _l["choice"][-1])
+                random.randint = lambda a, b, _l=log: (_l["randint"].append(orig_randint(a, b)) or _l["randint"][-1])
+                try:
+                    recs.append(run_ref_updates(agent, 1))
+                finally:
+                    random.choice, random.randint = orig_choice, orig_randint
+                draws.append(log)
         finally:
             F.dropout = orig_dropout
             for h in hooks:
@@ -764,6 +773,9 @@ def gen_G10():
         names9 = ["obss", "actions", "rewards", "next_obss", "next_actions", "dones", "ep_lens", "bag_obss", "bag_actions"]
         for it, rec in enumerate(recs):
             out.update({f"{name}_u{it}_{k}": np.asarray(a) for k, a in zip(names9, rec["batches"][0])})
+            assert len(draws[it]["choice"]) == B and len(draws[it]["randint"]) == B
+            out[f"{name}_u{it}_ep_idx"] = np.array(draws[it]["choice"], dtype=np.int32)
+            out[f"{name}_u{it}_start"] = np.array(draws[it]["randint"], dtype=np.int32)
             out[f"{name}_u{it}_q_all"], out[f"{name}_u{it}_q_next_pol"], out[f"{name}_u{it}_q_next_tgt"] = qs[3 * it:3 * it + 3]
             gl = {n: g for n, g in zip(pnames, rec["grads"][0]) if g is not None}
             assert sorted(gl) == sorted(keys)
