@@ -310,6 +310,8 @@ class DtqnAgent:
             n_valid, exclude = rb.valid_range()
             if self._separate_sample_launch:          # DTQN_SAMPLE_LAUNCH=1: A/B knob, one extra launch per update
                 eng.sample_on_device(rb.dev, n_valid, exclude, self.sample_seed, sp)
+                if self.bag.size > 0:             # the windows' bags: same device draw as the in-kernel sampler's
+                    eng.gather_bag_on_device(rb.dev, self.sample_seed)
             else:
                 eng.sample_in_forward(n_valid, exclude, self.sample_seed)      # the forward kernel draws its own windows
         if self._actor_inflight:

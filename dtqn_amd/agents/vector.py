@@ -36,7 +36,6 @@ class VectorActor:
         # bag networks: one bag per environment (utils/bag.py; dtqn.py:66-74 keeps one per agent because it steps one environment)
         self.bags = [Bag(agent.bag.size, agent.obs_mask, O, discrete=agent.is_discrete_env, ref_quirks=ref_quirks)
                      for _ in range(N)] if agent.bag.size > 0 else None
-        self._q_pending = None
         self.episodes = [[] for _ in range(N)]            # per env: [first_obs, (obs, action, reward, done), ...]
         self.returns = np.zeros(N)
         cuda = agent.device.type == "cuda"
@@ -82,11 +81,29 @@ class VectorActor:
             # bag networks: the module forward with the N bags (dtqn_forward_bag); every sequence runs the longest prefix, the
             # rows behind a shorter one cannot reach its last live row (causal), its own bag attends row by row
             lens = [min(c.max_length, c.timestep + 1) for c in self.contexts]
-            n_max = max(lens)
-            obs = np.stack([c.obs[:n_max] for c in self.contexts])
-            act = np.stack([c.action[:n_max] for c in self.contexts])
-            q = a._bag_forward(obs, act, np.stack([b.obss for b in self.bags]), np.stack([b.actions for b in self.bags]))
-            self._q_pending = (q, lens)
+            groups = [list(range(self.n))]
+            if a.policy_network.net.action_dim > 0 and max(lens) > 1 and min(lens) == 1:
+                # a ONE-row sequence keeps its action embedding un-rolled (dtqn.py:187-191: `if history_len > 1`); run next to longer
+                # prefixes it would be rolled and zeroed, so the fresh episodes of this vector step get a forward of their own
+                groups = [[i for i in range(self.n) if lens[i] > 1], [i for i in range(self.n) if lens[i] == 1]]
+            q_rows = None
+            for idx in groups:
+                n_max = max(lens[i] for i in idx)
+                obs = np.stack([self.contexts[i].obs[:n_max] for i in idx])
+                act = np.stack([self.contexts[i].action[:n_max] for i in idx])
+                q = a._bag_forward(obs, act, np.stack([self.bags[i].obss for i in idx]), np.stack([self.bags[i].actions for i in idx]))
+                rows = torch.as_tensor(np.asarray([lens[i] for i in idx]) - 1, device=q.device)
+                last = q[torch.arange(len(idx), device=q.device), rows]           # the last live row of every sequence
+                if q_rows is None:
+                    q_rows = torch.empty(self.n, self.A, dtype=q.dtype, device=q.device)
+                q_rows[torch.as_tensor(idx, device=q.device)] = last
+            # -> pinned memory with one asynchronous copy, and an event right behind it: updates queued after this point
+            # (step_all's `between`) no longer stand between the host and its Q-values
+            if self._ev is not None:
+                self._q_h.copy_(q_rows, non_blocking=True)
+                self._ev.record(torch.cuda.current_stream(a.device))
+            else:
+                self._q_h.copy_(q_rows)
             return
         n_max = 1
         for i, ctx in enumerate(self.contexts):
@@ -97,7 +114,7 @@ class VectorActor:
             n_max = max(n_max, n)
         a._actor_calls += 1
         rc = eng.lib.dtqn_actor_forward_batch(eng._actor_net_ref, a._theta_p, self._p[0], self._p[1], self.n, n_max, self._p[2], self._p[3],
-                                              self._ws_p, 1, eng.td.dropout_seed ^ 0xAC70, a._actor_calls & 0xFFFFFFFF, eng._stream())
+                                              self._ws_p, 1 if a.train_mode.name == "TRAIN" else 0, eng.td.dropout_seed ^ 0xAC70, a._actor_calls & 0xFFFFFFFF, eng._stream())
         if rc == B.DEFINES["DTQN_ERR_ARG"]:
             raise AssertionError("Cannot forward, history is longer than expected.")   # dtqn.py:170-173
         if rc != 0:
@@ -106,12 +123,6 @@ class VectorActor:
             self._ev.record(a._main_stream)
 
     def _wait_q(self) -> np.ndarray:
-        if self._q_pending is not None:
-            q, lens = self._q_pending
-            self._q_pending = None
-            qh = q.cpu().numpy()
-            self._q_np[:] = np.stack([qh[i, n - 1] for i, n in enumerate(lens)])
-            return self._q_np
         if self._ev is not None:
             self._ev.synchronize()              # the forward only: work queued behind it (TD updates) keeps running
         return self._q_np

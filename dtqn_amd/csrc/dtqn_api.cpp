@@ -79,7 +79,7 @@ int forward_infer(const DtqnNet* net, const float* theta, const float* obs, cons
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows, int in_rows,
                   uint32_t drop_seed, uint32_t drop_step, int train_mode);
 int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
-                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream);
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream, const int32_t* lens = nullptr);
 }
 extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,
                                           int batch, int n, int in_rows, float* q_out, float* workspace, void* stream);
@@ -134,6 +134,11 @@ extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, 
     const size_t obs_bytes = sizeof(float) * (size_t)n_envs * L * net->obs_dim;
     const size_t act_bytes = (((size_t)n_envs * L) + 3) & ~(size_t)3;       // keeps the int32 block 4-byte aligned
     const size_t total = obs_bytes + act_bytes + sizeof(int32_t) * (size_t)n_envs;
+    // the live-row counts index q_dev (tiled path) and name the rows the kernel reports (whole-sequence path): the pinned host
+    // copy is already written, so a bad count is refused here instead of becoming an out-of-bounds device access
+    const int32_t* lens_h = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_host) + obs_bytes + act_bytes);
+    for (int i = 0; i < n_envs; ++i)
+        if (lens_h[i] < 1 || lens_h[i] > n_max) return DTQN_ERR_ARG;
     if (hipMemcpyAsync(ctx_dev, ctx_host, total, hipMemcpyHostToDevice, s) != hipSuccess) return DTQN_ERR_LAUNCH;
     const float* obs = static_cast<const float*>(ctx_dev);
     const uint8_t* actions = static_cast<const uint8_t*>(ctx_dev) + obs_bytes;
@@ -141,9 +146,8 @@ extern "C" int dtqn_actor_forward_batch(const DtqnNet* net, const float* theta, 
     if (net->tiled) {
         // row-block tiled nets: the forward leaves Q in q_dev; the last rows come back with one small copy per actor
         const int rc = dtqn::tiled_forward_actor(net, theta, obs, actions, n_envs, n_max, L, q_dev, workspace, train_mode, dropout_seed,
-                                                 dropout_step, (hipStream_t)stream);
+                                                 dropout_step, (hipStream_t)stream, lens);
         if (rc != DTQN_OK) return rc;
-        const int32_t* lens_h = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(ctx_host) + obs_bytes + act_bytes);
         for (int i = 0; i < n_envs; ++i)
             if (hipMemcpyAsync(q_last_host + (size_t)i * net->num_actions, q_dev + ((size_t)i * n_max + (lens_h[i] - 1)) * net->num_actions,
                                sizeof(float) * net->num_actions, hipMemcpyDeviceToHost, s) != hipSuccess)

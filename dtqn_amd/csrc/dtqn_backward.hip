@@ -73,6 +73,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     using Own = Owned<D, MT, MGX, NW>;          // fixed ownership of a [LP][D] register-accumulated output
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
+    const Thr& t_outer = t;
     const int b = (int)blockIdx.x / RS;
     const int slice = RS - 1 - ((int)blockIdx.x - b * RS);     // the upper slice (the producer of this kernel) first
     const int R0 = slice * LP;
@@ -174,6 +175,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     };
     float st_next = st_fetch(net.num_layers - 1);
     for (int l = net.num_layers - 1; l >= 0; --l) {
+        // D >= 128: the thread coordinates of this iteration are made opaque to the optimiser, at the top of the layer and of its two
+        // big stages.  Otherwise it hoists dozens of per-thread address computations out of the layer loop and keeps them live across
+        // the whole body; at D = 128 that ended in 316 bytes of scratch per lane (now 0; backward 748 -> 692 us at BASELINE config 3
+        // shapes).  At D <= 64 the hoisted addresses are the faster code even where they spill a little (measured round 3: the 16-row
+        // slices of latency mode lose 2 us with the same trick, the full 64-row tile is unchanged), so those keep them.
+        Thr t = t_outer;
+#define DTQN_RELAUNDER() do { if constexpr (D >= 128 && MT >= 4) { DTQN_ASM_KEEP(t.tid); DTQN_ASM_KEEP(t.lane); DTQN_ASM_KEEP(t.wave); DTQN_ASM_KEEP(t.i); DTQN_ASM_KEEP(t.kq); } } while (0)
+        DTQN_RELAUNDER();
         const float* __restrict__ th = layer_theta(net, theta, l);
         const float* lrec = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
         float* lgrd = grec + net.go_layer0 + (size_t)l * net.grd_layer_stride;
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         }
         __syncthreads();
         // FFN backward: dh = df W2 (masked by h > 0), du2 = dh W1, in hidden-column passes
+        DTQN_RELAUNDER();
         {
             f32x4 xacc[Own::PER_WAVE][MGX];
 #pragma unroll
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             }
         }
         // attention backward, one head group (GW columns) at a time; du1 = dqkv W_in accumulates in registers
+        DTQN_RELAUNDER();
         {
             f32x4 xacc[Own::PER_WAVE][MGX];
 #pragma unroll

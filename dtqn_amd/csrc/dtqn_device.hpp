@@ -26,7 +26,7 @@ namespace dtqn {
 int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
-                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream);
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream, const int32_t* lens = nullptr);
 // dtqn_forward with an optional pinned-host destination for Q of the last row of sequence 0 (dtqn_actor_forward)
 int forward_infer(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n,
                   float* q_out, float* q_last_host, void* stream, float* xch, int32_t* xflags, const int32_t* last_rows = nullptr, int in_rows = 0,

@@ -88,6 +88,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;                      // live rows of this slice (may be <= 0: all padding)
+    // history_len == 1: no roll, row 0 keeps its own action embedding (dtqn.py:187-191) -- per SEQUENCE when ragged prefixes share a launch
+    const bool single = (a.last_rows != nullptr ? a.last_rows[seq] : nfull) == 1;
     const bool ident = RS > 1 ? false : net.identity != 0;     // row slices are dispatched for post-LN nets only: folds away
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
             float v = 0.f;
             if (r < n) {
                 if (d < adim) {
-                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
                     else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;
@@ -174,7 +176,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
             if (r < n) {
                 if (d < adim) {
                     // previous-action embedding rolled right by one, row 0 zeroed unless n == 1 (dtqn.py:184-192)
-                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
                     else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;
@@ -416,6 +418,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;
+    const bool single = (a.last_rows != nullptr ? a.last_rows[seq] : nfull) == 1;      // see forward_body
     const bool ident = RS > 1 ? false : net.identity != 0;
     float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
     auto rf = [&](float* base, int off, int w) -> float* { return TRAIN ? base + off + (size_t)R0 * w : nullptr; };
@@ -462,7 +465,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             float v = 0.f;
             if (r < n) {
                 if (d < adim) {
-                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
                     else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;
@@ -506,7 +509,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             float v = 0.f;
             if (r < n) {
                 if (d < adim) {
-                    if (nfull == 1) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
                     else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     const float* w = We + (size_t)(d - adim) * KE;

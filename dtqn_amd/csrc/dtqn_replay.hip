@@ -15,36 +15,64 @@ struct ApplyArgs {
     int n;
 };
 
-// One workgroup walks the records IN ORDER (a store_obs cleanses the slot its later stores write).
+// One workgroup applies the records IN ORDER (a store_obs cleanses the slot its later stores write), but not one record at a
+// time: the records sit in pinned HOST memory (dtqn_replay_push), so every dependent read is a PCIe round trip.  The records of
+// a chunk are pulled into LDS with one coalesced pass; a store_obs is a barrier-separated fill of its slot by all threads; the
+// run of stores up to the next store_obs touches disjoint rows and is applied in ONE pass over (record, element) pairs, the
+// observation rows read straight from the staging.  256 records of an env-step stream: 211 -> ~15 us.
 __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyArgs a) {
+    constexpr int CH = 256;
+    __shared__ DtqnReplayRecord recs[CH];
+    static_assert(sizeof(DtqnReplayRecord) == 32, "eight dwords per record");
     const int tid = (int)threadIdx.x;
     const int T = a.rp.max_steps, O = a.rp.obs_dim;
-    for (int i = 0; i < a.n; ++i) {
-        const DtqnReplayRecord r = a.recs[i];
-        const int ep = r.ep;
-        float* obs = a.rp.obs + (size_t)ep * (T + 1) * O;
-        uint8_t* act = a.rp.actions + (size_t)ep * (T + 1);
-        float* rew = a.rp.rewards + (size_t)ep * T;
-        uint8_t* don = a.rp.dones + (size_t)ep * T;
-        const float* src = a.obs_rows + (size_t)r.obs_index * O;
-        if (r.kind == 0) {
-            // cleanse_episode (:100-135): obs <- mask, actions <- 0, rewards <- 0, dones <- True, length <- 0
-            for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? src[k] : a.rp.obs_mask;
-            for (int k = tid; k < T + 1; k += DTQN_THREADS) act[k] = 0;
-            for (int k = tid; k < T; k += DTQN_THREADS) { rew[k] = 0.f; don[k] = 1; }
-            if (tid == 0) a.rp.ep_len[ep] = 0;
-        } else {
-            // store (:71-86): obs at row t+1, action / reward / done at row t, episode length
-            const int t = r.t;
-            for (int k = tid; k < O; k += DTQN_THREADS) obs[(size_t)(t + 1) * O + k] = src[k];
-            if (tid == 0) {
-                act[t] = (uint8_t)r.action;
-                rew[t] = r.reward;
-                don[t] = r.done ? 1 : 0;
-                a.rp.ep_len[ep] = r.ep_len;
-            }
+    for (int c0 = 0; c0 < a.n; c0 += CH) {
+        const int m = a.n - c0 < CH ? a.n - c0 : CH;
+        {
+            const int32_t* src = reinterpret_cast<const int32_t*>(a.recs + c0);
+            int32_t* dst = reinterpret_cast<int32_t*>(recs);
+            for (int k = tid; k < m * 8; k += DTQN_THREADS) dst[k] = src[k];
         }
         __syncthreads();
+        int i = 0;
+        while (i < m) {                                   // uniform control flow: every thread walks the same LDS records
+            const DtqnReplayRecord r = recs[i];
+            if (r.kind == 0) {
+                // cleanse_episode (:100-135): obs <- mask, actions <- 0, rewards <- 0, dones <- True, length <- 0; row 0 <- the observation
+                const int ep = r.ep;
+                float* obs = a.rp.obs + (size_t)ep * (T + 1) * O;
+                uint8_t* act = a.rp.actions + (size_t)ep * (T + 1);
+                float* rew = a.rp.rewards + (size_t)ep * T;
+                uint8_t* don = a.rp.dones + (size_t)ep * T;
+                const float* src = a.obs_rows + (size_t)r.obs_index * O;
+                for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? src[k] : a.rp.obs_mask;
+                for (int k = tid; k < T + 1; k += DTQN_THREADS) act[k] = 0;
+                for (int k = tid; k < T; k += DTQN_THREADS) { rew[k] = 0.f; don[k] = 1; }
+                if (tid == 0) a.rp.ep_len[ep] = 0;
+                __syncthreads();
+                ++i;
+                continue;
+            }
+            // store (:71-86) x run: obs at row t+1, action / reward / done at row t, episode length (the last store of a slot wins)
+            int j = i + 1;
+            while (j < m && recs[j].kind != 0) ++j;
+            const int cnt = j - i;
+            for (int q = tid; q < cnt * O; q += DTQN_THREADS) {
+                const int ri = i + q / O, k = q - (q / O) * O;
+                const DtqnReplayRecord s = recs[ri];
+                a.rp.obs[((size_t)s.ep * (T + 1) + (s.t + 1)) * O + k] = a.obs_rows[(size_t)s.obs_index * O + k];
+            }
+            for (int ri = i + tid; ri < j; ri += DTQN_THREADS) {
+                const DtqnReplayRecord s = recs[ri];
+                a.rp.actions[(size_t)s.ep * (T + 1) + s.t] = (uint8_t)s.action;
+                a.rp.rewards[(size_t)s.ep * T + s.t] = s.reward;
+                a.rp.dones[(size_t)s.ep * T + s.t] = s.done ? 1 : 0;
+                if (ri + 1 >= j || recs[ri + 1].ep != s.ep) a.rp.ep_len[s.ep] = s.ep_len;
+            }
+            __syncthreads();
+            i = j;
+        }
+        __syncthreads();                                  // the next chunk overwrites the LDS records
     }
 }
 

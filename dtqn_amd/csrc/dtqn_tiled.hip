@@ -79,6 +79,8 @@ struct TlEmbedArgs {
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
     int src_mod;                       // > 0: sequence s reads source sequence s % src_mod (one bag per window, three forwards)
     int bag;                           // 1: bag entries (dtqn.py:203-210): no position, the action embedding is not rolled
+    const int32_t* lens;               // ragged prefixes in one launch (dtqn_actor_forward_batch): live rows of sequence s, or nullptr = n.
+                                       // Only the "a one-row sequence keeps its action embedding" rule (dtqn.py:187) looks at it
     TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     }
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row_first * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
+    const bool single = (a.lens != nullptr ? a.lens[s] : n) == 1;     // history_len == 1: no roll, row 0 keeps its action (dtqn.py:187-191)
     const Thr t = make_thr();
     const int tid = t.tid;
     float* El = reinterpret_cast<float*>(dtqn_smem);                  // [64][kEmbLD]  e_in chunk
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
             if (r < n) {
                 if (d < adim) {
                     // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
-                    if (n == 1 || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
+                    if (single || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
                     else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
                 } else {
                     v = acc[q][r4] + theta[net.off_obs_b + d - adim];
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
     static_assert(NKA == 1 || NKA == 2, "step sequence written for D in {64, 128, 256}");
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging (plain) | [MR][LDX] all columns (LN)
-    const Thr t = make_thr();
+    Thr t = make_thr();
     const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W = second ? a.Wb : a.Wa;
@@ -444,7 +447,13 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         const bool live = !LN || j * 128 + wc < D;                     // D = 64: waves 4..7 have no column
         if (NKA == 1) {
             if (j + 1 < NB) fetch(nxt, j + 1, 0);
-            if (live) frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+            if constexpr (!LN && KA == 128 && MT == 4) {
+                // two weight fragments (64 registers) + four accumulators + the double-buffered A fragments of four row tiles do not
+                // fit the 128 registers of four workgroups per CU (round 2: 72 bytes of scratch per lane): the row tiles go through
+                // in two pairs against the same weight fragment
+                frag16_mma<KA, 2, 8>(Xt, LDX, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[0]));
+                frag16_mma<KA, 2, 8>(Xt + 32 * LDX, LDX, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[2]));
+            } else if (live) frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
         } else {
             fetch(nxt, j, 1);
             frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
@@ -479,6 +488,10 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         __syncthreads();                                               // staging tile free for the next block
     };
     for (int j = 0; j < NB; ++j) {
+        // thread coordinates opaque per column block: the per-thread LDS / global addresses are recomputed instead of being hoisted
+        // out of the loop and kept live next to two weight fragments and MT accumulators (72 bytes of scratch per lane at
+        // <128, 64> under the 128-register bound of four workgroups per CU)
+        DTQN_ASM_KEEP(t.tid); DTQN_ASM_KEEP(t.lane); DTQN_ASM_KEEP(t.wave); DTQN_ASM_KEEP(t.i); DTQN_ASM_KEEP(t.kq);
         if (NKA == 2 || (j & 1) == 0) block(bf0, bf1, j);
         else block(bf1, bf0, j);
     }
@@ -1787,6 +1800,7 @@ struct EmbedSrc {
     const float* bag_obs = nullptr;
     const uint8_t* bag_actions = nullptr;
     int bag_batch = 0;
+    const int32_t* lens = nullptr;     // ragged prefixes (device array [S]); nullptr: every sequence has n live rows
 };
 
 // All S sequences through the network.  theta_a serves sequences [0, split), theta_b the rest.
@@ -1808,7 +1822,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.n = n; e.rpb = rpb;
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
-        e.src_mod = 0; e.bag = 0; e.drop = drop;
+        e.src_mod = 0; e.bag = 0; e.drop = drop; e.lens = src.lens;
         const size_t elds = tl_embed_lds(D);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
@@ -1953,7 +1967,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.n = bag; e.rpb = rpb;
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
-            e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none();
+            e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none(); e.lens = nullptr;
             const size_t elds = tl_embed_lds(D);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
@@ -2209,7 +2223,7 @@ extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
 
 static int forward_tiled_impl(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
                               const uint8_t* bag_actions, int batch, int n, int in_rows, float* q_out, float* workspace, void* stream,
-                              int train_mode = 0, uint32_t drop_seed = 0u, uint32_t drop_step = 0u) {
+                              int train_mode = 0, uint32_t drop_seed = 0u, uint32_t drop_step = 0u, const int32_t* lens = nullptr) {
     if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len || in_rows < n) return DTQN_ERR_ARG;  // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
@@ -2221,6 +2235,7 @@ static int forward_tiled_impl(const DtqnNet* net, const float* theta, const floa
     src.obs_ep_stride = (long long)in_rows * net->obs_dim; src.act_ep_stride = in_rows;
     src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
     src.bag_obs = bag_obs; src.bag_actions = bag_actions; src.bag_batch = batch;
+    src.lens = lens;
     const long long qs = (long long)n * net->num_actions;
     // a train-mode forward of the actor (the reference's policy network stays in train mode during rollouts): one pass, sequence = salt
     const TlDrop drop = tl_drop_make(*net, drop_seed, drop_step, nullptr, batch, train_mode ? 0x1 : 0);
@@ -2235,10 +2250,11 @@ static int forward_tiled_impl(const DtqnNet* net, const float* theta, const floa
 namespace dtqn {
 // dtqn_actor_forward / dtqn_actor_forward_batch on a row-block net: the strided forward with the actor's train-mode dropout
 int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
-                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream) {
+                        float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream,
+                        const int32_t* lens) {
     if (net && net->bag_size > 0) return DTQN_ERR_ARG;
     return forward_tiled_impl(net, theta, obs, actions, nullptr, nullptr, batch, n, in_rows, q_out, workspace, stream, train_mode, drop_seed,
-                              drop_step);
+                              drop_step, lens);
 }
 }  // namespace dtqn
 

@@ -158,7 +158,10 @@ class TdEngine:
             self.bag_actions = torch.zeros(Bn, net.bag_size, dtype=torch.uint8, device=dev)
             td.bag_obs, td.bag_actions = self.bag_obs.data_ptr(), self.bag_actions.data_ptr()
             self._bag_rows_dev = torch.zeros(Bn, 2, net.bag_size, dtype=torch.int32, device=dev)
-            self._bag_rows_ring = []
+            # pinned slots for host-drawn bag rows: allocated up front, walked by their own counter
+            self._bag_rows_ring = [dict(h=torch.zeros(Bn, 2, net.bag_size, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), busy=False)
+                                   for _ in range(self.IDX_RING)] if dev.type == "cuda" else []
+            self._bag_rows_i = 0
         td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
@@ -219,10 +222,8 @@ class TdEngine:
         h = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int32).reshape(self._bag_rows_dev.shape))
         if self.device.type == "cuda":
             # small pinned ring: the async copy must not read a buffer the next draw overwrites
-            ring = self._bag_rows_ring
-            if len(ring) < self.IDX_RING:
-                ring.append(dict(h=torch.zeros_like(h).pin_memory(), event=torch.cuda.Event(), busy=False))
-            slot = ring[self._idx_i % len(ring)]
+            slot = self._bag_rows_ring[self._bag_rows_i % len(self._bag_rows_ring)]
+            self._bag_rows_i += 1
             if slot["busy"]:
                 slot["event"].synchronize()
             slot["h"].copy_(h)
@@ -236,6 +237,15 @@ class TdEngine:
         self._check(self.lib.dtqn_replay_gather_bag(replay.view_ref, _p(self.ep_idx), _p(self.start), _p(self._bag_rows_dev), self.batch,
                                                     self.net.bag_size, 0, None, _p(self.bag_obs), _p(self.bag_actions), self._stream()),
                     "dtqn_replay_gather_bag")
+
+    def gather_bag_on_device(self, replay: "DeviceReplay", seed: int) -> None:
+        """Bags of windows that dtqn_replay_sample drew in its own launch (sample_on_device): the rows are drawn on the device
+        too, keyed by (seed, step counter) exactly as dtqn_td_forward draws them when it samples in-kernel."""
+        if self.net.bag_size <= 0:
+            raise RuntimeError("this network has no bag")
+        self._check(self.lib.dtqn_replay_gather_bag(replay.view_ref, _p(self.ep_idx), _p(self.start), None, self.batch, self.net.bag_size,
+                                                    ctypes.c_uint32(seed & 0xFFFFFFFF), _p(self.step_counter), _p(self.bag_obs),
+                                                    _p(self.bag_actions), self._stream()), "dtqn_replay_gather_bag")
 
     def set_bag(self, bag_obs, bag_actions) -> None:
         """Bags of the windows set_indices named: bag_obs [B, bag_size, obs_dim], bag_actions [B, bag_size(, 1)]."""

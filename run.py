@@ -138,8 +138,11 @@ def prepopulate(agent, prepop_steps: int, envs) -> None:
 def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, eval_episodes, policy_path, save_policy,
           logger, mean_success_rate, mean_episode_length, mean_reward, time_remaining, verbose=False, is_main=True,
           overlap=False, vector=None):
-    """Main loop: one env step, one TD update (run.py:246-353).  vector: a VectorActor over N environments; then every
-    N-th iteration steps all N environments at once (the other iterations only train), which keeps one update per env step."""
+    """Main loop: one env step, one TD update (run.py:246-353).  vector: a VectorActor over N environments; then one iteration in
+    N steps all N environments at once with that vector step's N updates queued behind the actor forward (the other N - 1
+    iterations only account for them), which keeps one update per env step.  The vector steps are driven by the updates still
+    owed, not by `timestep % N`: a resumed run steps on its first iteration, and the time limit is only honoured at a
+    vector-step boundary, so a checkpoint's `num_train_steps` always equals the loop's timestep."""
     start = time()
     agent.eval_off()
     if vector is None:
@@ -147,10 +150,13 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
         agent.context_reset(env.reset())
     else:
         vector.reset_all()
+    owed = 0                 # updates of the current vector step the loop has not accounted for yet
     for timestep in range(agent.num_train_steps, total_steps):
         if vector is not None:
-            if timestep % vector.n == 0:       # N env steps and the N updates that go with them (queued behind the actor forward)
-                vector.step_all(eps.val, updates=min(vector.n, total_steps - timestep))
+            if owed == 0:                      # N env steps and the N updates that go with them (queued behind the actor forward)
+                owed = min(vector.n, total_steps - timestep)
+                vector.step_all(eps.val, updates=owed)
+            owed -= 1
         elif overlap:
             if step_overlapped(agent, env, eps):       # includes this step's train()
                 agent.replay_buffer.flush()
@@ -163,7 +169,9 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
                 agent.context_reset(env.reset())
             agent.train()
         eps.anneal()
-        if timestep % eval_frequency == 0 and is_main:
+        if timestep % eval_frequency == 0:
+            # data parallel: EVERY rank evaluates (on its own evaluation environments) so that no replica sits blocked in the next
+            # gradient all-reduce while rank 0 plays its episodes; only the main rank logs
             hours = (time() - start) / 3600
             log = {"losses/TD_Error": agent.td_errors.mean(), "losses/Grad_Norm": agent.grad_norms.mean(),
                    "losses/Max_Q_Value": agent.qvalue_max.mean(), "losses/Mean_Q_Value": agent.qvalue_mean.mean(),
@@ -173,13 +181,14 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
             for env_str, eval_env in zip(env_strs, eval_envs):
                 sr, ret, length = evaluate(agent, eval_env, eval_episodes)
                 log.update({f"{env_str}/SuccessRate": sr, f"{env_str}/Return": ret, f"{env_str}/EpisodeLength": length})
-                if verbose:
+                if verbose and is_main:
                     print(f"[ {timestamp()} ] Training Steps: {timestep}, Env: {env_str}, Success Rate: {sr:.2f}, "
                           f"Return: {ret:.2f}, Episode Length: {length:.2f}, Hours: {hours:.2f}", flush=True)
-            logger.log(log, step=timestep)
+            if is_main:
+                logger.log(log, step=timestep)
         if save_policy and timestep % 50_000 == 0 and is_main:
             torch.save(agent.policy_network.state_dict(), policy_path)
-        if time_remaining:
+        if time_remaining and owed == 0:
             # one process: the wall clock decides.  Data parallel: every rank must leave on the SAME iteration (the others
             # would block in the gradient all-reduce), so the ranks vote every TIME_CHECK_PERIOD steps
             if not ddp.is_distributed():

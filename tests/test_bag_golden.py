@@ -249,16 +249,15 @@ class _ScriptedEnv:
         return self.traj[self.t], 0.0, False, {}
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_vectorised_rollout_keeps_one_bag_per_environment(emu, name):
+def check_vector_bag_rollout(lib, name, device="cpu"):
     """VectorActor with a bag network: N environments, N bags, one batched forward per vector step.  Fed the golden rollout's
     observations in two environments (one of them a step behind, so the prefixes are ragged), every environment reproduces the
-    reference's greedy actions and bag contents step by step."""
+    reference's greedy actions and bag contents step by step (G9's rollout, generated from the reference)."""
     import dtqn_amd.utils.random as rnd
     from dtqn_amd.agents.vector import VectorActor
     z, cfg, meta, pol, tgt = load_case(name)
     rnd.RNG.rng = np.random.Generator(np.random.PCG64(meta["seed"] + 3))
-    agent = make_bag_agent(emu, cfg, meta, pol, tgt)
+    agent = make_bag_agent(lib, cfg, meta, pol, tgt, device)
     agent.eval_off()
     traj = z[f"{name}_act_traj"]
     vec = VectorActor(agent, [_ScriptedEnv(traj), _ScriptedEnv(traj)])
@@ -294,6 +293,11 @@ def test_vectorised_rollout_keeps_one_bag_per_environment(emu, name):
     # and the public loop: one vector step through step_all keeps going from here without error, bags reset with their envs
     vec._reset(1)
     assert vec.bags[1].pos == 0
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_vectorised_rollout_keeps_one_bag_per_environment(emu, name):
+    check_vector_bag_rollout(emu, name)
 
 
 def test_vectorised_rollout_with_bags_runs_the_public_loop(emu):

@@ -6,7 +6,7 @@ import pytest
 from oracle import dtqn_oracle as O
 
 from helpers import make_td_case, check_td_updates
-from test_bag_golden import NAMES, check_bag_surface, check_device_drawn_bags
+from test_bag_golden import NAMES, check_bag_surface, check_device_drawn_bags, check_vector_bag_rollout
 
 pytestmark = pytest.mark.gpu
 
@@ -54,3 +54,10 @@ def test_bag_surface_vs_the_reference(lib, name):
 
 def test_device_drawn_bags(lib):
     check_device_drawn_bags(None, device="cuda")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_vectorised_bag_rollout_on_the_device_vs_the_reference(lib, name):
+    """The vectorised bag rollout (agents/vector.py: one batched dtqn_forward_bag per vector step, last rows through pinned memory
+    behind an event) against G9's greedy rollout with bag evictions."""
+    check_vector_bag_rollout(None, name, device="cuda")
