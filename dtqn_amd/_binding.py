@@ -114,6 +114,8 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_reduce": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_gradnorm": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_clip_adam": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_xch_publish": [vp, i32, vp],
+        "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
         "dtqn_debug_set_profile_buffer": [vp],

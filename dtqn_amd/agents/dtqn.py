@@ -317,10 +317,11 @@ class DtqnAgent:
         if self._actor_inflight:
             # the gradient kernels overlap the actor forward; only the optimizer kernel (which overwrites theta)
             # has to wait for it
-            eng.forward_backward(rb.dev)
             if self.dp is not None:
-                self.dp.allreduce_gradient()
-                eng.recompute_gradnorm()
+                self.dp.forward_backward(rb.dev)
+                self.dp.reduce()
+            else:
+                eng.forward_backward(rb.dev)
             self._main_stream.wait_event(self._ev_actor_done)
             eng.clip_adam()
             self._actor_inflight = False

@@ -30,6 +30,9 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 // hand tiles to each other through global memory with these (sc1 loads / stores: coherent without L2 write-backs).
 #define DTQN_AGENT_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_AGENT_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// System-scope (other GPUs over xGMI, other processes on this GPU) relaxed atomics: the gradient exchange of the data-parallel update
+#define DTQN_SYSTEM_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define DTQN_SYSTEM_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define DTQN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
 // for global stores)

@@ -76,6 +76,58 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_gradnorm_kernel(NormArgs a) 
     if (tid == 0) a.norm_partial[blockIdx.x] = ss;
 }
 
+// ---- device-side gradient exchange (include/dtqn_hip.h, dtqn_td_xreduce) ---------------------------------------------------
+struct PublishArgs {
+    int32_t* flag;
+    int32_t gen;
+};
+__global__ void dtqn_xch_publish_kernel(PublishArgs a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) DTQN_SYSTEM_STORE(a.flag, a.gen);
+}
+struct XreduceArgs {
+    const float* const* peer_grad;
+    int32_t* const* peer_flag;
+    float* gsum;
+    float* norm_partial;
+    int32_t* status;
+    int n, n_parts, world;
+    int32_t gen;
+};
+// Block b owns parameters [1024 b, 1024 b + 1024): wait for the `world` flag words, then one pass over the `world` buffers in rank
+// order.  Peer buffers are read with system-scope loads (they were written by another GPU / process: nothing of them may come
+// out of this GPU's caches), 16 floats per thread and peer at cfg 1.  HBM / xGMI-bound: 4 * world * n bytes in, 4 * n out.
+__global__ __launch_bounds__(kOptThreads) void dtqn_xreduce_kernel(XreduceArgs a) {
+    __shared__ float red[kOptThreads / 64];
+    const int tid = (int)threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kOptThreads) a.norm_partial[i] = 0.f;
+    if (tid < a.world) {
+        const int32_t* f = a.peer_flag[tid];
+        const long long t0 = wall_clock64();
+        // generations only grow (and wrap after 2^31 updates): "reached" = not behind
+        while ((int32_t)(DTQN_SYSTEM_LOAD(f) - a.gen) < 0) {
+            if (wall_clock64() - t0 > 500000000ll) {          // 5 s at 100 MHz: a peer died or never entered this update
+                DTQN_SYSTEM_STORE(a.status, (int32_t)1);
+                break;
+            }
+            DTQN_SPIN_PAUSE();
+        }
+    }
+    __syncthreads();
+    const int p0 = ((int)blockIdx.x * kOptThreads + tid) * kOptVec;
+    float v[kOptVec] = {0.f, 0.f, 0.f, 0.f};
+    if (p0 < a.n) {
+        for (int r = 0; r < a.world; ++r) {
+            const int32_t* g = reinterpret_cast<const int32_t*>(a.peer_grad[r] + p0);
+#pragma unroll
+            for (int c = 0; c < kOptVec; ++c) v[c] += __int_as_float(DTQN_SYSTEM_LOAD(g + c));
+        }
+        st4(a.gsum + p0, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    const float ss = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), red, tid);
+    if (tid == 0) a.norm_partial[blockIdx.x] = ss;
+}
+
 struct AdamArgs {
     float* theta;
     float* theta_tgt;
@@ -216,6 +268,30 @@ extern "C" int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stre
     a.grad = td->grad; a.norm_partial = td->norm_partial; a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_gradnorm_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_xch_publish(int32_t* own_flag_dev, int32_t gen, void* stream) {
+    if (!own_flag_dev) return DTQN_ERR_ARG;
+    PublishArgs a;
+    a.flag = own_flag_dev; a.gen = gen;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dtqn_xch_publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+
+extern "C" int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_ptrs_dev, const void* peer_flag_ptrs_dev, int world,
+                               int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream) {
+    if (!net || !td || !peer_grad_ptrs_dev || !peer_flag_ptrs_dev || !gsum_dev || !status_dev) return DTQN_ERR_ARG;
+    if (world < 1 || world > kOptThreads) return DTQN_ERR_ARG;
+    if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
+    XreduceArgs a;
+    a.peer_grad = static_cast<const float* const*>(peer_grad_ptrs_dev);
+    a.peer_flag = static_cast<int32_t* const*>(peer_flag_ptrs_dev);
+    a.gsum = gsum_dev; a.norm_partial = td->norm_partial; a.status = status_dev;
+    a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net); a.world = world; a.gen = gen;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dtqn_xreduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 

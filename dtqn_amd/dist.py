@@ -58,14 +58,77 @@ def agree_any(flag: bool, device) -> bool:
     return bool(t.item())
 
 
-class DataParallel:
-    """Wraps a TdEngine: update() = local gradient kernels -> all-reduce -> clip + Adam."""
+class P2PExchange:
+    """Device-side gradient exchange (include/dtqn_hip.h, dtqn_td_xreduce): every rank exports one allocation
+    [gx generation 0 | gx generation 1 | flag word] to its peers and maps theirs; an update then needs no library call --
+    one 1-thread publish launch and one reduce launch that reads all peers directly (7 xGMI links per GPU on an MI355X node: a
+    rank reads its 7 peers at once).  The handles travel through torch's own IPC reductions (hipIpcGetMemHandle over dmabuf:
+    HSA_ENABLE_IPC_MODE_LEGACY=0) and `all_gather_object`; on a CPU test build the buffer is POSIX shared memory."""
 
     def __init__(self, engine, group=None):
+        from torch.multiprocessing import reductions  # noqa: F401  (registers the reducers with ForkingPickler)
+        self.engine, self.group = engine, group
+        self.world, self.rank = td.get_world_size(group), td.get_rank(group)
+        n = self.n = engine.net.n_trainable
+        dev = engine.device
+        self.buf = torch.zeros(2 * n + 16, dtype=torch.float32, device=dev)
+        if dev.type != "cuda":
+            torch.multiprocessing.set_sharing_strategy("file_system")      # handles that survive pickling through a collective
+            self.buf.share_memory_()
+        # ForkingPickler carries torch's IPC reducers (a storage travels as its shared-memory / IPC handle, not as a copy of its bytes)
+        import pickle
+        from multiprocessing.reduction import ForkingPickler
+        handles = [None] * self.world
+        td.all_gather_object(handles, bytes(ForkingPickler.dumps(self.buf)), group=group)
+        self.peers = [self.buf if r == self.rank else pickle.loads(h) for r, h in enumerate(handles)]
+        if dev.type == "cuda":
+            for r, p in enumerate(self.peers):          # a first copy makes torch enable peer access to that device
+                if r != self.rank and p.device != dev:
+                    p[:1].to(dev)
+        esz = 4
+        ptrs = lambda off: torch.tensor([p.data_ptr() + off * esz for p in self.peers], dtype=torch.int64, device=dev)
+        self.grad_ptrs = [ptrs(0), ptrs(n)]
+        self.flag_ptrs = ptrs(2 * n)
+        self.own = [self.buf[:n], self.buf[n:2 * n]]
+        self.own_flag = self.buf[2 * n:2 * n + 1]
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.k = 0
+        td.barrier(group=group)                         # every rank has mapped every buffer before anyone publishes
+
+    def begin(self) -> None:
+        """Point the gradient kernels of the next update at this generation's exchange buffer."""
+        self.k += 1
+        self.engine.td.grad = self.own[self.k & 1].data_ptr()
+
+    def reduce(self) -> None:
+        import ctypes
+        e = self.engine
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        s = e._stream()
+        e._check(e.lib.dtqn_xch_publish(vp(self.own_flag), self.k, s), "dtqn_xch_publish")
+        e._check(e.lib.dtqn_td_xreduce(e._net_ref, e._td_ref, vp(self.grad_ptrs[self.k & 1]), vp(self.flag_ptrs), self.world, self.k,
+                                       vp(e.grad), vp(self.status), s), "dtqn_td_xreduce")
+        e.td.grad = e.grad.data_ptr()
+
+    def check(self) -> None:
+        """Raise if a wait inside dtqn_td_xreduce ran out (a peer died or skipped an update).  Synchronises."""
+        if int(self.status.item()) != 0:
+            raise RuntimeError("device-side gradient exchange: a peer's gradient never arrived (bounded wait expired)")
+
+
+class DataParallel:
+    """Wraps a TdEngine: update() = local gradient kernels -> exchange (sum over ranks) -> clip + Adam.
+    DTQN_DP_EXCHANGE=rccl (default): torch.distributed.all_reduce + a norm-recompute launch; =p2p: the device-side exchange."""
+
+    def __init__(self, engine, group=None, exchange=None):
         self.engine = engine
         self.group = group
         self.world = td.get_world_size(group)
         engine.td.grad_scale = 1.0 / self.world          # mean over ranks, applied inside the optimizer kernel
+        kind = (exchange or os.environ.get("DTQN_DP_EXCHANGE", "rccl")).lower()
+        if kind not in ("rccl", "p2p"):
+            raise ValueError("DTQN_DP_EXCHANGE must be 'rccl' or 'p2p'")
+        self.p2p = P2PExchange(engine, group) if kind == "p2p" else None
 
     def broadcast_parameters(self, src: int = 0) -> None:
         e = self.engine
@@ -73,14 +136,32 @@ class DataParallel:
             td.broadcast(t, src=src, group=self.group)
 
     def exchange_kind(self) -> str:
-        return "rccl all_reduce"
+        return "device-side p2p reduce (dtqn_td_xreduce)" if self.p2p is not None else "rccl all_reduce + dtqn_td_gradnorm"
 
     def allreduce_gradient(self) -> None:
+        """The exchange step by itself (bench.py times it): e.grad <- sum over ranks, norm partials of the sum."""
+        if self.p2p is not None:
+            self.p2p.k += 1                 # a generation of its own: what it exchanges is whatever the buffer holds
+            self.p2p.reduce()
+            return
         td.all_reduce(self.engine.grad, op=td.ReduceOp.SUM, group=self.group)
+        self.engine.recompute_gradnorm()
+
+    def forward_backward(self, replay) -> None:
+        """forward x3, loss + backward, weight gradients, reduce -> the local mean gradient, where the exchange reads it."""
+        if self.p2p is not None:
+            self.p2p.begin()
+        self.engine.forward_backward(replay)
+
+    def reduce(self) -> None:
+        """The one exchange step: after it e.grad holds the sum over ranks and norm_partial its sums of squares."""
+        if self.p2p is not None:
+            self.p2p.reduce()
+        else:
+            td.all_reduce(self.engine.grad, op=td.ReduceOp.SUM, group=self.group)
+            self.engine.recompute_gradnorm()              # global norm of the summed gradient (scaled by 1/world in the kernel)
 
     def update(self, replay) -> None:
-        e = self.engine
-        e.forward_backward(replay)          # forward x3, loss + backward, weight gradients, reduce -> e.grad (local mean)
-        self.allreduce_gradient()           # the one exchange step
-        e.recompute_gradnorm()              # global norm of the summed gradient (scaled by 1/world in the kernel)
-        e.clip_adam()
+        self.forward_backward(replay)
+        self.reduce()
+        self.engine.clip_adam()

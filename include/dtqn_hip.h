@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 9
+#define DTQN_ABI_VERSION 10
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -365,6 +365,24 @@ int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stream);
  * (dtqn.py:257-269, dqn.py:64,208-210) + final stats.  Non-finite norm: sets stats[11] and skips
  * the update (the host raises RuntimeError like error_if_nonfinite=True). */
 int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
+/* ---- device-side gradient exchange of the data-parallel update (new; the reference is single-process) ----
+ * One process per GPU.  Every rank owns an exchange buffer gx[2][n_trainable] (two generations) and a flag word, exported to its
+ * peers over HIP IPC / peer access (the caller maps them; this library only sees device pointers).  Update k (k = 1, 2, ...):
+ *   1. the rank points DtqnTd.grad at its gx[k & 1] and runs forward / backward / wgrad / reduce: its local mean gradient lands there;
+ *   2. dtqn_xch_publish raises its flag word to k (system-scope store; the kernel boundary in front of it has made the gradient
+ *      visible beyond this GPU's caches);
+ *   3. dtqn_td_xreduce: every block waits (bounded spin, system-scope loads) until all `world` flag words have reached k, then sums
+ *      its 1024 parameters over the `world` buffers IN RANK ORDER -- every rank computes the same bits, so replicas stay identical
+ *      without an all-gather --, writes the sum to gsum and its sum of squares to DtqnTd.norm_partial;
+ *   4. the rank points DtqnTd.grad at gsum and runs dtqn_td_clip_adam with grad_scale = 1 / world.
+ * Replaces {RCCL all-reduce + dtqn_td_gradnorm} with one launch and no library call.  Two generations make step 1 of update k + 2
+ * safe: a rank gets past step 3 of update k + 1 only after every peer published k + 1, i.e. finished reading generation k.
+ *   peer_grad_ptrs_dev  device array of `world` pointers (const float*): generation (gen & 1) of every rank's buffer, own included
+ *   peer_flag_ptrs_dev  device array of `world` pointers (int32_t*): every rank's flag word
+ *   status_dev          int32: set to 1 by a block whose wait ran out (~5 s): the caller raises instead of hanging the GPU */
+int dtqn_xch_publish(int32_t* own_flag_dev, int32_t gen, void* stream);
+int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_ptrs_dev, const void* peer_flag_ptrs_dev, int world,
+                    int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream);
 /* Convenience: forward, backward, wgrad, reduce, clip_adam back to back (single GPU). */
 int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */

@@ -25,6 +25,8 @@ template <typename T> static inline T hipemu_agent_load(const T* p) { T v; __ato
 template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomic_store(p, &v, __ATOMIC_RELEASE); }
 #define DTQN_AGENT_LOAD(p) hipemu_agent_load(p)
 #define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
+#define DTQN_SYSTEM_LOAD(p) hipemu_agent_load(p)
+#define DTQN_SYSTEM_STORE(p, v) hipemu_agent_store(p, v)
 #define DTQN_SPIN_PAUSE() ((void)0)
 #define DTQN_WAIT_VMEM() ((void)0)
 #define DTQN_SCHED_FENCE() ((void)0)
@@ -208,6 +210,7 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 using std::isfinite;
 
 static inline long long wall_clock64() { return 0; }
+static inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 static inline long long clock64() { return 0; }
 
 // ---- atomics ----------------------------------------------------------------

@@ -230,9 +230,13 @@ from dtqn_amd import _binding as B, dist as ddp
 from oracle import dtqn_oracle as O
 from helpers import make_td_case
 on_gpu = os.environ.get("DP_DEVICE", "cpu") == "cuda"
-rank, world, local = ddp.init_from_env("cuda" if on_gpu else "cpu")
+same_dev = os.environ.get("DP_SAME_DEVICE", "0") == "1"       # both ranks on cuda:0 (one-GPU box): gloo as the control plane
+rank, world, local = ddp.init_from_env("cuda" if on_gpu and not same_dev else "cpu")
 if on_gpu:
     from dtqn_amd import engine
+    if same_dev:
+        local = 0
+    torch.cuda.set_device(local)
     lib, dev, kw = engine.get_lib(), f"cuda:{local}", dict(device=f"cuda:{local}", test_lib=False)
 else:
     from emu import emu_build
@@ -243,21 +247,27 @@ Bl, T = int(os.environ.get("DP_BATCH", "4")), int(os.environ.get("DP_T", "12"))
 net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=Bl, T=T, n_eps=9 + 2 * Bl, mask=-5, **kw)
 random.seed(77)
 eps, starts = host.sample_indices(world * Bl)
-dp = ddp.DataParallel(eng)
-dp.broadcast_parameters()
+dp = ddp.DataParallel(eng, exchange=os.environ.get("DP_EXCHANGE", "rccl"))
+vote_dev = "cpu" if same_dev else dev
+if not same_dev:
+    dp.broadcast_parameters()           # (same-device mode: gloo cannot move device tensors; both ranks built identical parameters)
 # collective votes used by DtqnAgent.train() / run.py --time-limit: every rank gets the same answer
-assert ddp.agree_all(True, dev) is True and ddp.agree_all(rank != 1, dev) is False
-assert ddp.agree_any(False, dev) is False and ddp.agree_any(rank == 1, dev) is True
-for it in range(2):
+assert ddp.agree_all(True, vote_dev) is True and ddp.agree_all(rank != 1, vote_dev) is False
+assert ddp.agree_any(False, vote_dev) is False and ddp.agree_any(rank == 1, vote_dev) is True
+n_updates = int(os.environ.get("DP_UPDATES", "2"))
+for it in range(n_updates):
     eng.set_indices(eps[rank * Bl:(rank + 1) * Bl], starts[rank * Bl:(rank + 1) * Bl])
     dp.update(rep)
 if on_gpu:
     torch.cuda.synchronize()
+if dp.p2p is not None:
+    dp.p2p.check()
+    assert dp.p2p.k == n_updates and "p2p" in dp.exchange_kind()
 np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.cpu().numpy())
 if rank == 0:
     # single learner on the union batch
     net1, _, host1, eng1, rep1 = make_td_case(lib, cfg, seed=21, batch=world * Bl, T=T, n_eps=9 + 2 * Bl, mask=-5, **kw)
-    for it in range(2):
+    for it in range(n_updates):
         eng1.set_indices(eps, starts)
         eng1.update(rep1)
     np.save(os.environ["OUT"] + ".single.npy", eng1.theta_pol.cpu().numpy())
@@ -274,21 +284,34 @@ def run_dp_script(tmp_path, env_extra, port):
     env = dict(os.environ, OUT=out, HIPEMU_THREADS="2", MASTER_ADDR="127.0.0.1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     r0, r1, single = (np.load(out + s) for s in (".rank0.npy", ".rank1.npy", ".single.npy"))
     assert np.array_equal(r0, r1)                               # replicas stay bit-identical
     norms = np.load(out + ".stats.npy")
     assert abs(norms[0] - norms[1]) <= 1e-5 * norms[1]
-    # two Adam steps from the same state; gradients equal up to summation order (a noise-floor gradient may flip a step's sign)
-    assert np.abs(r0 - single).max() <= 2.01 * 2 * 3e-4
-    assert np.mean(np.abs(r0 - single) <= 2e-6) > 0.98
+    # Adam steps from the same state; gradients equal up to summation order (a noise-floor gradient may flip a step's sign)
+    n_updates = int(env_extra.get("DP_UPDATES", "2"))
+    assert np.abs(r0 - single).max() <= 2.01 * n_updates * 3e-4
+    assert np.mean(np.abs(r0 - single) <= 2e-6 * n_updates / 2) > (0.98 if n_updates <= 2 else 0.9)
+    return r0
 
 
 def test_data_parallel_equals_single_learner_gloo(emu, tmp_path):
     """world_size 2 on CPU (gloo): all-reduced half-batches == one learner on the union batch, over two updates, plus the
     collective votes DtqnAgent.train() and run.py use to keep ranks in the same control flow."""
     run_dp_script(tmp_path, {}, 29611)
+
+
+def test_device_side_exchange_equals_the_all_reduce(emu, tmp_path):
+    """DTQN_DP_EXCHANGE=p2p on the emulation: two processes, exchange buffers in shared memory, dtqn_xch_publish +
+    dtqn_td_xreduce (flags, two generations, rank-ordered sum) instead of the collective.  Replicas bit-identical, equal to one
+    learner on the union batch, and BIT-EQUAL to what the all-reduce path leaves after the same five updates (two ranks: a + b is
+    the same sum in either order)."""
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    p2p = run_dp_script(tmp_path / "a", {"DP_EXCHANGE": "p2p", "DP_UPDATES": "5"}, 29613)
+    ref = run_dp_script(tmp_path / "b", {"DP_EXCHANGE": "rccl", "DP_UPDATES": "5"}, 29615)
+    assert np.array_equal(p2p, ref)
 
 
 def test_vector_actor_matches_single_actor_and_reference_buffer(emu):
