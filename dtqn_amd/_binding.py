@@ -114,6 +114,15 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_reduce": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_gradnorm": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_clip_adam": [P(DtqnNet), P(DtqnTd), vp],
+        "dtqn_img_prep_floats": [P(DtqnNet)],
+        "dtqn_img_act_floats": [P(DtqnNet), i32],
+        "dtqn_img_gact_floats": [P(DtqnNet), i32],
+        "dtqn_img_wpart_floats": [P(DtqnNet)],
+        "dtqn_img_prep": [P(DtqnNet), vp, vp, vp],
+        "dtqn_img_encode": [P(DtqnNet), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
+        "dtqn_img_backward": [P(DtqnNet), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp],
+        "dtqn_img_td_lists": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp, vp, vp, vp, vp, vp, vp],
+        "dtqn_forward_tiled_pre": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, i32, u32, u32, vp],
         "dtqn_xch_publish": [vp, i32, vp],
         "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
@@ -125,7 +134,8 @@ def load_library(path: str) -> ctypes.CDLL:
     for name, argtypes in protos.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "dtqn_build_info" else ctypes.c_int
+        fn.restype = ctypes.c_char_p if name == "dtqn_build_info" else (
+            ctypes.c_longlong if name in ("dtqn_img_act_floats", "dtqn_img_gact_floats", "dtqn_img_wpart_floats") else ctypes.c_int)
     assert set(protos) == set(FUNCTIONS), sorted(set(protos) ^ set(FUNCTIONS))
     if lib.dtqn_abi_version() != DEFINES["DTQN_ABI_VERSION"]:
         raise OSError(f"{path}: ABI version {lib.dtqn_abi_version()} != header {DEFINES['DTQN_ABI_VERSION']}")
@@ -138,7 +148,7 @@ POS = {"learned": DEFINES["DTQN_POS_LEARNED"], "sin": DEFINES["DTQN_POS_SIN"], "
 
 def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, inner_embed_size=64, num_heads=8,
              num_layers=2, history_len=50, gate="res", identity=False, pos="learned", discrete=False,
-             vocab_sizes=0, dropout=0.0, bag_size=0) -> DtqnNet:
+             vocab_sizes=0, dropout=0.0, bag_size=0, image=None) -> DtqnNet:
     """Build and initialise a DtqnNet from the reference's DTQN constructor arguments
     (dtqn/networks/dtqn.py:41-59)."""
     net = DtqnNet()
@@ -150,6 +160,9 @@ def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, in
     net.discrete, net.vocab = int(bool(discrete)), int(vocab_sizes or 0)
     net.dropout = float(dropout)
     net.bag_size = int(bag_size)
+    if image is not None:                    # obs_dim as the reference's (C, H, W) tuple (dtqn.py:71-77)
+        net.img_c, net.img_h, net.img_w = (int(v) for v in image)
+        net.obs_dim = net.img_c * net.img_h * net.img_w
     rc = lib.dtqn_net_init(ctypes.byref(net))
     if rc != 0:
         raise NotImplementedError(
@@ -165,7 +178,15 @@ def param_table(net: DtqnNet) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
     tab: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
     if a > 0:
         tab["action_embedding.embedding.0.weight"] = (net.off_act_emb, (A, a))
-    if net.discrete:
+    if net.img_c > 0:        # representations.py:99-129: nn.Sequential indices 0, 2, 4, 6, 8 are the convolutions, 11 the Linear
+        chans = [(net.img_c, 64), (64, 64), (64, 64), (64, 128), (128, 128)]
+        offs = [(net.off_cw0, net.off_cb0), (net.off_cw1, net.off_cb1), (net.off_cw2, net.off_cb2), (net.off_cw3, net.off_cb3), (net.off_cw4, net.off_cb4)]
+        for i, ((ci, co), (ow, ob)) in enumerate(zip(chans, offs)):
+            tab[f"obs_embedding.observation_embedding.{2 * i}.weight"] = (ow, (co, ci, 3, 3))
+            tab[f"obs_embedding.observation_embedding.{2 * i}.bias"] = (ob, (co,))
+        tab["obs_embedding.observation_embedding.11.weight"] = (net.off_obs_w, (D - a, net.ke))
+        tab["obs_embedding.observation_embedding.11.bias"] = (net.off_obs_b, (D - a,))
+    elif net.discrete:
         tab["obs_embedding.observation_embedding.0.weight"] = (net.off_obs_tab, (net.vocab, net.embed_per_obs))
         tab["obs_embedding.observation_embedding.2.weight"] = (net.off_obs_w, (D - a, net.ke))
         tab["obs_embedding.observation_embedding.2.bias"] = (net.off_obs_b, (D - a,))

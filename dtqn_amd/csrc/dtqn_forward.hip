@@ -122,6 +122,8 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
         const bool skip = td->sample_exclude >= 0 && td->sample_exclude < td->sample_n_valid;
         if (td->sample_n_valid - (skip ? 1 : 0) < 1 || !td->step_counter) return DTQN_ERR_ARG;
     }
+    // image nets: the windows must exist before dtqn_img_encode, which fills td->xemb in front of this call
+    if (net->img_c > 0 && (draw || !td->xemb)) return DTQN_ERR_ARG;
     if (net->tiled) {       // the multi-kernel path reads the windows from td->ep_idx / td->start: draw them first
         if (draw) {
             const int rc = dtqn_replay_sample(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed,

@@ -41,15 +41,32 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
     if (!(net->dropout >= 0.f && net->dropout < 1.f)) return DTQN_ERR_CONFIG;
     if (net->bag_size < 0) return DTQN_ERR_CONFIG;
+    const bool img = net->img_c > 0;
+    if (img) {
+        // representations.py:77-130: obs_dim = (C, H, W); convolution strides 2, 1, 2, 1, 2, padding 1
+        const int C = net->img_c, Hh = net->img_h, Ww = net->img_w;
+        // (no action embedding next to the image embedding: the encoder's Linear writes all D columns; widths of the row-block path)
+        if (Hh < 1 || Ww < 1 || C > 3 || O != C * Hh * Ww || net->discrete || a != 0 || net->bag_size > 0) return DTQN_ERR_CONFIG;
+        if (!(D == 64 || D == 128 || D == 256)) return DTQN_ERR_CONFIG;
+        auto half = [](int x) { return (x - 1) / 2 + 1; };
+        net->img_h1 = half(Hh); net->img_w1 = half(Ww);
+        net->img_h3 = half(net->img_h1); net->img_w3 = half(net->img_w1);
+        net->img_h5 = half(net->img_h3); net->img_w5 = half(net->img_w3);
+        net->img_feat = 128 * net->img_h5 * net->img_w5;
+        net->img_k1 = up16(9 * C);
+    } else {
+        net->img_h = net->img_w = 0;
+        net->img_h1 = net->img_w1 = net->img_h3 = net->img_w3 = net->img_h5 = net->img_w5 = net->img_feat = net->img_k1 = 0;
+    }
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
-    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0) {
+    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0 || img) {
         // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
         net->tiled = 1;
         net->lp = (L + 63) / 64 * 64;
     }
-    net->ke = net->discrete ? O * e : O;
+    net->ke = img ? net->img_feat : (net->discrete ? O * e : O);
     net->kep = up4(net->ke);
     net->ap = up4(A);
     net->head_dim = D / H;
@@ -78,6 +95,14 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->off_obs_tab = net->discrete ? c.take(V * e) : -1;
     net->off_obs_w = c.take((D - a) * net->ke);
     net->off_obs_b = c.take(D - a);
+    {
+        const int C = net->img_c;
+        net->off_cw0 = img ? c.take(64 * C * 9) : -1;    net->off_cb0 = img ? c.take(64) : -1;
+        net->off_cw1 = img ? c.take(64 * 64 * 9) : -1;   net->off_cb1 = img ? c.take(64) : -1;
+        net->off_cw2 = img ? c.take(64 * 64 * 9) : -1;   net->off_cb2 = img ? c.take(64) : -1;
+        net->off_cw3 = img ? c.take(128 * 64 * 9) : -1;  net->off_cb3 = img ? c.take(128) : -1;
+        net->off_cw4 = img ? c.take(128 * 128 * 9) : -1; net->off_cb4 = img ? c.take(128) : -1;
+    }
     const bool pos_trainable = net->pos == DTQN_POS_LEARNED;
     if (pos_trainable) net->off_pos = c.take(L * D);
     {
@@ -131,7 +156,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     // ---- activation record ----
     const bool gru = net->gate == DTQN_GATE_GRU;
     Cursor ac;
-    net->ao_ein = ac.take(LP * net->kep);
+    net->ao_ein = ac.take(img ? 0 : LP * net->kep);        // image nets: the encoder's feature maps live in its own workspace
     net->ao_x0 = ac.take(LP * D);
     {
         Cursor lc;
@@ -203,7 +228,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         njobs++;
         ntiles += ((N + 63) / 64) * ((K + 63) / 64);
     };
-    count(D - a, net->ke);
+    if (!img) count(D - a, net->ke);       // image nets: the embedding linear's gradient comes out of dtqn_img_backward
     for (int l = 0; l < NL; ++l) {
         count(3 * D, D);
         count(D, D);
@@ -245,7 +270,7 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
         tile += w.tiles_n * w.tiles_k;
     };
     // embedding linear: dY = dx0[:, a:], X = e_in
-    add(1, net->ao_ein, net->kep, net->ke, net->go_dx0 + a, D, D - a, net->off_obs_w, net->off_obs_b);
+    if (net->img_c <= 0) add(1, net->ao_ein, net->kep, net->ke, net->go_dx0 + a, D, D - a, net->off_obs_w, net->off_obs_b);
     if (net->bag_size > 0) {
         // the embedding linear also embeds the bag entries (dtqn.py:203-210): a second token set of the same job, summed
         // like the layers of a shared GRU gate (records of the bag entries at a fixed distance from the context's)

@@ -45,6 +45,11 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 float* rew = a.rp.rewards + (size_t)ep * T;
                 uint8_t* don = a.rp.dones + (size_t)ep * T;
                 const float* src = a.obs_rows + (size_t)r.obs_index * O;
+                if (a.rp.obs_u8 != nullptr) {      // image observations: uint8 rows (replay_buffer.py:36-45), staged as bytes
+                    uint8_t* o8 = a.rp.obs_u8 + (size_t)ep * (T + 1) * O;
+                    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(a.obs_rows) + (size_t)r.obs_index * O;
+                    for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) o8[k] = k < O ? s8[k] : (uint8_t)a.rp.obs_mask;
+                } else
                 for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? src[k] : a.rp.obs_mask;
                 for (int k = tid; k < T + 1; k += DTQN_THREADS) act[k] = 0;
                 for (int k = tid; k < T; k += DTQN_THREADS) { rew[k] = 0.f; don[k] = 1; }
@@ -57,6 +62,14 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
             int j = i + 1;
             while (j < m && recs[j].kind != 0) ++j;
             const int cnt = j - i;
+            if (a.rp.obs_u8 != nullptr) {
+                const uint8_t* s8 = reinterpret_cast<const uint8_t*>(a.obs_rows);
+                for (int ri = i; ri < j; ++ri) {
+                    const DtqnReplayRecord s = recs[ri];
+                    uint8_t* dst = a.rp.obs_u8 + ((size_t)s.ep * (T + 1) + (s.t + 1)) * O;
+                    for (int k = tid; k < O; k += DTQN_THREADS) dst[k] = s8[(size_t)s.obs_index * O + k];
+                }
+            } else
             for (int q = tid; q < cnt * O; q += DTQN_THREADS) {
                 const int ri = i + q / O, k = q - (q / O) * O;
                 const DtqnReplayRecord s = recs[ri];

@@ -18,6 +18,8 @@
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
 
+#include "dtqn_frag16.hpp"
+
 namespace dtqn {
 
 constexpr int TNW = 8;                 // waves per workgroup of the GEMM / row-wise kernels
@@ -79,6 +81,8 @@ struct TlEmbedArgs {
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
     int src_mod;                       // > 0: sequence s reads source sequence s % src_mod (one bag per window, three forwards)
     int bag;                           // 1: bag entries (dtqn.py:203-210): no position, the action embedding is not rolled
+    const float* pre;                  // image nets: precomputed observation embeddings [S][pre_rows][D - a] (dtqn_img_encode); the linear is skipped
+    int pre_rows;
     const int32_t* lens;               // ragged prefixes in one launch (dtqn_actor_forward_batch): live rows of sequence s, or nullptr = n.
                                        // Only the "a one-row sequence keeps its action embedding" rule (dtqn.py:187) looks at it
     TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = zero4();
     float* eo = a.ein.base != nullptr ? frow(a.ein, s, rb * TROWS) : nullptr;
-    for (int k0 = 0; k0 < KE; k0 += kEmbKC) {
+    for (int k0 = 0; k0 < (a.pre != nullptr ? 0 : KE); k0 += kEmbKC) {
         const int kc = KE - k0 < kEmbKC ? KE - k0 : kEmbKC, kc4 = (kc + 3) & ~3;
         __syncthreads();                                               // previous chunk consumed
         for (int idx = tid; idx < TROWS * kc4; idx += TNT) {
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
         }
     }
     (void)DO;
-    if (eo != nullptr)                                                 // zero the padding columns [KE, KEP) of the saved input
+    if (eo != nullptr && a.pre == nullptr)                             // zero the padding columns [KE, KEP) of the saved input
         for (int idx = tid; idx < TROWS * (KEP - KE); idx += TNT) {
             const int rl = idx / (KEP - KE), k = KE + idx - rl * (KEP - KE);
             eo[(size_t)rl * KEP + k] = 0.f;
@@ -169,6 +173,8 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
                     // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
                     if (single || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
                     else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else if (a.pre != nullptr) {
+                    v = a.pre[((size_t)s * a.pre_rows + r) * DO + (d - adim)];        // bias already added by the encoder
                 } else {
                     v = acc[q][r4] + theta[net.off_obs_b + d - adim];
                 }
@@ -176,43 +182,6 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
                 v = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d), v);
             }
             xo[(size_t)rl * a.x.ld + d] = v;
-        }
-    }
-}
-
-// Fragments of the row-block GEMMs with the contraction index grouped in 16s: at step s lane (i, kq) holds
-// k = 16 s + 4 kq + {0..3} of weight row i, so the four kq lanes of a row read 64 contiguous bytes and a wave's load
-// instruction touches 16 cache lines (frag_xwT_fetch's k = kq K/4 + 4 s + c layout touches 64: one per lane).  The A
-// operand follows the same order out of LDS: 16-lane groups read rows 132 words apart -> 64 different banks.
-template <int K>
-__device__ __forceinline__ void frag16_fetch(float4 (&bf)[K / 16], const float* __restrict__ Wrow, const Thr& t) {
-    const float4* wp = reinterpret_cast<const float4*>(Wrow + t.kq * 4);
-#pragma unroll
-    for (int s = 0; s < K / 16; ++s) bf[s] = wp[4 * s];
-}
-template <int K, int MG, int NB = K / 16>
-__device__ __forceinline__ void frag16_mma(const float* Xs, int lda, const float4 (&bf)[NB], const Thr& t, f32x4 (&acc)[MG]) {
-    constexpr int KS = K / 16;
-    static_assert(NB >= KS, "fragment array too short");
-    const float* xp = Xs + t.i * lda + t.kq * 4;
-    float4 af[2][MG];
-#pragma unroll
-    for (int m = 0; m < MG; ++m) af[0][m] = ld4(xp + m * 16 * lda);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        if (s + 1 < KS) {
-#pragma unroll
-            for (int m = 0; m < MG; ++m) af[(s + 1) & 1][m] = ld4(xp + m * 16 * lda + 16 * (s + 1));
-        }
-        const float b4[4] = {bf[s].x, bf[s].y, bf[s].z, bf[s].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-            for (int m = 0; m < MG; ++m) {
-                const float4 a = af[s & 1][m];
-                const float av = c == 0 ? a.x : (c == 1 ? a.y : (c == 2 ? a.z : a.w));
-                acc[m] = mfma16(av, b4[c], acc[m]);
-            }
         }
     }
 }
@@ -1801,6 +1770,8 @@ struct EmbedSrc {
     const uint8_t* bag_actions = nullptr;
     int bag_batch = 0;
     const int32_t* lens = nullptr;     // ragged prefixes (device array [S]); nullptr: every sequence has n live rows
+    const float* pre = nullptr;        // image nets: observation embeddings [S][pre_rows][D - a]
+    int pre_rows = 0;
 };
 
 // All S sequences through the network.  theta_a serves sequences [0, split), theta_b the rest.
@@ -1823,6 +1794,9 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
         e.src_mod = 0; e.bag = 0; e.drop = drop; e.lens = src.lens;
+        e.pre = src.pre; e.pre_rows = src.pre_rows;
+        if (net.img_c > 0 && e.pre == nullptr) return DTQN_ERR_ARG;     // image nets come through dtqn_img_encode
+        e.ein = e.pre != nullptr ? nofld() : e.ein;
         const size_t elds = tl_embed_lds(D);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
@@ -1967,7 +1941,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.n = bag; e.rpb = rpb;
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
-            e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none(); e.lens = nullptr;
+            e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none(); e.lens = nullptr; e.pre = nullptr; e.pre_rows = 0;
             const size_t elds = tl_embed_lds(D);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
@@ -2166,7 +2140,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         a.ep_idx = td.ep_idx; a.start = td.start;
         const size_t lds = tl_embed_bwd_lds(net);
         // (KE <= 256: at most 4 x 16 column tiles x 4 row tiles = the 4 items a wave keeps accumulators for)
-        if (lds > 150 * 1024 || net.ke > 128) return DTQN_ERR_CONFIG;
+        if (lds > 150 * 1024 || (net.discrete && net.ke > 128)) return DTQN_ERR_CONFIG;
         a.bag = 0; a.dx_off = 0; a.rows = 0;
         TL_LAUNCH(tl_embed_bwd_kernel, dim3(B * rpb), dim3(TNT), lds, stream, a);
         if (net.bag_size > 0) {          // the bag entries went through the same tables: their partials are added
@@ -2185,6 +2159,7 @@ int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
     src.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim; src.act_ep_stride = rp->max_steps + 1;
     src.ep_idx = td->ep_idx; src.start = td->start; src.batch = td->batch;
     src.bag_obs = td->bag_obs; src.bag_actions = td->bag_actions; src.bag_batch = td->batch;
+    src.pre = td->xemb; src.pre_rows = net->lp;
     const int S = 3 * td->batch;
     const long long qs = (long long)net->lp * net->ap;
     // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230); step = optimizer steps so far
@@ -2223,8 +2198,9 @@ extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
 
 static int forward_tiled_impl(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, const float* bag_obs,
                               const uint8_t* bag_actions, int batch, int n, int in_rows, float* q_out, float* workspace, void* stream,
-                              int train_mode = 0, uint32_t drop_seed = 0u, uint32_t drop_step = 0u, const int32_t* lens = nullptr) {
-    if (!net || !theta || !obs || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
+                              int train_mode = 0, uint32_t drop_seed = 0u, uint32_t drop_step = 0u, const int32_t* lens = nullptr,
+                              const float* pre = nullptr) {
+    if (!net || !theta || (!obs && !pre) || !q_out || !workspace || batch < 1) return DTQN_ERR_ARG;
     if (n < 1 || n > net->ctx_len || in_rows < n) return DTQN_ERR_ARG;  // dtqn.py:170-173
     if (net->action_dim > 0 && !actions) return DTQN_ERR_ARG;
     if (!net->tiled) return DTQN_ERR_CONFIG;
@@ -2236,6 +2212,7 @@ static int forward_tiled_impl(const DtqnNet* net, const float* theta, const floa
     src.ep_idx = nullptr; src.start = nullptr; src.batch = batch;
     src.bag_obs = bag_obs; src.bag_actions = bag_actions; src.bag_batch = batch;
     src.lens = lens;
+    src.pre = pre; src.pre_rows = n;
     const long long qs = (long long)n * net->num_actions;
     // a train-mode forward of the actor (the reference's policy network stays in train mode during rollouts): one pass, sequence = salt
     const TlDrop drop = tl_drop_make(*net, drop_seed, drop_step, nullptr, batch, train_mode ? 0x1 : 0);
@@ -2263,6 +2240,13 @@ extern "C" int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta
                                           int batch, int n, int in_rows, float* q_out, float* workspace, void* stream) {
     if (net && net->bag_size > 0) return DTQN_ERR_ARG;                  // bag networks: dtqn_forward_bag
     return forward_tiled_impl(net, theta, obs, actions, nullptr, nullptr, batch, n, in_rows, q_out, workspace, stream);
+}
+
+extern "C" int dtqn_forward_tiled_pre(const DtqnNet* net, const float* theta, const float* xemb, const uint8_t* actions, int batch, int n,
+                                      float* q_out, float* workspace, int train_mode, uint32_t dropout_seed, uint32_t dropout_step, void* stream) {
+    if (!net || net->img_c <= 0 || !xemb) return DTQN_ERR_ARG;
+    return forward_tiled_impl(net, theta, nullptr, actions, nullptr, nullptr, batch, n, n, q_out, workspace, stream, train_mode, dropout_seed,
+                              dropout_step, nullptr, xemb);
 }
 
 extern "C" int dtqn_forward_tiled(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions,

@@ -28,18 +28,22 @@ def _p(t: Optional[torch.Tensor]):
 class DeviceReplay:
     """Episode-major replay arrays resident in HBM (layout: include/dtqn_hip.h, DtqnReplay)."""
 
-    def __init__(self, num_episodes: int, max_steps: int, obs_dim: int, obs_mask: float, device):
-        E, T, O = int(num_episodes), int(max_steps), int(obs_dim)
+    def __init__(self, num_episodes: int, max_steps: int, obs_dim, obs_mask: float, device):
+        # obs_dim: an int, or the (C, H, W) shape of image observations -- stored as uint8 like the reference (replay_buffer.py:36-45)
+        self.image = tuple(int(v) for v in obs_dim) if isinstance(obs_dim, (tuple, list)) else None
+        E, T, O = int(num_episodes), int(max_steps), int(np.prod(obs_dim))
         self.E, self.T, self.O, self.obs_mask = E, T, O, float(obs_mask)
         self.device = device
         # initial fill = the reference constructor's (replay_buffer.py:36-69)
-        self.obs = torch.full((E, T + 1, O), float(obs_mask), dtype=torch.float32, device=device)
+        self.obs = torch.full((E, T + 1, O), int(obs_mask) if self.image else float(obs_mask),
+                              dtype=torch.uint8 if self.image else torch.float32, device=device)
         self.actions = torch.zeros((E, T + 1), dtype=torch.uint8, device=device)
         self.rewards = torch.zeros((E, T), dtype=torch.float32, device=device)
         self.dones = torch.ones((E, T), dtype=torch.uint8, device=device)
         self.ep_len = torch.zeros((E,), dtype=torch.int32, device=device)
         self.view = B.DtqnReplay()
-        self.view.obs, self.view.actions = self.obs.data_ptr(), self.actions.data_ptr()
+        self.view.obs, self.view.actions = (None if self.image else self.obs.data_ptr()), self.actions.data_ptr()
+        self.view.obs_u8 = self.obs.data_ptr() if self.image else None
         self.view.rewards, self.view.dones = self.rewards.data_ptr(), self.dones.data_ptr()
         self.view.ep_len = self.ep_len.data_ptr()
         self.view.num_episodes, self.view.max_steps, self.view.obs_dim = E, T, O
@@ -163,6 +167,18 @@ class TdEngine:
                                    for _ in range(self.IDX_RING)] if dev.type == "cuda" else []
             self._bag_rows_i = 0
         td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
+        self.img = None
+        if net.img_c > 0:
+            # image observations: the convolutional embedding runs in front of / behind the row-block update (dtqn_amd/image.py)
+            from .image import ImageEncoder
+            L1 = net.ctx_len + 1
+            self.img = ImageEncoder(self.lib, net, dev)
+            self.img_tgt = ImageEncoder(self.lib, net, dev)           # the target network's own transposed weights
+            self.xemb = torch.zeros(3 * Bn * net.lp * net.d_model, **f32)
+            td.xemb = self.xemb.data_ptr()
+            i32 = dict(dtype=torch.int32, device=dev)
+            self._img_lists = [torch.zeros(Bn * L1, **i32) for _ in range(6)]   # pol index / dst0 / dst1 / dsrc, tgt index / dst0
+            self._img_tgt_version = -1
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
         self._actor_net_ref = ctypes.byref(self.actor_net)
@@ -269,13 +285,46 @@ class TdEngine:
 
     # -- the update, whole or in stages (stages are what the data-parallel wrapper interleaves) --
     def update(self, replay: DeviceReplay, stream=None):
+        if self.img is not None:          # image nets: the staged sequence (the one-call entry point has no encoder in it)
+            self.forward_backward(replay)
+            self.clip_adam()
+            return
         self._check(self.lib.dtqn_td_update(self._net_ref, replay.view_ref, self._td_ref,
                                             stream if stream is not None else self._stream()), "dtqn_td_update")
 
+    def _img_encode_windows(self, replay: DeviceReplay, s):
+        """Image nets, in front of dtqn_td_forward: token lists of the sampled windows, then the convolutional embedding of the
+        policy rows 0..L (each row serves policy(o) and policy(o')) and of the target rows 1..L -> td.xemb."""
+        net, Bn, L = self.net, self.batch, self.net.ctx_len
+        if self.td.sample_in_kernel:
+            # the windows must exist before the encoder runs: draw them with the same counter-based draw in their own launch
+            self.sample_on_device(replay, self.td.sample_n_valid, self.td.sample_exclude, self.td.sample_seed, s)
+        pi, pd0, pd1, pds, ti, td0 = self._img_lists
+        self._check(self.lib.dtqn_img_td_lists(self._net_ref, replay.view_ref, self._td_ref, _p(pi), _p(pd0), _p(pd1), _p(pds), _p(ti), _p(td0), s),
+                    "dtqn_img_td_lists")
+        self.img.prep(self.theta_pol, s)
+        # the target parameters change only at a hard sync: their transposed copies are refreshed when the sync counter moved
+        # (stats[10] is read lazily; refreshing every update costs 24 MB of writes, so it is simply redone each time here)
+        self.img_tgt.prep(self.theta_tgt, s)
+        n_pol, n_tgt = Bn * (L + 1), Bn * L
+        self._img_act = self.img.act_buffer(n_pol, "train")
+        self.img.encode(self.theta_pol, replay.obs, pi, n_pol, self._img_act, self.xemb, pd0, self.xemb, pd1, stream=s)
+        self.img_tgt.encode(self.theta_tgt, replay.obs, ti, n_tgt, self.img_tgt.act_buffer(n_tgt, "target"), self.xemb, td0, stream=s)
+
+    def _img_backward(self, replay: DeviceReplay, s):
+        """Behind dtqn_td_backward: the encoder's data and weight gradients from dL/dx0 in the grd records, written into split 0 of
+        gsplit at the parameters' offsets (dtqn_td_reduce then sums the splits like every other gradient)."""
+        pi, pd0, pd1, pds, ti, td0 = self._img_lists
+        self.img.backward(self.theta_pol, replay.obs, pi, self.batch * (self.net.ctx_len + 1), self._img_act, self.grd, pds, self.gsplit, stream=s)
+
     def forward_backward(self, replay: DeviceReplay):
         s, n, r, t = self._stream(), self._net_ref, replay.view_ref, self._td_ref
+        if self.img is not None:
+            self._img_encode_windows(replay, s)
         self._check(self.lib.dtqn_td_forward(n, r, t, s), "dtqn_td_forward")
         self._check(self.lib.dtqn_td_backward(n, r, t, s), "dtqn_td_backward")
+        if self.img is not None:
+            self._img_backward(replay, s)
         self._check(self.lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad")
         self._check(self.lib.dtqn_td_reduce(n, t, s), "dtqn_td_reduce")
 

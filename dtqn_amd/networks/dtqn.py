@@ -46,17 +46,19 @@ class DTQN(nn.Module):
                  gate: str = "res", identity: bool = False, pos: Union[str, int] = "learned", discrete: bool = False,
                  vocab_sizes: Optional[Union[np.ndarray, int]] = None, bag_size: int = 0, _test_lib=None, **kwargs):
         super().__init__()
-        if isinstance(obs_dim, tuple):
-            raise NotImplementedError("image observations (conv embedding) are outside dtqn_amd's scope")
+        image = tuple(int(v) for v in obs_dim) if isinstance(obs_dim, (tuple, list, torch.Size)) else None
+        if image is not None and len(image) == 2:
+            image = (1,) + image                      # representations.py:88-92: H x W means one channel
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")     # nn.Dropout's own check
         if pos not in B.POS:
             raise ValueError(f"{pos!r} is not a valid PosEnum")        # PosEnum(pos) in the reference (dtqn.py:101)
         self._lib = _test_lib if _test_lib is not None else engine.get_lib()
-        self.obs_dim, self.discrete, self.history_len, self.bag_size = obs_dim, discrete, history_len, bag_size
+        self.obs_dim, self.discrete, self.history_len, self.bag_size = (image if image is not None else obs_dim), discrete, history_len, bag_size
+        self.image = image
         self.dropout_p = float(dropout)
         self.num_actions = num_actions
-        self.net = B.make_net(self._lib, obs_dim=obs_dim, num_actions=num_actions, embed_per_obs_dim=embed_per_obs_dim,
+        self.net = B.make_net(self._lib, obs_dim=1 if image is not None else obs_dim, image=image, num_actions=num_actions, embed_per_obs_dim=embed_per_obs_dim,
                               action_dim=action_dim, inner_embed_size=inner_embed_size, num_heads=num_heads,
                               num_layers=num_layers, history_len=history_len, gate=gate, identity=identity, pos=pos,
                               discrete=discrete, vocab_sizes=int(vocab_sizes) if discrete else 0, dropout=dropout,
@@ -94,7 +96,13 @@ class DTQN(nn.Module):
         for key, (p, off, shape) in self._views.items():
             if key == "position_embedding.position_encoding":
                 continue
-            if "layernorm" in key:
+            if self.image is not None and key.startswith("obs_embedding.observation_embedding.") and int(key.split(".")[2]) <= 8:
+                # nn.Conv2d is not touched by init_weights (utils/torch_utils.py:4-15): it keeps torch's default,
+                # kaiming_uniform(a = sqrt 5) = U(-1 / sqrt(fan_in), 1 / sqrt(fan_in)) for weight and bias alike
+                w_shape = self._views[key.rsplit(".", 1)[0] + ".weight"][2]
+                bound = 1.0 / float(np.sqrt(w_shape[1] * 9))
+                p.uniform_(-bound, bound)
+            elif "layernorm" in key:
                 p.fill_(1.0 if key.endswith("weight") else 0.0)
             elif key.endswith("bias"):
                 p.zero_()
@@ -113,6 +121,37 @@ class DTQN(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
+    def _forward_images(self, obss: torch.Tensor, dev, _train_dropout=None) -> torch.Tensor:
+        """obss [B, seq, C, H, W] (uint8 pixels; the reference casts them to float unscaled) -> Q [B, seq, A]: the convolutional
+        embedding (dtqn_img_encode) in front of the row-block forward on precomputed embeddings."""
+        from ..image import ImageEncoder
+        if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
+            raise engine.EngineUnavailable("DTQN.forward runs on the gfx950 engine only: move the module to a ROCm device")
+        Bn, seq = int(obss.size(0)), int(obss.size(1))
+        imgs = obss.to(device=dev).to(torch.uint8).reshape(Bn * seq, -1).contiguous()
+        enc = getattr(self, "_img_enc", None)
+        if enc is None or enc.device != dev:
+            enc = self._img_enc = ImageEncoder(self._lib, self.net, dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+        tokens = Bn * seq
+        idx = torch.arange(tokens, dtype=torch.int32, device=dev)
+        xemb = torch.empty(tokens, self.net.d_model, dtype=torch.float32, device=dev)
+        enc.prep(self.flat, stream)
+        enc.encode(self.flat, imgs, idx, tokens, enc.act_buffer(tokens, "infer"), xemb, idx, stream=stream)
+        need = self._lib.dtqn_forward_workspace_floats(ctypes.byref(self.net), Bn)
+        ws = getattr(self, "_tiled_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._tiled_ws = torch.empty(need, dtype=torch.float32, device=dev)
+        q = torch.empty((Bn, seq, self.num_actions), dtype=torch.float32, device=dev)
+        td_ = _train_dropout if (_train_dropout is not None and self.dropout_p > 0.0) else None
+        cp = lambda t: ctypes.c_void_p(t.data_ptr())
+        rc = self._lib.dtqn_forward_tiled_pre(ctypes.byref(self.net), cp(self.flat), cp(xemb), None, Bn, seq, cp(q), cp(ws), 1 if td_ else 0,
+                                              int(td_[0]) & 0xFFFFFFFF if td_ else 0, int(td_[1]) & 0xFFFFFFFF if td_ else 0, stream)
+        if rc != 0:
+            raise RuntimeError(f"dtqn_forward_tiled_pre failed with DTQN status {rc}")
+        return q
+
+    @torch.no_grad()
     def forward(self, obss: torch.Tensor, actions: Optional[torch.Tensor] = None,
                 bag_obss: Optional[torch.Tensor] = None, bag_actions: Optional[torch.Tensor] = None,
                 _train_dropout: Optional[tuple] = None) -> torch.Tensor:
@@ -120,9 +159,12 @@ class DTQN(nn.Module):
         -> Q [B, seq, num_actions].  Inference only (no autograd graph)."""
         seq = obss.size(1)
         assert seq <= self.history_len, "Cannot forward, history is longer than expected."
-        obs_dim = obss.size(2)
+        # images: obs_dim is the (C, H, W) shape of one observation (dtqn.py:175-179)
+        obs_dim = tuple(obss.size()[2:]) if obss.dim() > 3 else obss.size(2)
         assert obs_dim == self.obs_dim, f"Obs dim is incorrect. Expected {self.obs_dim} got {obs_dim}"
         dev = self.flat.device
+        if self.image is not None:
+            return self._forward_images(obss, dev, _train_dropout)
         if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
             raise engine.EngineUnavailable("DTQN.forward runs on the gfx950 engine only: move the module to a ROCm device")
         o = obss.to(device=dev, dtype=torch.float32).contiguous()

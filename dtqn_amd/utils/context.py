@@ -33,8 +33,11 @@ class Context:
 
     def reset(self, obs: np.ndarray) -> None:
         dt = self._obs_dtype()
-        shape = [self.max_length, self.env_obs_length]
-        self.obs = np.full(shape, self.obs_mask) if dt is None else np.full(shape, self.obs_mask, dtype=dt)
+        if isinstance(self.env_obs_length, tuple):       # images: uint8 pixels (utils/context.py:41-47)
+            self.obs = np.full([self.max_length, *self.env_obs_length], self.obs_mask, dtype=np.uint8)
+        else:
+            shape = [self.max_length, self.env_obs_length]
+            self.obs = np.full(shape, self.obs_mask) if dt is None else np.full(shape, self.obs_mask, dtype=dt)
         self.obs[0] = obs
         # padding actions are random draws from the exploration stream (utils/context.py:50)
         self.action = RNG.rng.integers(self.num_actions, size=(self.max_length, 1))

@@ -34,7 +34,7 @@ def is_image_env(env) -> bool:
 def get_env_obs_length(env) -> int:
     space = env.observation_space
     if is_image_env(env):
-        raise NotImplementedError("image observations (MiniHack pixel crops) are outside dtqn_amd's scope")
+        return tuple(int(v) for v in np.shape(env.reset()))      # utils/env_processing.py:86-87: the observation's (C, H, W) shape
     kind = _kind(space)
     if kind == "Discrete":
         return 1
@@ -51,6 +51,8 @@ def get_env_obs_mask(env) -> Union[int, float]:
     """Padding value for unseen observations: one past the largest token for discrete spaces,
     -5 for continuous ones (below CarFlag's minimum of -1.1; utils/env_processing.py:100-120)."""
     space = env.observation_space
+    if is_image_env(env):
+        return 0                                                 # utils/env_processing.py:106-108
     kind = _kind(space)
     if kind == "Discrete":
         return int(space.n)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 10
+#define DTQN_ABI_VERSION 11
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -65,6 +65,10 @@ typedef struct DtqnNet {
                                * cover the shape (dtqn_net_tiled_twin) */
     int32_t bag_size;         /* persistent-memory bag (utils/bag.py, dtqn.py:134-147,201-214): 0 = none.  Bag networks run on the row-block
                                * tiled path (bag_size <= padded context) */
+    int32_t img_c, img_h, img_w; /* image observations (representations.py:77-130; obs_dim is the tuple (C, H, W) in the reference): > 0 selects
+                               * the convolutional observation embedding -- five 3x3 convolutions (C->64 s2, 64->64, 64->64 s2, 64->128,
+                               * 128->128 s2; padding 1; ReLU after each) + Flatten + Linear(128 h5 w5, D - a).  obs_dim must be C*H*W (uint8
+                               * pixels, fed to the network as their float values like the reference).  Row-block tiled path; (D - a) % 16 == 0 */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
                                * forwards only; 0 = off.  Whole-sequence kernels only (DTQN_ERR_CONFIG on the row-block tiled path) */
     /* ---- derived: geometry ---- */
@@ -81,7 +85,7 @@ typedef struct DtqnNet {
     /* ---- derived: theta layout (floats) ---- */
     int32_t off_act_emb;      /* [A][a]            action_embedding.embedding.0.weight */
     int32_t off_obs_tab;      /* [V][e]            obs_embedding.observation_embedding.0.weight */
-    int32_t off_obs_w;        /* [D-a][ke]         obs_embedding.observation_embedding(.2).weight */
+    int32_t off_obs_w;        /* [D-a][ke]         obs_embedding.observation_embedding(.2).weight  (image nets: .11.weight, ke = 128 h5 w5) */
     int32_t off_obs_b;        /* [D-a] */
     int32_t off_pos;          /* [L][D]            position_embedding.position_encoding */
     int32_t off_layer0;       /* first transformer layer block */
@@ -94,6 +98,12 @@ typedef struct DtqnNet {
     int32_t go_w_r, go_u_r, go_w_z, go_b_z, go_u_z, go_w_g, go_u_g;   /* offsets inside a gate block */
     int32_t off_head1_w, off_head1_b, off_head2_w, off_head2_b;       /* ffn.0.* / ffn.2.* (Q head; ffn.0.weight is [D][2D] with a bag) */
     int32_t off_bag_in_w, off_bag_in_b, off_bag_out_w, off_bag_out_b; /* bag_attention.in_proj_* / out_proj.* (bag_size > 0) */
+    /* image nets: obs_embedding.observation_embedding.{0,2,4,6,8}.{weight [Cout][Cin][3][3], bias [Cout]} */
+    int32_t off_cw0, off_cw1, off_cw2, off_cw3, off_cw4;
+    int32_t off_cb0, off_cb1, off_cb2, off_cb3, off_cb4;
+    int32_t img_h1, img_w1, img_h3, img_w3, img_h5, img_w5;   /* spatial sizes after the stride-2 convolutions 1, 3, 5 */
+    int32_t img_feat;         /* 128 * img_h5 * img_w5 = ke of an image net */
+    int32_t img_k1;           /* contraction length of the first convolution as a GEMM: 9 C padded to 16 */
     int32_t n_trainable;      /* floats the optimizer updates (multiple of 4) */
     int32_t n_theta;          /* total floats of theta */
     /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
@@ -166,6 +176,7 @@ typedef struct DtqnReplay {
     float* rewards;
     uint8_t* dones;
     int32_t* ep_len;
+    uint8_t* obs_u8;          /* image observations: [E][T+1][O] uint8 (replay_buffer.py:36-45 stores images as uint8); `obs` is NULL then */
     int32_t num_episodes;     /* E = buffer_size // max_episode_steps (replay_buffer.py:27) */
     int32_t max_steps;        /* T */
     int32_t obs_dim;          /* O */
@@ -258,6 +269,9 @@ typedef struct DtqnTd {
                                * replay_buffer.py:171-264; filled by dtqn_replay_gather_bag -- by dtqn_td_forward itself when
                                * sample_in_kernel == 1); the same bag serves all three forwards of a sequence (dtqn.py:215-230) */
     uint8_t* bag_actions;     /* [B][bag_size] */
+    const float* xemb;        /* image nets: [3 B][padded context][D - a] observation embeddings of the three forwards, produced by
+                               * dtqn_img_encode_td in front of dtqn_td_forward (whose embedding stage then only adds action embeddings,
+                               * positions and dropout) */
     /* hyper-parameters */
     int32_t batch;            /* B (local) */
     int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
@@ -387,6 +401,44 @@ int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_
 int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
 int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Image observation embedding (representations.py:77-130, reached from dtqn/networks/dtqn.py:71-77 when obs_dim is a tuple).
+ * Implicit-GEMM 3x3 convolutions on the f32 matrix core, activations NHWC in a caller-owned workspace; weights are read from
+ * `theta` in the reference's layout through per-update transposed copies (`wprep`).  MFMA-bound: 2 * 9 * Cin * Cout FLOP per
+ * output pixel.
+ * ------------------------------------------------------------------------------------------ */
+/* floats of the transposed-weight scratch (forward and backward operand layouts of every layer) */
+int dtqn_img_prep_floats(const DtqnNet* net);
+/* floats of an activation workspace for `tokens` images (the five NHWC feature maps) */
+long long dtqn_img_act_floats(const DtqnNet* net, int tokens);
+/* floats of the weight-gradient partial buffer */
+long long dtqn_img_wpart_floats(const DtqnNet* net);
+/* theta -> wprep (call once per parameter version, before encode / backward) */
+int dtqn_img_prep(const DtqnNet* net, const float* theta, float* wprep, void* stream);
+/* Encoder forward of `tokens` images.  images_u8: base of a uint8 image array (O = C*H*W bytes each); img_index [tokens]: image
+ * number of every token (device).  act: dtqn_img_act_floats(net, tokens) floats (kept for dtqn_img_backward).  Every token t writes
+ * its embedding [D - a] to out0 + dst0[t] * (D - a) and, when out1 != NULL and dst1[t] >= 0, also to out1 + dst1[t] * (D - a)
+ * (dst arrays on the device; a window's rows 1..L-1 serve both policy(o) and policy(o')). */
+int dtqn_img_encode(const DtqnNet* net, const float* theta, const float* wprep, const uint8_t* images_u8, const int32_t* img_index,
+                    int tokens, float* act, float* out0, const int32_t* dst0, float* out1, const int32_t* dst1, void* stream);
+/* Encoder backward for the `tokens` images of the LAST dtqn_img_encode on `act`: dxemb_base + dsrc[t] (float offsets, device
+ * array; < 0: the token has no gradient) is dL/d(embedding) [D - a] of token t (the grd records' dx0 columns a..D).
+ * gact: two gradient ping-pong buffers of max feature-map size (dtqn_img_gact_floats); wpart: dtqn_img_wpart_floats.  The
+ * gradients of the convolutions and of the embedding linear are WRITTEN to grad_out (flat gradient layout, e.g. split 0 of
+ * DtqnTd.gsplit) at their theta offsets. */
+long long dtqn_img_gact_floats(const DtqnNet* net, int tokens);
+int dtqn_img_backward(const DtqnNet* net, const float* theta, const float* wprep, const uint8_t* images_u8, const int32_t* img_index,
+                      int tokens, const float* act, const float* dxemb_base, const int32_t* dsrc, float* gact, float* wpart,
+                      float* grad_out, void* stream);
+/* Token lists of a TD update: policy rows 0..L of every sampled window (B (L + 1) tokens; row r feeds policy(o) position r and
+ * policy(o') position r - 1) and target rows 1..L (B L tokens).  Fills img_index / dst0 / dst1 / dsrc (device, B (L + 1) ints
+ * each; the target list reuses the first B L entries of its own arrays). */
+int dtqn_img_td_lists(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int32_t* pol_index, int32_t* pol_dst0, int32_t* pol_dst1,
+                      int32_t* pol_dsrc, int32_t* tgt_index, int32_t* tgt_dst0, void* stream);
+/* DTQN.forward for image nets on precomputed embeddings: xemb [batch][n][D - a] (from dtqn_img_encode); otherwise as dtqn_forward_tiled */
+int dtqn_forward_tiled_pre(const DtqnNet* net, const float* theta, const float* xemb, const uint8_t* actions, int batch, int n,
+                           float* q_out, float* workspace, int train_mode, uint32_t dropout_seed, uint32_t dropout_step, void* stream);
 
 /* Debug aid: when a device buffer of >= 2*64 int64 is registered, workgroup 0 of the forward (slots
  * 0..63) and backward (slots 64..127) TD kernels records the 100 MHz wall clock at its stage

@@ -289,9 +289,10 @@ def run_dp_script(tmp_path, env_extra, port):
     r0, r1, single = (np.load(out + s) for s in (".rank0.npy", ".rank1.npy", ".single.npy"))
     assert np.array_equal(r0, r1)                               # replicas stay bit-identical
     norms = np.load(out + ".stats.npy")
-    assert abs(norms[0] - norms[1]) <= 1e-5 * norms[1]
-    # Adam steps from the same state; gradients equal up to summation order (a noise-floor gradient may flip a step's sign)
     n_updates = int(env_extra.get("DP_UPDATES", "2"))
+    # gradient norm of the LAST update: the trajectories of the two computations drift apart by noise-floor Adam steps (below)
+    assert abs(norms[0] - norms[1]) <= (1e-5 if n_updates <= 2 else 1e-3) * norms[1]
+    # Adam steps from the same state; gradients equal up to summation order (a noise-floor gradient may flip a step's sign)
     assert np.abs(r0 - single).max() <= 2.01 * n_updates * 3e-4
     assert np.mean(np.abs(r0 - single) <= 2e-6 * n_updates / 2) > (0.98 if n_updates <= 2 else 0.9)
     return r0
