@@ -64,6 +64,7 @@ class DtqnAgent:
                  history: int = 50, bag_size: int = 0, sampler: str = "reference", ref_quirks: bool = False,
                  sample_seed: int = 0, **kwargs):
         self.context_len, self.env_obs_length = context_len, env_obs_length
+        self.image = tuple(env_obs_length) if isinstance(env_obs_length, (tuple, list)) else None     # (C, H, W) pixel observations
         self.device = torch.device(device)
         self.policy_network = network_factory()
         self.target_network = network_factory()
@@ -115,8 +116,12 @@ class DtqnAgent:
         if bag_size > 0 and self.policy_network.bag_size != bag_size:
             raise ValueError("the agent's bag_size must match the network's")
         # actor staging: rolling context -> pinned -> device, Q row -> pinned
-        L, O, A = context_len, env_obs_length, num_actions
+        L, O, A = context_len, int(np.prod(env_obs_length)), num_actions
         pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        if self.image is not None:
+            # image nets act through the module forward (encoder + row-block forward): the context images are staged as uint8
+            self._img_ctx_h = pin(torch.zeros(L, O, dtype=torch.uint8))
+            O = 1
         # one packed staging buffer [L*O f32 | L u8] -> ONE host-to-device copy per action
         nbytes = L * O * 4 + L
         self._ctx_h = pin(torch.zeros(nbytes, dtype=torch.uint8))
@@ -202,6 +207,20 @@ class DtqnAgent:
         return self.policy_network(t(obs, self.obs_tensor_type), t(actions, torch.long), t(bag_obss, self.obs_tensor_type),
                                    t(bag_actions, torch.long), _train_dropout=drop)
 
+    def _image_action(self) -> int:
+        """get_action of an image net (dtqn.py:79-108): the unpadded context prefix through DTQN.forward (convolutional embedding
+        + row-block forward); the policy network is in train mode during rollouts like the reference's (dropout keyed per call)."""
+        ctx = self.context
+        n = min(ctx.max_length, ctx.timestep + 1)
+        self._img_ctx_h[:n] = torch.from_numpy(ctx.obs[:n].reshape(n, -1))
+        drop = None
+        if self.train_mode == TrainMode.TRAIN and self.policy_network.dropout_p > 0.0:
+            self._actor_calls += 1
+            drop = (int(self.engine.td.dropout_seed) ^ 0xAC70, self._actor_calls)
+        obs = self._img_ctx_h[:n].to(self.device, non_blocking=True).reshape(1, n, *self.image)
+        q = self.policy_network(obs, None, _train_dropout=drop)
+        return int(torch.argmax(q[0, -1]).item())
+
     def _bag_action(self) -> int:
         """get_action of a bag network (dtqn.py:79-108): the unpadded context prefix plus the WHOLE bag, padding included."""
         ctx = self.context
@@ -215,6 +234,8 @@ class DtqnAgent:
             return RNG.rng.integers(self.num_actions)
         if self.bag.size > 0:
             return self._bag_action()
+        if self.image is not None:
+            return self._image_action()
         self._launch_actor_forward(self.engine._stream())
         if self._main_stream is not None:
             self._main_stream.synchronize()
@@ -229,6 +250,8 @@ class DtqnAgent:
             return int(RNG.rng.integers(self.num_actions))
         if self.bag.size > 0:                     # bag networks act through the module forward (no second stream)
             return self._bag_action()
+        if self.image is not None:
+            return self._image_action()
         if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
             return self._sync_forward_action()
         if not getattr(self, "_update_recorded", True):       # order the actor behind the last TD update (pipelined mode only)

@@ -533,6 +533,7 @@ using namespace dtqn;
 // overrides, for A/B timing).
 extern "C" int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch) {
     if (!net || batch < 1 || net->n_wjobs > kMaxWJobs) return 0;
+    if (net->img_c > 0) return 0;      // image nets: the encoder's gradients join the others in dtqn_td_reduce (split 0 of gsplit)
     const char* e = getenv("DTQN_WGRAD_DIRECT");
     if (e != nullptr) return atoi(e) != 0 ? 1 : 0;
     // shared GRU gate matrices contract over the tokens of every layer (measured at cfg-1 shapes with GRU gates, 2 layers:

@@ -12,8 +12,8 @@ class Bag:
     same quirk as the Context's).  The default stores float32 for continuous observations, int64 for discrete ones."""
 
     def __init__(self, bag_size: int, obs_mask, obs_length: int, discrete: Optional[bool] = None, ref_quirks: bool = False):
-        if isinstance(obs_length, tuple):
-            raise NotImplementedError("image observations are outside dtqn_amd's scope")
+        if isinstance(obs_length, tuple) and bag_size > 0:
+            raise NotImplementedError("a persistent-memory bag of image observations is outside the gfx950 kernels' coverage")
         self.size = bag_size
         self.obs_mask = obs_mask
         self.obs_length = obs_length
@@ -38,7 +38,7 @@ class Bag:
         return self.obss[: self.pos], self.actions[: self.pos]
 
     def make_empty_bag(self) -> Tuple[np.ndarray, np.ndarray]:
-        shape = (self.size, self.obs_length)
+        shape = (self.size, *self.obs_length) if isinstance(self.obs_length, tuple) else (self.size, self.obs_length)
         if self.ref_quirks or self.discrete is None:
             obss = np.full(shape, self.obs_mask)
         else:

@@ -122,7 +122,7 @@ def checksum(params):
 
 
 def make_ref_net(cfg: O.NetCfg, params):
-    net = RefDTQN(cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size,
+    net = RefDTQN(tuple(cfg.image) if cfg.image is not None else cfg.obs_dim, cfg.num_actions, cfg.embed_per_obs_dim, cfg.action_dim, cfg.inner_embed_size,
                   cfg.num_heads, cfg.num_layers, cfg.history_len, dropout=cfg.dropout, gate=cfg.gate,
                   identity=cfg.identity, pos=cfg.pos, discrete=cfg.discrete,
                   vocab_sizes=cfg.vocab_sizes if cfg.discrete else None, bag_size=cfg.bag_size)
@@ -794,6 +794,57 @@ def gen_G10():
     np.savez_compressed(os.path.join(HERE, "G10_dropout.npz"), **out)
 
 
+def gen_G11():
+    """Image observations (dtqn/networks/representations.py:77-130 reached from dtqn/networks/dtqn.py:71-77): the REFERENCE's DTQN built
+    with obs_dim = (C, H, W), on uint8 pixel windows cast to float32 unscaled as DtqnAgent.train() does (dtqn/agents/dtqn.py:199-202).
+      td_*   two shapes: the three forwards of a TD update, the loss of dtqn.py:219-243 evaluated with the reference modules, and its
+             gradient w.r.t. every parameter (autograd through the reference network);
+      fwd144 one forward at the MiniHack pixel-crop size 3 x 144 x 144 (obs_crop 9 x 16-pixel tiles, envs/mini_hack.py:18-76)."""
+    out = {"stamp": json.dumps(STAMP)}
+    cases = [("a", O.NetCfg(obs_dim=3 * 16 * 16, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=6, image=(3, 16, 16)), 3),
+             ("b", O.NetCfg(obs_dim=1 * 21 * 13, num_actions=3, inner_embed_size=128, num_heads=8, num_layers=2, history_len=5, image=(1, 21, 13),
+                            pos="sin"), 2)]
+    out["names"] = json.dumps([c[0] for c in cases])
+    for name, cfg, B in cases:
+        seed, L, A = 400 + len(out), cfg.history_len, cfg.num_actions
+        rng = np.random.Generator(np.random.PCG64(seed))
+        pol, tgt = O.init_params(cfg, seed=seed, perturb=True), O.init_params(cfg, seed=seed + 1, perturb=True)
+        npol, ntgt = make_ref_net(cfg, pol), make_ref_net(cfg, tgt)
+        npol.train(); ntgt.eval()
+        rows = rng.integers(0, 256, size=(B, L + 1, *cfg.image)).astype(np.uint8)
+        rows[0, L - 1:] = 0                                          # a padded tail (obs_mask 0 for images, env_processing.py:106-108)
+        acts = rng.integers(0, A, size=(B, L + 1, 1))
+        rew = rng.choice(np.array([0, 0, 1, -1], dtype=np.float32), size=(B, L, 1))
+        done = (rng.random((B, L, 1)) < 0.2)
+        o, o2 = torch.as_tensor(rows[:, :L], dtype=torch.float32), torch.as_tensor(rows[:, 1:], dtype=torch.float32)
+        a, a2 = torch.as_tensor(acts[:, :L]), torch.as_tensor(acts[:, 1:])
+        q_all = npol(o, a)                                           # dtqn.py:215
+        q_sel = q_all.gather(2, a).squeeze()
+        with torch.no_grad():
+            q_np = npol(o2, a2)                                      # :226
+            amax = torch.argmax(q_np, dim=2).unsqueeze(-1)
+            q_nt = ntgt(o2, a2)                                      # :230
+            nq = q_nt.gather(2, amax).squeeze()
+            targets = torch.as_tensor(rew).squeeze() + (1 - torch.as_tensor(done, dtype=torch.long).squeeze()) * (nq * 0.99)
+        loss = torch.nn.functional.mse_loss(q_sel, targets)          # :243 (history == context)
+        loss.backward()
+        keys = O.trainable_keys(cfg)
+        named = dict(npol.named_parameters())
+        assert sorted(k for k, p in named.items() if p.requires_grad) == sorted(keys)
+        out.update({f"{name}_cfg": json.dumps(cfg.to_json()), f"{name}_seed": seed, f"{name}_B": B, f"{name}_pol_checksum": checksum(pol),
+                    f"{name}_rows": rows, f"{name}_actions": acts, f"{name}_rewards": rew, f"{name}_dones": done,
+                    f"{name}_q_all": q_all.detach().numpy(), f"{name}_q_next_pol": q_np.numpy(), f"{name}_q_next_tgt": q_nt.numpy(),
+                    f"{name}_loss": float(loss), f"{name}_grad_flat": np.concatenate([named[k].grad.numpy().ravel() for k in keys])})
+    cfg = O.NetCfg(obs_dim=3 * 144 * 144, num_actions=8, inner_embed_size=64, num_heads=8, num_layers=2, history_len=4, image=(3, 144, 144))
+    pol = O.init_params(cfg, seed=440, perturb=True)
+    rng = np.random.Generator(np.random.PCG64(441))
+    obs = rng.integers(0, 256, size=(1, 3, 3, 144, 144)).astype(np.uint8)
+    with torch.no_grad():
+        q = make_ref_net(cfg, pol)(torch.as_tensor(obs, dtype=torch.float32), torch.zeros(1, 3, 1, dtype=torch.long)).numpy()
+    out.update({"fwd144_cfg": json.dumps(cfg.to_json()), "fwd144_seed": 440, "fwd144_obs": obs, "fwd144_q": q, "fwd144_pol_checksum": checksum(pol)})
+    np.savez_compressed(os.path.join(HERE, "G11_image.npz"), **out)
+
+
 def time_reference():
     """the reference's OWN DtqnAgent.train() on this container's CPU cores, BASELINE
     configs 1-5 (synthetic replay of SURVEY.md section 8d; configs 3-5 at their per-GPU batch, a handful of updates
@@ -843,10 +894,10 @@ def time_reference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "time"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "time"]
     torch.manual_seed(0)
     for w in which:
         t0 = time.time()
         {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
-         "G8": gen_G8, "G9": gen_G9, "G10": gen_G10, "time": time_reference}[w]()
+         "G8": gen_G8, "G9": gen_G9, "G10": gen_G10, "G11": gen_G11, "time": time_reference}[w]()
         print(f"{w}: done in {time.time() - t0:.1f}s")
