@@ -63,10 +63,16 @@ class SyntheticEnv:
             self.observation_space = spaces.Box(low=-1.1, high=1.1, shape=(c["O"],), dtype=np.float32)
         elif c["kind"] == "multidiscrete":
             self.observation_space = spaces.MultiDiscrete([c["nvec"]] * c["O"])
+        elif c["kind"] == "image":
+            self.observation_space = spaces.Box(low=0, high=255, shape=tuple(c["image"]), dtype=np.uint8)
+            self._shape = tuple(c["image"])
         else:
             self.observation_space = spaces.Discrete(c["nvec"])
         self.action_space = spaces.Discrete(c["A"])
         self._max_episode_steps = c["T"]
+
+    def reset(self):          # image envs: get_env_obs_length reads the observation's shape off a reset (utils/env_processing.py:86-87)
+        return np.zeros(self._shape, dtype=np.uint8)
 
 
 def f_tok(c):
@@ -403,6 +409,59 @@ def other_configs(device, steps: int = 500, with_cpu: bool = True) -> dict:
     return out
 
 
+IMAGE_CFG = dict(name="MiniHack pixel-crop shapes", kind="image", image=(3, 144, 144), A=8, T=100, L=50, D=64, H=8, NL=2, B=32)
+
+
+def f_img(c) -> int:
+    """Algorithmic forward FLOPs per token of the convolutional observation embedding (representations.py:77-130): 2 * 9 * Cin * Cout
+    per output pixel of the five 3x3 convolutions (strides 2, 1, 2, 1, 2, padding 1) + the Linear(128 h5 w5, D)."""
+    C, h, w = c["image"]
+    half = lambda x: (x - 1) // 2 + 1
+    h1, w1 = half(h), half(w); h3, w3 = half(h1), half(w1); h5, w5 = half(h3), half(w3)
+    conv = h1 * w1 * 64 * 9 * C + h1 * w1 * 64 * 9 * 64 + h3 * w3 * 64 * 9 * 64 + h3 * w3 * 128 * 9 * 64 + h5 * w5 * 128 * 9 * 128
+    return 2 * conv + 2 * 128 * h5 * w5 * c["D"]
+
+
+def image_config(device, steps: int = 8) -> dict:
+    """The image-observation variant of the path (SURVEY.md section 8f rank 4 tail) at MiniHack's 3 x 144 x 144 pixel crop, cfg-1
+    network and batch: uint8 replay on the device, the convolutional embedding of B (L + 1) policy rows and B L target rows in front
+    of the row-block update, its backward behind it.  Algorithmic FLOPs: encoder forward of both token lists + 2 x the policy
+    list for the backward, + the transformer's 5 B L F_tok."""
+    c = IMAGE_CFG
+    env = SyntheticEnv(c)
+    agent = get_agent("DTQN", [env], 8, 0, c["D"], 4000, device, 3e-4, c["B"], c["L"], c["T"], c["L"], 10_000, 0.99, c["H"], c["NL"], 0.0, False,
+                      "res", "learned", 0, sampler="device", sample_seed=1)
+    rb = agent.replay_buffer
+    E, T = rb.max_size, c["T"]
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rb.dev.obs.copy_(torch.randint(0, 256, tuple(rb.dev.obs.shape), dtype=torch.uint8, generator=g))
+    rb.dev.actions.copy_(torch.randint(0, c["A"], tuple(rb.dev.actions.shape), dtype=torch.uint8, generator=g))
+    rb.dev.rewards.copy_((torch.randint(0, 3, tuple(rb.dev.rewards.shape), generator=g) - 1).float())
+    rb.dev.dones.zero_(); rb.dev.dones[:, -1] = 1
+    rb.episode_lengths[:] = T
+    rb.dev.ep_len.fill_(T)
+    rb.pos = [E + 1, 0]
+    for _ in range(2):
+        agent.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        agent.train()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    agent._drain_stats(block=True)
+    tokens_pol, tokens_tgt = c["B"] * (c["L"] + 1), c["B"] * c["L"]
+    ftok = 2 * 0 + c["NL"] * (24 * c["D"] ** 2 + 4 * c["L"] * c["D"]) + 2 * c["D"] ** 2 + 2 * c["D"] * c["A"]
+    flops = f_img(c) * (tokens_pol + tokens_tgt + 2 * tokens_pol) + 5 * c["B"] * c["L"] * ftok
+    out = {"workload": f"{c['name']}: obs {c['image']} uint8, ctx={c['L']}, d_model={c['D']}, batch {c['B']} ({tokens_pol} + {tokens_tgt} encoder tokens)",
+           "td_updates_per_s": 1.0 / dt, "ms_per_update": dt * 1e3, "algorithmic_tflop_per_update": flops / 1e12,
+           "achieved_tflops": flops / dt / 1e12, "frac_of_f32_mfma_peak": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+           "encoder_gflop_per_token_forward": f_img(c) / 1e9}
+    del agent
+    torch.cuda.empty_cache()
+    return out
+
+
 def time_clip_adam(agent, iters: int = 20) -> dict:
     """The optimizer launch by itself (HIP events), priced against HBM: 28 * P_t bytes per launch."""
     eng = agent.engine
@@ -631,6 +690,10 @@ def main():
         if world == 1 and args.config == 1 and not args.no_other_configs:
             oc = other_configs(device, with_cpu=not args.no_cpu_baseline)
             detail["other_configs"] = {k: dict(v, mfma_counters=mfma_counters(int(k[-1]))) for k, v in oc.items()}
+            img = image_config(device)
+            detail["image_config"] = img
+            line["image_obs_config"] = {"updates_per_s": img["td_updates_per_s"], "frac_mfma": img["frac_of_f32_mfma_peak"],
+                                        "tflop_per_update": img["algorithmic_tflop_per_update"]}
             line["other_configs"] = {k[-1]: {"B": CONFIGS[int(k[-1])]["B"], "updates_per_s": v["td_updates_per_s"],
                                              "frac_mfma": v["frac_of_f32_mfma_peak"], "clip_adam_frac_hbm": v["clip_adam_hbm"]["frac"],
                                              "cpu_updates_per_s": v.get("cpu_baseline", {}).get("value")} for k, v in oc.items()}
@@ -659,7 +722,7 @@ def main():
         line = _r(line)
         line["value"], line["ms_per_step"] = ups, ms              # the two the driver cross-checks: full precision
         text = json.dumps(line, separators=(",", ":"))
-        for k in ("env_steps_per_sec_cfg3", "hbm_view", "kernels_us", "hbm_kernels", "other_configs", "env_steps_per_sec"):
+        for k in ("env_steps_per_sec_cfg3", "image_obs_config", "hbm_view", "kernels_us", "hbm_kernels", "other_configs", "env_steps_per_sec"):
             if len(text) <= LINE_LIMIT:
                 break
             line.pop(k, None)                                     # never reached with today's keys; the contract keys always stay

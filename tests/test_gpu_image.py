@@ -51,8 +51,9 @@ class _PixelEnv:
         done = self.x >= 28 or self.t >= self._max_episode_steps
         return self._obs(), (1.0 if self.x >= 28 else 0.0), done, {"TimeLimit.truncated": self.t >= self._max_episode_steps and self.x < 28}
 
-    def seed(self, s=None):
-        self.rng = np.random.default_rng(s)
+    def seed(self, seed=None):
+        self.rng = np.random.default_rng(seed)
+        return [seed]
 
 
 def test_agent_trains_on_pixel_observations(lib):
