@@ -127,6 +127,9 @@ struct ImgGemmArgs {
     float* out1;               // LIN_FWD: optional second destination
     const int32_t *dst0, *dst1, *dsrc;
     int tokens, hi, wi, ho, wo, stride, C, taps, tiles_per_tok;
+    // CONV_DGRAD with stride 2: the input pixels of a workgroup share their row / column parity, so that only the taps that can reach
+    // them are walked (1, 2, 2 or 4 of the 9: an even row is reached by ky = 1 only, an odd one by ky = 0 and 2)
+    int cls_tiles[4], cls_first[4];          // tiles of parity class c = 2 * (iy & 1) + (ix & 1) and the first tile index of the class
 };
 // K: contraction per tap, N: output columns.  Wave w owns column tiles w, w + 4, ... (N / 64 of them) x four 16-row tiles.
 template <int K, int N, int MODE>
@@ -146,13 +149,24 @@ __global__ __launch_bounds__(IT) void img_gemm_kernel(ImgGemmArgs a) {
         tile = (int)blockIdx.x - tok0 * a.tiles_per_tok;
     }
     // rows of this workgroup: output pixels of token tok0 (convolutions; input pixels for the data gradient) or tokens (linear)
-    const int npix = MODE == IMG_CONV_DGRAD ? a.hi * a.wi : a.ho * a.wo;
+    int npix = MODE == IMG_CONV_DGRAD ? a.hi * a.wi : a.ho * a.wo;
+    int py = 0, px = 0, ch = 0, cw = 0;          // stride-2 data gradient: parity class of this workgroup's pixels and its extent
+    const bool classes = MODE == IMG_CONV_DGRAD && a.stride == 2;
+    if (classes) {
+        int c = 3;
+        while (c > 0 && tile < a.cls_first[c]) --c;
+        tile -= a.cls_first[c];
+        py = c >> 1; px = c & 1;
+        ch = (a.hi - py + 1) / 2; cw = (a.wi - px + 1) / 2;
+        npix = ch * cw;
+    }
     f32x4 acc[NCT][4];
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[c][m] = zero4();
     for (int tap = tap_lo; tap < tap_hi; ++tap) {
+        if (classes && ((((py + 1 - tap / 3) & 1) != 0) || (((px + 1 - tap % 3) & 1) != 0))) continue;
         // the tap's weight fragments go in flight before the staging barrier
         float4 bf[NCT][K / 16];
         const float* Wt = a.W + (size_t)tap * N * K;
@@ -185,7 +199,8 @@ __global__ __launch_bounds__(IT) void img_gemm_kernel(ImgGemmArgs a) {
                 } else if (MODE == IMG_CONV_DGRAD) {
                     const int q = tile * IROWS + r;
                     if (q < npix) {
-                        const int iy = q / a.wi, ix = q - iy * a.wi, ty = iy + 1 - ky, tx = ix + 1 - kx;
+                        const int iy = classes ? 2 * (q / cw) + py : q / a.wi, ix = classes ? 2 * (q % cw) + px : q - (q / a.wi) * a.wi;
+                        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
                         if (ty >= 0 && tx >= 0 && ty % a.stride == 0 && tx % a.stride == 0) {
                             const int oy = ty / a.stride, ox = tx / a.stride;
                             if (oy < a.ho && ox < a.wo) {
@@ -225,7 +240,10 @@ __global__ __launch_bounds__(IT) void img_gemm_kernel(ImgGemmArgs a) {
                     if (p < npix) a.out[((size_t)tok0 * npix + p) * N + col] = fmaxf(v, 0.f);
                 } else if (MODE == IMG_CONV_DGRAD) {
                     const int q = tile * IROWS + r;
-                    if (q < npix) a.out[((size_t)tok0 * npix + q) * N + col] = v;
+                    if (q < npix) {
+                        const int pix = classes ? (2 * (q / cw) + py) * a.wi + 2 * (q % cw) + px : q;
+                        a.out[((size_t)tok0 * a.hi * a.wi + pix) * N + col] = v;
+                    }
                 } else if (MODE == IMG_LIN_FWD) {
                     const int tk = tok0 + r;
                     if (tk < a.tokens) {
@@ -465,6 +483,16 @@ static int img_conv_dgrad(const DtqnNet& net, int l, const float* dy, const floa
     a.in = dy; a.mask = y; a.W = Wd; a.out = dx;
     a.tokens = tokens; a.hi = L.hi; a.wi = L.wi; a.ho = L.ho; a.wo = L.wo; a.stride = L.stride; a.taps = 9;
     a.tiles_per_tok = (L.hi * L.wi + IROWS - 1) / IROWS;
+    if (L.stride == 2) {
+        int first = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int ch = (L.hi - (c >> 1) + 1) / 2, cw = (L.wi - (c & 1) + 1) / 2;
+            a.cls_first[c] = first;
+            a.cls_tiles[c] = (ch * cw + IROWS - 1) / IROWS;
+            first += a.cls_tiles[c];
+        }
+        a.tiles_per_tok = first;
+    }
     const int grid = tokens * a.tiles_per_tok;
     // contraction over the convolution's output channels, columns = its input channels
     if (L.cin == 64 && L.cout == 64) return img_gemm<64, 64, IMG_CONV_DGRAD>(a, grid, s);
