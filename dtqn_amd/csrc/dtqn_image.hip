@@ -132,7 +132,10 @@ struct ImgGemmArgs {
     int cls_tiles[4], cls_first[4];          // tiles of parity class c = 2 * (iy & 1) + (ix & 1) and the first tile index of the class
 };
 // K: contraction per tap, N: output columns.  Wave w owns column tiles w, w + 4, ... (N / 64 of them) x four 16-row tiles.
-template <int K, int N, int MODE>
+// DB: two LDS tiles, the next tap's rows and fragments in flight during this tap's MFMAs (one barrier per tap).  It pays where the
+// fragments are long (K or N = 128 forward, the Linear: -9 ... -42 % per launch) and costs occupancy where they are short or the
+// gather is masked (64 x 64 forward +5 %, data gradients +14 ... +43 %): measured per instantiation, selected in img_gemm().
+template <int K, int N, int MODE, bool DB>
 __global__ __launch_bounds__(IT) void img_gemm_kernel(ImgGemmArgs a) {
     constexpr int LDA = K + 4, NCT = N / 64;
     static_assert(K % 16 == 0 && N % 64 == 0, "fragment shapes");
@@ -165,64 +168,126 @@ __global__ __launch_bounds__(IT) void img_gemm_kernel(ImgGemmArgs a) {
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[c][m] = zero4();
-    for (int tap = tap_lo; tap < tap_hi; ++tap) {
-        if (classes && ((((py + 1 - tap / 3) & 1) != 0) || (((px + 1 - tap % 3) & 1) != 0))) continue;
-        // the tap's weight fragments go in flight before the staging barrier
+    auto tap_live = [&](int tap) { return !(classes && ((((py + 1 - tap / 3) & 1) != 0) || (((px + 1 - tap % 3) & 1) != 0))); };
+    if (MODE == IMG_CONV1_FWD) {
+        // one contraction step of K = 9 C (padded): uint8 pixels gathered in the reference's (ci, ky, kx) order
         float4 bf[NCT][K / 16];
-        const float* Wt = a.W + (size_t)tap * N * K;
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf[c], Wt + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
-        __syncthreads();                                        // previous tap's tile consumed
-        const int ky = tap / 3, kx = tap - ky * 3;
-        if (MODE == IMG_CONV1_FWD) {
-            for (int idx = t.tid; idx < IROWS * K; idx += IT) {
-                const int r = idx / K, k = idx - r * K, p = tile * IROWS + r;
-                float v = 0.f;
-                if (p < npix && k < 9 * a.C) {
-                    const int ci = k / 9, kk = k - ci * 9, qy = kk / 3, qx = kk - qy * 3;
-                    const int oy = p / a.wo, ox = p - oy * a.wo, iy = oy * a.stride + qy - 1, ix = ox * a.stride + qx - 1;
-                    if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi)
-                        v = (float)a.img[(size_t)a.img_index[tok0] * a.C * a.hi * a.wi + ((size_t)ci * a.hi + iy) * a.wi + ix];
-                }
-                As[r * LDA + k] = v;
+        for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf[c], a.W + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
+        for (int idx = t.tid; idx < IROWS * K; idx += IT) {
+            const int r = idx / K, k = idx - r * K, p = tile * IROWS + r;
+            float v = 0.f;
+            if (p < npix && k < 9 * a.C) {
+                const int ci = k / 9, kk = k - ci * 9, qy = kk / 3, qx = kk - qy * 3;
+                const int oy = p / a.wo, ox = p - oy * a.wo, iy = oy * a.stride + qy - 1, ix = ox * a.stride + qx - 1;
+                if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi)
+                    v = (float)a.img[(size_t)a.img_index[tok0] * a.C * a.hi * a.wi + ((size_t)ci * a.hi + iy) * a.wi + ix];
             }
-        } else {
-            for (int idx = t.tid; idx < IROWS * (K / 4); idx += IT) {
-                const int r = idx / (K / 4), c4 = (idx - r * (K / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (MODE == IMG_CONV_FWD) {
-                    const int p = tile * IROWS + r;
-                    if (p < npix) {
-                        const int oy = p / a.wo, ox = p - oy * a.wo, iy = oy * a.stride + ky - 1, ix = ox * a.stride + kx - 1;
-                        if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) v = ld4(a.in + (((size_t)tok0 * a.hi + iy) * a.wi + ix) * K + c4);
-                    }
-                } else if (MODE == IMG_CONV_DGRAD) {
-                    const int q = tile * IROWS + r;
-                    if (q < npix) {
-                        const int iy = classes ? 2 * (q / cw) + py : q / a.wi, ix = classes ? 2 * (q % cw) + px : q - (q / a.wi) * a.wi;
-                        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
-                        if (ty >= 0 && tx >= 0 && ty % a.stride == 0 && tx % a.stride == 0) {
-                            const int oy = ty / a.stride, ox = tx / a.stride;
-                            if (oy < a.ho && ox < a.wo) {
-                                const size_t at = (((size_t)tok0 * a.ho + oy) * a.wo + ox) * K + c4;
-                                const float4 g = ld4(a.in + at), y = ld4(a.mask + at);
-                                v = make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
-                            }
-                        }
-                    }
-                } else if (MODE == IMG_LIN_FWD) {
-                    const int tk = tok0 + r;
-                    if (tk < a.tokens) v = ld4(a.in + ((size_t)tk * a.taps + tap) * K + c4);
-                } else {   // IMG_LIN_DGRAD
-                    const int tk = tok0 + r;
-                    if (tk < a.tokens && a.dsrc[tk] >= 0) v = ld4(a.in + (size_t)a.dsrc[tk] + c4);
-                }
-                st4(As + r * LDA + c4, v);
-            }
+            As[r * LDA + k] = v;
         }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NCT; ++c) frag16_mma<K, 4>(As, LDA, bf[c], t, acc[c]);
+    } else {
+        // Two LDS tiles: the shifted input rows of tap t + 1 (and its weight fragments) are in flight as global loads while tap t
+        // multiplies; they are dropped into the other tile behind the MFMAs -- one barrier per tap.
+        constexpr int NV = IROWS * (K / 4) / IT;                       // float4 pieces of the 64 x K tile per thread
+        static_assert(IROWS * (K / 4) % IT == 0, "tile pieces per thread");
+        float* As1 = As + IROWS * LDA;
+        auto gather = [&](int tap, int idx) -> float4 {
+            const int r = idx / (K / 4), c4 = (idx - r * (K / 4)) * 4;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == IMG_CONV_FWD) {
+                const int p = tile * IROWS + r;
+                if (p >= npix) return z;
+                const int oy = p / a.wo, ox = p - oy * a.wo, iy = oy * a.stride + ky - 1, ix = ox * a.stride + kx - 1;
+                if (iy < 0 || iy >= a.hi || ix < 0 || ix >= a.wi) return z;
+                return ld4(a.in + (((size_t)tok0 * a.hi + iy) * a.wi + ix) * K + c4);
+            } else if (MODE == IMG_CONV_DGRAD) {
+                const int q = tile * IROWS + r;
+                if (q >= npix) return z;
+                const int iy = classes ? 2 * (q / cw) + py : q / a.wi, ix = classes ? 2 * (q % cw) + px : q - (q / a.wi) * a.wi;
+                const int ty = iy + 1 - ky, tx = ix + 1 - kx;
+                if (ty < 0 || tx < 0 || ty % a.stride != 0 || tx % a.stride != 0) return z;
+                const int oy = ty / a.stride, ox = tx / a.stride;
+                if (oy >= a.ho || ox >= a.wo) return z;
+                const size_t at = (((size_t)tok0 * a.ho + oy) * a.wo + ox) * K + c4;
+                const float4 g = ld4(a.in + at), y = ld4(a.mask + at);
+                return make_float4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+            } else if (MODE == IMG_LIN_FWD) {
+                const int tk = tok0 + r;
+                return tk < a.tokens ? ld4(a.in + ((size_t)tk * a.taps + tap) * K + c4) : z;
+            } else {   // IMG_LIN_DGRAD
+                const int tk = tok0 + r;
+                return (tk < a.tokens && a.dsrc[tk] >= 0) ? ld4(a.in + (size_t)a.dsrc[tk] + c4) : z;
+            }
+        };
+        auto next_live = [&](int tap) { while (tap < tap_hi && !tap_live(tap)) ++tap; return tap; };
+        if constexpr (!DB) {
+            for (int tap = tap_lo; tap < tap_hi; ++tap) {
+                if (!tap_live(tap)) continue;
+                float4 bf1[NCT][K / 16];                                // the tap's weight fragments go in flight before the staging barrier
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf1[c], a.W + (size_t)tap * N * K + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
+                __syncthreads();                                        // previous tap's tile consumed
+                for (int idx = t.tid; idx < IROWS * (K / 4); idx += IT) {
+                    const int r = idx / (K / 4), c4 = (idx - r * (K / 4)) * 4;
+                    st4(As + r * LDA + c4, gather(tap, idx));
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) frag16_mma<K, 4>(As, LDA, bf1[c], t, acc[c]);
+            }
+        } else {
+        float4 av[NV], bf[2][NCT][K / 16];
+        int tap = next_live(tap_lo), buf = 0;
+        if (tap < tap_hi) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf[0][c], a.W + (size_t)tap * N * K + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) av[v] = gather(tap, t.tid + v * IT);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int idx = t.tid + v * IT, r = idx / (K / 4), c4 = (idx - r * (K / 4)) * 4;
+                st4(As + r * LDA + c4, av[v]);
+            }
+        }
+        __syncthreads();
+        while (tap < tap_hi) {
+            const int nxt = next_live(tap + 1);
+            float* cur = buf ? As1 : As;
+            float* oth = buf ? As : As1;
+            if (nxt < tap_hi) {
+                if (buf == 0) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf[1][c], a.W + (size_t)nxt * N * K + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) frag16_fetch<K>(bf[0][c], a.W + (size_t)nxt * N * K + (size_t)((t.wave + c * IW) * 16 + t.i) * K, t);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) av[v] = gather(nxt, t.tid + v * IT);
+            }
+            if (buf == 0) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) frag16_mma<K, 4>(cur, LDA, bf[0][c], t, acc[c]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) frag16_mma<K, 4>(cur, LDA, bf[1][c], t, acc[c]);
+            }
+            if (nxt < tap_hi) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int idx = t.tid + v * IT, r = idx / (K / 4), c4 = (idx - r * (K / 4)) * 4;
+                    st4(oth + r * LDA + c4, av[v]);
+                }
+            }
+            __syncthreads();                     // tile of the next tap published; this tap's tile free again
+            tap = nxt;
+            buf ^= 1;
+        }
+        }
     }
     // epilogue: lane (i, kq) holds column ct * 16 + i of rows m * 16 + kq * 4 + r
 #pragma unroll
@@ -269,6 +334,7 @@ struct ImgWgradArgs {
     const int32_t* dsrc;
     float* part;               // [splits][taps][N][Kp]
     float* bpart;              // [splits][N]
+    float* direct;             // LIN (one split): the gradient of W_e itself, written in the reference layout [d][c * P + p]
     int tokens, hi, wi, ho, wo, stride, C, taps, N, K, Kp, splits;
     long long rows;            // tokens * ho * wo (convolutions) or tokens (linear)
 };
@@ -379,7 +445,13 @@ __global__ __launch_bounds__(IT) void img_wgrad_kernel(ImgWgradArgs a) {
                 const float4 x = ld4(s0 + (size_t)wv * 65 * SLD + nl * SLD + k4);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
-            st4(out + (size_t)n * a.Kp + k, v);
+            if (MODE == IMG_WG_LIN && a.direct != nullptr) {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a.direct[((size_t)n * a.K + k + c) * a.taps + tap] = vv[c];
+            } else {
+                st4(out + (size_t)n * a.Kp + k, v);
+            }
         }
     }
     if (tap == 0 && bk == 0 && t.tid < 64) {
@@ -387,6 +459,117 @@ __global__ __launch_bounds__(IT) void img_wgrad_kernel(ImgWgradArgs a) {
 #pragma unroll
         for (int wv = 0; wv < IW; ++wv) v += s0[(size_t)wv * 65 * SLD + 64 * SLD + t.tid];
         a.bpart[(size_t)split * a.N + bn * 64 + t.tid] = v;
+    }
+}
+
+// ---- weight gradients of the 64- / 128-channel convolutions: operands through LDS, taps dealt to the waves ------------------------
+// The per-tap kernel above reads dY, the ReLU mask and the shifted input once PER TAP from global memory (27 map reads per layer:
+// HBM-bound, 9.9 ms per launch at 1632 tokens of 72 x 72).  Here a workgroup walks 8 x 8 output patches: the patch's masked dY
+// [64 pixels][64 channels] and the (7 s + 3)^2 input halo it touches are staged in LDS ONCE, and the nine taps are dealt to the four
+// waves (wave w owns taps w, w + 4, w + 8): every wave contracts all 64 pixels of the patch for its taps out of LDS, keeping its
+// 64 x 64 tap tiles in registers across the whole patch range.  No cross-wave reduction; one partial per (split, tap).
+struct ImgWgradLdsArgs {
+    const float* dy;           // dL/d(output map) [tok][ho wo][N]
+    const float* y;            // the layer's output (ReLU mask)
+    const float* x;            // input map [tok][hi wi][K]
+    float* part;               // [splits][9][N][K]
+    float* bpart;              // [splits][N]
+    int tokens, hi, wi, ho, wo, N, K, splits, py_n, px_n;      // py_n x px_n patches per token
+    long long patches;
+};
+template <int S>
+__global__ __launch_bounds__(IT) void img_wgrad_lds_kernel(ImgWgradLdsArgs a) {
+    constexpr int HW = 7 * S + 3, LDT = 68;
+    float* dYs = reinterpret_cast<float*>(dtqn_smem);          // [64][LDT]
+    float* Xs = dYs + 64 * LDT;                                // [HW * HW][LDT]
+    const Thr t = make_thr();
+    const int tiles_k = a.K / 64, tiles_n = a.N / 64;
+    int id = (int)blockIdx.x;
+    const int bk = id % tiles_k; id /= tiles_k;
+    const int bn = id % tiles_n; id /= tiles_n;
+    const int split = id;
+    const long long per = (a.patches + a.splits - 1) / a.splits;
+    const long long p_lo = (long long)split * per, p_hi = p_lo + per < a.patches ? p_lo + per : a.patches;
+    const int ppt = a.py_n * a.px_n;
+    // work units of this wave: unit u = (tap u / 2, half u % 2 of the 64 dY columns: cn in {2 h, 2 h + 1}); 18 units dealt round-robin
+    // -> 5, 5, 4, 4 per wave (whole taps would be 3, 2, 2, 2: the busiest wave sets the pace)
+    constexpr int NU = 5;
+    int toff[NU], uh[NU], utap[NU];
+    bool ulive[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int u = t.wave + 4 * j;
+        ulive[j] = u < 18;
+        utap[j] = u >> 1; uh[j] = u & 1;
+        toff[j] = ((utap[j] / 3) * HW + utap[j] % 3) * LDT;
+    }
+    f32x4 acc[NU][2][4];
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int cn = 0; cn < 2; ++cn)
+#pragma unroll
+            for (int ck = 0; ck < 4; ++ck) acc[j][cn][ck] = zero4();
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long p = p_lo; p < p_hi; ++p) {
+        const int tk = (int)(p / ppt), pp = (int)(p - (long long)tk * ppt);
+        const int oy0 = (pp / a.px_n) * 8, ox0 = (pp % a.px_n) * 8;
+        __syncthreads();                                        // previous patch consumed
+        for (int idx = t.tid; idx < 64 * 16; idx += IT) {
+            const int r = idx >> 4, c4 = (idx & 15) * 4, oy = oy0 + (r >> 3), ox = ox0 + (r & 7);
+            float4 v = z4;
+            if (oy < a.ho && ox < a.wo) {
+                const size_t at = (((size_t)tk * a.ho + oy) * a.wo + ox) * a.N + bn * 64 + c4;
+                const float4 g = ld4(a.dy + at), yv = ld4(a.y + at);
+                v = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
+            }
+            st4(dYs + r * LDT + c4, v);
+        }
+        for (int idx = t.tid; idx < HW * HW * 16; idx += IT) {
+            const int r = idx >> 4, c4 = (idx & 15) * 4, iy = oy0 * S - 1 + r / HW, ix = ox0 * S - 1 + r % HW;
+            float4 v = z4;
+            if (iy >= 0 && iy < a.hi && ix >= 0 && ix < a.wi) v = ld4(a.x + (((size_t)tk * a.hi + iy) * a.wi + ix) * a.K + bk * 64 + c4);
+            st4(Xs + r * LDT + c4, v);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int step = 0; step < 16; ++step) {
+            const int pl = 4 * step + t.kq, oy = pl >> 3, ox = pl & 7;
+            const float4 a4 = ld4(dYs + pl * LDT + 4 * t.i);
+            const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (t.wave == 0) { bsum.x += a4.x; bsum.y += a4.y; bsum.z += a4.z; bsum.w += a4.w; }
+            const float* xb = Xs + ((oy * S) * HW + ox * S) * LDT + 4 * t.i;
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                if (!ulive[j]) continue;
+                const float4 b4 = ld4(xb + toff[j]);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float a0 = uh[j] ? aa[2] : aa[0], a1 = uh[j] ? aa[3] : aa[1];
+#pragma unroll
+                for (int ck = 0; ck < 4; ++ck) {
+                    acc[j][0][ck] = mfma16(a0, bb[ck], acc[j][0][ck]);
+                    acc[j][1][ck] = mfma16(a1, bb[ck], acc[j][1][ck]);
+                }
+            }
+        }
+    }
+    // acc[j][c][ck][r]: n = 4 * (kq * 4 + r) + 2 h + c, k = 4 * i + ck of tap utap[j]
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        if (!ulive[j]) continue;
+        float* out = a.part + ((((size_t)split * 9 + utap[j]) * a.N + bn * 64) * a.K) + bk * 64;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st4(out + (size_t)(4 * (t.kq * 4 + r) + 2 * uh[j] + c) * a.K + 4 * t.i,
+                    make_float4(acc[j][c][0][r], acc[j][c][1][r], acc[j][c][2][r], acc[j][c][3][r]));
+    }
+    if (t.wave == 0 && bk == 0) {
+        bsum.x += __shfl_xor(bsum.x, 16); bsum.y += __shfl_xor(bsum.y, 16); bsum.z += __shfl_xor(bsum.z, 16); bsum.w += __shfl_xor(bsum.w, 16);
+        bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32); bsum.z += __shfl_xor(bsum.z, 32); bsum.w += __shfl_xor(bsum.w, 32);
+        if (t.kq == 0) st4(a.bpart + (size_t)split * a.N + bn * 64 + 4 * t.i, bsum);
     }
 }
 
@@ -400,28 +583,35 @@ struct ImgReduceArgs {
     long long n;
 };
 __global__ __launch_bounds__(IT) void img_reduce_kernel(ImgReduceArgs a) {
-    const long long idx = (long long)blockIdx.x * IT + threadIdx.x;
-    if (idx < a.N) {
+    // 64 elements per workgroup, the splits of an element summed by 4 threads (every 4th split each) and folded in a fixed order
+    // through LDS: a single thread per element walked up to 768 partials in one dependent chain (1.5 ms for the 64 x 64 layers)
+    __shared__ float red[IT];
+    const int el = (int)threadIdx.x & 63, q = (int)threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + el;
+    if (blockIdx.x * 64 + threadIdx.x < (unsigned)a.N && threadIdx.x < 64) {
         float v = 0.f;
         for (int s = 0; s < a.splits; ++s) v += a.bpart[(size_t)s * a.N + idx];
         a.grad[a.off_b + idx] = v;
     }
-    if (idx >= a.n) return;
-    int tap, n, k;
-    size_t dst;
-    if (a.kind == 0) {             // idx over [co][9 C]
-        n = (int)(idx / (9 * a.C)); k = (int)(idx % (9 * a.C)); tap = 0;
-        dst = (size_t)idx;
-    } else if (a.kind == 1) {      // idx over [co][ci][tap]
-        tap = (int)(idx % 9); k = (int)((idx / 9) % a.K); n = (int)(idx / (9LL * a.K));
-        dst = (size_t)idx;
-    } else {                       // idx over [d][c][p]  ->  W_e[d][c * P + p]
-        tap = (int)(idx % a.taps); k = (int)((idx / a.taps) % a.K); n = (int)(idx / ((long long)a.taps * a.K));
-        dst = (size_t)idx;
+    int tap = 0, n = 0, k = 0;
+    size_t dst = 0;
+    const bool live = idx < a.n;
+    if (live) {
+        if (a.kind == 0) {             // idx over [co][9 C]
+            n = (int)(idx / (9 * a.C)); k = (int)(idx % (9 * a.C)); tap = 0;
+            dst = (size_t)idx;
+        } else {                       // idx over the partial's [tap][n][k] (reads coalesced over the splits); one scattered write:
+            k = (int)(idx % a.K); n = (int)((idx / a.K) % a.N); tap = (int)(idx / ((long long)a.K * a.N));
+            dst = a.kind == 1 ? ((size_t)n * a.K + k) * 9 + tap                      // conv  [co][ci][ky][kx]
+                              : ((size_t)n * a.K + k) * a.taps + tap;                 // W_e   [d][c * P + p]
+        }
     }
     float v = 0.f;
-    for (int s = 0; s < a.splits; ++s) v += a.part[(((size_t)s * a.taps + tap) * a.N + n) * a.Kp + k];
-    a.grad[a.off_w + dst] = v;
+    if (live)
+        for (int s = q; s < a.splits; s += 4) v += a.part[(((size_t)s * a.taps + tap) * a.N + n) * a.Kp + k];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (live && q == 0) a.grad[a.off_w + dst] = ((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el];
 }
 
 // token lists of a TD update
@@ -459,10 +649,11 @@ __global__ __launch_bounds__(IT) void img_lists_kernel(ImgListArgs a) {
 
 template <int K, int N, int MODE>
 static int img_gemm(const ImgGemmArgs& a, int grid, hipStream_t s) {
-    const size_t lds = (size_t)IROWS * (K + 4) * sizeof(float);
+    constexpr bool DB = MODE == IMG_LIN_FWD || (MODE == IMG_CONV_FWD && (K == 128 || N == 128));
+    const size_t lds = (size_t)(DB ? 2 : 1) * IROWS * (K + 4) * sizeof(float);
     static size_t attr_lds[kMaxDevices] = {};      // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&img_gemm_kernel<K, N, MODE>), lds, attr_lds);
-    IMG_LAUNCH((img_gemm_kernel<K, N, MODE>), grid, lds, s, a);
+    raise_lds_limit(reinterpret_cast<const void*>(&img_gemm_kernel<K, N, MODE, DB>), lds, attr_lds);
+    IMG_LAUNCH((img_gemm_kernel<K, N, MODE, DB>), grid, lds, s, a);
     return DTQN_OK;
 }
 
@@ -533,12 +724,21 @@ extern "C" long long dtqn_img_gact_floats(const DtqnNet* net, int tokens) {
     return 2 * mx;
 }
 static void img_wgrad_plan(const DtqnNet& net, int which, long long& part_floats, int& splits, long long rows) {
-    // which 0..4: convolutions, 5: linear
+    // which 0: first convolution (per-tap kernel, one "tap"), 1..4: LDS-staged kernel over 8 x 8 patches, 5: linear (per-tap kernel)
     int taps, N, Kp;
     if (which == 5) { taps = net.img_h5 * net.img_w5; N = net.d_model; Kp = 128; }
     else { const ImgLayer L = img_layer(net, which); taps = which == 0 ? 1 : 9; N = L.cout; Kp = which == 0 ? net.img_k1 : L.cin; }
-    const int groups = taps * (N / 64) * ((Kp + 63) / 64);
-    splits = which == 5 ? 1 : img_splits(rows, groups);
+    if (which >= 1 && which <= 4) {
+        const ImgLayer L = img_layer(net, which);
+        const long long tokens = rows / ((long long)L.ho * L.wo);
+        const long long patches = tokens * ((L.ho + 7) / 8) * ((L.wo + 7) / 8);
+        long long want = 512 / ((N / 64) * (Kp / 64)), cap = patches / 4;       // two workgroups per CU
+        if (cap < 1) cap = 1;
+        splits = (int)(want < cap ? want : cap);
+    } else {
+        const int groups = taps * (N / 64) * ((Kp + 63) / 64);
+        splits = which == 5 ? 1 : img_splits(rows, groups);
+    }
     part_floats = (long long)splits * taps * N * Kp;
 }
 extern "C" long long dtqn_img_wpart_floats(const DtqnNet* net) {
@@ -550,7 +750,7 @@ extern "C" long long dtqn_img_wpart_floats(const DtqnNet* net) {
         img_wgrad_plan(*net, w, pf, sp, 1LL << 40);
         if (pf > mx) mx = pf;
     }
-    return mx + 2048LL * 256;
+    return mx + 2048LL * 256;      // + the bias partials ([splits][N], splits <= 2048)
 }
 
 extern "C" int dtqn_img_prep(const DtqnNet* net, const float* theta, float* wprep, void* stream) {
@@ -632,6 +832,7 @@ extern "C" int dtqn_img_backward(const DtqnNet* net, const float* theta, const f
         int off_w, off_b, kind;
         if (which == 5) {
             a.taps = P; a.N = DO; a.K = 128; a.Kp = 128; a.rows = tokens; a.ho = a.wo = 1;
+            a.direct = grad_out + net->off_obs_w;          // one split: no partial, no reduce pass over 2.65 M elements
             off_w = net->off_obs_w; off_b = net->off_obs_b; kind = 2;
         } else {
             const ImgLayer L = img_layer(*net, which);
@@ -644,6 +845,25 @@ extern "C" int dtqn_img_backward(const DtqnNet* net, const float* theta, const f
         a.splits = splits;
         a.part = wpart;
         a.bpart = wpart + pf;
+        if (which >= 1 && which <= 4) {
+            const ImgLayer L = img_layer(*net, which);
+            ImgWgradLdsArgs w = {};
+            w.dy = dy; w.y = y; w.x = x; w.part = wpart; w.bpart = wpart + pf;
+            w.tokens = tokens; w.hi = L.hi; w.wi = L.wi; w.ho = L.ho; w.wo = L.wo; w.N = L.cout; w.K = L.cin; w.splits = splits;
+            w.py_n = (L.ho + 7) / 8; w.px_n = (L.wo + 7) / 8;
+            w.patches = (long long)tokens * w.py_n * w.px_n;
+            const int hw = 7 * L.stride + 3;
+            const size_t lds2 = ((size_t)64 + (size_t)hw * hw) * 68 * sizeof(float);
+            const int grid2 = splits * (L.cout / 64) * (L.cin / 64);
+            static size_t attr2[2][kMaxDevices] = {};
+            if (L.stride == 1) {
+                raise_lds_limit(reinterpret_cast<const void*>(&img_wgrad_lds_kernel<1>), lds2, attr2[0]);
+                IMG_LAUNCH((img_wgrad_lds_kernel<1>), grid2, lds2, s, w);
+            } else {
+                raise_lds_limit(reinterpret_cast<const void*>(&img_wgrad_lds_kernel<2>), lds2, attr2[1]);
+                IMG_LAUNCH((img_wgrad_lds_kernel<2>), grid2, lds2, s, w);
+            }
+        } else {
         const int grid = splits * a.taps * (a.N / 64) * ((a.Kp + 63) / 64);
         const size_t lds = (size_t)IW * 65 * 68 * sizeof(float);
         static size_t attr_lds[3][kMaxDevices] = {};
@@ -657,12 +877,13 @@ extern "C" int dtqn_img_backward(const DtqnNet* net, const float* theta, const f
             raise_lds_limit(reinterpret_cast<const void*>(&img_wgrad_kernel<IMG_WG_CONV>), lds, attr_lds[2]);
             IMG_LAUNCH((img_wgrad_kernel<IMG_WG_CONV>), grid, lds, s, a);
         }
+        }
         ImgReduceArgs r = {};
         r.part = wpart; r.bpart = wpart + pf; r.grad = grad_out; r.off_w = off_w; r.off_b = off_b; r.kind = kind;
         r.taps = a.taps; r.N = a.N; r.K = a.K; r.Kp = a.Kp; r.splits = splits; r.C = net->img_c;
-        r.n = (long long)a.N * a.K * a.taps;
-        const long long nthreads = r.n > a.N ? r.n : a.N;
-        IMG_LAUNCH(img_reduce_kernel, (unsigned)((nthreads + IT - 1) / IT), 0, s, r);
+        r.n = which == 5 ? 0 : (long long)a.N * a.K * a.taps;      // (linear: weights already in place, biases only)
+        const long long nel = r.n > a.N ? r.n : a.N;
+        IMG_LAUNCH(img_reduce_kernel, (unsigned)((nel + 63) / 64), 0, s, r);
         return DTQN_OK;
     };
     // Linear: dfeat = dxemb W_e (per spatial position), dW_e, db_e
