@@ -15,6 +15,17 @@
 #endif
 // Item guard of the register-accumulated stages.  -DDTQN_BWD_FOLD_GUARD=1 folds it for full rounds of items (as the
 // forward does): see DESIGN.md section 6 for what that exposed in the <D = 128, 16-row slice> instantiation.
+// Row slices, attention backward: 1 = every slice broadcasts its dO tile (+ delta) to the slices below it BEFORE the attention passes
+// and owns dK | dV of its own rows (attention_backward_group_mfma, "own keys" form); 0 = the round-1 / round-2 scheme, every slice
+// hands its queries' share of dK | dV down AFTER the passes.
+#ifndef DTQN_BWD_DOX
+#define DTQN_BWD_DOX 1
+#endif
+// 1: the sender waits for its write-through stores and raises its flags BEFORE its own pass 1 (receivers never wait for a sender's
+// attention pass); 0: behind pass 1 (the acknowledgements are hidden, the receivers wait longer)
+#ifndef DTQN_BWD_DOX_EARLY_FLAG
+#define DTQN_BWD_DOX_EARLY_FLAG 1
+#endif
 #ifndef DTQN_BWD_FOLD_GUARD
 #define DTQN_BWD_FOLD_GUARD 0
 #endif
@@ -287,10 +298,16 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         tr.to_lds(T2, LDX, t);                         // s1
         // q | k | v (| o) of head group 0 go in flight now; they land in W5 after the LayerNorm backward
         // q, o: this slice's rows; k, v: every row up to the end of the slice, in LP-row chunks (chunk j = rows j*LP..)
-        TileRegs<NW, LP, GW> tq, to, tk[RS], tv[RS];
+        constexpr bool DOX = RS > 1 && DTQN_BWD_DOX && DTQN_SPLIT_ATTN_MFMA;
+        TileRegs<NW, LP, GW> tq, to, tk[RS], tv[RS], tqu[DOX ? RS : 1];
         auto load_group = [&](int g) {
             const float* qkv0 = lrec + net.al_qkv + g * GW;
             tq.load(qkv0 + (size_t)R0 * 3 * D, 3 * D, t);
+            if constexpr (DOX) {       // queries of the slices ABOVE this one: pass 2 runs this slice's keys against them
+#pragma unroll
+                for (int j = 1; j < RS; ++j)
+                    if (j > slice) tqu[j].load(qkv0 + (size_t)j * LP * 3 * D, 3 * D, t);
+            }
 #pragma unroll
             for (int j = 0; j < RS; ++j)
                 if (j <= slice) {
@@ -341,6 +358,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             for (int g = 0; g < NG; ++g) {          // unrolled: the g == 0 / g + 1 < NG cases fold
                 // q, k, v (o) of this head group -> W5   (W5 is free: the FFN / previous group are behind a barrier)
                 tq.to_lds(W5r, LD5, t);
+                if constexpr (DOX) {
+#pragma unroll
+                    for (int j = 1; j < RS; ++j)
+                        if (j > slice) tqu[j].to_lds(W5 + j * LP * LD5, LD5, t);
+                }
 #pragma unroll
                 for (int j = 0; j < RS; ++j)
                     if (j <= slice) {
@@ -377,6 +399,67 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
+                if constexpr (DOX) {
+                    // dO (own rows, this head group) and delta go to the slices below: sc1 stores now, acknowledged behind pass 1;
+                    // what the slices above sent is picked up between the passes
+                    constexpr int PAIRS = RS * (RS - 1) / 2, SEG = LP * GW + (GW / HD) * LP;
+                    const size_t grp = ((size_t)b * net.num_layers + l) * NG + g;
+                    float* xg = a.xch + grp * PAIRS * LP * 2 * GW;          // (RS - 1) segments of SEG floats fit the pair regions
+                    int32_t* fg = a.xflags + grp * PAIRS;
+                    auto pair_id = [](int s_, int r_) { return s_ * (s_ - 1) / 2 + r_; };
+                    static_assert((RS - 1) * SEG <= PAIRS * LP * 2 * GW, "dO segments fit the exchange region");
+                    if (slice > 0) {
+                        const DtqnRsrc rs = DTQN_XCH_RSRC(xg + (size_t)(slice - 1) * SEG, SEG * 4);
+                        constexpr int C4 = GW / 4;
+                        for (int idx = t.tid; idx < LP * C4; idx += NT) {
+                            const int r = idx / C4, c = (idx - r * C4) * 4;
+                            dtqn_xch_store4(rs, idx * 16, ld4(W5r + r * LD5 + 3 * GW + c));
+                        }
+                        for (int idx = t.tid; idx < (GW / HD) * LP / 4; idx += NT) {
+                            const int h = idx / (LP / 4), r4 = (idx - h * (LP / 4)) * 4;
+                            dtqn_xch_store4(rs, (LP * GW + h * LP + r4) * 4, ld4(delta_s + h * LPF + R0 + r4));
+                        }
+#if DTQN_BWD_DOX_EARLY_FLAG
+                        DTQN_WAIT_VMEM();
+                        __syncthreads();
+                        if (t.tid < slice) DTQN_AGENT_STORE(fg + pair_id(slice, t.tid), (int32_t)1);
+#endif
+                    }
+                    auto between = [&]() {
+#if !DTQN_BWD_DOX_EARLY_FLAG
+                        if (slice > 0) {
+                            DTQN_WAIT_VMEM();
+                            __syncthreads();
+                            if (t.tid < slice) DTQN_AGENT_STORE(fg + pair_id(slice, t.tid), (int32_t)1);
+                        }
+#endif
+                        // every sender above this slice at once: one thread per flag spins, then one pass over all their segments
+                        const int nsnd = RS - 1 - slice;
+                        if (nsnd > 0) {
+                            if (t.tid < nsnd)
+                                while (DTQN_AGENT_LOAD(fg + pair_id(slice + 1 + t.tid, slice)) == 0) DTQN_SPIN_PAUSE();
+                            __syncthreads();
+                            constexpr int C4 = GW / 4, TILE4 = LP * C4, DEL4 = (GW / HD) * LP / 4, SEG4 = TILE4 + DEL4;
+                            const DtqnRsrc rs = DTQN_XCH_RSRC(xg + (size_t)slice * SEG, nsnd * SEG * 4);      // segments of senders slice + 1 ...
+                            for (int idx = t.tid; idx < nsnd * SEG4; idx += NT) {
+                                const int k = idx / SEG4, e = idx - k * SEG4, sndr = slice + 1 + k;
+                                const float4 v = dtqn_xch_load4(rs, (k * SEG + e * 4) * 4);
+                                if (e < TILE4) {
+                                    const int r = e / C4, c = (e - r * C4) * 4;
+                                    st4(W5 + (sndr * LP + r) * LD5 + 3 * GW + c, v);
+                                } else {
+                                    const int d = e - TILE4, h = d / (LP / 4), r4 = (d - h * (LP / 4)) * 4;
+                                    st4(delta_s + h * LPF + sndr * LP + r4, v);
+                                }
+                            }
+                            __syncthreads();
+                            if (t.tid < nsnd) DTQN_AGENT_STORE(fg + pair_id(slice + 1 + t.tid, slice), (int32_t)0);
+                        }
+                    };
+                    attention_backward_group_mfma<HD, NW>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF, dr, l, g * (GW / HD),
+                                                          true, LPF / 16, between);
+                    __syncthreads();
+                } else {
                 attention_backward_group<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS > 1 && DTQN_SPLIT_ATTN_MFMA)>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF, dr, l, g * (GW / HD));
                 __syncthreads();
                 if (RS > 1) {
@@ -403,6 +486,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     for (int sndr = slice + 1; sndr < RS; ++sndr)
                         xch_recv<NW, true>(W5r + GW, LD5, xg + (size_t)pair_id(sndr, slice) * LP * 2 * GW, LP, 2 * GW,
                                            fg + pair_id(sndr, slice), t);
+                }
                 }
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
                 if (DTQN_BWD_GUARD(t.wave, 0)) {

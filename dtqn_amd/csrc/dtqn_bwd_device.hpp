@@ -102,11 +102,19 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
 //       S = Q K^T and dP = dO V^T (rows t = kq*4 + r, column s = i); P and dS are the B operands of
 //       dV^T[c][s] += dO^T[c][t] P[t][s] and dK^T[c][s] += Q^T[c][t] dS[t][s]        (in place over k, v at the end)
 // Lane (i, kq) ends up with four consecutive columns c = kq*4.. of output row i: one 16-byte store.
-template <int HD, int NW>
+// Row slices, "own keys" form (round 3; p2_own = true): pass 2 covers the KEY tiles of this slice only, against every query tile at or
+// above them (q | dO | lse | delta of the rows above this slice must be in the tiles: the caller's `between` functor, run between the
+// passes, receives what the upper slices broadcast).  dk | dv of the slice's rows are then complete here and nothing is handed down
+// afterwards; the work is (keys below) + (queries above) = RS + 1 tile pairs for EVERY slice instead of 2 ... 2 RS.
+struct AttnNoBetween {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int HD, int NW, typename BT = AttnNoBetween>
 __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld, int GW, int LP, int n,
                                                               const float* delta_s, const float* lse_s, const Thr& t,
                                                               float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
-                                                              const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+                                                              const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                              bool p2_own = false, int q_tiles = 0, BT between = BT()) {
     // dr / layer / head0 (global index of the group's first head): attention-probability dropout of the forward, recomputed:
     // o = (P * M) v with M = keep / (1 - p), so dV takes P * M, and dP = M * (dO v^T) before the softmax backward
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
@@ -179,10 +187,13 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
                                          (acc[ct][0][2] + acc[ct][1][2]) * f, (acc[ct][0][3] + acc[ct][1][3]) * f));
         }
     }
+    between();
     __syncthreads();
-    const int ti_hi = last_tile < MTK - 1 ? last_tile : MTK - 1;      // last query tile of this slice with live rows
-    for (int item = t.wave; item < HG * MTK; item += NW) {
-        const int h = item % HG, tj = item / HG;
+    const int qt_top = p2_own ? q_tiles - 1 : MTK - 1;                // last query tile pass 2 may look at
+    const int ti_hi = last_tile < qt_top ? last_tile : qt_top;        // ... with live rows
+    const int kt_lo = p2_own ? T0 : 0;                                // first key tile of pass 2
+    for (int item = t.wave; item < HG * (MTK - kt_lo); item += NW) {
+        const int h = item % HG, tj = kt_lo + item / HG;
         const int s0 = tj * 16, srow = s0 + t.i;
         float* kout = W5 + srow * ld + GW + h * HD;
         float* vout = kout + GW;
