@@ -54,7 +54,8 @@ extern "C" int dtqn_td_xch_floats(const DtqnNet* net, int batch) {
 }
 extern "C" int dtqn_td_xch_flags(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
-    return 3 * batch * net->num_layers * 4;                   // backward: one per 64-column head group (<= 4)
+    // backward: one per 64-column head group (<= 4); + the event counters of the fused weight gradients (dtqn_wgrad_direct.hpp: kFuseWords)
+    return 3 * batch * net->num_layers * 4 + 16;
 }
 
 // DtqnAgent.train() after sampling (dtqn/agents/dtqn.py:215-269) on one GPU: five launches.

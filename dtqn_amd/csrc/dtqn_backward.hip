@@ -9,6 +9,7 @@
 #include "dtqn_device.hpp"
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
+#include "dtqn_wgrad_direct.hpp"
 
 #ifndef DTQN_SPLIT_ATTN_MFMA
 #define DTQN_SPLIT_ATTN_MFMA 1
@@ -61,13 +62,17 @@ struct BwdArgs {
     uint32_t drop_thresh, drop_seed;
     float drop_scale;
     const int32_t* step_counter;
+    FuseArgs fuse;               // weight-gradient workgroups in this launch (n_role == 0: none)
 };
 
 // RS = row slices per sequence (see dtqn_forward.hip).  RS == 2: the workgroup owns rows [R0, R0 + LP); attention is
 // the only stage that looks below R0 (keys / values of the lower rows, read from the forward's record) and the only one
 // that hands something over: the upper slice's contribution to dK | dV of the lower rows (slice 1 -> slice 0).
 // DROP: the training forward ran with dropout (compile-time: the default build of a network carries no keep-mask code)
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP>
+// FUSE: the launch carries a.fuse.n_role extra workgroups behind the batch * RS of the data-gradient chain; they compute the weight
+// gradients (dtqn_wgrad_direct.hpp), layer by layer as the chain publishes its gradient records: every record store of the chain is
+// then a write-through (sc1) store, and the chain counts itself in at an event once a layer's stores are acknowledged.
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
     constexpr int NT = NW * 64;
@@ -85,6 +90,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
     const Thr& t_outer = t;
+    if constexpr (FUSE) {
+        if ((int)blockIdx.x >= a.batch * RS) {
+            const DirectCtx ctx{a.act, a.grd, a.small, a.fuse.grad, a.batch, RS, a.fuse.n_small};
+            fuse_role<NW>(net, a.fuse, ctx, (int)blockIdx.x - a.batch * RS, reinterpret_cast<float*>(dtqn_smem), t);
+            return;
+        }
+    }
     const int b = (int)blockIdx.x / RS;
     const int slice = RS - 1 - ((int)blockIdx.x - b * RS);     // the upper slice (the producer of this kernel) first
     const int R0 = slice * LP;
@@ -100,6 +112,29 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     auto rf = [&](const float* base, int off, int w) -> const float* { return base + off + (size_t)R0 * w; };
     auto gf = [&](float* base, int off, int w) -> float* { return base + off + (size_t)R0 * w; };
     auto mf = [&](const float* base, int off, int ctiles) -> const float* { return base + off + (size_t)(R0 / 16) * ctiles * 8; };
+    // record stores: plain, or write-through through a descriptor of this sequence's record (FUSE)
+    const DtqnRsrc grs = DTQN_XCH_RSRC(grec, (size_t)net.grd_stride * 4);
+    auto g_store4 = [&](float* p, float4 v) {
+        if constexpr (FUSE) dtqn_xch_store4(grs, (int)(p - grec) * 4, v);
+        else st4(p, v);
+    };
+    auto g_tile_store = [&](const float* s_, int ld_, float* g_, int rows, int cols, int gld = 0) {
+        if constexpr (FUSE) {
+            const int c4 = cols >> 2;
+            if (gld == 0) gld = cols;
+            const int base = (int)(g_ - grec);
+            for (int idx = t_outer.tid; idx < rows * c4; idx += NT) {
+                const int r = idx / c4, c = (idx - r * c4) * 4;
+                dtqn_xch_store4(grs, (base + r * gld + c) * 4, ld4(s_ + r * ld_ + c));
+            }
+        } else {
+            tile_store<NW>(s_, ld_, g_, rows, cols, t_outer, gld);
+        }
+    };
+    auto s_store = [&](float* p, float v) {      // per-sequence partials (`small` record)
+        if constexpr (FUSE) DTQN_AGENT_STORE(p, v);
+        else *p = v;
+    };
 
     float* DX = reinterpret_cast<float*>(dtqn_smem);   // dL/d(residual stream)        [LP][LDX]
     float* T2 = DX + LP * LDX;                         // narrow temp                   [LP][LDX]
@@ -139,7 +174,11 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                          a.actions + (size_t)ep * a.act_ep_stride + st0, a.rewards + (size_t)ep * a.rew_ep_stride + st0,
                          a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + ((size_t)b * RS + slice) * 8, t.lane);
         __syncthreads();
-        for (int idx = t.tid; idx < LP * AP; idx += NT) gf(grec, net.go_dq, AP)[idx] = dq_s[idx];
+        if constexpr (FUSE) {
+            for (int idx = t.tid; idx < LP * AP / 4; idx += NT) g_store4(gf(grec, net.go_dq, AP) + 4 * idx, ld4(dq_s + 4 * idx));   // AP = up4(A)
+        } else {
+            for (int idx = t.tid; idx < LP * AP; idx += NT) gf(grec, net.go_dq, AP)[idx] = dq_s[idx];
+        }
     }
 
     DTQN_PROF(a.prof, ps++);   // loss done
@@ -171,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
     }
     __syncthreads();
     g_h1.retire();
-    tile_store<NW>(T2, LDX, gf(grec, net.go_dhh, D), LP, D, t);
+    g_tile_store(T2, LDX, gf(grec, net.go_dhh, D), LP, D);
     g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
     __syncthreads();
     DTQN_PROF(a.prof, ps++);   // head done
@@ -210,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
             __syncthreads();
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
             for (int c0 = 0; c0 < 4 * D; c0 += NC) {   // unrolled (D <= 64): exact s_waitcnt counts across the chunk boundary; at D = 128
                                                        // the four unrolled chunks let the scheduler hoist loads until 630 bytes per lane spilled
                 g_dh.retire();
-                if (c0 == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_df, D), LP, D, t);
+                if (c0 == 0) g_tile_store(T2, LDX, gf(lgrd, net.gl_df, D), LP, D);
                 unsigned long long mw[MGH][4];         // ReLU ballots of the item's accumulator registers
                 g_dh.run(T2, LDX, t,
                          [&](int kt, int mg) {
@@ -262,12 +301,21 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                          });
                 if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
+                if constexpr (FUSE) {
+                    // the layer above is complete in memory once every wave has drained its vmcnt here: its last record stores (dq | dk | dv)
+                    // were issued before this layer's first fragment fetch.  Waiting for w1f[0] in front of the barrier instead of behind
+                    // it costs nothing: every wave needs it right after.
+                    if (c0 == 0 && l + 1 < net.num_layers) DTQN_WAIT_VMEM();
+                }
                 __syncthreads();
+                if constexpr (FUSE) {
+                    if (c0 == 0 && l + 1 < net.num_layers) fuse_arrive(a.fuse.counters, net.num_layers - 2 - l, t);
+                }
                 if (DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
                     for (int q = 0; q < NC / 4; ++q) DTQN_ASM_KEEP(w1f[0][q]);
                 }
-                tile_store<NW>(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, t, 4 * D);
+                g_tile_store(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, 4 * D);
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
                     if (q + 1 < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, q + 1))
@@ -324,9 +372,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
-            layernorm_backward<D, NW>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
         else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
-            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
         // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
@@ -374,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 for (int idx = t.tid; idx < (GW / HD) * LPF; idx += NT) lse_s[idx] = lrec[net.al_lse + g * (GW / HD) * LPF + idx];
                 __syncthreads();                   // da (T2) visible
                 g_do.retire();
-                if (g == 0) tile_store<NW>(T2, LDX, gf(lgrd, net.gl_da, D), LP, D, t);
+                if (g == 0) g_tile_store(T2, LDX, gf(lgrd, net.gl_da, D), LP, D);
                 // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW];  delta = do . o per (row, head)
                 float ov[MGO][4];
                 g_do.run(T2, LDX, t,
@@ -498,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
                     const int which = rem / (GW / 4), c = (rem - which * (GW / 4)) * 4;
                     const float* sp = W5r + r * LD5 + (which == 0 ? 4 * GW : which * GW) + c;
-                    st4(gf(lgrd, net.gl_dqkv, 3 * D) + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
+                    g_store4(gf(lgrd, net.gl_dqkv, 3 * D) + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
                 }
                 // du1 += dq W_in[q rows] + dk W_in[k rows] + dv W_in[v rows]: 3 fragments per owned item, double-buffered
 #pragma unroll
@@ -549,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
             __syncthreads();
         }
     }
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
         }
         __syncthreads();
     }
-    tile_store<NW>(DX, LDX, gf(grec, net.go_dx0, D), LP, D, t);
+    g_tile_store(DX, LDX, gf(grec, net.go_dx0, D), LP, D);
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)st0 * net.obs_dim;
     const uint8_t* act_rows = a.actions + (size_t)ep * a.act_ep_stride + st0;
     if (net.discrete) {
@@ -587,7 +635,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                     tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
                     if (tok == v) g += dein[r * KEP + j * e + c];
                 }
-            srec[net.so_tab + idx] = g;
+            s_store(srec + net.so_tab + idx, g);
         }
     }
     if (adim > 0) {
@@ -600,8 +648,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
                 for (int r = R0 > 0 ? 0 : 1; r < L; ++r)      // global row >= 1: the action that led to this observation
                     if ((int)act_rows[r - 1] == v) g += DX[r * LDX + c];
             }
-            srec[net.so_act + idx] = g;
+            s_store(srec + net.so_act + idx, g);
         }
+    }
+    if constexpr (FUSE) {     // everything this workgroup publishes is in memory: the last event
+        DTQN_WAIT_VMEM();
+        __syncthreads();
+        fuse_arrive(a.fuse.counters, net.num_layers, t);
     }
 }
 
@@ -618,17 +671,27 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP>
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false>
 static int launch_bwd3(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(&a.net);
     static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP>), lds, attr_lds);
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP, FUSE>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP>), dim3(a.batch * RS), dim3(NW * 64), lds, stream, a);
+    const int grid = a.batch * RS + (FUSE ? a.fuse.n_role : 0);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP, FUSE>), dim3(grid), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 static int launch_bwd2(const BwdArgs& a, hipStream_t stream) {
+    if constexpr (RS == 4 && !GRU && NW == kFuseWaves) {
+        if (a.fuse.n_role > 0) {
+            if (bwd_lds_bytes(&a.net) < (kFuseWaves + (size_t)(kDSmallFused / 64) * kFuseWaves * 64) * sizeof(float) ||
+                bwd_lds_bytes(&a.net) < direct_lds_floats(kFuseWaves) * sizeof(float)) return DTQN_ERR_CONFIG;
+            if (a.drop_thresh != 0u) return launch_bwd3<D, MT, HD, NW, GRU, RS, true, true>(a, stream);
+            return launch_bwd3<D, MT, HD, NW, GRU, RS, false, true>(a, stream);
+        }
+    }
+    if (a.fuse.n_role > 0) return DTQN_ERR_CONFIG;
     if (a.drop_thresh != 0u) return launch_bwd3<D, MT, HD, NW, GRU, RS, true>(a, stream);
     return launch_bwd3<D, MT, HD, NW, GRU, RS, false>(a, stream);
 }
@@ -651,6 +714,13 @@ extern "C" int dtqn_lds_bytes_backward(const DtqnNet* net) {
     return b <= 160 * 1024 ? (int)b : 0;
 }
 
+// 1: dtqn_td_backward also computes the weight gradients (grad, norm_partial, step_counter[0]) in the same launch and
+// dtqn_td_wgrad has nothing left to do
+extern "C" int dtqn_td_wgrad_is_fused(const DtqnNet* net, const DtqnTd* td) {
+    FuseArgs f;
+    return fuse_plan(net, td, &f) ? 1 : 0;
+}
+
 extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (td->history < 1 || td->history > net->ctx_len) return DTQN_ERR_ARG;
@@ -671,6 +741,7 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
     a.drop_thresh = net->dropout > 0.f ? (uint32_t)((double)net->dropout * 4294967296.0) : 0u;
     a.drop_scale = net->dropout > 0.f ? 1.0f / (1.0f - net->dropout) : 1.0f;
     a.drop_seed = td->dropout_seed; a.step_counter = td->step_counter;
+    fuse_plan(net, td, &a.fuse);
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
     if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)

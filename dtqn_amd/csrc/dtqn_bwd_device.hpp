@@ -12,7 +12,8 @@ namespace dtqn {
 //   dst  : receives rstd*(g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy; assigned or accumulated
 //   dgb  : per-sequence partial of d gamma ([D]) followed (at +D) by d beta ([D])   (global)
 // Contains two __syncthreads(); caller must sync before (inputs ready) and after (dst ready).
-template <int D, int NW>
+// WT: dgb is read by other workgroups of the same launch (fused weight gradients): agent-scope (write-through) stores
+template <int D, int NW, bool WT = false>
 __device__ __forceinline__ void layernorm_backward(const float* dy, const float* xin, float* dst, bool accumulate,
                                                    int ld, int LP, const float* __restrict__ st,
                                                    const float* __restrict__ gamma, float* __restrict__ dgb,
@@ -40,6 +41,7 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
         float s = 0.f;
         for (int p = 0; p < PARTS; ++p) s += red[(p * 2 + which) * D + d];
         if (dgb_accumulate) dgb[which * D + d] += s;     // later row blocks of the same sequence (tiled path)
+        else if constexpr (WT) DTQN_AGENT_STORE(dgb + which * D + d, s);
         else dgb[which * D + d] = s;
     }
     // pass B: rows (LPR lanes per row)

@@ -33,7 +33,9 @@ __device__ __forceinline__ LanePair dtqn_lane_swap16(float x) {
 // System-scope (other GPUs over xGMI, other processes on this GPU) relaxed atomics: the gradient exchange of the data-parallel update
 #define DTQN_SYSTEM_LOAD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define DTQN_SYSTEM_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define DTQN_AGENT_ADD(p, v) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define DTQN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
+#define DTQN_SPIN_PAUSE_LONG() __builtin_amdgcn_s_sleep(12)     /* pollers that wait for microseconds (one lane per workgroup) */
 // all of this wave's outstanding global stores acknowledged at their scope (the workgroup barrier alone does not wait
 // for global stores)
 #define DTQN_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -52,6 +54,13 @@ __device__ __forceinline__ void dtqn_xch_store4(DtqnRsrc r, int byte_off, float4
 __device__ __forceinline__ float4 dtqn_xch_load4(DtqnRsrc r, int byte_off) {
     const dtqn_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
     return make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+}
+// dword forms (few, small records only: a dword sc1 store is one fabric write)
+__device__ __forceinline__ void dtqn_xch_store1(DtqnRsrc r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, 16);
+}
+__device__ __forceinline__ float dtqn_xch_load1(DtqnRsrc r, int byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
 }
 // DPP rotate of a 16-lane row by n lanes (VALU-rate; 0x120 + n = row_ror:n)
 #define DTQN_ROW_ROR(x, n) __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(x), 0x120 + (n), 0xf, 0xf, true))

@@ -12,6 +12,7 @@
 // coalesced 16 B/lane load, 16 MFMAs per pair of loads.  The four waves take different sequences
 // and are summed through LDS; splits are summed by dtqn_td_reduce (deterministic, no atomics).
 #include "dtqn_device.hpp"
+#include "dtqn_wgrad_direct.hpp"
 
 namespace dtqn {
 
@@ -261,13 +262,8 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
 // one weight matrix, which share their dY / X columns) are dealt to the SAME XCD: workgroup b runs on XCD b % 8
 // (round-robin dispatch) and takes tile (b % 8) * per_xcd + b / 8 (direct_plan).  Inside a matrix the tiles run along its
 // SHORTER tile axis first, so that a run of consecutive tiles touches as few distinct column blocks as possible.
-constexpr int kDirectWaves = 8;
-constexpr int kDirectThreads = kDirectWaves * 64;
-constexpr int kDirectMaxTokens = 2048;
-constexpr int kDTN = 16, kDTK = 32;         // tile: dY columns x X columns
-constexpr int kDGroup = 8;                  // 16-token units in flight per wave and buffer
-constexpr int kDSmall = 128;                // per-sequence-partial elements per workgroup
-
+// The tile / partial-block bodies live in dtqn_wgrad_direct.hpp: the row-slice backward launch runs the same code in its
+// own weight-gradient workgroups (dtqn_td_wgrad_is_fused), and this launch then does not happen at all.
 struct WgradDirectArgs {
     DtqnNet net;
     DtqnWJob jobs[kMaxWJobs];
@@ -288,206 +284,25 @@ struct WgradDirectArgs {
 __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(WgradDirectArgs a) {
     const Thr t = make_thr();
     const DtqnNet& net = a.net;
-    const int LP = net.lp, tid = t.tid;
-    float* red = reinterpret_cast<float*>(dtqn_smem);                     // [8] block reduction of the sum of squares
-    float* slabs = red + 8;
+    const int tid = t.tid;
+    float* red = reinterpret_cast<float*>(dtqn_smem);                     // [waves] block reduction of the sum of squares
+    float* slabs = red + kDirectWaves;
     float ss = 0.f;                                                       // this thread's share of sum(g^2)
     const int b = (int)blockIdx.x, tile_blocks = a.slots * 8;
     if (b == 0 && tid == 0) a.step_counter[0] = a.step_counter[1];        // publish the step count of the previous update
     if (b == 0)                                                           // partials nobody writes this time
         for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kDirectThreads) a.norm_partial[i] = 0.f;
     const int tile = b >= tile_blocks ? a.n_tiles : !a.xcd_map ? b : b / 8 < a.xcd_ntiles[b % 8] ? a.xcd_tile0[b % 8] + b / 8 : a.n_tiles;
+    const DirectCtx ctx{a.act, a.grd, a.small, a.grad, a.batch, a.row_split, a.n_small};
     if (b >= tile_blocks) {
-        // per-sequence partials of the backward kernel (LayerNorm affine, embedding tables, learned positions = dL/dx0)
-        const int D = net.d_model;
-        const int n_ln = net.num_layers * 4 * D;
-        const int n_tab = net.discrete ? net.vocab * net.embed_per_obs : 0;
-        const int n_act = net.action_dim > 0 ? net.num_actions * net.action_dim : 0;
-        // kDSmall elements per workgroup, two per lane; wave p sums records p, p + 8, ... (independent loads in flight),
-        // then the eight partial sums are added in wave order
-        const int sb = b - tile_blocks;
-        int dst[2] = {-1, -1};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int e = sb * kDSmall + h * 64 + t.lane;
-            float v = 0.f;
-            if (e < a.n_small) {
-                int src;
-                const float* base = a.small;
-                size_t stride = (size_t)net.sp_stride;
-                if (e < n_ln) {
-                    const int l = e / (4 * D);
-                    dst[h] = net.off_layer0 + l * net.layer_stride + (e - l * 4 * D);
-                    src = net.so_ln + e;
-                } else if (e < n_ln + n_tab) {
-                    dst[h] = net.off_obs_tab + (e - n_ln);
-                    src = net.so_tab + (e - n_ln);
-                } else if (e < n_ln + n_tab + n_act) {
-                    dst[h] = net.off_act_emb + (e - n_ln - n_tab);
-                    src = net.so_act + (e - n_ln - n_tab);
-                } else {
-                    dst[h] = net.off_pos + (e - n_ln - n_tab - n_act);
-                    src = net.go_dx0 + (e - n_ln - n_tab - n_act);
-                    base = a.grd;
-                    stride = (size_t)net.grd_stride;
-                }
-                const int cnt = a.batch * (base == a.small ? a.row_split * net.sp_parts : 1);
-#pragma unroll 8
-                for (int q = t.wave; q < cnt; q += kDirectWaves) v += base[(size_t)q * stride + src];
-            }
-            slabs[(h * kDirectWaves + t.wave) * 64 + t.lane] = v;
-        }
-        __syncthreads();
-        if (t.wave < 2 && dst[t.wave] >= 0) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < kDirectWaves; ++w) tot += slabs[(t.wave * kDirectWaves + w) * 64 + t.lane];
-            a.grad[dst[t.wave]] = tot;
-            ss = tot * tot;
-        }
+        ss = direct_small<false, kDSmall, kDirectWaves>(net, ctx, b - tile_blocks, slabs, t);
     } else if (tile < a.n_tiles) {
         int j = 0;
         for (int k = 1; k < a.n_jobs; ++k)
             if (a.dtile0[k] <= tile) j = k;
-        const DtqnWJob& job = a.jobs[j];
-        const int tiles_k = (job.K + kDTK - 1) / kDTK;
-        const int local = tile - a.dtile0[j];
-        const int tiles_n = (job.N + kDTN - 1) / kDTN;
-        const bool k_major = tiles_k > tiles_n;                            // e.g. ffn.2: 4 x 8 tiles, walk the 4 first
-        const int bn = k_major ? local % tiles_n : local / tiles_k, bk = k_major ? local / tiles_n : local - bn * tiles_k;
-        const int nbase = bn * kDTN, kbase = bk * kDTK;
-        const float* xbase = (job.x_in_act ? a.act : a.grd) + job.x_off;
-        const size_t xstride = job.x_in_act ? (size_t)net.act_stride : (size_t)net.grd_stride;
-        const float* ybase = a.grd + job.dy_off;
-        const size_t ystride = (size_t)net.grd_stride;
-        // MFMA 16x16x4: A[n = i][token = kq] = dY[4s + kq][nbase + i];  B[token = kq][k-tile c, column i] = X[4s + kq][kbase + 2i + c]
-        const int ycol = nbase + t.i, xcol = kbase + 2 * t.i;
-        const bool yok = ycol < job.ldy, xok = xcol < job.ldx;            // ldx is a multiple of 4: the whole float2 is in range
-        f32x4 acc[2] = {zero4(), zero4()};
-        float bsum = 0.f;
-        const int nsub = LP / 16;                                         // 16-token units per sequence
-        const int per_layer = a.batch * nsub, units = per_layer * job.n_layers;
-        const int mine = (units - t.wave + kDirectWaves - 1) / kDirectWaves;   // units w, w + 8, ... of this wave
-        float av[2][kDGroup][4];
-        float2 bv[2][kDGroup][4];
-        // every load is issued unconditionally (out-of-range columns / units read a valid stand-in address and are zeroed
-        // afterwards): a load under a branch would hide the number of outstanding loads from the compiler and turn
-        // every wait into "wait for all of them"
-        const int ycol_c = yok ? ycol : 0, xcol_c = xok ? xcol : 0;
-        // units w, w + 8, ... of this wave, walked incrementally as (layer, sequence, 16-token block): no divisions in
-        // front of the loads; all of it is wave-uniform (scalar registers)
-        const int wv = __builtin_amdgcn_readfirstlane(t.wave);
-        int u_lyr = 0, u_sq = wv / nsub, u_sub = wv - u_sq * nsub, u_m = 0;
-        while (u_sq >= a.batch) { u_sq -= a.batch; ++u_lyr; }
-        const int inc_sq = kDirectWaves / nsub, inc_sub = kDirectWaves - inc_sq * nsub;
-        const float* ylane = ybase + (size_t)t.kq * job.ldy + ycol_c;
-        const float* xlane = xbase + (size_t)t.kq * job.ldx + xcol_c;
-        auto group_load = [&](float (&a4)[kDGroup][4], float2 (&b4)[kDGroup][4]) {
-#pragma unroll
-            for (int q = 0; q < kDGroup; ++q) {
-                const bool live = u_m < mine;                             // past the end: re-read unit (0, 0, 0), zeroed in group_mma
-                const int lyr = live ? u_lyr : 0, sq = live ? u_sq : 0, sub = live ? u_sub : 0;
-                const float* yp = ylane + (size_t)sq * ystride + (size_t)lyr * job.dy_lstride + (size_t)(sub * 16) * job.ldy;
-                const float* xp = xlane + (size_t)sq * xstride + (size_t)lyr * job.x_lstride + (size_t)(sub * 16) * job.ldx;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    a4[q][k] = yp[(size_t)4 * k * job.ldy];
-                    b4[q][k] = *reinterpret_cast<const float2*>(xp + (size_t)4 * k * job.ldx);
-                }
-                ++u_m;
-                u_sub += inc_sub; u_sq += inc_sq;
-                if (u_sub >= nsub) { u_sub -= nsub; ++u_sq; }
-                while (u_sq >= a.batch) { u_sq -= a.batch; ++u_lyr; }
-            }
-        };
-        auto group_mma = [&](int g, const float (&a4)[kDGroup][4], const float2 (&b4)[kDGroup][4]) {
-#pragma unroll
-            for (int q = 0; q < kDGroup; ++q) {
-                const float keep = (yok && g * kDGroup + q < mine) ? 1.f : 0.f;     // zero A: the product and the bias sum vanish
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float av_ = keep != 0.f ? a4[q][k] : 0.f;
-                    bsum += av_;
-                    acc[0] = mfma16(av_, b4[q][k].x, acc[0]);
-                    acc[1] = mfma16(av_, b4[q][k].y, acc[1]);
-                }
-            }
-        };
-        const int ngroups = (mine + kDGroup - 1) / kDGroup;
-        if (ngroups > 0) group_load(av[0], bv[0]);
-        DTQN_SCHED_FENCE();
-        int g = 0;
-        for (; g + 2 < ngroups; g += 2) {                                 // buffers alternate without dynamic indexing
-            group_load(av[1], bv[1]);
-            DTQN_SCHED_FENCE();
-            group_mma(g, av[0], bv[0]);
-            DTQN_SCHED_FENCE();
-            group_load(av[0], bv[0]);
-            DTQN_SCHED_FENCE();
-            group_mma(g + 1, av[1], bv[1]);
-            DTQN_SCHED_FENCE();
-        }
-        if (g + 1 < ngroups) {                                            // last pair (cfg 1: the only one -- all 16 units in flight at once)
-            group_load(av[1], bv[1]);
-            DTQN_SCHED_FENCE();
-            group_mma(g, av[0], bv[0]);
-            DTQN_SCHED_FENCE();
-            group_mma(g + 1, av[1], bv[1]);
-        } else if (g < ngroups) {
-            group_mma(g, av[0], bv[0]);
-        }
-        // bias: sum over the 4 token phases of this lane's dY column
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        // cross-wave sum through LDS, fixed order: slab[n][k] (+ a bias row) per wave
-        constexpr int SLD = kDTK + 4;
-        float* slab = slabs + (size_t)t.wave * (kDTN + 1) * SLD;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<float2*>(slab + (t.kq * 4 + r) * SLD + 2 * t.i) = make_float2(acc[0][r], acc[1][r]);
-        if (t.kq == 0) slab[kDTN * SLD + t.i] = bsum;
-        __syncthreads();
-        if (tid < kDTN * (kDTK / 4)) {
-            const int nl = tid / (kDTK / 4), k4 = (tid % (kDTK / 4)) * 4;
-            const int n = nbase + nl, k = kbase + k4;
-            if (n < job.N && k < job.K) {
-                float4 v = ld4(slabs + nl * SLD + k4);
-#pragma unroll
-                for (int wv = 1; wv < kDirectWaves; ++wv) {
-                    const float4 x = ld4(slabs + (size_t)wv * (kDTN + 1) * SLD + nl * SLD + k4);
-                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-                }
-                float* op = a.grad + job.w_off + (size_t)n * job.K + k;
-                if (k + 3 < job.K && (job.K & 3) == 0) {
-                    st4(op, v);
-                    ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-                } else {
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
-                    for (int c = 0; c < 4; ++c)
-                        if (k + c < job.K) { op[c] = vv[c]; ss += vv[c] * vv[c]; }
-                }
-            }
-        } else if (tid >= 256 && tid < 256 + kDTN && job.b_off >= 0 && bk == 0) {
-            const int nl = tid - 256, n = nbase + nl;
-            if (n < job.N) {
-                float v = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < kDirectWaves; ++wv) v += slabs[(size_t)wv * (kDTN + 1) * SLD + kDTN * SLD + nl];
-                a.grad[job.b_off + n] = v;
-                ss = v * v;
-            }
-        }
+        ss = direct_tile<false, kDirectWaves>(net, ctx, a.jobs[j], tile - a.dtile0[j], slabs, t);
     }
-    // sum of squares of everything this workgroup wrote (fixed order: lanes, then waves)
-    ss = wave_sum(ss);
-    __syncthreads();
-    if (t.lane == 0) red[t.wave] = ss;
-    __syncthreads();
-    if (tid == 0) {
-        float tot = 0.f;
-        for (int w = 0; w < kDirectWaves; ++w) tot += red[w];
-        a.norm_partial[b] = tot;
-    }
+    direct_norm_partial<kDirectWaves>(ss, red, a.norm_partial, b, t);
 }
 
 // direct tiles of a net: per job ceil(N / 16) * ceil(K / 32)
@@ -495,14 +310,9 @@ static int direct_tiles(const DtqnNet* net, const DtqnWJob* jobs, int* dtile0) {
     int tiles = 0;
     for (int j = 0; j < net->n_wjobs; ++j) {
         if (dtile0) dtile0[j] = tiles;
-        tiles += ((jobs[j].N + kDTN - 1) / kDTN) * ((jobs[j].K + kDTK - 1) / kDTK);
+        tiles += direct_tiles_of(jobs[j]);
     }
     return tiles;
-}
-static int small_elems(const DtqnNet* net) {
-    return net->num_layers * 4 * net->d_model + (net->discrete ? net->vocab * net->embed_per_obs : 0) +
-           (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
-           (net->pos == DTQN_POS_LEARNED ? net->ctx_len * net->d_model : 0);
 }
 struct DirectPlan {
     int dtile0[kMaxWJobs];
@@ -568,7 +378,7 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
     const char* xm = getenv("DTQN_WGRAD_XCD");
     a.xcd_map = xm != nullptr ? atoi(xm) : 1;
     const int grid = plan.grid;
-    const size_t lds = (8 + (size_t)kDirectWaves * (kDTN + 1) * (kDTK + 4)) * sizeof(float);
+    const size_t lds = kDirectLdsFloats * sizeof(float);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_wgrad_direct_kernel, dim3(grid), dim3(kDirectThreads), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
@@ -577,6 +387,7 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
 extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td || td->batch < 1 || td->n_split < 1) return DTQN_ERR_ARG;
     if (net->n_wjobs > kMaxWJobs) return DTQN_ERR_CONFIG;
+    if (dtqn_td_wgrad_is_fused(net, td)) return DTQN_OK;       // the backward launch wrote grad / norm_partial itself
     if (dtqn_td_wgrad_is_direct(net, td->batch)) return wgrad_direct(net, td, (hipStream_t)stream);
     WgradArgs a;
     a.net = *net;

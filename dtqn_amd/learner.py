@@ -181,6 +181,8 @@ class TdEngine:
             self._img_tgt_version = -1
         self.td = td
         self._net_ref, self._td_ref = ctypes.byref(self.net), ctypes.byref(td)
+        # latency mode: the backward launch also computes the weight gradients (dtqn_td_wgrad then launches nothing)
+        self.wgrad_fused = bool(self.lib.dtqn_td_wgrad_is_fused(self._net_ref, self._td_ref))
         self._actor_net_ref = ctypes.byref(self.actor_net)
 
     # -- helpers ------------------------------------------------------------------------------

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 11
+#define DTQN_ABI_VERSION 12
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -368,6 +368,12 @@ int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
  * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
 int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
 int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch);
+/* Fused weight gradients (latency mode, row_split == 4, small batches; reference: the same loss.backward(), dtqn.py:256): the
+ * dtqn_td_backward launch carries extra workgroups on the compute units its row slices leave idle; they contract a layer's
+ * weight gradients as soon as every sequence has published that layer's gradient records (write-through stores + event
+ * counters behind DtqnTd.xflags), while the data-gradient chain works on the layers below.  Returns 1 when dtqn_td_backward
+ * does so for this (net, td): it then writes grad / norm_partial / step_counter[0] itself and dtqn_td_wgrad launches nothing. */
+int dtqn_td_wgrad_is_fused(const DtqnNet* net, const DtqnTd* td);
 /* Sums gsplit / small partials into grad (mean-loss scaling is already in dL/dQ), writes
  * norm_partial.  After this call `grad` is ready for a data-parallel all-reduce. */
 int dtqn_td_reduce(const DtqnNet* net, const DtqnTd* td, void* stream);

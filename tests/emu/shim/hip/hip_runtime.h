@@ -27,7 +27,10 @@ template <typename T> static inline void hipemu_agent_store(T* p, T v) { __atomi
 #define DTQN_AGENT_STORE(p, v) hipemu_agent_store(p, v)
 #define DTQN_SYSTEM_LOAD(p) hipemu_agent_load(p)
 #define DTQN_SYSTEM_STORE(p, v) hipemu_agent_store(p, v)
+template <typename T> static inline T hipemu_agent_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+#define DTQN_AGENT_ADD(p, v) hipemu_agent_add(p, v)
 #define DTQN_SPIN_PAUSE() ((void)0)
+#define DTQN_SPIN_PAUSE_LONG() ((void)0)
 #define DTQN_WAIT_VMEM() ((void)0)
 #define DTQN_SCHED_FENCE() ((void)0)
 
@@ -53,6 +56,8 @@ struct DtqnRsrc { char* base; };
 #define DTQN_XCH_RSRC(ptr, bytes) DtqnRsrc{reinterpret_cast<char*>(const_cast<float*>(ptr))}
 static inline void dtqn_xch_store4(DtqnRsrc r, int byte_off, float4 v) { std::memcpy(r.base + byte_off, &v, 16); }
 static inline float4 dtqn_xch_load4(DtqnRsrc r, int byte_off) { float4 v; std::memcpy(&v, r.base + byte_off, 16); return v; }
+static inline void dtqn_xch_store1(DtqnRsrc r, int byte_off, float v) { std::memcpy(r.base + byte_off, &v, 4); }
+static inline float dtqn_xch_load1(DtqnRsrc r, int byte_off) { float v; std::memcpy(&v, r.base + byte_off, 4); return v; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef int hipError_t;
@@ -240,3 +245,5 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 template <typename F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }

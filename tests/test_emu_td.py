@@ -109,18 +109,24 @@ SPLIT = [
 ]
 
 
-@pytest.mark.parametrize("slices", ["1", "4"])
+@pytest.mark.parametrize("slices", ["1", "4", "4-unfused"])
 @pytest.mark.parametrize("kw", SPLIT)
 def test_td_update_row_split(emu, kw, slices, monkeypatch):
     """Latency mode: two workgroups per sequence (rows 0-31 / 32-63) with the K|V and dK|dV hand-over between them.
-    Same checks as one workgroup per sequence, including a short history window that lives entirely in the upper slice."""
-    monkeypatch.setenv("DTQN_ROW_SPLIT", slices)            # "1": two slices in both kernels; "4": four in the backward
+    Same checks as one workgroup per sequence, including a short history window that lives entirely in the upper slice.
+    Four slices with residual gates: the backward launch also carries the weight-gradient workgroups (dtqn_td_wgrad_is_fused),
+    "4-unfused" keeps them in their own launch."""
+    import ctypes
+    monkeypatch.setenv("DTQN_ROW_SPLIT", slices[0])         # "1": two slices in both kernels; "4": four in the backward
+    monkeypatch.setenv("DTQN_WGRAD_FUSED", "0" if slices == "4-unfused" else "1")      # opt-in (measured slower on the GPU)
     cfg = O.NetCfg(**kw)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=8, batch=3, T=80, n_eps=7, mask=-5 if not kw.get("discrete") else 8,
                                                history=None if kw["num_heads"] == 8 else 11, tuf=2)
     assert eng.row_split == (2 if slices == "1" else 4) and net.lp == 64
+    fused = emu.dtqn_td_wgrad_is_fused(ctypes.byref(net), ctypes.byref(eng.td))
+    assert fused == (1 if slices == "4" and kw.get("gate") != "gru" else 0)
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
-    assert int(eng.xflags.sum()) == 0                      # every hand-over flag was lowered again
+    assert int(eng.xflags.sum()) == 0                      # every hand-over flag was lowered again, every event counter reset
 
 
 @pytest.mark.parametrize("split", ["0", "1"])
