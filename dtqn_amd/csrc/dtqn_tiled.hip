@@ -92,9 +92,21 @@ struct TlEmbedArgs {
 // kEmbKC columns (padded with zeros to a multiple of 4); the product runs on the matrix cores: item = (16-column tile,
 // 16-row tile), D / 4 items dealt round-robin to the 8 waves, one v_mfma_f32_16x16x4_f32 per 4 contraction columns, both
 // operands read from LDS (leading dimensions of 4 mod 64 words: the 64 lanes of a fragment read hit 64 different banks).
+// Round 3 (HBM-bound kernel: 67 MB written per launch at BASELINE config 3, it took 83 us): the tokens of the block, the
+// embedding table and a column -> (token slot, table column) map are staged in LDS ONCE, so that the gather is LDS traffic
+// without a division or a dependent global load per element; the output tile goes through LDS too and leaves as whole rows
+// (16-byte stores, position rows added as 16-byte loads) instead of one dword per lane and 64-byte segments.
 constexpr int kEmbKC = 64;
 constexpr int kEmbLD = kEmbKC + 4;
-static inline size_t tl_embed_lds(int D) { return ((size_t)TROWS + (size_t)D) * kEmbLD * sizeof(float); }
+constexpr int kEmbTabMax = 2048;       // table floats staged in LDS (larger tables are read from global memory)
+static inline size_t tl_embed_lds(const DtqnNet& net) {
+    const int D = net.d_model;
+    size_t fl = ((size_t)TROWS + (size_t)D) * kEmbLD;                  // El | Wl, later the output tile [64][D + 4]
+    const size_t out = (size_t)TROWS * (D + 4);
+    fl = fl > out ? fl : out;
+    if (net.discrete) fl += (size_t)TROWS * net.obs_dim + (size_t)net.ke + (net.vocab * net.embed_per_obs <= kEmbTabMax ? net.vocab * net.embed_per_obs : 0);
+    return fl * sizeof(float);
+}
 __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const DtqnNet& net = a.net;
     const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n;
@@ -111,36 +123,59 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const bool single = (a.lens != nullptr ? a.lens[s] : n) == 1;     // history_len == 1: no roll, row 0 keeps its action (dtqn.py:187-191)
     const Thr t = make_thr();
     const int tid = t.tid;
+    const int LDO = D + 4;
     float* El = reinterpret_cast<float*>(dtqn_smem);                  // [64][kEmbLD]  e_in chunk
     float* Wl = El + TROWS * kEmbLD;                                   // [D][kEmbLD]   W_e chunk, row = OUTPUT column (rows < adim: zero)
+    float* Xl = El;                                                    // [64][LDO]     output tile (after the last chunk)
+    const size_t main_fl = ((size_t)TROWS + D) * kEmbLD > (size_t)TROWS * LDO ? ((size_t)TROWS + D) * kEmbLD : (size_t)TROWS * LDO;
+    int* tokl = reinterpret_cast<int*>(El + main_fl);                  // [64][O] clamped tokens of the block's rows (discrete)
+    int* kmap = tokl + TROWS * O;                                      // [KE] column k -> (token slot << 16) | table column
+    float* tabl = reinterpret_cast<float*>(kmap + KE);                 // [V * e] the embedding table
     const int DO = D - adim;                                           // outputs of the embedding linear
     const int per_wave = D / 4 / TNW;                                  // items per wave: 2 / 4 / 8 at D = 64 / 128 / 256
+    const int nrows = n - rb * TROWS < TROWS ? n - rb * TROWS : TROWS; // live rows of this block (may be <= 0)
+    const bool use_pre = a.pre != nullptr;
+    const bool tab_lds = net.discrete && net.vocab * net.embed_per_obs <= kEmbTabMax;
+    if (net.discrete && !use_pre) {
+        for (int idx = tid; idx < TROWS * O; idx += TNT) {
+            const int rl = idx / O;
+            int tok = rl < nrows ? (int)obs_rows[(size_t)rb * TROWS * O + idx] : 0;
+            tokl[idx] = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
+        }
+        for (int k = tid; k < KE; k += TNT) {
+            const int jj = k / net.embed_per_obs;
+            kmap[k] = (jj << 16) | (k - jj * net.embed_per_obs);
+        }
+        if (tab_lds)
+            for (int idx = tid; idx < net.vocab * net.embed_per_obs; idx += TNT) tabl[idx] = theta[net.off_obs_tab + idx];
+    }
     f32x4 acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = zero4();
     float* eo = a.ein.base != nullptr ? frow(a.ein, s, rb * TROWS) : nullptr;
-    for (int k0 = 0; k0 < (a.pre != nullptr ? 0 : KE); k0 += kEmbKC) {
+    const float* __restrict__ We = theta + net.off_obs_w;
+    for (int k0 = 0; k0 < (use_pre ? 0 : KE); k0 += kEmbKC) {
         const int kc = KE - k0 < kEmbKC ? KE - k0 : kEmbKC, kc4 = (kc + 3) & ~3;
-        __syncthreads();                                               // previous chunk consumed
+        __syncthreads();                                               // previous chunk consumed (first chunk: tokens / map / table staged)
+        // a full chunk is 64 columns wide: shifts instead of divisions
+        const int sh = kc4 == 64 ? 6 : -1;
         for (int idx = tid; idx < TROWS * kc4; idx += TNT) {
-            const int rl = idx / kc4, kl = idx - rl * kc4, k = k0 + kl, r = rb * TROWS + rl;
+            const int rl = sh >= 0 ? idx >> 6 : idx / kc4, kl = idx - rl * kc4, k = k0 + kl;
             float v = 0.f;
-            if (r < n && kl < kc) {
+            if (rl < nrows && kl < kc) {
                 if (net.discrete) {
-                    const int jj = k / net.embed_per_obs, cdim = k - jj * net.embed_per_obs;
-                    int tok = (int)obs_rows[(size_t)r * O + jj];
-                    tok = tok < 0 ? 0 : (tok >= net.vocab ? net.vocab - 1 : tok);
-                    v = theta[net.off_obs_tab + tok * net.embed_per_obs + cdim];
+                    const int m = kmap[k], tok = tokl[rl * O + (m >> 16)], te = tok * net.embed_per_obs + (m & 0xffff);
+                    v = tab_lds ? tabl[te] : theta[net.off_obs_tab + te];
                 } else {
-                    v = obs_rows[(size_t)r * O + k];
+                    v = obs_rows[(size_t)(rb * TROWS + rl) * O + k];
                 }
             }
             El[rl * kEmbLD + kl] = v;
             if (eo != nullptr && kl < kc) eo[(size_t)rl * KEP + k] = v;
         }
         for (int idx = tid; idx < D * kc4; idx += TNT) {
-            const int d = idx / kc4, kl = idx - d * kc4;
-            Wl[d * kEmbLD + kl] = (d >= adim && kl < kc) ? theta[net.off_obs_w + (size_t)(d - adim) * KE + k0 + kl] : 0.f;
+            const int d = sh >= 0 ? idx >> 6 : idx / kc4, kl = idx - d * kc4;
+            Wl[d * kEmbLD + kl] = (d >= adim && kl < kc) ? We[(size_t)(d - adim) * KE + k0 + kl] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -152,37 +187,60 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
             for (int k = 0; k < kc4; k += 4) acc[q] = mfma16(ap[k], bp[k], acc[q]);
         }
     }
-    (void)DO;
-    if (eo != nullptr && a.pre == nullptr)                             // zero the padding columns [KE, KEP) of the saved input
+    if (eo != nullptr && !use_pre)                                     // zero the padding columns [KE, KEP) of the saved input
         for (int idx = tid; idx < TROWS * (KEP - KE); idx += TNT) {
             const int rl = idx / (KEP - KE), k = KE + idx - rl * (KEP - KE);
             eo[(size_t)rl * KEP + k] = 0.f;
         }
-    float* xo = frow(a.x, s, rb * TROWS);
-    const Drop edr = tl_drop(a.drop, s);
+    __syncthreads();                                                   // El / Wl consumed: the output tile takes their place
+    // accumulators (+ bias) -> Xl; the action-embedding columns are filled by their own small pass
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         if (q >= per_wave) break;
         const int item = t.wave + q * TNW, nt = item >> 2, mt = item & 3, d = nt * 16 + t.i;
+        if (d >= adim) {
+            const float bias = use_pre ? 0.f : theta[net.off_obs_b + d - adim];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int rl = mt * 16 + t.kq * 4 + r4, r = rb * TROWS + rl;
-            float v = 0.f;
-            if (r < n) {
-                if (d < adim) {
-                    // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
-                    if (single || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
-                    else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
-                } else if (a.pre != nullptr) {
-                    v = a.pre[((size_t)s * a.pre_rows + r) * DO + (d - adim)];        // bias already added by the encoder
-                } else {
-                    v = acc[q][r4] + theta[net.off_obs_b + d - adim];
-                }
-                if (!a.bag) v += theta[net.off_pos + r * D + d];
-                v = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d), v);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rl = mt * 16 + t.kq * 4 + r4;
+                float v = acc[q][r4] + bias;
+                if (use_pre && rl < nrows) v = a.pre[((size_t)s * a.pre_rows + rb * TROWS + rl) * DO + (d - adim)];   // bias already added by the encoder
+                Xl[rl * LDO + d] = v;
             }
-            xo[(size_t)rl * a.x.ld + d] = v;
         }
+    }
+    for (int idx = tid; idx < TROWS * adim; idx += TNT) {
+        const int rl = idx / adim, d = idx - rl * adim, r = rb * TROWS + rl;
+        float v = 0.f;
+        if (rl < nrows) {
+            // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192); bag entries: their own action
+            if (single || a.bag) v = theta[net.off_act_emb + (int)act_rows[a.bag ? r : 0] * adim + d];
+            else if (r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+        }
+        Xl[rl * LDO + d] = v;
+    }
+    __syncthreads();
+    // whole rows out: + position (dtqn.py:193-199), dropout, zeros behind the live rows
+    float* xo = frow(a.x, s, rb * TROWS);
+    const Drop edr = tl_drop(a.drop, s);
+    const int c4n = D >> 2;
+    for (int idx = tid; idx < TROWS * c4n; idx += TNT) {
+        const int rl = idx / c4n, d = (idx - rl * c4n) * 4, r = rb * TROWS + rl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < nrows) {
+            v = ld4(Xl + rl * LDO + d);
+            if (!a.bag) {
+                const float4 pv = ld4(theta + net.off_pos + (size_t)r * D + d);
+                v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+            }
+            if (edr.thresh != 0u) {
+                v.x = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d), v.x);
+                v.y = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 1), v.y);
+                v.z = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 2), v.z);
+                v.w = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 3), v.w);
+            }
+        }
+        st4(xo + (size_t)rl * a.x.ld + d, v);
     }
 }
 
@@ -1797,7 +1855,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.pre = src.pre; e.pre_rows = src.pre_rows;
         if (net.img_c > 0 && e.pre == nullptr) return DTQN_ERR_ARG;     // image nets come through dtqn_img_encode
         e.ein = e.pre != nullptr ? nofld() : e.ein;
-        const size_t elds = tl_embed_lds(D);
+        const size_t elds = tl_embed_lds(net);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
     }
     auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
@@ -1942,7 +2000,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
             e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none(); e.lens = nullptr; e.pre = nullptr; e.pre_rows = 0;
-            const size_t elds = tl_embed_lds(D);
+            const size_t elds = tl_embed_lds(net);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
         const Fld xw = F(rm.xcat, 2 * D);                      // working memory = left half of xcat

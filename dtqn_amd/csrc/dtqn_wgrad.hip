@@ -348,7 +348,9 @@ extern "C" int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch) {
     if (e != nullptr) return atoi(e) != 0 ? 1 : 0;
     // shared GRU gate matrices contract over the tokens of every layer (measured at cfg-1 shapes with GRU gates, 2 layers:
     // 257 us per update direct, 247 us split)
-    const int layers = net->gate == DTQN_GATE_GRU ? net->num_layers : 1;
+    // (the embedding job of a bag network contracts the context tokens and the bag entries: two token sets)
+    const int gru_layers = net->gate == DTQN_GATE_GRU ? net->num_layers : 1, bag_sets = net->bag_size > 0 ? 2 : 1;
+    const int layers = gru_layers > bag_sets ? gru_layers : bag_sets;
     return (long long)batch * net->lp * layers <= kDirectMaxTokens ? 1 : 0;
 }
 
@@ -366,6 +368,8 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
     WgradDirectArgs a;
     a.net = *net;
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
+    for (int j = 0; j < net->n_wjobs; ++j)      // a wave's units must fit the register buffers direct_tile was compiled with
+        if ((long long)td->batch * net->lp * a.jobs[j].n_layers > kDirectMaxTokens) return DTQN_ERR_CONFIG;
     const DirectPlan plan = direct_plan(net, a.jobs);
     a.n_tiles = plan.n_tiles; a.slots = plan.slots;
     for (int j = 0; j < net->n_wjobs; ++j) a.dtile0[j] = plan.dtile0[j];
