@@ -268,6 +268,41 @@ def test_gradient_is_bit_reproducible_in_latency_mode(lib, split, D, gate, monke
     assert int(eng.xflags.sum()) == 0
 
 
+@pytest.mark.parametrize("D,discrete", [(64, False), (128, True)])
+def test_fused_weight_gradients_in_the_backward_launch(lib, D, discrete, monkeypatch):
+    """Opt-in DTQN_WGRAD_FUSED=1 (latency mode): the backward launch carries the weight-gradient workgroups (write-through records,
+    event counters, sc1 loads).  Same checks against the oracle as the separate launch, the gradient equals the separate launch's to
+    rounding (8- vs 16-wave summation order), it is bit-reproducible over repetitions under uneven timing, and the counters end at zero."""
+    import ctypes
+    kw = dict(obs_dim=6 if discrete else 3, num_actions=5, inner_embed_size=D, num_heads=8, history_len=50, num_layers=2 if D == 64 else 1)
+    if discrete:
+        kw.update(discrete=True, vocab_sizes=9)
+    cfg = O.NetCfg(**kw)
+    Bn = 32 if D == 64 else 16
+    mask = 8 if discrete else -5
+    grads = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("DTQN_WGRAD_FUSED", fused)
+        net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=3, batch=Bn, T=120, n_eps=40, mask=mask, device="cuda", test_lib=False)
+        assert eng.row_split == 4
+        assert lib.dtqn_td_wgrad_is_fused(ctypes.byref(net), ctypes.byref(eng.td)) == int(fused) and eng.wgrad_fused == (fused == "1")
+        eps, starts = host.sample_indices(Bn)
+        eng.set_indices(eps, starts)
+        eng.forward_backward(rep)
+        torch.cuda.synchronize()
+        grads[fused] = eng.grad.clone()
+        if fused == "1":
+            for it in range(40):
+                eng.forward_backward(rep)
+                if it % 10 == 9:
+                    torch.cuda.synchronize()
+                    assert torch.equal(eng.grad, grads["1"]), it
+            assert int(eng.xflags.sum()) == 0
+            check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    scale = float(grads["0"].abs().max())
+    assert scale > 0 and float((grads["0"] - grads["1"]).abs().max()) <= 2e-5 * scale
+
+
 DROPOUT_CASES = [
     # cfg-1 shapes in latency mode (weights-through-LDS forward, matrix-core attention in the row slices, 4 backward slices)
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, dropout=0.1), dict(batch=32, T=200, mask=-5, n_eps=40)),
