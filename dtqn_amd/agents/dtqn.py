@@ -56,6 +56,9 @@ class _AdamHandle:
 
 
 class DtqnAgent:
+    # updates whose statistics may sit in the pinned ring before the host folds them into the running averages (a non-finite
+    # gradient norm is therefore raised at most this many updates late; readers of the averages drain everything first)
+    STATS_DRAIN_EVERY = 16
 
     def __init__(self, network_factory: Callable[[], torch.nn.Module], buffer_size: int, device: torch.device,
                  env_obs_length: int, max_env_steps: int, obs_mask: Union[int, float], num_actions: int,
@@ -207,6 +210,7 @@ class DtqnAgent:
         return self.policy_network(t(obs, self.obs_tensor_type), t(actions, torch.long), t(bag_obss, self.obs_tensor_type),
                                    t(bag_actions, torch.long), _train_dropout=drop)
 
+    @torch.no_grad()
     def _image_action(self) -> int:
         """get_action of an image net (dtqn.py:79-108): the unpadded context prefix through DTQN.forward (convolutional embedding
         + row-block forward); the policy network is in train mode during rollouts like the reference's (dropout keyed per call)."""
@@ -221,6 +225,7 @@ class DtqnAgent:
         q = self.policy_network(obs, None, _train_dropout=drop)
         return int(torch.argmax(q[0, -1]).item())
 
+    @torch.no_grad()
     def _bag_action(self) -> int:
         """get_action of a bag network (dtqn.py:79-108): the unpadded context prefix plus the WHOLE bag, padding included."""
         ctx = self.context
@@ -242,7 +247,6 @@ class DtqnAgent:
         return int(np.argmax(self._q_np))                                # first max, like torch.argmax
 
     # ---- pipelined actor (same action semantics: the policy after the previous update) ----------------
-    @torch.no_grad()
     def begin_action(self, epsilon: float = 0.0):
         """Start choosing the action for the current context without blocking.  The forward is queued on the
         actor stream behind the last TD update; call train() next (it overlaps), then finish_action()."""
@@ -297,7 +301,6 @@ class DtqnAgent:
         keep = int(torch.argmax(torch.mean(torch.max(q, 2)[0], 1)).item())      # highest mean-over-time max-Q
         bag.obss, bag.actions = cand_obss[keep], cand_actions[keep]
 
-    @torch.no_grad()
     def observe(self, obs: np.ndarray, action: int, reward: float, done: bool) -> None:
         """Add a transition to the context; what the context evicts goes to the bag, and when the bag is full the policy
         network picks which of the bag_size + 1 candidate bags to keep (dtqn.py:116-160)."""
@@ -322,7 +325,7 @@ class DtqnAgent:
         self.eval_off()
         eng = self.engine
         sp = eng._stream()
-        rb.commit(sp, self._main_stream)
+        rb.commit_finished(sp, self._main_stream)
         if self.sampler == "reference" and self.bag.size > 0:
             eps, starts, rows = rb.sample_bag_indices(self.batch_size, self.bag.size)       # dtqn.py:166-177
             eng.set_indices(eps, starts)
@@ -366,22 +369,24 @@ class DtqnAgent:
     # tags the slot with k last; the host only polls memory: no copy, event or sync per update.
     def _enqueue_stats(self) -> None:
         self._calls_issued += 1
-        if self._calls_issued - self._calls_read >= self.engine.RING_SLOTS - 1:
+        backlog = self._calls_issued - self._calls_read
+        if backlog >= self.engine.RING_SLOTS - 1:
             self._drain_stats(block=True)
-        else:
+        elif backlog >= self.STATS_DRAIN_EVERY:     # readers (DeferredRunningAverage.mean, checkpoints) force a full drain themselves
             self._drain_stats(block=False)
 
     def _drain_stats(self, block: bool) -> None:
         eng = self.engine
         ring, slots = eng.stats_ring_np, eng.RING_SLOTS
         i_nonfinite, idx = self._stat_index
+        rows, nonfinite = [], False
         while self._calls_read < self._calls_issued:
             k = self._calls_read + 1
             row = ring[(k - 1) % slots]
             tag = float(k & 0x7FFFFF)                 # the kernel writes the call index modulo 2^23 (exact in f32)
             if row[9] != tag:
                 if not block:
-                    return
+                    break
                 if self.device.type == "cuda":
                     (self._main_stream if self._main_stream is not None else torch.cuda.current_stream(self.device)).synchronize()
                 if row[9] != tag:
@@ -389,10 +394,23 @@ class DtqnAgent:
             vals = row.copy()
             self._calls_read = k
             if vals[i_nonfinite] != 0.0:
-                # clip_grad_norm_(error_if_nonfinite=True) raises here in the reference (dtqn.py:257-261)
-                raise RuntimeError("The total norm for gradients from `parameters` is non-finite, so it cannot be clipped.")
-            for name, i in idx:
-                RunningAverage.add(self._stat_sinks[name], float(vals[i]))
+                nonfinite = True
+                break
+            rows.append(vals)
+        # RunningAverage.add per (statistic, update), in update order: same sums as one call per value, without the calls
+        for name, i in idx:
+            sink = self._stat_sinks[name]
+            q, size, tot = sink.q, sink.size, sink.sum
+            for vals in rows:
+                v = float(vals[i])
+                q.append(v)
+                tot += v
+                if len(q) > size:
+                    tot -= q.popleft()
+            sink.sum = tot
+        if nonfinite:
+            # clip_grad_norm_(error_if_nonfinite=True) raises here in the reference (dtqn.py:257-261)
+            raise RuntimeError("The total norm for gradients from `parameters` is non-finite, so it cannot be clipped.")
 
     # ---- checkpoints (dqn.py:212-327), plain arrays instead of pickled objects -------------------
     def save_mini_checkpoint(self, checkpoint_dir: str, wandb_id: Optional[str]) -> None:

@@ -95,10 +95,20 @@ class ReplayBuffer:
 
     def flush(self) -> None:
         self.pos = [self.pos[0] + 1, 0]
+        self._episode_finished = True
+
+    def commit_finished(self, stream_ptr=None, stream=None) -> None:
+        """commit(), but only when the staged records complete an episode.  The samplers never draw from the slot in
+        progress (valid_range / replay_buffer.py:141-145), so its records can wait in the pinned staging until the episode
+        ends or the staging is full: one scatter launch per episode (or per STAGE_CAPACITY steps) instead of one per
+        environment step in front of every TD update."""
+        if getattr(self, "_episode_finished", False):
+            self.commit(stream_ptr, stream)
 
     def commit(self, stream_ptr=None, stream=None) -> None:
         """Ship the queued records to the GPU (dtqn_replay_push) on torch's current stream, or on the raw stream
         handle `stream_ptr` when the caller already has it."""
+        self._episode_finished = False
         if self._n == 0:
             return
         st, n = self._stage[self._cur], self._n
