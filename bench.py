@@ -537,7 +537,7 @@ def _self_launch(args) -> None:
     GPU, rendezvous on 127.0.0.1) and hand the process over to the launcher; rank 0 of the job prints the line."""
     import socket
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not ddp.same_device():
         raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -626,6 +626,9 @@ def main():
         exchange_us = {"kind": agent.dp.exchange_kind(), "median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)),
                        "p90": float(np.percentile(ts, 90)), "bytes": int(agent.engine.grad.numel() * 4)}
         sync_all()
+    # per-update latency distribution: agent.train() takes part in the gradient exchange, so EVERY rank runs it (rank 0 reports)
+    lat = update_latency(agent)
+    sync_all()
 
     if rank == 0:
         ms = elapsed * 1e3 / args.steps
@@ -682,7 +685,6 @@ def main():
             detail["hbm_kernels"] = hb
             line["hbm_kernels"] = {k.replace("dtqn_", "").replace("_kernel", ""): {"bytes": v["bytes"], "us": v["us"], "frac_of_8TBs": v["frac"]}
                                    for k, v in hb.items()}
-        lat = update_latency(agent)
         detail["update_latency_us"] = lat
         line["update_us_median"] = lat["us_median"]
         if world > 1:

@@ -20,18 +20,26 @@ def is_distributed() -> bool:
     return td.is_available() and td.is_initialized() and td.get_world_size() > 1
 
 
+def same_device() -> bool:
+    """DTQN_DIST_SAME_DEVICE=1: every rank uses cuda:0 and gloo carries the collectives -- what a ONE-GPU box can run of the
+    multi-rank path (RCCL refuses two ranks on one GPU).  For smoke tests of the launch / timing / reporting code, not for numbers."""
+    return os.environ.get("DTQN_DIST_SAME_DEVICE", "0") == "1"
+
+
 def init_from_env(device_type: str = "cuda") -> tuple:
-    """Initialise the default process group from torchrun's environment.  Returns (rank, world, local_rank)."""
+    """Initialise the default process group from torchrun's environment.  Returns (rank, world, local device index)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if same_device() else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if device_type == "cuda":
+        if device_type == "cuda" and not same_device():
             torch.cuda.set_device(local)
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
+            if device_type == "cuda":
+                torch.cuda.set_device(local)
             td.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, local
 

@@ -95,3 +95,23 @@ def test_bench_line_contract():
     assert det["line"]["value"] == d["value"] and "update_latency_us" in det
     assert d["value"] == pytest.approx(1000.0 / d["ms_per_step"], rel=1e-6)
     assert d["value"] > 2000            # an order of magnitude above the CPU oracle; the tuned kernels do ~8.9k
+
+
+@pytest.mark.gpu
+def test_two_ranks_print_one_whole_job_line_on_a_one_gpu_box():
+    """`python bench.py --gpus 2` launches its own two ranks; with DTQN_DIST_SAME_DEVICE=1 both sit on cuda:0 and gloo carries the
+    gradient all-reduce (RCCL refuses two ranks on one GPU), which is what a one-GPU box can run of the N > 1 path: rendezvous on
+    127.0.0.1, barrier + max-over-ranks timing, the whole-job value, ONE line from rank 0.  The numbers are not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DTQN_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "10",
+                          "--no-other-configs", "--no-env-rate", "--no-cpu-baseline"], capture_output=True, text=True, timeout=240,
+                         cwd=REPO, env=env)        # (a rank-0-only collective hangs: this is the test that found update_latency's)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 64
+    assert d["value"] == pytest.approx(2 * 1000.0 / d["ms_per_step"], rel=1e-6) and d["value"] > 0
+    assert "exchange_us" in d and d["exchange_us"]["median"] > 0
