@@ -1,10 +1,13 @@
 """-m gpu: the data-parallel update on real devices -- the same script the gloo test runs on the CPU emulation, on the real engine at
 BASELINE config 1 shapes (latency-mode kernels, one-launch weight gradients).  Two ranks on RCCL need two GPUs (skipped on the
 one-GPU test box; runs on the 8-GPU node); the device-side exchange runs with two processes on ONE GPU."""
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
@@ -25,3 +28,20 @@ def test_device_side_exchange_two_processes_on_one_gpu(tmp_path):
                              "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                              "DP_CFG": "dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)"},
                   29641)
+
+
+def test_run_py_two_ranks_on_one_gpu(tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 run.py` end to end on a one-GPU box (DTQN_DIST_SAME_DEVICE=1: both ranks on cuda:0,
+    gloo for the collectives): prepopulation, the collectively decided first update, the gradient exchange inside every train(),
+    evaluation on every rank, logging on rank 0 only, both ranks leaving together.  A rank that enters a collective alone hangs --
+    the subprocess timeout is the assertion."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DTQN_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(REPO, "run.py"), "--disable-wandb", "--in-embed", "64", "--num-steps", "2500",
+           "--prepopulate", "4000", "--eval-frequency", "1000", "--eval-episodes", "2", "--sampler", "device", "--verbose"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.stdout.count("Training Steps: 2000") == 1          # rank 0 alone reports
