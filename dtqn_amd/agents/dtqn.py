@@ -148,6 +148,7 @@ class DtqnAgent:
         self._main_ptr = ctypes.c_void_p(self._main_stream.cuda_stream) if cuda else None
         if cuda:
             self.engine.bind_stream(self._main_stream)
+            self.replay_buffer.bind_stream(self._main_ptr, self._main_stream)
         self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
         self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream) if cuda else None
         self._ev_update_done = torch.cuda.Event() if cuda else None

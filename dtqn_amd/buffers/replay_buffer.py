@@ -93,6 +93,11 @@ class ReplayBuffer:
     def can_sample(self, batch_size: int) -> bool:
         return batch_size < self.pos[0]
 
+    def bind_stream(self, stream_ptr, stream) -> None:
+        """commit() calls without a stream (a full staging buffer inside store(), the samplers, export) go to this stream: the
+        learner's, so that the scatter launch stays ordered with the TD updates that read the arrays."""
+        self._bound_ptr, self._bound_stream = stream_ptr, stream
+
     def flush(self) -> None:
         self.pos = [self.pos[0] + 1, 0]
         self._episode_finished = True
@@ -112,6 +117,8 @@ class ReplayBuffer:
         if self._n == 0:
             return
         st, n = self._stage[self._cur], self._n
+        if stream_ptr is None and getattr(self, "_bound_ptr", None) is not None:
+            stream_ptr, stream = self._bound_ptr, self._bound_stream      # the learner's stream (bind_stream): same order as its updates
         if stream_ptr is None and self.device.type == "cuda":
             stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         # the scatter kernel reads the pinned staging in place: one launch, no copy

@@ -342,3 +342,18 @@ def test_td_update_tiled_path_width_256(emu, ffn_bwd, monkeypatch):
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=43, batch=2, T=20, n_eps=5, mask=-5)
     assert net.tiled == 1
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+
+
+def test_bag_network_counts_both_token_sets_for_the_one_launch_weight_gradients(emu):
+    """The embedding job of a bag network contracts the context tokens AND the bag entries.  With B * LP <= 2048 < 2 * B * LP the
+    one-launch weight-gradient kernel (whose tiles hold at most 2048 / 16 token units) must not be chosen -- found on the GPU at
+    B = 32 when the tiles went to 16 waves, where the second token set was silently dropped."""
+    import ctypes
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=50, bag_size=5)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=35, batch=17, T=80, n_eps=24, mask=-5)
+    assert net.tiled == 1 and 17 * net.lp <= 2048 < 2 * 17 * net.lp
+    assert emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 17) == 0 and emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 16) == 1
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    # B = 16: 2 * 16 * 64 tokens = exactly what a one-launch tile holds (eight units per wave on all 16 waves)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=36, batch=16, T=80, n_eps=24, mask=-5)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
