@@ -16,9 +16,8 @@ except Exception as e:
 PY
 }
 for rep in 1 2; do
-  run fused X=1
+  run fused DTQN_WGRAD_FUSED=1
   run unfused DTQN_WGRAD_FUSED=0
 done
-run role64 DTQN_FUSE_ROLE_WGS=64
-run role96 DTQN_FUSE_ROLE_WGS=96
-run fakeT DTQN_HIP_LIB=$PWD/tools/variants/libdtqn_hip_fakeT.so DTQN_WGRAD_FUSED=0
+run role64 DTQN_WGRAD_FUSED=1 DTQN_FUSE_ROLE_WGS=64
+run role96 DTQN_WGRAD_FUSED=1 DTQN_FUSE_ROLE_WGS=96
