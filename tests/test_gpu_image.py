@@ -124,3 +124,35 @@ def test_full_size_minihack_crop_update_properties(lib):
     with torch.no_grad():
         ref = O.forward(pol, cfg, torch.as_tensor(rows[0, 0:L].reshape(1, L, 3, 144, 144))).numpy()[0]
     assert np.abs(q4[0, 0] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_image_replay_producer_is_bit_exact(lib):
+    """uint8 pixel rows through observe() / context_reset() -> pinned staging -> dtqn_replay_push -> HBM, against the oracle buffer fed
+    the same calls (dtqn/buffers/replay_buffer.py:71-135 with the image array of :41-46): every byte of every slot, after the ring has
+    wrapped, with records of several episodes (and the slot cleanses between them) inside one staged batch."""
+    import run as runpy
+    from oracle import replay_oracle as RO
+    from dtqn_amd.utils.agent_utils import get_agent
+    from dtqn_amd.utils.random import set_global_seed
+    env = _PixelEnv(1)
+    set_global_seed(5, env)
+    T = env._max_episode_steps
+    agent = get_agent("DTQN", [env], 8, 0, 64, 10 * T, torch.device("cuda"), 3e-4, 4, 8, -1, 8, 1000, 0.99, 4, 1, 0.0, False, "res", "learned", 0,
+                      sampler="device", sample_seed=3)
+    rb = agent.replay_buffer
+    O_ = int(np.prod(agent.env_obs_length))
+    shadow = RO.ReplayOracle(rb.max_size * T, O_, agent.obs_mask, T, agent.context_len)
+    orig = (rb.store_obs, rb.store, rb.flush)
+    flat = lambda o: np.asarray(o).reshape(-1)
+    rb.store_obs = lambda o: (orig[0](o), shadow.store_obs(flat(o)))
+    rb.store = lambda o, a, r, d, n=0: (orig[1](o, a, r, d, n), shadow.store(flat(o), a, r, d, n))
+    rb.flush = lambda: (orig[2](), shadow.flush())
+    runpy.prepopulate(agent, 40 * T, [env])
+    assert rb.pos[0] > rb.max_size                      # the ring wrapped: slots were cleansed and rewritten on the device
+    arrays = rb.export_arrays()
+    assert arrays["obss"].dtype == np.uint8
+    assert np.array_equal(arrays["obss"].reshape(shadow.obss.shape), shadow.obss.astype(np.uint8))
+    assert np.array_equal(arrays["actions"], shadow.actions[:, :, 0])
+    assert np.array_equal(arrays["rewards"], shadow.rewards[:, :, 0])
+    assert np.array_equal(arrays["dones"].astype(bool), shadow.dones[:, :, 0])
+    assert np.array_equal(rb.dev.ep_len.cpu().numpy(), shadow.episode_lengths) and list(rb.pos) == list(shadow.pos)

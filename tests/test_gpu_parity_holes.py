@@ -139,7 +139,8 @@ def test_replay_producer_kernel_is_bit_exact(lib, env_id, steps):
         assert np.array_equal(arrays["dones"].astype(bool), shadow.dones[:, :, 0])
         assert np.array_equal(rb.dev.ep_len.cpu().numpy(), shadow.episode_lengths)
         assert list(rb.pos) == list(shadow.pos)
-        # an episode in progress, committed mid-way by train() (partial slot visible on the device)
+        # an episode in progress: its records stay in the pinned staging across train() (the samplers never draw from it) and
+        # reach the device with the next commit -- export_arrays above, or the flush below
         agent.context_reset(env.reset())
         for _ in range(3):
             a = int(RNG.rng.integers(env.action_space.n))
