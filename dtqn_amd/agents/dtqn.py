@@ -31,6 +31,12 @@ from ..utils.logging_utils import DeferredRunningAverage, RunningAverage
 from ..utils.random import RNG
 
 
+# text of torch.nn.utils.clip_grad_norm_'s exception (norm_type 2.0), which dtqn/agents/dtqn.py:257-261 lets escape; pinned to the
+# reference's own run by tests/golden G12 (`nonfinite/message`)
+NONFINITE_MESSAGE = ("The total norm of order 2.0 for gradients from `parameters` is non-finite, so it cannot be clipped. To disable this error "
+                     "and scale the gradients by the non-finite norm anyway, set `error_if_nonfinite=False`")
+
+
 class TrainMode(Enum):
     TRAIN = 1
     EVAL = 2
@@ -380,7 +386,7 @@ class DtqnAgent:
         eng = self.engine
         ring, slots = eng.stats_ring_np, eng.RING_SLOTS
         i_nonfinite, idx = self._stat_index
-        rows, nonfinite = [], False
+        rows, why = [], 0
         while self._calls_read < self._calls_issued:
             k = self._calls_read + 1
             row = ring[(k - 1) % slots]
@@ -394,24 +400,36 @@ class DtqnAgent:
                     raise RuntimeError(f"statistics of update call {k} never arrived (ring tag {row[9]})")
             vals = row.copy()
             self._calls_read = k
-            if vals[i_nonfinite] != 0.0:
-                nonfinite = True
-                break
             rows.append(vals)
-        # RunningAverage.add per (statistic, update), in update order: same sums as one call per value, without the calls
+            if vals[i_nonfinite] != 0.0:
+                why = int(vals[i_nonfinite])
+                break
+        # RunningAverage.add per (statistic, update), in update order: same sums as one call per value, without the calls.
+        # A skipped update still logs its loss and Q / target statistics -- the reference adds them before clip_grad_norm_ raises
+        # (dtqn.py:245-253) -- but not its gradient norm (:263 is never reached).
         for name, i in idx:
             sink = self._stat_sinks[name]
             q, size, tot = sink.q, sink.size, sink.sum
             for vals in rows:
+                if vals[i_nonfinite] != 0.0 and name == "grad_norm":
+                    continue
                 v = float(vals[i])
                 q.append(v)
                 tot += v
                 if len(q) > size:
                     tot -= q.popleft()
             sink.sum = tot
-        if nonfinite:
-            # clip_grad_norm_(error_if_nonfinite=True) raises here in the reference (dtqn.py:257-261)
-            raise RuntimeError("The total norm for gradients from `parameters` is non-finite, so it cannot be clipped.")
+        if why:
+            # The optimizer kernel skipped that update and every later one (include/dtqn_hip.h, step_counter[3]): parameters, Adam
+            # moments and the step count are those in front of the failing update, as after the reference's exception; the calls
+            # issued since were no-ops and are taken back.
+            self.num_train_steps -= self._calls_issued - (self._calls_read - 1)
+            self._calls_read = self._calls_issued
+            if why == 2:
+                raise RuntimeError("device-side gradient exchange: a peer's gradient never arrived (bounded wait expired); "
+                                   "the update was skipped on this rank")
+            # torch.nn.utils.clip_grad_norm_(..., error_if_nonfinite=True) raises this in the reference (dtqn.py:257-261)
+            raise RuntimeError(NONFINITE_MESSAGE)
 
     # ---- checkpoints (dqn.py:212-327), plain arrays instead of pickled objects -------------------
     def save_mini_checkpoint(self, checkpoint_dir: str, wandb_id: Optional[str]) -> None:

@@ -27,6 +27,10 @@ from ..utils.random import RNG
 
 class VectorActor:
     def __init__(self, agent, envs: Sequence, ref_quirks: bool = False):
+        if getattr(agent, "image", None) is not None:
+            # pixel observations act through DTQN.forward (convolutional embedding + row-block forward, one environment at a time);
+            # the float32 staging and dtqn_actor_forward_batch below have no image path
+            raise NotImplementedError("vectorised rollout of image observations (use --num-envs 1)")
         self.agent, self.envs = agent, list(envs)
         N = self.n = len(self.envs)
         L, O, A = agent.context_len, agent.env_obs_length, agent.num_actions

@@ -3,6 +3,8 @@
 // Replaces torch.nn.utils.clip_grad_norm_(params, 1.0, error_if_nonfinite=True), optim.Adam.step and
 // DqnAgent.target_update (dtqn/agents/dtqn.py:257-269, dtqn/agents/dqn.py:64,208-210), plus the seven
 // `.item()` statistics of dtqn.py:245-253,263 (reduced on the device, read back asynchronously).
+#include <cstdlib>
+
 #include "dtqn_device.hpp"
 
 namespace dtqn {
@@ -92,6 +94,7 @@ struct XreduceArgs {
     int32_t* status;
     int n, n_parts, world;
     int32_t gen;
+    long long timeout_ticks;       // bounded wait, in ticks of the 100 MHz wall clock
 };
 // Block b owns parameters [1024 b, 1024 b + 1024): wait for the `world` flag words, then one pass over the `world` buffers in rank
 // order.  Peer buffers are read with system-scope loads (they were written by another GPU / process: nothing of them may come
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_xreduce_kernel(XreduceArgs a
         const long long t0 = wall_clock64();
         // generations only grow (and wrap after 2^31 updates): "reached" = not behind
         while ((int32_t)(DTQN_SYSTEM_LOAD(f) - a.gen) < 0) {
-            if (wall_clock64() - t0 > 500000000ll) {          // 5 s at 100 MHz: a peer died or never entered this update
+            // a peer died or never entered this update (default 5 s), or another block already gave up
+            if (wall_clock64() - t0 > a.timeout_ticks || DTQN_SYSTEM_LOAD(a.status) != 0) {
                 DTQN_SYSTEM_STORE(a.status, (int32_t)1);
                 break;
             }
@@ -139,6 +143,7 @@ struct AdamArgs {
     float* stats;
     float* stats_ring;
     int32_t* step_counter;
+    const int32_t* xstatus;      // status word of the device-side gradient exchange (dtqn_td_xreduce), or NULL
     int n, n_norm_parts, batch, history, tuf, ring_slots;
     int n_stat_parts;            // batch * row_split per-workgroup statistics partials
     float lr, beta1, beta2, eps, clip, grad_scale;
@@ -160,7 +165,13 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     for (int i = tid; i < a.n_norm_parts; i += kOptThreads) part += a.norm_partial[i];
     const float total = block_sum(part, red, tid);
     const float norm = sqrtf(total) * a.grad_scale;
-    const bool finite = isfinite(norm);
+    // The update is SKIPPED (theta, moments, step count untouched) when the norm is non-finite -- clip_grad_norm_(error_if_nonfinite=True)
+    // raises before optimizer.step() in the reference (dtqn/agents/dtqn.py:257-265) --, when the device-side exchange gave up waiting
+    // for a peer (its sum is then stale: applying it would silently split the replicas), and from then on for every later call
+    // (step_counter[3], sticky): the host raises when it drains the statistics, up to a few calls late, and must find the state
+    // the reference's exception leaves behind.
+    const int why = !isfinite(norm) ? 1 : (a.xstatus != nullptr && *a.xstatus != 0) ? 2 : (a.step_counter[3] != 0) ? 3 : 0;
+    const bool finite = why == 0;
     const int k = a.step_counter[0] + 1;                      // 1-based index of this optimizer step
     if (tid == 0) {
         pw[0] = 1.0 - pow((double)a.beta1, (double)k);
@@ -215,8 +226,9 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
             a.stats[8] = fminf(1.0f, a.clip / (norm + 1e-6f));
             a.stats[9] = (float)k;
             a.stats[10] = sync_target ? 1.f : 0.f;
-            a.stats[11] = finite ? 0.f : 1.f;
+            a.stats[11] = (float)why;         // 0 applied | 1 non-finite norm | 2 exchange timed out | 3 skipped behind an earlier 1 / 2
             if (finite) a.step_counter[1] = k;
+            else a.step_counter[3] = 1;
             const int call = a.step_counter[2] + 1;       // every call counts, also a skipped (non-finite) one
             a.step_counter[2] = call;
             if (a.stats_ring != nullptr) {
@@ -290,6 +302,10 @@ extern "C" int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void*
     a.peer_flag = static_cast<int32_t* const*>(peer_flag_ptrs_dev);
     a.gsum = gsum_dev; a.norm_partial = td->norm_partial; a.status = status_dev;
     a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net); a.world = world; a.gen = gen;
+    // DTQN_XCH_TIMEOUT_MS: how long a block waits for a peer's flag before it sets *status_dev (default 5000; tests use less)
+    const char* tmo = getenv("DTQN_XCH_TIMEOUT_MS");
+    const long long ms = tmo != nullptr && atoll(tmo) > 0 ? atoll(tmo) : 5000ll;
+    a.timeout_ticks = ms * 100000ll;
     (void)hipGetLastError();
     hipLaunchKernelGGL(dtqn_xreduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
@@ -302,6 +318,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.theta = td->theta_pol; a.theta_tgt = td->theta_tgt; a.grad = td->grad; a.m = td->adam_m; a.v = td->adam_v;
     a.norm_partial = td->norm_partial; a.stats_partial = td->stats_partial; a.stats = td->stats;
     a.step_counter = td->step_counter;
+    a.xstatus = td->xstatus;
     a.stats_ring = td->stats_ring; a.ring_slots = td->stats_ring_slots > 0 ? td->stats_ring_slots : 1;
     a.n = net->n_trainable; a.n_norm_parts = dtqn_td_norm_partials(net); a.batch = td->batch; a.history = td->history;
     a.n_stat_parts = td->batch * (td->row_split > 1 ? td->row_split : 1);

@@ -80,7 +80,12 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 a.rp.actions[(size_t)s.ep * (T + 1) + s.t] = (uint8_t)s.action;
                 a.rp.rewards[(size_t)s.ep * T + s.t] = s.reward;
                 a.rp.dones[(size_t)s.ep * T + s.t] = s.done ? 1 : 0;
-                if (ri + 1 >= j || recs[ri + 1].ep != s.ep) a.rp.ep_len[s.ep] = s.ep_len;
+                // episode length: the LAST store of that slot inside the run wins (the serial order of replay_buffer.py:71-86),
+                // also when a producer interleaves the stores of two slots
+                bool last = true;
+                for (int rj = ri + 1; rj < j; ++rj)
+                    if (recs[rj].ep == s.ep) { last = false; break; }
+                if (last) a.rp.ep_len[s.ep] = s.ep_len;
             }
             __syncthreads();
             i = j;

@@ -100,6 +100,9 @@ class P2PExchange:
         self.own = [self.buf[:n], self.buf[n:2 * n]]
         self.own_flag = self.buf[2 * n:2 * n + 1]
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the optimizer kernel reads the status word: an exchange that gave up skips the update (and every later one) instead of
+        # applying a stale sum, and the host raises when it drains that update's statistics (DtqnAgent._drain_stats)
+        engine.td.xstatus = self.status.data_ptr()
         self.k = 0
         td.barrier(group=group)                         # every rank has mapped every buffer before anyone publishes
 

@@ -128,6 +128,13 @@ class DTQN(nn.Module):
         if dev.type != "cuda" and not getattr(self, "_allow_cpu", False):
             raise engine.EngineUnavailable("DTQN.forward runs on the gfx950 engine only: move the module to a ROCm device")
         Bn, seq = int(obss.size(0)), int(obss.size(1))
+        if obss.dtype != torch.uint8:
+            # the encoder's first layer gathers uint8 pixels (the reference's replay and context hold images as uint8 and the
+            # network sees their float VALUES, dtqn/agents/dtqn.py:199): integral values in 0..255 of any dtype are accepted,
+            # anything else (normalised 0..1 images, negative values) would be silently truncated or wrapped by a cast
+            o = obss.to(torch.float32)
+            if not bool(((o >= 0) & (o <= 255) & (o == o.round())).all()):
+                raise ValueError("image observations must be integral pixel values in 0..255 (uint8 in the replay and the context)")
         imgs = obss.to(device=dev).to(torch.uint8).reshape(Bn * seq, -1).contiguous()
         enc = getattr(self, "_img_enc", None)
         if enc is None or enc.device != dev:
@@ -161,6 +168,8 @@ class DTQN(nn.Module):
         assert seq <= self.history_len, "Cannot forward, history is longer than expected."
         # images: obs_dim is the (C, H, W) shape of one observation (dtqn.py:175-179)
         obs_dim = tuple(obss.size()[2:]) if obss.dim() > 3 else obss.size(2)
+        if self.image is not None and obss.dim() == 4 and self.image[0] == 1:
+            obs_dim = (1,) + obs_dim                  # an H x W observation is one channel (representations.py:88-92)
         assert obs_dim == self.obs_dim, f"Obs dim is incorrect. Expected {self.obs_dim} got {obs_dim}"
         dev = self.flat.device
         if self.image is not None:

@@ -31,8 +31,17 @@ def is_image_env(env) -> bool:
             and np.all(np.asarray(space.low) == 0) and np.all(np.asarray(space.high) == 255))
 
 
+def _probe_reset(env):
+    """The reference decides the observation type by looking at a SAMPLE observation: `get_env_obs_type` calls `env.reset()`
+    (utils/env_processing.py:63-66), and both get_env_obs_length and get_env_obs_mask go through it.  Those resets advance the
+    env's own random stream before the first rollout step (get_agent runs them on envs[0], agent_utils.py:87-88), so a seeded
+    run only visits the reference's episodes if they happen here too (pinned by tests/golden G12)."""
+    return env.reset()
+
+
 def get_env_obs_length(env) -> int:
     space = env.observation_space
+    _probe_reset(env)
     if is_image_env(env):
         return tuple(int(v) for v in np.shape(env.reset()))      # utils/env_processing.py:86-87: the observation's (C, H, W) shape
     kind = _kind(space)
@@ -51,6 +60,7 @@ def get_env_obs_mask(env) -> Union[int, float]:
     """Padding value for unseen observations: one past the largest token for discrete spaces,
     -5 for continuous ones (below CarFlag's minimum of -1.1; utils/env_processing.py:100-120)."""
     space = env.observation_space
+    _probe_reset(env)
     if is_image_env(env):
         return 0                                                 # utils/env_processing.py:106-108
     kind = _kind(space)

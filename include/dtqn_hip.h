@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 12
+#define DTQN_ABI_VERSION 13
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -261,7 +261,8 @@ typedef struct DtqnTd {
                                * dtqn_td_clip_adam also writes its statistics to slot ((call_index - 1) % slots), entry 9 (the
                                * 1-based call index modulo 2^23 -- exact in f32 --, written last) being the completion tag; the host polls it instead of
                                * enqueueing a device->host copy and an event per update */
-    int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls */
+    int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls, [3] poisoned: set by the
+                               * first call that skipped its update (non-finite norm, exchange time-out); every later call skips too */
     const DtqnWJob* wjobs;    /* device copy of the job table */
     float* xch;               /* row-split exchange buffer, dtqn_td_xch_floats(net, B) floats (row_split > 1 only) */
     int32_t* xflags;          /* row-split hand-over flags, dtqn_td_xch_flags(net, B) ints, ZEROED once by the caller */
@@ -269,6 +270,8 @@ typedef struct DtqnTd {
                                * replay_buffer.py:171-264; filled by dtqn_replay_gather_bag -- by dtqn_td_forward itself when
                                * sample_in_kernel == 1); the same bag serves all three forwards of a sequence (dtqn.py:215-230) */
     uint8_t* bag_actions;     /* [B][bag_size] */
+    const int32_t* xstatus;   /* data parallel, device-side exchange: the status word dtqn_td_xreduce sets when a peer's gradient never arrived
+                               * (NULL otherwise).  dtqn_td_clip_adam skips the update while it is non-zero (stats[11] = 2) */
     const float* xemb;        /* image nets: [3 B][padded context][D - a] observation embeddings of the three forwards, produced by
                                * dtqn_img_encode_td in front of dtqn_td_forward (whose embedding stage then only adds action embeddings,
                                * positions and dropout) */
@@ -382,8 +385,9 @@ int dtqn_td_norm_partials(const DtqnNet* net);
 /* Recomputes norm_partial from `grad` (used after an all-reduce changed it). */
 int dtqn_td_gradnorm(const DtqnNet* net, const DtqnTd* td, void* stream);
 /* clip_grad_norm_(1.0) + Adam + step counters + hard target sync every tuf steps
- * (dtqn.py:257-269, dqn.py:64,208-210) + final stats.  Non-finite norm: sets stats[11] and skips
- * the update (the host raises RuntimeError like error_if_nonfinite=True). */
+ * (dtqn.py:257-269, dqn.py:64,208-210) + final stats.  Non-finite norm: sets stats[11] = 1 and skips
+ * the update (the host raises RuntimeError like error_if_nonfinite=True); stats[11] = 2: the device-side exchange
+ * timed out (DtqnTd.xstatus); 3: skipped because an earlier call was (sticky, step_counter[3]). */
 int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
 /* ---- device-side gradient exchange of the data-parallel update (new; the reference is single-process) ----
  * One process per GPU.  Every rank owns an exchange buffer gx[2][n_trainable] (two generations) and a flag word, exported to its
@@ -399,7 +403,8 @@ int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
  * safe: a rank gets past step 3 of update k + 1 only after every peer published k + 1, i.e. finished reading generation k.
  *   peer_grad_ptrs_dev  device array of `world` pointers (const float*): generation (gen & 1) of every rank's buffer, own included
  *   peer_flag_ptrs_dev  device array of `world` pointers (int32_t*): every rank's flag word
- *   status_dev          int32: set to 1 by a block whose wait ran out (~5 s): the caller raises instead of hanging the GPU */
+ *   status_dev          int32: set to 1 by a block whose wait ran out (5 s; DTQN_XCH_TIMEOUT_MS overrides): the caller raises instead of
+ *                       hanging the GPU.  The sum is then stale: point DtqnTd.xstatus at this word and dtqn_td_clip_adam skips the update */
 int dtqn_xch_publish(int32_t* own_flag_dev, int32_t gen, void* stream);
 int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_ptrs_dev, const void* peer_flag_ptrs_dev, int world,
                     int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream);

@@ -151,6 +151,7 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
     else:
         vector.reset_all()
     owed = 0                 # updates of the current vector step the loop has not accounted for yet
+    last_vote = -1           # data parallel: period index of the last time-limit vote
     for timestep in range(agent.num_train_steps, total_steps):
         if vector is not None:
             if owed == 0:                      # N env steps and the N updates that go with them (queued behind the actor forward)
@@ -190,10 +191,14 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
             torch.save(agent.policy_network.state_dict(), policy_path)
         if time_remaining and owed == 0:
             # one process: the wall clock decides.  Data parallel: every rank must leave on the SAME iteration (the others
-            # would block in the gradient all-reduce), so the ranks vote every TIME_CHECK_PERIOD steps
+            # would block in the gradient all-reduce), so the ranks vote once per TIME_CHECK_PERIOD steps -- at the first
+            # vector-step boundary (owed == 0) inside each period: with N environments those boundaries sit at timestep
+            # = N - 1 (mod N) and need never coincide with a multiple of the period.  Every rank runs the same loop, so every rank
+            # evaluates the same condition on the same iteration.
             if not ddp.is_distributed():
                 stop = time() - start >= time_remaining
-            elif timestep % TIME_CHECK_PERIOD == 0:
+            elif timestep // TIME_CHECK_PERIOD != last_vote:
+                last_vote = timestep // TIME_CHECK_PERIOD
                 stop = ddp.agree_any(time() - start >= time_remaining, agent.device)
             else:
                 stop = False

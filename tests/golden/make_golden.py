@@ -845,6 +845,220 @@ def gen_G11():
     np.savez_compressed(os.path.join(HERE, "G11_image.npz"), **out)
 
 
+# --------------------------------------------------------------------------- #
+# G12: the coupled loop (run.py) -- THE REFERENCE's own run.py functions, imported unmodified
+# --------------------------------------------------------------------------- #
+def install_run_stubs():
+    """What /root/reference/run.py, utils/env_processing.py and envs/__init__.py import on top of install_stubs():
+    `gym.wrappers.time_limit.TimeLimit` (third-party gym 0.18.0, requirements.txt; its step-count semantics are restated
+    here: count steps since reset, at the cap set done and info["TimeLimit.truncated"] = not done) and
+    `gym.envs.registration.register` (a no-op: the envs are built directly below, as envs/__init__.py:31-48 registers them)."""
+    gym = sys.modules["gym"]
+    gym.__path__ = []
+
+    class TimeLimit(gym.Wrapper):
+        def __init__(self, env, max_episode_steps=None):
+            super().__init__(env)
+            self._max_episode_steps, self._elapsed_steps = max_episode_steps, None
+            self.observation_space, self.action_space = env.observation_space, env.action_space
+
+        def seed(self, seed=None):
+            return self.env.seed(seed)
+
+        def reset(self, **kw):
+            self._elapsed_steps = 0
+            return self.env.reset(**kw)
+
+        def step(self, action):
+            obs, reward, done, info = self.env.step(action)
+            self._elapsed_steps += 1
+            if self._elapsed_steps >= self._max_episode_steps:
+                info["TimeLimit.truncated"] = not done
+                done = True
+            return obs, reward, done, info
+
+    wr = types.ModuleType("gym.wrappers")
+    wr.__path__ = []
+    tl = types.ModuleType("gym.wrappers.time_limit")
+    tl.TimeLimit = TimeLimit
+    wr.time_limit = tl
+    ge = types.ModuleType("gym.envs")
+    ge.__path__ = []
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda **kw: None
+    sys.modules.update({"gym.wrappers": wr, "gym.wrappers.time_limit": tl, "gym.envs": ge, "gym.envs.registration": reg})
+    return TimeLimit
+
+
+class _DrawRecorder:
+    """Stands in for the `random` module inside dtqn/buffers/replay_buffer.py: same stream, draws logged."""
+
+    def __init__(self):
+        self.choices, self.randints = [], []
+
+    def choice(self, seq):
+        v = random.choice(seq)
+        self.choices.append(int(v))
+        return v
+
+    def randint(self, a, b):
+        v = random.randint(a, b)
+        self.randints.append(int(v))
+        return v
+
+    def __getattr__(self, name):
+        return getattr(random, name)
+
+
+def loop_case(ref_run, make_env, *, seed, D, H, NL, L, B, buf_size, prepop, steps, tuf, eval_frequency, eval_episodes, lr=3e-4):
+    """run_experiment (run.py:408-523) for one DiscreteCarFlag run, with run.py's OWN set_global_seed / get_agent / prepopulate /
+    train (hence step and evaluate) and the weights replaced by oracle.init_params so that the other side can regenerate them.
+    Everything the loop does is logged from the outside: every get_action (epsilon, action, Q of the last row when greedy),
+    every observe, the sampler's draws and the statistics of every update, the logger rows."""
+    import dtqn.buffers.replay_buffer as rbmod
+    envs, eval_envs = [make_env()], [make_env()]
+    ref_run.set_global_seed(seed, *(envs + eval_envs))                      # run.py:418
+    eps = ref_run.epsilon_anneal.LinearAnneal(1.0, 0.1, steps // 10)        # run.py:420
+    agent = ref_run.get_agent("DTQN", envs, 8, 0, D, buf_size, torch.device("cpu"), lr, B, L, -1, L, tuf, 0.99, H, NL, 0.0, False,
+                              "res", "learned", 0)                         # run.py:422-445 (positional, like the reference)
+    agent.replay_buffer.episode_lengths = agent.replay_buffer.episode_lengths.astype(np.int64)   # quirk 1
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=D, num_heads=H, num_layers=NL, history_len=L)
+    pol = O.init_params(cfg, seed=seed + 100, perturb=True)
+    assert list(agent.policy_network.state_dict().keys()) == O.state_dict_keys(cfg)
+    agent.policy_network.load_state_dict({k: v.clone() for k, v in pol.items()})
+    agent.target_update()                                                   # DqnAgent.__init__'s hard copy (dqn.py:49), redone
+    ref_run.prepopulate(agent, prepop, envs)                                # run.py:499 (there with 50 000 steps)
+    rb = agent.replay_buffer
+    n_used = min(rb.pos[0] + 1, rb.max_size)
+    out = {"cfg": json.dumps(cfg.to_json()), "seed": seed, "B": B, "buf_size": buf_size, "prepop": prepop, "steps": steps, "tuf": tuf,
+           "lr": lr, "eval_frequency": eval_frequency, "eval_episodes": eval_episodes, "pol_seed": seed + 100,
+           "pol_checksum": checksum(pol), "stamp": json.dumps(STAMP),
+           "prepop/pos": np.array(rb.pos), "prepop/obss": rb.obss[:n_used].copy(), "prepop/actions": rb.actions[:n_used, :, 0].copy(),
+           "prepop/rewards": rb.rewards[:n_used, :, 0].copy(), "prepop/dones": rb.dones[:n_used, :, 0].copy(),
+           "prepop/eplens": rb.episode_lengths[:n_used].copy(), "prepop/rng_probe": ref_random.RNG.rng.bit_generator.state["state"]["state"] % (1 << 53)}
+    # ---- instrumentation (outside the reference's code) ----
+    ev = {"act_mode": [], "act_eps": [], "act_action": [], "act_greedy": [], "act_q": [], "obs_mode": [], "obs_obs": [], "obs_action": [],
+          "obs_reward": [], "obs_done": [], "upd_ep": [], "upd_start": [], "upd_stats": [], "upd_after_act": [], "flush_after_obs": []}
+    state = {"in_action": False, "q": None}
+    agent.policy_network.register_forward_hook(lambda m, i, o: state.__setitem__("q", o.detach()[0, -1].numpy().copy()) if state["in_action"] else None)
+    orig_get, orig_obs, orig_train, orig_flush = agent.get_action, agent.observe, agent.train, rb.flush
+    is_eval = lambda: int(agent.train_mode.name == "EVAL")
+
+    def get_action(epsilon=0.0):
+        state["in_action"], state["q"] = True, None
+        a = orig_get(epsilon=epsilon)
+        state["in_action"] = False
+        ev["act_mode"].append(is_eval()); ev["act_eps"].append(float(epsilon)); ev["act_action"].append(int(a))
+        ev["act_greedy"].append(state["q"] is not None)
+        ev["act_q"].append(state["q"] if state["q"] is not None else np.full(3, np.nan, dtype=np.float32))
+        return a
+
+    def observe(obs, action, reward, done):
+        ev["obs_mode"].append(is_eval()); ev["obs_obs"].append(np.asarray(obs, dtype=np.float64).copy()); ev["obs_action"].append(int(action))
+        ev["obs_reward"].append(float(reward)); ev["obs_done"].append(bool(done))
+        return orig_obs(obs, action, reward, done)
+
+    rec = _DrawRecorder()
+    rbmod.random = rec
+
+    def train():
+        n0 = agent.num_train_steps
+        rec.choices.clear(); rec.randints.clear()
+        orig_train()
+        if agent.num_train_steps != n0:
+            ev["upd_ep"].append(np.array(rec.choices)); ev["upd_start"].append(np.array(rec.randints))
+            ev["upd_after_act"].append(len(ev["act_action"]))
+            ev["upd_stats"].append([agent.td_errors.q[-1], agent.grad_norms.q[-1], agent.qvalue_max.q[-1], agent.qvalue_mean.q[-1],
+                                    agent.qvalue_min.q[-1], agent.target_max.q[-1], agent.target_mean.q[-1], agent.target_min.q[-1]])
+
+    def flush():
+        ev["flush_after_obs"].append(len(ev["obs_action"]))
+        return orig_flush()
+
+    agent.get_action, agent.observe, agent.train, rb.flush = get_action, observe, train, flush
+    rows = []
+
+    class Logger:
+        def log(self, results, step):
+            rows.append((int(step), {k: float(v) for k, v in results.items() if k != "losses/hours"}))
+
+    RA = ref_run.RunningAverage
+    try:
+        ref_run.train(agent, envs, eval_envs, ["DiscreteCarFlag-v0"], steps, eps, eval_frequency, eval_episodes, "/nonexistent/policy", False,
+                      Logger(), RA(10), RA(10), RA(10), None, False)           # run.py:503-520
+    finally:
+        rbmod.random = random
+    out.update({f"ev/{k}": np.array(v) for k, v in ev.items()})
+    out["log_steps"] = np.array([s for s, _ in rows])
+    out["log_rows"] = json.dumps([r for _, r in rows])
+    keys = O.trainable_keys(cfg)
+    sd = agent.policy_network.state_dict()
+    out["final_flat"] = np.concatenate([sd[k].numpy().ravel() for k in keys])
+    out["final/pos"] = np.array(rb.pos)
+    out["final/eps"] = float(eps.val)
+    out["final/num_train_steps"] = int(agent.num_train_steps)
+    out["final/rng_probe"] = ref_random.RNG.rng.bit_generator.state["state"]["state"] % (1 << 53)
+    return out
+
+
+def gen_G12():
+    """The coupled actor / learner loop: run.py:287-298 (step -> flush / reset -> train -> anneal), :356-377 (step), :380-405
+    (prepopulate), :187-243 (evaluate, at timestep % eval_frequency == 0), driven by run.py's own code on the reference's CarFlag
+    (envs/car_flag.py, discrete, 200-step cap as envs/__init__.py:44-48 registers it).  Pins WHICH RNG stream is consumed WHEN
+    (env resets inside get_agent's space probes, context padding draws, epsilon draws, sampler draws), when the first update happens,
+    what the buffer holds, and the evaluation interleave."""
+    TimeLimit = install_run_stubs()
+    import run as ref_run
+    assert os.path.realpath(ref_run.__file__) == os.path.join(REF, "run.py")
+    car = load_by_path("ref_car_flag", os.path.join(REF, "envs/car_flag.py"))
+    make_env = lambda: TimeLimit(car.CarFlag(discrete=True), max_episode_steps=200)
+    out = {}
+    cases = {"small": dict(seed=1, D=16, H=2, NL=2, L=8, B=4, buf_size=12 * 200, prepop=1200, steps=150, tuf=25, eval_frequency=60, eval_episodes=2),
+             "cfg1": dict(seed=1, D=64, H=8, NL=2, L=50, B=32, buf_size=500_000, prepop=10_000, steps=200, tuf=50, eval_frequency=100, eval_episodes=2)}
+    for name, kw in cases.items():
+        res = loop_case(ref_run, make_env, **kw)
+        out.update({f"{name}/{k}": v for k, v in res.items()})
+        print(name, "updates", res["final/num_train_steps"], "actions", len(res["ev/act_action"]), "greedy", int(np.sum(res["ev/act_greedy"])))
+        # The loop is free-running: every update starts from the previous one's parameters, and Adam turns noise-floor gradient
+        # differences into +-lr steps, so two correct fp32 implementations drift apart.  How fast is a property of the trajectory, and
+        # the reference measures it itself: the SAME run with one torch thread (only the summation order inside the CPU kernels
+        # changes).  The trace of that twin is stored as `<name>_t1/*`; tests bound their distance to the reference by the
+        # reference's distance to its own twin (tests/loop_harness.py).
+        nthreads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            twin = loop_case(ref_run, make_env, **kw)
+        finally:
+            torch.set_num_threads(nthreads)
+        for k in ("ev/act_action", "ev/act_greedy", "ev/act_q", "ev/upd_stats", "ev/upd_after_act"):
+            out[f"{name}_t1/{k}"] = twin[k]
+        a, b = np.array(res["ev/act_action"]), np.array(twin["ev/act_action"])
+        n = min(len(a), len(b))
+        d = np.nonzero(a[:n] != b[:n])[0]
+        print(name, "twin (1 thread): first differing action event", d[:1], "of", n, "threads", nthreads)
+    # the non-finite branch of dtqn/agents/dtqn.py:257-261 (clip_grad_norm_(error_if_nonfinite=True)): the reference's own exception
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, num_layers=2, history_len=8)
+    random.seed(5)
+    ref_random.RNG.rng = np.random.Generator(np.random.PCG64(5))
+    pol = O.init_params(cfg, seed=5, perturb=True)
+    agent = make_ref_agent(cfg, pol, pol, 4, 20, 10, -5)
+    fill_agent(agent, synth_episodes(np.random.Generator(np.random.PCG64(6)), 8, 20, cfg))
+    agent.replay_buffer.rewards[:] = np.inf
+    pre = np.concatenate([p.detach().numpy().ravel() for p in agent.policy_network.parameters()])
+    try:
+        agent.train()
+        raise AssertionError("the reference did not raise")
+    except RuntimeError as e:
+        out["nonfinite/message"] = str(e)
+        out["nonfinite/type"] = type(e).__name__
+    post = np.concatenate([p.detach().numpy().ravel() for p in agent.policy_network.parameters()])
+    out["nonfinite/params_untouched"] = bool(np.array_equal(pre, post))
+    out["nonfinite/num_train_steps"] = int(agent.num_train_steps)
+    out["nonfinite/td_errors_len"] = len(agent.td_errors.q)          # the loss was logged before the clip raised (dtqn.py:253)
+    print("nonfinite:", out["nonfinite/message"])
+    np.savez_compressed(os.path.join(HERE, "G12_loop.npz"), **out)
+
+
 def time_reference():
     """the reference's OWN DtqnAgent.train() on this container's CPU cores, BASELINE
     configs 1-5 (synthetic replay of SURVEY.md section 8d; configs 3-5 at their per-GPU batch, a handful of updates
@@ -894,10 +1108,10 @@ def time_reference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "time"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "time"]
     torch.manual_seed(0)
     for w in which:
         t0 = time.time()
         {"G1": gen_G1, "G2": gen_G2, "G3": gen_G3, "G4": gen_G4, "G5": gen_G5, "G6": gen_G6, "G7": gen_G7,
-         "G8": gen_G8, "G9": gen_G9, "G10": gen_G10, "G11": gen_G11, "time": time_reference}[w]()
+         "G8": gen_G8, "G9": gen_G9, "G10": gen_G10, "G11": gen_G11, "G12": gen_G12, "time": time_reference}[w]()
         print(f"{w}: done in {time.time() - t0:.1f}s")

@@ -422,3 +422,38 @@ def test_agent_with_dropout_acts_in_train_mode_and_evaluates_without(emu, tiled,
     assert DTQN(3, 3, 8, 0, 64, 8, 2, 20, dropout=0.1, bag_size=4, _test_lib=emu).net.tiled == 1
     with pytest.raises(ValueError):
         DTQN(3, 3, 8, 0, 32, 4, 2, 20, dropout=1.5, _test_lib=emu)
+
+
+def test_time_limit_vote_happens_at_vector_step_boundaries(emu, monkeypatch):
+    """run.py --time-limit under data parallel with N = 8 environments: the vote (dist.agree_any) must happen once per
+    TIME_CHECK_PERIOD at a vector-step boundary -- those sit at timestep = 7 (mod 8) and never at a multiple of 256 -- and
+    the rank must stop and checkpoint on the iteration where the vote says so."""
+    import run as runpy
+    from dtqn_amd import dist as ddp, envs
+    from dtqn_amd.agents.vector import VectorActor
+    from dtqn_amd.utils.epsilon_anneal import LinearAnneal
+    from dtqn_amd.utils.logging_utils import RunningAverage
+    from dtqn_amd.utils.random import set_global_seed
+    N = 8
+    env_list = [envs.make("DiscreteCarFlag-v0") for _ in range(N)]
+    set_global_seed(6, *env_list)
+    agent = make_agent(emu, env_list[0], batch=4, L=8, D=16, H=2)
+    runpy.prepopulate(agent, 1300, [env_list[0]])
+    votes, saved = [], []
+    monkeypatch.setattr(ddp, "is_distributed", lambda: True)
+    monkeypatch.setattr(ddp, "agree_any", lambda flag, device: (votes.append(len(votes)), len(votes) >= 2)[1])
+    monkeypatch.setattr(agent, "save_checkpoint", lambda *a, **k: saved.append(agent.num_train_steps))
+    eps = LinearAnneal(1.0, 0.1, 100)
+    monkeypatch.setattr(runpy, "time", lambda: 0.0)
+
+    class Logger:
+        def log(self, *a, **k):
+            pass
+    vec = VectorActor(agent, env_list)
+    eval_env = envs.make("DiscreteCarFlag-v0")
+    eval_env.seed(6)
+    runpy.train(agent, [env_list[0]], [eval_env], ["DiscreteCarFlag-v0"], 600, eps, 10_000, 1, "/nonexistent", False,
+                Logger(), RunningAverage(10), RunningAverage(10), RunningAverage(10), 1e9, False, True, False, vec)
+    # votes at the first boundary of period 0 (timestep 7) and of period 1 (timestep 263); the second one stops the loop
+    assert len(votes) == 2
+    assert saved == [264] and agent.num_train_steps == 264

@@ -1,0 +1,39 @@
+"""G12 on the MI355X: dtqn_amd's run.py loop (prepopulate -> step / flush / reset / train / anneal, evaluation every
+eval_frequency steps) with `--sampler reference --ref-quirks` semantics against the trace THE REFERENCE's own run.py left
+(tests/golden/make_golden.py gen_G12), at a small shape and at BASELINE config 1's shapes (ctx 50, d_model 64, batch 32).
+Comparison rules: tests/loop_harness.py (exact events, absolute 1e-4 on the acting Q row, 2e-4 on the statistics; where the
+trajectory is chaotic the bounds widen to a multiple of the reference's distance to its own one-thread twin)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "G12_loop.npz")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return dict(np.load(GOLDEN))
+
+
+def test_small_loop_reproduces_the_reference_trace_on_the_device(fx):
+    from loop_harness import run_loop, compare_loop
+    tr, agent, prepop = run_loop(fx, "small", torch.device("cuda:0"))
+    s = compare_loop(fx, "small", tr, prepop, min_actions=150)
+    print(s)
+    assert s["updates_compared"] >= 50
+
+
+def test_cfg1_loop_follows_the_reference_trace_on_the_device(fx):
+    from loop_harness import run_loop, compare_loop
+    tr, agent, prepop = run_loop(fx, "cfg1", torch.device("cuda:0"))
+    s = compare_loop(fx, "cfg1", tr, prepop, min_actions=100)
+    print(s)
+    # the first updates are the exact pin: before the trajectory's chaos has amplified anything the bounds are the absolute ones
+    early = [u for u in range(10)]
+    ref, got = fx["cfg1/ev/upd_stats"], np.array(tr.ev["upd_stats"])
+    assert (np.abs(got[early] - ref[early]) / np.maximum(1.0, np.abs(ref[early]))).max() <= 2e-4
+    assert s["updates_compared"] >= 90
