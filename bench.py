@@ -263,13 +263,13 @@ def reference_cpu_numbers(cid: int):
             "runs": [{k: r[k] for k in ("threads", "updates", "ms_median", "ms_p10", "ms_p90", "td_updates_per_s")} for r in runs]}
 
 
-def make_agent(c, batch, device, rank, sampler):
+def make_agent(c, batch, device, rank, sampler, data_parallel=True):
     env = dt_envs.make("DiscreteCarFlag-v0") if c["kind"] == "box" else SyntheticEnv(c)
     from dtqn_amd.utils.random import set_global_seed
     if c["kind"] == "box":
         set_global_seed(1 + rank, env)
     agent = get_agent("DTQN", [env], 8, 0, c["D"], 500_000, device, 3e-4, batch, c["L"], c["T"], c["L"], 10_000, 0.99,
-                      c["H"], c["NL"], 0.0, False, "res", "learned", 0, sampler=sampler, sample_seed=1 + rank)
+                      c["H"], c["NL"], 0.0, False, "res", "learned", 0, sampler=sampler, sample_seed=1 + rank, data_parallel=data_parallel)
     fill_synthetic_replay(agent, seed=1 + rank, c=c)
     return agent
 
@@ -609,22 +609,37 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
     agent._drain_stats(block=True)
-    exchange_us = None
+    exchange = None
     if world > 1:
-        # the one exchange step of an update, timed by itself (every rank takes part; rank 0 reports), HIP events on the
-        # launch stream
-        stream = torch.cuda.current_stream()
-        ts = []
-        for i in range(60):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            agent.dp.allreduce_gradient()
-            e1.record(stream)
-            e1.synchronize()
-            if i >= 10:
-                ts.append(e0.elapsed_time(e1) * 1e3)
-        exchange_us = {"kind": agent.dp.exchange_kind(), "median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)),
-                       "p90": float(np.percentile(ts, 90)), "bytes": int(agent.engine.grad.numel() * 4)}
+        # the one exchange step of an update, timed by itself (every rank takes part; rank 0 reports), HIP events on the launch
+        # stream: the exchange the start-up check SELECTED (dist.DataParallel.selection) and, beside it, the library collective
+        pct = lambda ts: None if not ts else {"median": float(np.median(ts)), "p10": float(np.percentile(ts, 10)), "p90": float(np.percentile(ts, 90))}
+        sel = agent.dp.selection
+        exchange = {"kind": sel["kind"], "validated": sel["validated"], "reason": sel["reason"], "bytes": int(agent.engine.grad.numel() * 4),
+                    "selected_us": pct(agent.dp.time_exchange("selected")),
+                    "rccl_us": pct(agent.dp.time_exchange("rccl")) if sel["kind"] != "rccl" else None}
+        if exchange["rccl_us"] is None and sel["kind"] == "rccl":
+            exchange["rccl_us"] = exchange["selected_us"]
+        sync_all()
+        # the one-GPU rate, measured by THIS job on this rank's own GPU (a solo learner: no exchange), so that the line can state the
+        # weak-scaling efficiency against a number from the same run; every rank does it at the same time
+        solo = make_agent(c, args.batch, device, rank, args.sampler, data_parallel=False)
+        for _ in range(max(args.warmup, 20)):
+            solo.train()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            solo.train()
+        torch.cuda.synchronize()
+        solo_rate = args.steps / (time.perf_counter() - t1)
+        solo._drain_stats(block=True)
+        # per-rank kernel sums (HIP events, one launch at a time): the slowest rank's kernels bound the data-parallel step
+        ksum = torch.tensor([float(sum(time_kernels(solo, 20).values()))], dtype=torch.float64)
+        allk = [torch.zeros_like(ksum) for _ in range(world)]
+        torch.distributed.all_gather(allk, ksum.to(device) if not ddp.same_device() else ksum)
+        exchange["solo_updates_per_s_rank0"] = solo_rate
+        exchange["kernels_us_sum_per_rank"] = [float(k.item()) for k in allk]
+        del solo
         sync_all()
     # per-update latency distribution: agent.train() takes part in the gradient exchange, so EVERY rank runs it (rank 0 reports)
     lat = update_latency(agent)
@@ -688,7 +703,8 @@ def main():
         detail["update_latency_us"] = lat
         line["update_us_median"] = lat["us_median"]
         if world > 1:
-            line["exchange_us"] = exchange_us
+            exchange["weak_scaling_efficiency"] = (ups / world) / exchange["solo_updates_per_s_rank0"]
+            line["exchange"] = exchange
         if world == 1 and args.config == 1 and not args.no_other_configs:
             oc = other_configs(device, with_cpu=not args.no_cpu_baseline)
             detail["other_configs"] = {k: dict(v, mfma_counters=mfma_counters(int(k[-1]))) for k, v in oc.items()}

@@ -57,8 +57,8 @@ class _AdamHandle:
     def load_state_dict(self, sd: dict) -> None:
         e = self._eng
         e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
-        e.step_counter.fill_(int(sd["step"]))
-        e.step_counter[2] = 0          # statistics-ring call counter: DtqnAgent.load_checkpoint restarts its host side too
+        e.step_counter[:2] = int(sd["step"])     # optimizer steps: published | next
+        e.step_counter[2:] = 0         # statistics-ring call counter (DtqnAgent.load_checkpoint restarts its host side too) | skip flag
 
 
 class DtqnAgent:
@@ -71,7 +71,7 @@ class DtqnAgent:
                  is_discrete_env: bool, learning_rate: float = 0.0003, batch_size: int = 32, context_len: int = 50,
                  gamma: float = 0.99, grad_norm_clip: float = 1.0, target_update_frequency: int = 10_000,
                  history: int = 50, bag_size: int = 0, sampler: str = "reference", ref_quirks: bool = False,
-                 sample_seed: int = 0, **kwargs):
+                 sample_seed: int = 0, data_parallel: bool = True, **kwargs):
         self.context_len, self.env_obs_length = context_len, env_obs_length
         self.image = tuple(env_obs_length) if isinstance(env_obs_length, (tuple, list)) else None     # (C, H, W) pixel observations
         self.device = torch.device(device)
@@ -99,7 +99,9 @@ class DtqnAgent:
         self.optimizer = _AdamHandle(self.engine)
         self.replay_buffer = ReplayBuffer(buffer_size, env_obs_length=env_obs_length, obs_mask=obs_mask,
                                           max_episode_steps=max_env_steps, context_len=context_len, device=self.device, lib=lib)
-        self.dp = ddp.DataParallel(self.engine) if ddp.is_distributed() else None
+        # one process per GPU under torch.distributed: the gradient exchange joins the update (data_parallel=False keeps this agent a
+        # solo learner inside a distributed job -- bench.py measures its own one-GPU rate that way)
+        self.dp = ddp.DataParallel(self.engine) if (data_parallel and ddp.is_distributed()) else None
         self._dp_ready = False
         if self.dp is not None:
             self.dp.broadcast_parameters()

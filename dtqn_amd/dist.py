@@ -129,17 +129,106 @@ class P2PExchange:
 
 class DataParallel:
     """Wraps a TdEngine: update() = local gradient kernels -> exchange (sum over ranks) -> clip + Adam.
-    DTQN_DP_EXCHANGE=rccl (default): torch.distributed.all_reduce + a norm-recompute launch; =p2p: the device-side exchange."""
+
+    Two exchanges exist: `rccl` = torch.distributed.all_reduce + a norm-recompute launch, and `p2p` = the device-side exchange
+    (P2PExchange: no library call, one reduce launch reading every peer directly).  DTQN_DP_EXCHANGE / `exchange` = rccl | p2p |
+    auto; the default is AUTO: map the peers, run the device-side exchange on known vectors for both buffer generations,
+    compare with the sums an all_reduce gives, and keep it only if EVERY rank got every element right -- otherwise (mapping
+    failed, a wait timed out, a sum is off) all ranks fall back to the collective together.  `selection` records what happened
+    (bench.py prints it): {"kind": ..., "validated": ..., "reason": ...}."""
 
     def __init__(self, engine, group=None, exchange=None):
         self.engine = engine
         self.group = group
         self.world = td.get_world_size(group)
         engine.td.grad_scale = 1.0 / self.world          # mean over ranks, applied inside the optimizer kernel
-        kind = (exchange or os.environ.get("DTQN_DP_EXCHANGE", "rccl")).lower()
-        if kind not in ("rccl", "p2p"):
-            raise ValueError("DTQN_DP_EXCHANGE must be 'rccl' or 'p2p'")
-        self.p2p = P2PExchange(engine, group) if kind == "p2p" else None
+        kind = (exchange or os.environ.get("DTQN_DP_EXCHANGE", "auto")).lower()
+        if kind not in ("rccl", "p2p", "auto"):
+            raise ValueError("DTQN_DP_EXCHANGE must be 'rccl', 'p2p' or 'auto'")
+        self.p2p = None
+        self.selection = {"kind": "rccl", "validated": False, "reason": "requested"}
+        if kind == "rccl":
+            return
+        err = None
+        try:
+            self.p2p = P2PExchange(engine, group)
+        except Exception as exc:                          # IPC export / mapping refused on this node
+            err = f"{type(exc).__name__}: {exc}"[:200]
+        mapped = agree_all(self.p2p is not None, self._vote_device())
+        if not mapped:
+            if kind == "p2p":
+                raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p but the peers' exchange buffers could not be mapped on every rank ({err})")
+            self._drop_p2p()
+            self.selection = {"kind": "rccl", "validated": False, "reason": f"peer mapping failed on some rank ({err or 'another rank'})"}
+            return
+        ok, why = self._validate_p2p()
+        if ok:
+            self.selection = {"kind": "p2p", "validated": True, "reason": why}
+        elif kind == "p2p":
+            raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p failed its start-up check: {why}")
+        else:
+            self._drop_p2p()
+            self.selection = {"kind": "rccl", "validated": False, "reason": f"device-side exchange failed its start-up check: {why}"}
+
+    def _vote_device(self):
+        # same-device smoke mode runs the collectives over gloo (host tensors)
+        return "cpu" if (same_device() or self.engine.device.type != "cuda") else self.engine.device
+
+    def _drop_p2p(self) -> None:
+        self.p2p = None
+        self.engine.td.xstatus = None
+        self.engine.td.grad = self.engine.grad.data_ptr()
+
+    def _validate_p2p(self):
+        """Two exchanges (one per buffer generation) of vectors whose sums are exact in any order: rank r contributes
+        (r + 1) * (i mod 7 + g) -- small integers --, so the rank-ordered device-side sum must EQUAL the collective's."""
+        e, p = self.engine, self.p2p
+        n = p.n
+        os.environ.setdefault("DTQN_XCH_TIMEOUT_MS", "2000")      # a start-up check must not sit out the 5 s of a training run
+        had = "DTQN_XCH_TIMEOUT_MS" in os.environ and os.environ["DTQN_XCH_TIMEOUT_MS"] != "2000"
+        ok, why = True, "two generations equal to all_reduce on every rank"
+        try:
+            base = torch.arange(n, dtype=torch.float32, device=e.device) % 7
+            for g in (1, 2):
+                # no early exit: every rank walks through the same collectives whatever its own findings are
+                vec = (base + g) * float(p.rank + 1)
+                p.k += 1
+                p.own[p.k & 1].copy_(vec)
+                p.reduce()
+                want = vec.clone() if not (same_device() or e.device.type != "cuda") else vec.cpu()
+                td.all_reduce(want, op=td.ReduceOp.SUM, group=self.group)
+                got = e.grad.to(want.device)
+                if not ok:
+                    continue
+                if int(p.status.item()) != 0:
+                    ok, why = False, f"generation {g}: a peer's flag never arrived (bounded wait expired)"
+                elif not torch.equal(got, want):
+                    bad = int((got != want).sum().item())
+                    ok, why = False, f"generation {g}: {bad} of {n} sums differ from all_reduce"
+                else:
+                    norm_got = float(e.norm_partial.sum().item())
+                    norm_want = float((want.double() ** 2).sum().item())
+                    if abs(norm_got - norm_want) > 1e-5 * norm_want:
+                        ok, why = False, f"generation {g}: sum of squares {norm_got} != {norm_want}"
+        except Exception as exc:
+            ok, why = False, f"{type(exc).__name__}: {exc}"[:200]
+        finally:
+            if not had:
+                os.environ.pop("DTQN_XCH_TIMEOUT_MS", None)
+        all_ok = agree_all(ok, self._vote_device())
+        if not all_ok and ok:
+            why = "another rank's check failed"
+        # the gradient kernels never write the padding between tensors and rely on it being zero: wipe the test vectors (a failed
+        # wait leaves the status word set: those buffers are dropped together with the exchange)
+        e.grad.zero_()
+        e.norm_partial.zero_()
+        if all_ok:
+            p.own[0].zero_()
+            p.own[1].zero_()
+            if e.device.type == "cuda":
+                torch.cuda.synchronize(e.device)
+        td.barrier(group=self.group)               # nobody publishes a real gradient before every buffer is clean
+        return all_ok, why
 
     def broadcast_parameters(self, src: int = 0) -> None:
         e = self.engine
@@ -148,6 +237,31 @@ class DataParallel:
 
     def exchange_kind(self) -> str:
         return "device-side p2p reduce (dtqn_td_xreduce)" if self.p2p is not None else "rccl all_reduce + dtqn_td_gradnorm"
+
+    def time_exchange(self, which: str, iters: int = 50, warm: int = 10):
+        """HIP-event timing of ONE exchange step by itself (every rank must call it): `which` = "selected" | "rccl".
+        Returns per-iteration microseconds (list) or None when that exchange is not available."""
+        e = self.engine
+        if e.device.type != "cuda":
+            return None
+        stream = e._bound_torch_stream or torch.cuda.current_stream(e.device)
+        ts = []
+        with torch.cuda.stream(stream):
+            for i in range(warm + iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                if which == "rccl":
+                    if same_device():
+                        return None               # gloo moves host tensors: not an exchange worth timing
+                    td.all_reduce(e.grad, op=td.ReduceOp.SUM, group=self.group)
+                    e.recompute_gradnorm()
+                else:
+                    self.allreduce_gradient()
+                e1.record(stream)
+                e1.synchronize()
+                if i >= warm:
+                    ts.append(e0.elapsed_time(e1) * 1e3)
+        return ts
 
     def allreduce_gradient(self) -> None:
         """The exchange step by itself (bench.py times it): e.grad <- sum over ranks, norm partials of the sum."""

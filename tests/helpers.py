@@ -124,7 +124,7 @@ def engine_probe(cfg, net, eng):
     return {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
 
 
-def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False):
+def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False, q_rel=False):
     """Run n_updates on both sides from identical (episode, start) draws and compare every stage:
     the three Q tensors, pre-clip gradients, statistics, parameters after the step.
     one_call: the whole update through dtqn_td_update, as the agent's train() issues it, instead of stage by stage;
@@ -167,10 +167,10 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         assert probe.get("max_flip_preact", 0.0) <= 2e-5 * max(1.0, float(out[4].detach().abs().max())), probe
         assert probe.get("argmax_flips", 0) <= max(1, Bn * L // 500), probe
         assert probe.get("max_flip_qgap", 0.0) <= 2e-4 * max(1.0, float(out[4].detach().abs().max())), probe
-        scale = max(1.0, float(out[4].detach().abs().max()))
         for w, ref in enumerate((out[4], out[5], out[6])):
             err = np.abs(q3[w] - ref.detach().numpy()).max()
-            assert err <= q_tol * scale, (it, w, err)
+            # ABSOLUTE (north_star: 1e-4 fp32); q_rel: relative to |Q|max, for the one case that is ill-conditioned on purpose
+            assert err <= q_tol * (max(1.0, float(ref.detach().abs().max())) if q_rel else 1.0), (it, w, err)
         # --- gradients (flat, engine layout), relative to the largest entry as in the oracle's own golden check
         ref_flat = flat_from_params(net, grads, keys)
         got = eng.grad.cpu().numpy().copy()

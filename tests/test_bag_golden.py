@@ -361,11 +361,11 @@ def test_bag_agent_with_dropout_acts_in_train_mode(emu):
         spec = O.DropSpec(cfg.dropout, int(eng.td.dropout_seed) ^ 0xAC70, agent._actor_calls, 0)
         with torch.no_grad():
             ref = O.forward(pol, cfg, *args, None, spec, **bargs).numpy()[0]
-        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        assert np.abs(q - ref).max() <= 1e-4
         qs.append(q)
     assert not np.array_equal(qs[0], qs[1])
     agent.eval_on()
     ev = [agent._bag_forward(ctx.obs[None], ctx.action[None], bag.obss[None], bag.actions[None]).numpy()[0] for _ in range(2)]
     with torch.no_grad():
         ref = O.forward(pol, cfg, *args, **bargs).numpy()[0]
-    assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(ev[0], ev[1]) and np.abs(ev[0] - ref).max() <= 1e-4

@@ -114,4 +114,10 @@ def test_two_ranks_print_one_whole_job_line_on_a_one_gpu_box():
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
     assert d["config"]["global_batch"] == 64
     assert d["value"] == pytest.approx(2 * 1000.0 / d["ms_per_step"], rel=1e-6) and d["value"] > 0
-    assert "exchange_us" in d and d["exchange_us"]["median"] > 0
+    # the exchange the start-up check selected (two processes on one GPU: the device-side exchange maps and validates), timed by itself,
+    # beside the solo rate this job measured and the efficiency that follows from it
+    ex = d["exchange"]
+    assert ex["kind"] in ("p2p", "rccl") and isinstance(ex["validated"], bool) and ex["reason"]
+    assert ex["selected_us"]["median"] > 0 and ex["solo_updates_per_s_rank0"] > 0 and ex["weak_scaling_efficiency"] > 0
+    assert len(ex["kernels_us_sum_per_rank"]) == 2 and all(v > 0 for v in ex["kernels_us_sum_per_rank"])
+    assert ex["kind"] == "p2p" and ex["validated"], ex      # no environment variable needed to take the fast path

@@ -248,7 +248,20 @@ Bl, T = int(os.environ.get("DP_BATCH", "4")), int(os.environ.get("DP_T", "12"))
 net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=21, batch=Bl, T=T, n_eps=9 + 2 * Bl, mask=-5, **kw)
 random.seed(77)
 eps, starts = host.sample_indices(world * Bl)
+if os.environ.get("DP_BREAK_P2P") == "1":
+    # a device-side exchange that returns wrong sums on rank 1: the start-up check must notice and send EVERY rank to the collective
+    _orig_reduce = ddp.P2PExchange.reduce
+    def _bad_reduce(self):
+        _orig_reduce(self)
+        if self.rank == 1:
+            self.engine.grad[5] += 1.0
+    ddp.P2PExchange.reduce = _bad_reduce
 dp = ddp.DataParallel(eng, exchange=os.environ.get("DP_EXCHANGE", "rccl"))
+if os.environ.get("DP_BREAK_P2P") == "1":
+    ddp.P2PExchange.reduce = _orig_reduce
+with open(os.environ["OUT"] + f".sel{rank}.json", "w") as f:
+    import json
+    json.dump(dp.selection, f)
 vote_dev = "cpu" if same_dev else dev
 if not same_dev:
     dp.broadcast_parameters()           # (same-device mode: gloo cannot move device tensors; both ranks built identical parameters)
@@ -263,7 +276,7 @@ if on_gpu:
     torch.cuda.synchronize()
 if dp.p2p is not None:
     dp.p2p.check()
-    assert dp.p2p.k == n_updates and "p2p" in dp.exchange_kind()
+    assert dp.p2p.k == n_updates + 2 and "p2p" in dp.exchange_kind()      # + the two generations of the start-up check
 np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.cpu().numpy())
 if rank == 0:
     # single learner on the union batch
@@ -314,6 +327,23 @@ def test_device_side_exchange_equals_the_all_reduce(emu, tmp_path):
     p2p = run_dp_script(tmp_path / "a", {"DP_EXCHANGE": "p2p", "DP_UPDATES": "5"}, 29613)
     ref = run_dp_script(tmp_path / "b", {"DP_EXCHANGE": "rccl", "DP_UPDATES": "5"}, 29615)
     assert np.array_equal(p2p, ref)
+
+
+def test_exchange_is_selected_and_validated_at_start_up(emu, tmp_path):
+    """DTQN_DP_EXCHANGE unset (auto): the device-side exchange is mapped, checked against all_reduce on known vectors for both buffer
+    generations and selected; the updates that follow equal the all-reduce path's bit for bit.  With an exchange that returns a
+    wrong sum on ONE rank, every rank falls back to the collective and says why."""
+    import json
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir(); (tmp_path / "c").mkdir()
+    auto = run_dp_script(tmp_path / "a", {"DP_EXCHANGE": "auto", "DP_UPDATES": "3"}, 29617)
+    sel = [json.load(open(str(tmp_path / "a" / "out") + f".sel{r}.json")) for r in (0, 1)]
+    assert all(s["kind"] == "p2p" and s["validated"] for s in sel), sel
+    ref = run_dp_script(tmp_path / "b", {"DP_EXCHANGE": "rccl", "DP_UPDATES": "3"}, 29619)
+    assert np.array_equal(auto, ref)
+    broken = run_dp_script(tmp_path / "c", {"DP_EXCHANGE": "auto", "DP_UPDATES": "3", "DP_BREAK_P2P": "1"}, 29621)
+    sel = [json.load(open(str(tmp_path / "c" / "out") + f".sel{r}.json")) for r in (0, 1)]
+    assert all(s["kind"] == "rccl" and not s["validated"] and "start-up check" in s["reason"] for s in sel), sel
+    assert np.array_equal(broken, ref)
 
 
 def test_vector_actor_matches_single_actor_and_reference_buffer(emu):

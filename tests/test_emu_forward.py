@@ -60,7 +60,7 @@ def test_forward_small_variants(emu, kw):
                             torch.as_tensor(act, dtype=torch.long)).numpy()
         got = _fwd(emu, cfg, params, obs, act)
         assert np.isfinite(got).all()
-        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(got - ref).max())
+        assert np.abs(got - ref).max() <= 1e-4, (n, np.abs(got - ref).max())
 
 
 def test_forward_cfg1_size(emu):
@@ -72,7 +72,7 @@ def test_forward_cfg1_size(emu):
     with torch.no_grad():
         ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act)).numpy()
     got = _fwd(emu, cfg, params, obs, act)
-    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 1e-4
 
 
 TILED = [
@@ -108,7 +108,7 @@ def test_tiled_forward_path(emu, kw, monkeypatch):
         act_u8 = np.ascontiguousarray(act.reshape(Bn, n), dtype=np.uint8)
         rc = emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), ptr(ws), None)
         assert rc == 0
-        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
+        assert np.abs(q - ref).max() <= 1e-4, (n, np.abs(q - ref).max())
     # the whole-sequence kernels refuse a tiled net, and the training entry points are not built for it
     assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs_f), ptr(act_u8), Bn, n, ptr(q), None) == B.DEFINES["DTQN_ERR_CONFIG"]
 
@@ -133,7 +133,7 @@ def test_variants_beyond_the_lds_tile_take_the_tiled_path(emu):
     q = np.full((1, 9, 3), np.nan, dtype=np.float32)
     ws = np.zeros(emu.dtqn_forward_workspace_floats(ctypes.byref(net), 1), dtype=np.float32)
     assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 1, 9, ptr(q), ptr(ws), None) == 0
-    assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(q - ref).max() <= 1e-4
 
 
 @pytest.mark.parametrize("kw", [dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
@@ -166,7 +166,7 @@ def test_actor_forward_one_call(emu, kw, monkeypatch):
             rc = emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), n, ptr(q_d), ptr(q_last),
                                         None if workspace is None else ptr(workspace), 0, 0, 0, None)
             assert rc == 0
-            assert np.abs(q_last - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, workspace is None)
+            assert np.abs(q_last - ref).max() <= 1e-4, (n, workspace is None)
             assert np.array_equal(q_last, q_d[n - 1])
         assert not ws[emu.dtqn_td_xch_floats(ctypes.byref(net), 1):].any()      # hand-over flags lowered again
     assert emu.dtqn_actor_forward(ctypes.byref(net), ptr(theta), ptr(ctx_h), ptr(ctx_d), L + 1, ptr(q_d), ptr(q_last), None, 0, 0, 0, None) == B.DEFINES["DTQN_ERR_ARG"]
@@ -210,7 +210,7 @@ def test_forward_with_a_bag(emu, kw):
         rc = emu.dtqn_forward_bag(ctypes.byref(net), ptr(theta), ptr(f32(obs)), ptr(u8(act)), ptr(f32(bag_obs)), ptr(u8(bag_act)), Bn, n,
                                   ptr(q), ptr(ws), 0, 0, 0, None)
         assert rc == 0
-        assert np.abs(q - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (n, np.abs(q - ref).max())
+        assert np.abs(q - ref).max() <= 1e-4, (n, np.abs(q - ref).max())
     # the bag-less entry refuses a bag network
     assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(f32(obs)), ptr(u8(act)), Bn, n, ptr(q), ptr(ws), None) != 0
 

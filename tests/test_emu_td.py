@@ -175,7 +175,8 @@ def test_pad_rows_with_overflowing_scores_stay_out_of_the_gradient(emu, split, h
     eng.set_indices(eps, starts)
     eng.forward_backward(rep)
     assert bool(torch.isfinite(eng.grad).all())
-    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+    # scores of +-1e3 in front of the softmax: the one parity case whose Q tolerance is relative to |Q|max (measured 2e-4 absolute)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1, q_rel=True)
 
 
 DROPOUT_CASES = [

@@ -15,7 +15,7 @@ from helpers import net_from_cfg, pack_theta, ptr
 
 pytestmark = pytest.mark.gpu
 
-Q_TOL = 1e-4   # north_star: per-timestep Q-values within 1e-4 fp32 (scaled by max(1, |Q|max))
+Q_TOL = 1e-4   # north_star: per-timestep Q-values within 1e-4 fp32, ABSOLUTE (|Q| reaches 17 in these fixtures)
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +52,7 @@ def test_golden_G4_actor_variable_length(lib):
         for n in (1, 2, 17, 50):
             got = hip_forward(lib, cfg, params, z[f"{tag}/n{n}_obs"], z[f"{tag}/n{n}_act"])
             ref = z[f"{tag}/n{n}_q"]
-            assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), (tag, n)
+            assert np.abs(got - ref).max() <= Q_TOL, (tag, n)
 
 
 def test_golden_G1_q_values(lib):
@@ -61,7 +61,7 @@ def test_golden_G1_q_values(lib):
     seed = int(z["seed"])
     pol = O.init_params(cfg, seed=seed, perturb=True)
     tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
-    scale = max(1.0, np.abs(z["q_all"]).max())
+    scale = 1.0          # absolute tolerance
     got = hip_forward(lib, cfg, pol, z["batch0_obss"], z["batch0_actions"])
     assert np.abs(got - z["q_all"]).max() <= Q_TOL * scale
     got = hip_forward(lib, cfg, pol, z["batch0_next_obss"], z["batch0_next_actions"])
@@ -80,7 +80,7 @@ def test_golden_G3_cfg345_q_values(lib):
         seed = int(z[p + "seed"])
         pol = O.init_params(cfg, seed=seed, perturb=True)
         tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
-        scale = max(1.0, np.abs(z[p + "q_all"]).max())
+        scale = 1.0      # absolute tolerance
         for params, obs_k, act_k, q_k in ((pol, "batch0_obss", "batch0_actions", "q_all"),
                                           (pol, "batch0_next_obss", "batch0_next_actions", "q_next_pol"),
                                           (tgt, "batch0_next_obss", "batch0_next_actions", "q_next_tgt")):
@@ -119,7 +119,7 @@ def test_variants_vs_oracle(lib, kw):
                             torch.as_tensor(act, dtype=torch.long)).numpy()
         got = hip_forward(lib, cfg, params, obs, act)
         assert np.isfinite(got).all()
-        assert np.abs(got - ref).max() <= Q_TOL * max(1.0, np.abs(ref).max()), (n, np.abs(got - ref).max())
+        assert np.abs(got - ref).max() <= Q_TOL, (n, np.abs(got - ref).max())
 
 
 def test_seq_longer_than_context_is_rejected(lib):

@@ -148,7 +148,7 @@ def test_golden_G1_full_update(lib):
     eng.set_indices(np.arange(Bn), np.zeros(Bn))
     eng.forward_backward(rep)
     q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :cfg.num_actions]
-    scale = max(1.0, np.abs(z["q_all"]).max())
+    scale = 1.0          # absolute tolerance (north_star: 1e-4 fp32)
     for w, name in enumerate(("q_all", "q_next_pol", "q_next_tgt")):
         assert np.abs(q3[w] - z[name]).max() <= 1e-4 * scale, name
     keys = O.trainable_keys(cfg)
@@ -228,7 +228,7 @@ def test_golden_G3_tiled_update(lib, name):
     eng.set_indices(np.arange(Bn), np.zeros(Bn))
     eng.forward_backward(rep)
     q3 = eng.q3.cpu().numpy().reshape(3, Bn, net.lp, net.ap)[:, :, :L, :cfg.num_actions]
-    scale = max(1.0, np.abs(g("q_all")).max())
+    scale = 1.0          # absolute tolerance (north_star: 1e-4 fp32)
     for w, nm in enumerate(("q_all", "q_next_pol", "q_next_tgt")):
         assert np.abs(q3[w] - g(nm)).max() <= 1e-4 * scale, nm
     eng.clip_adam()
