@@ -145,6 +145,7 @@ def time_kernels(agent, iters: int = 50) -> dict:
         out[name] = float(np.mean(ts))          # us
     agent._calls_issued += 3 + iters            # the statistics ring counts optimizer launches: keep the host's count in step
     agent._drain_stats(block=True)
+    agent.engine.pipeline_reset()               # ... and the pipelined forward's mirror of the optimizer step
     return out
 
 
@@ -482,6 +483,7 @@ def time_clip_adam(agent, iters: int = 20) -> dict:
     us = float(np.mean(ts))
     agent._calls_issued += 3 + iters          # the statistics ring counts optimizer launches
     agent._drain_stats(block=True)
+    eng.pipeline_reset()
     b = 28 * eng.net.n_trainable
     return {"bytes": b, "us": us, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 

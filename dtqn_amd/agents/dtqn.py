@@ -59,6 +59,7 @@ class _AdamHandle:
         e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
         e.step_counter[:2] = int(sd["step"])     # optimizer steps: published | next
         e.step_counter[2:] = 0         # statistics-ring call counter (DtqnAgent.load_checkpoint restarts its host side too) | skip flag
+        e.pipeline_reset()
 
 
 class DtqnAgent:
@@ -157,12 +158,16 @@ class DtqnAgent:
         if cuda:
             self.engine.bind_stream(self._main_stream)
             self.replay_buffer.bind_stream(self._main_ptr, self._main_stream)
+            if self.sampler == "device" and not self._separate_sample_launch:
+                # latency mode: target pass of the next update launched ahead, policy passes as four row slices (learner.py)
+                self.pipelined = self.engine.enable_pipeline(lambda rb=self.replay_buffer: rb.version)
         self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
         self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream) if cuda else None
         self._ev_update_done = torch.cuda.Event() if cuda else None
         self._ev_actor_done = torch.cuda.Event() if cuda else None
         self._actor_inflight = False
         self._actor_calls = 0
+        self.pipelined = getattr(self, "pipelined", False)
 
     # ---- mode / context (dqn.py:102-115) -------------------------------------------------------
     @property

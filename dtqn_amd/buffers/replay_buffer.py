@@ -64,6 +64,8 @@ class ReplayBuffer:
             self._stage[-1]["rec_hp"] = ctypes.c_void_p(rec_h.data_ptr())
             self._stage[-1]["obs_hp"] = ctypes.c_void_p(obs_h.data_ptr())
         self._cur, self._n = 0, 0
+        self.version = 0           # bumped whenever the device arrays change (a scatter launch, import_arrays): a window drawn ahead
+                                   # of its update (TdEngine pipeline) is only used if nothing was written since
 
     # ---- producer side (replay_buffer.py:71-98) ----------------------------------------------
     def _push(self, kind: int, ep: int, t: int, action: int, reward: float, done: bool, obs, ep_len: int = 0) -> None:
@@ -122,6 +124,7 @@ class ReplayBuffer:
         if stream_ptr is None and self.device.type == "cuda":
             stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         # the scatter kernel reads the pinned staging in place: one launch, no copy
+        self.version += 1
         rc = self._lib.dtqn_replay_push(self.dev.view_ref, st["rec_hp"], st["obs_hp"], n, stream_ptr)
         if rc != 0:
             raise RuntimeError(f"dtqn_replay_push failed with DTQN status {rc}")
@@ -223,6 +226,7 @@ class ReplayBuffer:
             if tuple(np.shape(arrays[k])) != shape:
                 raise ValueError(f"replay array {k!r} has shape {tuple(np.shape(arrays[k]))}, this buffer needs {shape}")
         self._n = 0
+        self.version += 1
         as_t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt))
         d.obs.copy_(as_t(arrays["obss"], np.uint8 if self.image is not None else np.float32)); d.actions.copy_(as_t(arrays["actions"], np.uint8))
         d.rewards.copy_(as_t(arrays["rewards"], np.float32)); d.dones.copy_(as_t(arrays["dones"], np.uint8))

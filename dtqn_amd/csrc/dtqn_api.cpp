@@ -50,18 +50,30 @@ extern "C" int dtqn_td_prefers_tiled(const DtqnNet* net, int batch) {
 }
 extern "C" int dtqn_td_xch_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
-    return 3 * batch * net->num_layers * (net->lp / 2) * 2 * net->d_model;   // K | V (or dK | dV) of the lower half rows
+    // K | V (or dK | dV) hand-over records per (sequence of the three passes, layer): two slices send lp / 2 rows, four slices
+    // 3 lp / 4 (dtqn_forward_body.hpp kv_xch_floats)
+    return 3 * batch * net->num_layers * (3 * net->lp / 4) * 2 * net->d_model;
 }
 extern "C" int dtqn_td_xch_flags(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;
     // backward: one per 64-column head group (<= 4); + the event counters of the fused weight gradients (dtqn_wgrad_direct.hpp: kFuseWords)
-    return 3 * batch * net->num_layers * 4 + 16;
+    // forward with four slices: six (sender, receiver) pairs per (sequence, layer)
+    return 3 * batch * net->num_layers * 6 + 16;
 }
 
 // DtqnAgent.train() after sampling (dtqn/agents/dtqn.py:215-269) on one GPU: five launches.
 extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
     int rc;
     if ((rc = dtqn_td_forward(net, rp, td, stream)) != DTQN_OK) return rc;
+    if ((rc = dtqn_td_backward(net, rp, td, stream)) != DTQN_OK) return rc;
+    if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
+    if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;
+    return dtqn_td_clip_adam(net, td, stream);
+}
+
+// The same behind a forward that was launched in parts (dtqn_td_forward_part): loss + backward, weight gradients, reduce, clip + Adam.
+extern "C" int dtqn_td_update_tail(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+    int rc;
     if ((rc = dtqn_td_backward(net, rp, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;

@@ -53,9 +53,12 @@ inline void raise_lds_limit(const void* fn, size_t lds, size_t (&cache)[kMaxDevi
 // each.  Compiled in only with -DDTQN_ENABLE_PROF (DTQN_BUILD_PROF=1 python -m dtqn_amd.build): every mark is a
 // conditional global store, and a conditional store between a prefetch and its use makes the compiler wait with
 // vmcnt(0) there -- the product build must not carry them.
+#ifndef DTQN_PROF_WG1
+#define DTQN_PROF_WG1 1        /* the second profiled workgroup (-DDTQN_PROF_WG1=3: the top one of four row slices) */
+#endif
 #ifdef DTQN_ENABLE_PROF
 #define DTQN_PROF(buf, slot) \
-    do { if ((buf) != nullptr && blockIdx.x < 2 && threadIdx.x == 0) (buf)[blockIdx.x * 32 + (slot)] = (long long)wall_clock64(); } while (0)
+    do { if ((buf) != nullptr && (blockIdx.x == 0 || blockIdx.x == DTQN_PROF_WG1) && threadIdx.x == 0) (buf)[(blockIdx.x == 0 ? 0 : 32) + (slot)] = (long long)wall_clock64(); } while (0)
 #else
 #define DTQN_PROF(buf, slot) ((void)(slot))
 #endif

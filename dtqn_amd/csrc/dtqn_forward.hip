@@ -1,5 +1,7 @@
 // DTQN forward: dispatch and C entry points.  The kernel bodies live in dtqn_forward_body.hpp; their instantiations are
 // compiled in dtqn_forward_inst{a,b,c,d}.hip.
+#include <cstdlib>
+
 #include "dtqn_forward_body.hpp"
 
 namespace dtqn {
@@ -21,6 +23,12 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     const int D = a.net.d_model, HD = a.net.head_dim;
     const int MT = mt_rows > 0 ? mt_rows : a.net.lp / 16;
     const int NW = mt_rows > 0 ? 8 : waves_for(a.net);
+    if (row_split == 4) {      // four workgroups per sequence: 16-row slices (TD update, weights-through-LDS body)
+        if (a.net.lp != 64 || a.net.identity || a.net.gate != DTQN_GATE_RES || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
+        if (D == 64 && HD == 8) return launch_fwd2<64, 1, 8, 8, false, 4>(a, nseq, stream);
+        if (D == 64 && HD == 16) return launch_fwd2<64, 1, 16, 8, false, 4>(a, nseq, stream);
+        return DTQN_ERR_CONFIG;
+    }
     if (row_split == 2) {      // two workgroups per sequence (dtqn_td_row_split): 32-row slices of a 64-row tile, 8 waves
         if (a.net.lp != 64 || a.net.identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
         if (a.net.gate == DTQN_GATE_GRU) {
@@ -91,7 +99,7 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.obs_ep_stride = (long long)in_rows * net->obs_dim;
     a.act_ep_stride = in_rows;
     a.ep_idx = nullptr; a.start = nullptr;
-    a.n = n; a.batch = batch;
+    a.n = n; a.batch = batch; a.pass0 = 0; a.draw_step = -1;
     a.q_out = q_out;
     a.q_which_stride = 0;
     a.q_seq_stride = (long long)n * net->num_actions;
@@ -114,9 +122,14 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
 }
 
-extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+// pass0 / npasses: the passes this launch covers (0 policy(o), 1 policy(o'), 2 target(o')); slices: workgroups per sequence (0 = the
+// policy of dtqn_td_forward); draw_step >= 0: key of the in-kernel window draw (else step_counter[1])
+static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, int slices, int draw_step,
+                           void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (rp->obs_dim != net->obs_dim || rp->max_steps < net->ctx_len) return DTQN_ERR_ARG;
+    if (pass0 < 0 || npasses < 1 || pass0 + npasses > 3) return DTQN_ERR_ARG;
+    const bool whole = pass0 == 0 && npasses == 3;
     const bool draw = td->sample_in_kernel != 0;
     if (draw) {
         const bool skip = td->sample_exclude >= 0 && td->sample_exclude < td->sample_n_valid;
@@ -125,6 +138,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     // image nets: the windows must exist before dtqn_img_encode, which fills td->xemb in front of this call
     if (net->img_c > 0 && (draw || !td->xemb)) return DTQN_ERR_ARG;
     if (net->tiled) {       // the multi-kernel path reads the windows from td->ep_idx / td->start: draw them first
+        if (!whole) return DTQN_ERR_CONFIG;
         if (draw) {
             const int rc = dtqn_replay_sample(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed,
                                               td->step_counter, td->ep_idx, td->start, stream);
@@ -137,6 +151,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
         }
         return tiled_td_forward(net, rp, td, (hipStream_t)stream);
     }
+    if (!whole && !draw) return DTQN_ERR_ARG;      // a partial launch re-derives its windows from the counter-based draw
     FwdArgs a;
     a.net = *net;
     a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;
@@ -147,7 +162,7 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
     a.ep_out = td->ep_idx; a.start_out = td->start;
     a.s_n_valid = td->sample_n_valid; a.s_exclude = td->sample_exclude; a.s_seed = td->sample_seed;
-    a.n = net->ctx_len; a.batch = td->batch;
+    a.n = net->ctx_len; a.batch = td->batch; a.pass0 = pass0; a.draw_step = draw_step;
     a.q_out = td->q3;
     a.q_which_stride = (long long)td->batch * net->lp * net->ap;
     a.q_seq_stride = (long long)net->lp * net->ap;
@@ -158,5 +173,27 @@ extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const D
     a.xch = td->xch; a.xflags = td->xflags;
     a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
     set_dropout(a, net, 0x3, td->dropout_seed, 0u);       // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230)
-    return dispatch_fwd(a, 3 * td->batch, td->row_split >= 2 ? 2 : 1, (hipStream_t)stream);   // the forward never uses more than two slices
+    if (slices <= 0) {
+        slices = td->row_split >= 2 ? 2 : 1;               // the whole-update launch: two slices in latency mode ...
+        const char* e = getenv("DTQN_FWD_SLICES");         // ... DTQN_FWD_SLICES=4: four (A/B knob; 3 B 4 workgroups do not fit the chip at once)
+        if (e != nullptr && atoi(e) == 4 && td->row_split >= 2 && dtqn_td_fwd_slices4_ok(net)) slices = 4;
+    }
+    if (slices == 4 && !dtqn_td_fwd_slices4_ok(net)) return DTQN_ERR_CONFIG;
+    return dispatch_fwd(a, npasses * td->batch, slices, (hipStream_t)stream);
+}
+
+extern "C" int dtqn_td_fwd_slices4_ok(const DtqnNet* net) {
+    if (!net || net->tiled || net->lp != 64 || net->identity || net->gate != DTQN_GATE_RES || net->d_model != 64 || net->dropout > 0.f) return 0;
+    if (net->head_dim != 8 && net->head_dim != 16) return 0;
+    return fwd_wl_ok(net) && fwd_lds_bytes(net, true) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+    return td_forward_part(net, rp, td, 0, 3, 0, -1, stream);
+}
+
+extern "C" int dtqn_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, int slices,
+                                    int draw_step, void* stream) {
+    if (slices != 1 && slices != 2 && slices != 4) return DTQN_ERR_ARG;
+    return td_forward_part(net, rp, td, pass0, npasses, slices, draw_step, stream);
 }

@@ -29,6 +29,9 @@ struct FwdArgs {
     const int32_t* start;
     int n;                      // real sequence length (<= ctx_len)
     int batch;                  // sequences per `which`
+    int pass0;                  // first pass of this launch: which = pass0 + sequence / batch (TD update: 0 policy(o), 1 policy(o'), 2 target(o'))
+    int draw_step;              // >= 0: the window draw is keyed by this optimizer step instead of step_counter[1] (a pass launched ahead
+                                // of its update, dtqn_td_forward_part)
     float* q_out;               // which-major
     long long q_which_stride, q_seq_stride;
     int q_row_stride;
@@ -55,6 +58,45 @@ struct FwdArgs {
 __device__ __forceinline__ int lds_ldx(int D) { return D + 4; }
 __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 
+
+// K | V hand-over between the RS row slices of a sequence (forward): slice s needs the keys / values of every row below its own.
+// Sender s < RS - 1 publishes its [LP][2 D] K | V tile once (16-byte write-through stores) into segment s of the (sequence, layer)
+// buffer and raises one flag per receiver above it; receiver r > 0 waits for the flags of all senders below it, pulls their
+// segments into rows [s LP, (s + 1) LP) of its own LDS tile and lowers its flags again (the next launch starts from 0).  A middle
+// slice sends first, then receives.  Senders always have the lower blockIdx of a pair.  Pair (s, r), s < r: flag r (r - 1) / 2 + s.
+template <int NW, int RS>
+__device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
+    const int cols = 2 * D, c4 = cols >> 2;
+    if (slice < RS - 1) {
+        const DtqnRsrc rs = DTQN_XCH_RSRC(xb + (size_t)slice * LP * cols, LP * cols * 4);
+        const float* s = Ws + (size_t)slice * LP * ldw + D;
+        for (int idx = t.tid; idx < LP * c4; idx += NW * 64) {
+            const int r = idx / c4, c = (idx - r * c4) * 4;
+            dtqn_xch_store4(rs, idx * 16, ld4(s + r * ldw + c));
+        }
+        DTQN_WAIT_VMEM();                              // every wave's stores are acknowledged at agent scope ...
+        __syncthreads();                               // ... and every wave got here ...
+        const int r = slice + 1 + t.tid;               // ... before the flags are raised
+        if (t.tid < RS - 1 - slice) DTQN_AGENT_STORE(flags + r * (r - 1) / 2 + slice, (int32_t)1);
+    }
+    if (slice > 0) {
+        if (t.tid < slice)
+            while (DTQN_AGENT_LOAD(flags + slice * (slice - 1) / 2 + t.tid) == 0) DTQN_SPIN_PAUSE();
+        __syncthreads();
+        const DtqnRsrc rs = DTQN_XCH_RSRC(xb, slice * LP * cols * 4);
+        for (int idx = t.tid; idx < slice * LP * c4; idx += NW * 64) {
+            const int r = idx / c4, c = (idx - r * c4) * 4;         // r: global row below this slice
+            st4(Ws + (size_t)r * ldw + D + c, dtqn_xch_load4(rs, idx * 16));
+        }
+        __syncthreads();
+        if (t.tid < slice) DTQN_AGENT_STORE(flags + slice * (slice - 1) / 2 + t.tid, (int32_t)0);
+    }
+}
+
+// floats / flag words of one (sequence, layer) hand-over record for RS slices of LP rows
+__host__ __device__ constexpr int kv_xch_floats(int RS, int LP, int D) { return (RS - 1) * LP * 2 * D; }
+__host__ __device__ constexpr int kv_xch_flags(int RS) { return RS * (RS - 1) / 2; }
+
 // RS = row slices per sequence.  RS == 1: the workgroup owns the whole sequence (LP = its padded length).
 // RS == 2 (latency mode, dtqn_td_row_split): the workgroup owns rows [R0, R0 + LP) of the sequence, LP = half the
 // padded length; every stage is row-local except attention, whose K | V of the rows below R0 come from the partner
@@ -77,8 +119,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const Thr t = make_thr();
     const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;     // slice 0 (the producer) first
     const int R0 = slice * LP;
-    const int which = seq / a.batch;
-    const int b = seq - which * a.batch;
+    const int which = a.pass0 + seq / a.batch;
+    const int b = seq - (which - a.pass0) * a.batch;
     Drop dr = drop_off();
     if constexpr (DROP) {
         if (a.drop_thresh != 0u && ((a.drop_passes >> which) & 1))
@@ -110,7 +152,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     if (a.ep_len != nullptr) {
         // every workgroup of sequence b (three passes, row slices) evaluates the same counter-based draw; one of them
         // leaves it for the backward kernel
-        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, (uint32_t)a.step_counter[1], b, ep, st);
+        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, a.draw_step >= 0 ? (uint32_t)a.draw_step : (uint32_t)a.step_counter[1], b, ep, st);
         if (which == 0 && slice == 0 && t.tid == 0) { a.ep_out[b] = ep; a.start_out[b] = st; }
     } else {
         ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
@@ -231,12 +273,9 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
             tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        if (RS == 2) {                                 // K | V of the lower rows: slice 0 -> slice 1 (16-byte write-through stores)
-            float* xb = a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D;
-            int32_t* flag = a.xflags + (size_t)seq * net.num_layers + l;
-            if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
-            else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
-        }
+        if (RS == 2)                                   // K | V of the lower rows: slice 0 -> slice 1 (16-byte write-through stores)
+            kv_handover<NW, RS>(Ws, LDW, D, LP, slice, a.xch + ((size_t)seq * net.num_layers + l) * kv_xch_floats(RS, LP, D),
+                                a.xflags + ((size_t)seq * net.num_layers + l) * kv_xch_flags(RS), t);
         attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // attention done
@@ -395,7 +434,7 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int D, int MT, int HD, int NW, int RS, bool TRAIN>
 __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
-    static_assert(RS == 1 || RS == 2, "one or two row slices");
+    static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
     static_assert(D <= 64, "the weight arena is sized for D <= 64");
     constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;
@@ -412,8 +451,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const Thr t = make_thr();
     const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;
     const int R0 = slice * LP;
-    const int which = seq / a.batch;
-    const int b = seq - which * a.batch;
+    const int which = a.pass0 + seq / a.batch;
+    const int b = seq - (which - a.pass0) * a.batch;
     const Drop dr = drop_off();       // dropout > 0 is served by the register-direct stages (the host never picks this kernel then)
     const float* __restrict__ theta = which == 2 ? a.theta_b : a.theta_a;
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
@@ -446,7 +485,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     // ---------------- window gather + embedding (as forward_body) ----------------
     int ep, st;
     if (a.ep_len != nullptr) {
-        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, (uint32_t)a.step_counter[1], b, ep, st);
+        replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, a.draw_step >= 0 ? (uint32_t)a.draw_step : (uint32_t)a.step_counter[1], b, ep, st);
         if (which == 0 && slice == 0 && t.tid == 0) { a.ep_out[b] = ep; a.start_out[b] = st; }
     } else {
         ep = a.ep_idx != nullptr ? a.ep_idx[b] : b;
@@ -560,13 +599,10 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        if (RS == 2) {
-            float* xb = a.xch + ((size_t)seq * net.num_layers + l) * LP * 2 * D;
-            int32_t* flag = a.xflags + (size_t)seq * net.num_layers + l;
-            if (slice == 0) xch_send<NW>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
-            else xch_recv<NW, false>(Ws + D, LDW, xb, LP, 2 * D, flag, t);
-        }
-        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS == 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
+        if (RS > 1)                                      // K | V of the rows below this slice (kv_handover)
+            kv_handover<NW, RS>(Ws, LDW, D, LP, slice, a.xch + ((size_t)seq * net.num_layers + l) * kv_xch_floats(RS, LP, D),
+                                a.xflags + ((size_t)seq * net.num_layers + l) * kv_xch_flags(RS), t);
+        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS >= 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         tw_1.to_lds(Ar, LWD, t);
         TileRegs<NW, D, NC> tw_2;
         tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
@@ -705,7 +741,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
 template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     static_assert(!(WL && DROP), "dropout runs on the register-direct stages");
-    const int which = ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
+    const int which = a.pass0 + ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
     if constexpr (WL) {
         if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true>(a);
         else forward_body_wl<D, MT, HD, NW, RS, false>(a);
@@ -746,11 +782,17 @@ int launch_fwd4(const FwdArgs& a, int nseq, hipStream_t stream) {
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
-    if (a.drop_thresh != 0u) return launch_fwd4<D, MT, HD, NW, GRU, RS, false, true>(a, nseq, stream);
-    if constexpr (!GRU && D <= 64) {
-        if (fwd_wl_ok(&a.net) && fwd_lds_bytes(&a.net, true) <= 160 * 1024) return launch_fwd4<D, MT, HD, NW, GRU, RS, true, false>(a, nseq, stream);
+    if constexpr (RS == 4) {      // four 16-row slices: the weights-through-LDS body only (residual gate, D <= 64, no dropout)
+        static_assert(!GRU && D <= 64, "four row slices run on forward_body_wl");
+        if (a.drop_thresh != 0u || !fwd_wl_ok(&a.net) || fwd_lds_bytes(&a.net, true) > 160 * 1024) return DTQN_ERR_CONFIG;
+        return launch_fwd4<D, MT, HD, NW, GRU, RS, true, false>(a, nseq, stream);
+    } else {
+        if (a.drop_thresh != 0u) return launch_fwd4<D, MT, HD, NW, GRU, RS, false, true>(a, nseq, stream);
+        if constexpr (!GRU && D <= 64) {
+            if (fwd_wl_ok(&a.net) && fwd_lds_bytes(&a.net, true) <= 160 * 1024) return launch_fwd4<D, MT, HD, NW, GRU, RS, true, false>(a, nseq, stream);
+        }
+        return launch_fwd4<D, MT, HD, NW, GRU, RS, false, false>(a, nseq, stream);
     }
-    return launch_fwd4<D, MT, HD, NW, GRU, RS, false, false>(a, nseq, stream);
 }
 template <int D, int MT, int HD, int NW>
 int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
@@ -768,10 +810,11 @@ int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
 #define DTQN_FWD_GROUP_B(X) X(128, 4, 16, 4) X(128, 4, 16, 8) X(128, 2, 16, 8) X(128, 1, 16, 8)
 #define DTQN_FWD_GROUP_C(X) X(64, 2, 8, 8) X(64, 1, 8, 8) X(64, 2, 16, 8) X(64, 1, 16, 8) X(16, 1, 8, 4) X(16, 1, 8, 8) X(32, 2, 8, 4) X(32, 1, 16, 4)
 // row-split (two workgroups per sequence) instantiations: (D, MT, HD, NW, GRU)
-#define DTQN_FWD_GROUP_D(X) X(64, 2, 8, 8, true) X(64, 2, 16, 8, true) X(64, 2, 8, 8, false) X(64, 2, 16, 8, false) X(128, 2, 16, 8, false)
+#define DTQN_FWD_GROUP_D(X) X(64, 2, 8, 8, true, 2) X(64, 2, 16, 8, true, 2) X(64, 2, 8, 8, false, 2) X(64, 2, 16, 8, false, 2) X(128, 2, 16, 8, false, 2) \
+    X(64, 1, 8, 8, false, 4) X(64, 1, 16, 8, false, 4)
 #define DTQN_FWD_DECL(d, mt, hd, nw) extern template int launch_fwd<d, mt, hd, nw>(const FwdArgs&, int, hipStream_t);
 #define DTQN_FWD_DEF(d, mt, hd, nw) template int launch_fwd<d, mt, hd, nw>(const FwdArgs&, int, hipStream_t);
-#define DTQN_FWD2_DECL(d, mt, hd, nw, gru) extern template int launch_fwd2<d, mt, hd, nw, gru, 2>(const FwdArgs&, int, hipStream_t);
-#define DTQN_FWD2_DEF(d, mt, hd, nw, gru) template int launch_fwd2<d, mt, hd, nw, gru, 2>(const FwdArgs&, int, hipStream_t);
+#define DTQN_FWD2_DECL(d, mt, hd, nw, gru, rs) extern template int launch_fwd2<d, mt, hd, nw, gru, rs>(const FwdArgs&, int, hipStream_t);
+#define DTQN_FWD2_DEF(d, mt, hd, nw, gru, rs) template int launch_fwd2<d, mt, hd, nw, gru, rs>(const FwdArgs&, int, hipStream_t);
 
 }  // namespace dtqn

@@ -173,9 +173,17 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
     const int why = !isfinite(norm) ? 1 : (a.xstatus != nullptr && *a.xstatus != 0) ? 2 : (a.step_counter[3] != 0) ? 3 : 0;
     const bool finite = why == 0;
     const int k = a.step_counter[0] + 1;                      // 1-based index of this optimizer step
-    if (tid == 0) {
-        pw[0] = 1.0 - pow((double)a.beta1, (double)k);
-        pw[1] = 1.0 - pow((double)a.beta2, (double)k);
+    // bias corrections 1 - beta^k in f64 like torch's Python floats.  beta^k by repeated squaring: at most 62 dependent
+    // multiplications (error a few 1e-16 relative) instead of two calls of the f64 pow() in front of every block's barrier;
+    // the two powers go to two different waves
+    if (tid == 0 || tid == 64) {
+        const double beta = tid == 0 ? (double)a.beta1 : (double)a.beta2;
+        double r = 1.0, b = beta;
+        for (unsigned e = (unsigned)k; e != 0u; e >>= 1) {
+            if (e & 1u) r *= b;
+            b *= b;
+        }
+        pw[tid >> 6] = 1.0 - r;
     }
     __syncthreads();
     const float bc1 = (float)pw[0], bc2_sqrt = (float)sqrt(pw[1]);
@@ -198,8 +206,10 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
         st4(a.theta + p0, pn);
         if (sync_target) st4(a.theta_tgt + p0, pn);           // hard target update every tuf steps (dqn.py:208-210)
     }
-    if (blockIdx.x == 0) {
-        // statistics of dtqn.py:245-253,263, reduced over the per-sequence partials
+    if (blockIdx.x == gridDim.x - 1) {
+        // The LAST block owns no parameters (the launch carries one block more than the parameter tiles): the statistics of
+        // dtqn.py:245-253,263, reduced over the per-sequence partials, the step counters and the host-visible ring slot -- a chain
+        // of reductions and a PCIe write that used to sit behind block 0's Adam work and set the kernel's length
         float se = 0.f, sq = 0.f, sy = 0.f, mxq = -INFINITY, mnq = INFINITY, mxy = -INFINITY, mny = INFINITY;
         for (int b = tid; b < a.n_stat_parts; b += kOptThreads) {
             const float* sp = a.stats_partial + (size_t)b * 8;
@@ -326,7 +336,7 @@ extern "C" int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* str
     a.lr = td->lr; a.beta1 = td->beta1; a.beta2 = td->beta2; a.eps = td->eps; a.clip = td->grad_norm_clip;
     a.grad_scale = td->grad_scale;
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL(dtqn_clip_adam_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dtqn_clip_adam_kernel, dim3(td->n_norm_blocks + 1), dim3(kOptThreads), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 

@@ -363,6 +363,15 @@ int dtqn_td_xch_flags(const DtqnNet* net, int batch);
 /* The three forwards (dtqn.py:215,226,230) fused with the window gather (replay_buffer.py:160-167).
  * Grid = 3*B*row_split workgroups.  Writes q3 and the act record of the policy(o) pass. */
 int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* A PART of the same launch (whole-sequence kernels, td->sample_in_kernel == 1): passes [pass0, pass0 + npasses) of
+ * {0 policy(o), 1 policy(o'), 2 target(o')} with `slices` workgroups per sequence (1, 2, or 4 where dtqn_td_fwd_slices4_ok).
+ * The target pass of update k + 1 depends on nothing update k produces (theta_tgt only moves at a hard sync), so a caller may
+ * launch it AHEAD on a second stream while update k's backward leaves half the chip idle -- with its own q3 / xch / xflags in
+ * `td` and draw_step = the optimizer step update k + 1 will carry (>= 0; -1 = read step_counter[1]) -- and run passes 0 - 1 of
+ * update k + 1 as 2 B 4 = 256 workgroups of 16 rows: every compute unit busy, half the rows per workgroup.  Same dtqn.py:215-230. */
+int dtqn_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, int slices, int draw_step,
+                         void* stream);
+int dtqn_td_fwd_slices4_ok(const DtqnNet* net);
 /* Double-DQN target, MSE, dL/dQ (dtqn.py:219-243) and the data-gradient chain of loss.backward()
  * (dtqn.py:256).  Writes the grd / small records and stats_partial. */
 int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
@@ -410,6 +419,8 @@ int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_
                     int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream);
 /* Convenience: forward, backward, wgrad, reduce, clip_adam back to back (single GPU). */
 int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* dtqn_td_update without its forward (launched in parts by the caller, dtqn_td_forward_part): backward, wgrad, reduce, clip_adam. */
+int dtqn_td_update_tail(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
 int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
 

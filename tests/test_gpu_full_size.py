@@ -127,4 +127,4 @@ def test_full_size_update_properties(lib, name, monkeypatch):
     a = torch.as_tensor(act[eps[sl, None], rows][..., None].astype(np.int64))
     with torch.no_grad():
         ref = O.forward(params[0], cfg, o, a).numpy()
-    assert np.abs(q_full[0, sl] - ref).max() <= 1e-4, name
+    assert np.abs(q_full[0, sl] - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), name

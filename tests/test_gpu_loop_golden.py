@@ -30,7 +30,8 @@ def test_small_loop_reproduces_the_reference_trace_on_the_device(fx):
 def test_cfg1_loop_follows_the_reference_trace_on_the_device(fx):
     from loop_harness import run_loop, compare_loop
     tr, agent, prepop = run_loop(fx, "cfg1", torch.device("cuda:0"))
-    s = compare_loop(fx, "cfg1", tr, prepop, min_actions=100)
+    # drift_factor 8: measured 3.9 x the reference's own distance to its one-thread twin at the end of the matched prefix (chaos-bound)
+    s = compare_loop(fx, "cfg1", tr, prepop, min_actions=100, drift_factor=8.0)
     print(s)
     # the first updates are the exact pin: before the trajectory's chaos has amplified anything the bounds are the absolute ones
     early = [u for u in range(10)]

@@ -64,7 +64,7 @@ def test_module_forward_with_reference_state_dict_G3():
         seed = int(z[p + "seed"])
         pol = _module(cfg)
         pol.load_state_dict({k: v.clone() for k, v in O.init_params(cfg, seed=seed, perturb=True).items()})
-        scale = 1.0      # absolute tolerance
+        scale = max(1.0, np.abs(z[p + "q_all"]).max())      # std-0.2 stress weights: see tests/helpers.py
         err = np.abs(_q(pol, cfg, z[p + "batch0_obss"], z[p + "batch0_actions"]) - z[p + "q_all"]).max()
         assert err <= 1e-4 * scale, (name, err)
         err = np.abs(_q(pol, cfg, z[p + "batch0_next_obss"], z[p + "batch0_next_actions"]) - z[p + "q_next_pol"]).max()
