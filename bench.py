@@ -110,14 +110,30 @@ def fill_synthetic_replay(agent, seed: int, c) -> None:
     rb.pos = [E + 1, 0]            # all slots finished (slot (E+1) % E is "in progress" and excluded, like the reference)
 
 
+def _event_pair_overhead(stream, iters: int = 200) -> float:
+    """Microseconds an EMPTY HIP event pair reads on this stream (record, record, synchronise): what every one-launch-at-a-time
+    timing below carries on top of the kernel.  Subtracted, so that the per-kernel figures add up to a step."""
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        e1.record(stream)
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(ts))
+
+
 def time_kernels(agent, iters: int = 50) -> dict:
-    """Average duration of each launch of one update (five; four when the one-launch weight-gradient kernel of small
-    batches makes dtqn_td_reduce a no-op), HIP events on the launch stream."""
+    """Average duration of each launch of one update, HIP events on the launch stream, one launch at a time, minus the reading of an
+    empty event pair.  Latency mode with the pipelined update (learner.py): the launches of a step are the two policy passes (four
+    16-row slices), the backward launch that also carries the NEXT update's target pass, weight gradients, clip + Adam; the target
+    pass by itself (the inline fallback after a replay write or a target sync) is listed apart (`..._target_inline`)."""
     eng, rep = agent.engine, agent.replay_buffer.dev
     lib = eng.lib
     n, r, t = ctypes.byref(eng.net), ctypes.byref(rep.view), ctypes.byref(eng.td)
     stream = torch.cuda.current_stream()
     s = ctypes.c_void_p(stream.cuda_stream)
+    pipelined = getattr(eng, "_pipe", None) is not None and bool(eng.td.sample_in_kernel)
     stages = {"dtqn_forward_kernel": lambda: lib.dtqn_td_forward(n, r, t, s),
               "dtqn_backward_kernel": lambda: lib.dtqn_td_backward(n, r, t, s),
               "dtqn_wgrad_kernel": lambda: lib.dtqn_td_wgrad(n, t, s),
@@ -127,6 +143,17 @@ def time_kernels(agent, iters: int = 50) -> dict:
         stages["dtqn_wgrad_direct_kernel"] = stages.pop("dtqn_wgrad_kernel")
         del stages["dtqn_reduce_kernel"]
         stages["dtqn_clip_adam_kernel"] = stages.pop("dtqn_clip_adam_kernel")      # keep launch order
+    if pipelined:
+        # what an update launches in this mode: the policy passes as four slices, and a backward launch that carries the next
+        # update's target pass; the target pass by itself (the inline fallback) is listed apart, it is not part of a steady-state step
+        d, _, nxt = eng._pipe_begin(rep)
+        if nxt is None:
+            d, _, nxt = eng._pipe_begin(rep)
+        lib.dtqn_td_forward_part(n, r, t, 2, 1, 4, d, s)
+        stages["dtqn_forward_kernel"] = lambda: lib.dtqn_td_forward_part(n, r, t, 0, 2, 4, d, s)
+        stages["dtqn_backward_kernel"] = lambda: lib.dtqn_td_backward_ahead(n, r, t, nxt, d + 1, s)
+        stages["dtqn_forward_kernel_target_inline"] = lambda: lib.dtqn_td_forward_part(n, r, t, 2, 1, 4, d, s)
+    empty = _event_pair_overhead(stream)
     out = {}
     for name, fn in stages.items():
         for _ in range(3):
@@ -142,7 +169,8 @@ def time_kernels(agent, iters: int = 50) -> dict:
             e1.record(stream)
             e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
-        out[name] = float(np.mean(ts))          # us
+        out[name] = max(0.0, float(np.mean(ts)) - empty)          # us
+    out["_event_pair_us"] = empty
     agent._calls_issued += 3 + iters            # the statistics ring counts optimizer launches: keep the host's count in step
     agent._drain_stats(block=True)
     agent.engine.pipeline_reset()               # ... and the pipelined forward's mirror of the optimizer step
@@ -304,8 +332,9 @@ def time_hbm_kernels(agent, c, kern: dict, iters: int = 50) -> dict:
             e1.record(stream)
             e1.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
-        return float(np.mean(ts))
+        return max(0.0, float(np.mean(ts)) - empty)
 
+    empty = kern.get("_event_pair_us", 0.0)
     n_valid, exclude = rb.valid_range()
     out["dtqn_replay_sample_kernel"] = {"bytes": 12 * eng.batch,
                                         "us": timed(lambda: eng.sample_on_device(rep, n_valid, exclude, 1, stream=s))}
@@ -333,7 +362,8 @@ def time_hbm_kernels(agent, c, kern: dict, iters: int = 50) -> dict:
         if i >= 3:
             ts.append(e0.elapsed_time(e1) * 1e3)
     apply_bytes = n_rec * (32 + 4 * O) + (n_rec - 1) * (4 * O + 1 + 4 + 1 + 4) + ((T + 1) * (4 * O + 1) + 5 * T)
-    out["dtqn_replay_apply_kernel"] = {"bytes": apply_bytes, "us": float(np.mean(ts)), "records": n_rec}
+    us_apply = max(0.0, float(np.mean(ts)) - empty)
+    out["dtqn_replay_apply_kernel"] = {"bytes": apply_bytes, "us": us_apply, "records": n_rec, "us_per_record": us_apply / n_rec}
     for k in ("obs", "actions", "rewards", "dones"):
         getattr(rep, k)[slot].copy_(keep[k])
     rb.episode_lengths[slot] = keep_len
@@ -636,7 +666,7 @@ def main():
         solo_rate = args.steps / (time.perf_counter() - t1)
         solo._drain_stats(block=True)
         # per-rank kernel sums (HIP events, one launch at a time): the slowest rank's kernels bound the data-parallel step
-        ksum = torch.tensor([float(sum(time_kernels(solo, 20).values()))], dtype=torch.float64)
+        ksum = torch.tensor([float(sum(v for k, v in time_kernels(solo, 20).items() if not k.startswith("_") and not k.endswith("_target_inline")))], dtype=torch.float64)
         allk = [torch.zeros_like(ksum) for _ in range(world)]
         torch.distributed.all_gather(allk, ksum.to(device) if not ddp.same_device() else ksum)
         exchange["solo_updates_per_s_rank0"] = solo_rate
@@ -657,7 +687,9 @@ def main():
         dom = max(("dtqn_forward_kernel", "dtqn_backward_kernel"), key=lambda k: kern[k])
         # algorithmic FLOPs per launch: forward kernel = 3 forwards; backward kernel = data-gradient half
         # of the backward (~ 1x forward; the weight-gradient half runs in dtqn_wgrad_kernel)
-        stage_flops = {"dtqn_forward_kernel": 3 * tokens * ft, "dtqn_backward_kernel": 1 * tokens * ft}
+        # (pipelined forward: the launch on the update's stream carries the two policy passes)
+        piped = "dtqn_forward_kernel_target_inline" in kern
+        stage_flops = {"dtqn_forward_kernel": (2 if piped else 3) * tokens * ft, "dtqn_backward_kernel": (2 if piped else 1) * tokens * ft}
         flops = stage_flops[dom]
         ach = flops / (kern[dom] * 1e-6) / 1e12
         p_t = agent.engine.net.n_trainable
@@ -666,7 +698,10 @@ def main():
         alg_bytes = gather_bytes + 4 * 2 * p_all + 4 * p_t + 28 * p_t
         traffic, traffic_src = (None, None) if tiled else pmc_traffic(dom, args.batch, args.config)
         whole_frac = 5 * tokens * ft / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
-        detail = {"build": build_digest(), "kernels_us": kern, "kernels_us_sum": float(sum(kern.values()))}
+        crit = {k: v for k, v in kern.items() if not k.startswith("_") and not k.endswith("_target_inline")}
+        detail = {"build": build_digest(), "kernels_us": kern, "kernels_us_sum": float(sum(crit.values())),
+                  "forward": "policy passes as 2 x B x 4 workgroups of 16 rows; the next update's target pass rides in the backward launch"
+                  if "dtqn_forward_kernel_target_inline" in kern else "three passes in one launch"}
         # -------- the line: contract keys first, then roofline and cpu_baseline, then one-number summaries ---------------
         line = {
             "metric": "env-steps/sec + TD-updates/sec, DiscreteCarFlag-v0 ctx=50 b=32, 1/2/4/8 GPU",
@@ -694,13 +729,15 @@ def main():
                                     "sample": cb["sample"],
                                     "reference_train_in_build_container_updates_per_s":
                                         {str(r["threads"]): r["td_updates_per_s"] for r in ref.get("runs", [])}}
-        line["kernels_us"] = {k.replace("dtqn_", "").replace("_kernel", ""): v for k, v in kern.items()}
+        line["kernels_us"] = {k.replace("dtqn_", "").replace("_kernel", ""): v for k, v in kern.items() if not k.startswith("_")}
+        line["kernels_us"]["sum_on_stream"] = detail["kernels_us_sum"]
         line["hbm_view"] = {"algorithmic_bytes_per_update": alg_bytes, "achieved_GBs": alg_bytes / (ms * 1e-3) / 1e9,
                             "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if not tiled:
             hb = time_hbm_kernels(agent, c, kern)
             detail["hbm_kernels"] = hb
-            line["hbm_kernels"] = {k.replace("dtqn_", "").replace("_kernel", ""): {"bytes": v["bytes"], "us": v["us"], "frac_of_8TBs": v["frac"]}
+            line["hbm_kernels"] = {k.replace("dtqn_", "").replace("_kernel", ""): {"bytes": v["bytes"], "us": v["us"], "frac_of_8TBs": v["frac"],
+                                                                                    **({"us_per_record": v["us_per_record"]} if "us_per_record" in v else {})}
                                    for k, v in hb.items()}
         detail["update_latency_us"] = lat
         line["update_us_median"] = lat["us_median"]

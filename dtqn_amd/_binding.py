@@ -113,6 +113,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_forward_part": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), i32, i32, i32, i32, vp],
         "dtqn_td_fwd_slices4_ok": [P(DtqnNet)],
         "dtqn_td_backward": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
+        "dtqn_td_backward_ahead": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, vp],
         "dtqn_td_wgrad": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_reduce": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_gradnorm": [P(DtqnNet), P(DtqnTd), vp],
@@ -129,7 +130,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_xch_publish": [vp, i32, vp],
         "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
-        "dtqn_td_update_tail": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
+        "dtqn_td_update_pipelined": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, i32, vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
         "dtqn_debug_set_profile_buffer": [vp],
         "dtqn_abi_version": [],

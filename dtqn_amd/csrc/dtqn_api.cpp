@@ -71,10 +71,18 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
     return dtqn_td_clip_adam(net, td, stream);
 }
 
-// The same behind a forward that was launched in parts (dtqn_td_forward_part): loss + backward, weight gradients, reduce, clip + Adam.
-extern "C" int dtqn_td_update_tail(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+// The pipelined form of the same update (latency mode, dtqn_td_fwd_slices4_ok): the two policy passes as four row slices, the
+// target pass inline unless the previous update's backward launch already carried it (have_target), the backward launch carrying the
+// NEXT update's target pass when td_next is given, weight gradients, reduce, clip + Adam.  draw_step: the optimizer step this
+// update carries (key of its window draw); the next update's is draw_step + 1.
+extern "C" int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
+                                        int draw_step, void* stream) {
     int rc;
-    if ((rc = dtqn_td_backward(net, rp, td, stream)) != DTQN_OK) return rc;
+    if (draw_step < 0) return DTQN_ERR_ARG;
+    if ((rc = dtqn_td_forward_part(net, rp, td, 0, 2, 4, draw_step, stream)) != DTQN_OK) return rc;
+    if (!have_target && (rc = dtqn_td_forward_part(net, rp, td, 2, 1, 4, draw_step, stream)) != DTQN_OK) return rc;
+    rc = td_next != nullptr ? dtqn_td_backward_ahead(net, rp, td, td_next, draw_step + 1, stream) : dtqn_td_backward(net, rp, td, stream);
+    if (rc != DTQN_OK) return rc;
     if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
     if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;
     return dtqn_td_clip_adam(net, td, stream);

@@ -10,6 +10,7 @@
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
 #include "dtqn_wgrad_direct.hpp"
+#include "dtqn_forward_body.hpp"      // AHEAD: the next update's target pass rides in this launch (forward_body_wl)
 
 #ifndef DTQN_SPLIT_ATTN_MFMA
 #define DTQN_SPLIT_ATTN_MFMA 1
@@ -72,9 +73,23 @@ struct BwdArgs {
 // FUSE: the launch carries a.fuse.n_role extra workgroups behind the batch * RS of the data-gradient chain; they compute the weight
 // gradients (dtqn_wgrad_direct.hpp), layer by layer as the chain publishes its gradient records: every record store of the chain is
 // then a write-through (sc1) store, and the chain counts itself in at an event once a layer's stores are acknowledged.
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false>
-__global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a) {
+// AHEAD: the launch carries 4 * batch more workgroups behind the batch * RS of the data-gradient chain: the TARGET pass of the NEXT
+// update (forward_body_wl, four 16-row slices per sequence; dtqn_td_backward_ahead).  It depends on nothing this update computes,
+// the chain leaves half the compute units idle at batch 32, and riding in the same launch it needs no second stream, no event and no
+// launch of its own: its Q rows are simply there when the next update's loss stage wants them.
+template <bool AHEAD> struct AheadArgs {};
+template <> struct AheadArgs<true> { FwdArgs f; };
+
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false, bool AHEAD = false>
+__global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, AheadArgs<AHEAD> ahead) {
     static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
+    if constexpr (AHEAD) {
+        static_assert(RS == 4 && MT == 1 && !GRU && !DROP && !FUSE && D <= 64, "the target pass ahead rides with the four-slice residual-gate chain");
+        if ((int)blockIdx.x >= a.batch * RS) {
+            forward_body_wl<D, 1, HD, NW, 4, false>(ahead.f);
+            return;
+        }
+    }
     constexpr int NT = NW * 64;
     constexpr int LP = MT * 16;                   // rows this workgroup owns
     constexpr int LPF = LP * RS;                  // padded rows of the whole sequence (= net.lp)
@@ -680,7 +695,22 @@ static int launch_bwd3(const BwdArgs& a, hipStream_t stream) {
     raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP, FUSE>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     const int grid = a.batch * RS + (FUSE ? a.fuse.n_role : 0);
-    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP, FUSE>), dim3(grid), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_backward_kernel<D, MT, HD, NW, GRU, RS, DROP, FUSE>), dim3(grid), dim3(NW * 64), lds, stream, a, AheadArgs<false>{});
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+// the chain of this update + the target pass of the next one (four slices per sequence each: 8 * batch workgroups)
+template <int HD>
+static int launch_bwd_ahead(const BwdArgs& a, const FwdArgs& f, hipStream_t stream) {
+    const size_t lb = bwd_lds_bytes(&a.net), lf = fwd_lds_bytes(&a.net, true);
+    const size_t lds = lb > lf ? lb : lf;
+    if (lds > 160 * 1024) return DTQN_ERR_CONFIG;
+    static size_t attr_lds[kMaxDevices] = {};
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true>), lds, attr_lds);
+    (void)hipGetLastError();
+    AheadArgs<true> ah;
+    ah.f = f;
+    ah.f.block0 = a.batch * 4;
+    hipLaunchKernelGGL((dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true>), dim3(a.batch * 4 + f.batch * 4), dim3(8 * 64), lds, stream, a, ah);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
@@ -723,10 +753,22 @@ extern "C" int dtqn_td_wgrad_is_fused(const DtqnNet* net, const DtqnTd* td) {
     return fuse_plan(net, td, &f) ? 1 : 0;
 }
 
+static int td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int draw_step_next, void* stream);
+
 extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream) {
+    return td_backward(net, rp, td, nullptr, -1, stream);
+}
+
+extern "C" int dtqn_td_backward_ahead(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int draw_step_next,
+                                      void* stream) {
+    if (!td_next || draw_step_next < 0) return DTQN_ERR_ARG;
+    return td_backward(net, rp, td, td_next, draw_step_next, stream);
+}
+
+static int td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int draw_step_next, void* stream) {
     if (!net || !rp || !td || td->batch < 1) return DTQN_ERR_ARG;
     if (td->history < 1 || td->history > net->ctx_len) return DTQN_ERR_ARG;
-    if (net->tiled) return tiled_td_backward(net, rp, td, (hipStream_t)stream);
+    if (net->tiled) return td_next ? DTQN_ERR_CONFIG : tiled_td_backward(net, rp, td, (hipStream_t)stream);
     if (bwd_lds_bytes(net) > 160 * 1024) return DTQN_ERR_CONFIG;
     BwdArgs a;
     a.net = *net;
@@ -756,6 +798,17 @@ extern "C" int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const 
             }
             if (D == 64 && HD == 8) return launch_bwd2<64, 2, 8, 8, true, 2>(a, s);
             if (D == 64 && HD == 16) return launch_bwd2<64, 2, 16, 8, true, 2>(a, s);
+            return DTQN_ERR_CONFIG;
+        }
+        if (td_next != nullptr) {      // + the next update's target pass in the same launch
+            if (td->row_split != 4 || net->gate != DTQN_GATE_RES || a.drop_thresh != 0u || a.fuse.n_role > 0 || !dtqn_td_fwd_slices4_ok(net) ||
+                !td_next->sample_in_kernel || td_next->batch != td->batch || !td_next->xch || !td_next->xflags || !td_next->q3 || NW != 8)
+                return DTQN_ERR_CONFIG;
+            FwdArgs f;
+            td_forward_args(net, rp, td_next, 2, draw_step_next, &f);
+            f.prof = nullptr;
+            if (D == 64 && HD == 8) return launch_bwd_ahead<8>(a, f, s);
+            if (D == 64 && HD == 16) return launch_bwd_ahead<16>(a, f, s);
             return DTQN_ERR_CONFIG;
         }
         if (td->row_split == 4) {

@@ -99,7 +99,7 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.obs_ep_stride = (long long)in_rows * net->obs_dim;
     a.act_ep_stride = in_rows;
     a.ep_idx = nullptr; a.start = nullptr;
-    a.n = n; a.batch = batch; a.pass0 = 0; a.draw_step = -1;
+    a.n = n; a.batch = batch; a.block0 = 0; a.pass0 = 0; a.draw_step = -1;
     a.q_out = q_out;
     a.q_which_stride = 0;
     a.q_seq_stride = (long long)n * net->num_actions;
@@ -113,13 +113,45 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.prof = nullptr;
     // dropout in a train-mode actor forward (the reference's policy network stays in train mode during rollouts)
     set_dropout(a, net, train_mode ? 1 : 0, drop_seed, drop_step);
-    if (xch != nullptr && xflags != nullptr) return dispatch_fwd(a, batch, 2, (hipStream_t)stream);
+    if (xch != nullptr && xflags != nullptr) {
+        // latency mode of the actor: four 16-row workgroups per sequence where that body exists and all of them are resident at
+        // once (one forward of 50 rows: 38 -> 29 us per launch of the stage chain), else two 32-row ones
+        const bool four = batch * 4 <= 256 && dtqn_td_fwd_slices4_ok(net) != 0 && a.drop_thresh == 0u;
+        return dispatch_fwd(a, batch, four ? 4 : 2, (hipStream_t)stream);
+    }
     // short prefix of a 64-row context: 16- or 32-row instantiation (same kernel, fewer row tiles), else the full tile
     if (net->lp == 64 && n <= 32 && net->gate == DTQN_GATE_RES) {
         const int rc = dispatch_fwd(a, batch, 1, (hipStream_t)stream, n <= 16 ? 1 : 2);
         if (rc != DTQN_ERR_CONFIG) return rc;
     }
     return dispatch_fwd(a, batch, 1, (hipStream_t)stream);
+}
+
+// FwdArgs of a TD-update forward (all passes or a part of them); shared with the backward launch that carries the NEXT update's
+// target pass (dtqn_backward.hip, dtqn_td_backward_ahead)
+void dtqn::td_forward_args(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int draw_step, FwdArgs* out) {
+    FwdArgs& a = *out;
+    const bool draw = td->sample_in_kernel != 0;
+    a.net = *net;
+    a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;
+    a.obs = rp->obs; a.actions = rp->actions;
+    a.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim;
+    a.act_ep_stride = rp->max_steps + 1;
+    a.ep_idx = td->ep_idx; a.start = td->start;
+    a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
+    a.ep_out = td->ep_idx; a.start_out = td->start;
+    a.s_n_valid = td->sample_n_valid; a.s_exclude = td->sample_exclude; a.s_seed = td->sample_seed;
+    a.n = net->ctx_len; a.batch = td->batch; a.block0 = 0; a.pass0 = pass0; a.draw_step = draw_step;
+    a.q_out = td->q3;
+    a.q_which_stride = (long long)td->batch * net->lp * net->ap;
+    a.q_seq_stride = (long long)net->lp * net->ap;
+    a.q_row_stride = net->ap;
+    a.q_last_host = nullptr;
+    a.last_rows = nullptr;
+    a.act = td->act;
+    a.xch = td->xch; a.xflags = td->xflags;
+    a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
+    set_dropout(a, net, 0x3, td->dropout_seed, 0u);       // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230)
 }
 
 // pass0 / npasses: the passes this launch covers (0 policy(o), 1 policy(o'), 2 target(o')); slices: workgroups per sequence (0 = the
@@ -153,26 +185,7 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     }
     if (!whole && !draw) return DTQN_ERR_ARG;      // a partial launch re-derives its windows from the counter-based draw
     FwdArgs a;
-    a.net = *net;
-    a.theta_a = td->theta_pol; a.theta_b = td->theta_tgt;
-    a.obs = rp->obs; a.actions = rp->actions;
-    a.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim;
-    a.act_ep_stride = rp->max_steps + 1;
-    a.ep_idx = td->ep_idx; a.start = td->start;
-    a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
-    a.ep_out = td->ep_idx; a.start_out = td->start;
-    a.s_n_valid = td->sample_n_valid; a.s_exclude = td->sample_exclude; a.s_seed = td->sample_seed;
-    a.n = net->ctx_len; a.batch = td->batch; a.pass0 = pass0; a.draw_step = draw_step;
-    a.q_out = td->q3;
-    a.q_which_stride = (long long)td->batch * net->lp * net->ap;
-    a.q_seq_stride = (long long)net->lp * net->ap;
-    a.q_row_stride = net->ap;
-    a.q_last_host = nullptr;
-    a.last_rows = nullptr;
-    a.act = td->act;
-    a.xch = td->xch; a.xflags = td->xflags;
-    a.prof = static_cast<long long*>(dtqn_debug_profile_buffer());
-    set_dropout(a, net, 0x3, td->dropout_seed, 0u);       // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230)
+    td_forward_args(net, rp, td, pass0, draw_step, &a);
     if (slices <= 0) {
         slices = td->row_split >= 2 ? 2 : 1;               // the whole-update launch: two slices in latency mode ...
         const char* e = getenv("DTQN_FWD_SLICES");         // ... DTQN_FWD_SLICES=4: four (A/B knob; 3 B 4 workgroups do not fit the chip at once)

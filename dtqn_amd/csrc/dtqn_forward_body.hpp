@@ -29,6 +29,8 @@ struct FwdArgs {
     const int32_t* start;
     int n;                      // real sequence length (<= ctx_len)
     int batch;                  // sequences per `which`
+    int block0;                 // first workgroup of this forward inside its launch (> 0: the passes ride behind another kernel's workgroups,
+                                // dtqn_backward.hip AHEAD)
     int pass0;                  // first pass of this launch: which = pass0 + sequence / batch (TD update: 0 policy(o), 1 policy(o'), 2 target(o'))
     int draw_step;              // >= 0: the window draw is keyed by this optimizer step instead of step_counter[1] (a pass launched ahead
                                 // of its update, dtqn_td_forward_part)
@@ -449,7 +451,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     static_assert(PSN / 4 <= NT, "one float4 of the parameter block per thread");
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
-    const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;
+    const int bid = (int)blockIdx.x - a.block0;
+    const int seq = bid / RS, slice = bid - seq * RS;
     const int R0 = slice * LP;
     const int which = a.pass0 + seq / a.batch;
     const int b = seq - (which - a.pass0) * a.batch;
@@ -803,6 +806,9 @@ int launch_fwd(const FwdArgs& a, int nseq, hipStream_t stream) {
     return launch_fwd2<D, MT, HD, NW, false, 1>(a, nseq, stream);
 }
 
+
+// FwdArgs of a TD-update forward, passes [pass0 ..) (defined in dtqn_forward.hip)
+void td_forward_args(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int draw_step, FwdArgs* out);
 
 // The instantiations are spread over several translation units (dtqn_forward_inst*.hip) so that they compile in
 // parallel; the dispatcher (dtqn_forward.hip) only sees these declarations.

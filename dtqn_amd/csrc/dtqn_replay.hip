@@ -22,18 +22,31 @@ struct ApplyArgs {
 // observation rows read straight from the staging.  256 records of an env-step stream: 211 -> ~15 us.
 __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyArgs a) {
     constexpr int CH = 256;
+    constexpr int OBS_LDS = 4096;                         // floats: the chunk's observation rows ride along when they fit (vector observations)
     __shared__ DtqnReplayRecord recs[CH];
+    __shared__ float obs_l[OBS_LDS];
     static_assert(sizeof(DtqnReplayRecord) == 32, "eight dwords per record");
     const int tid = (int)threadIdx.x;
     const int T = a.rp.max_steps, O = a.rp.obs_dim;
+    // Records carry obs_index = their position in the staging (ReplayBuffer._push), so a chunk's rows are the contiguous block
+    // [c0, c0 + m) of obs_rows: pulled in the SAME pass as the records -- one PCIe round trip for the chunk instead of one for the
+    // records, one for a store_obs row and one for the rows of every run of stores.
+    const bool rows_in_lds = a.rp.obs_u8 == nullptr && CH * O <= OBS_LDS;
     for (int c0 = 0; c0 < a.n; c0 += CH) {
         const int m = a.n - c0 < CH ? a.n - c0 : CH;
         {
             const int32_t* src = reinterpret_cast<const int32_t*>(a.recs + c0);
             int32_t* dst = reinterpret_cast<int32_t*>(recs);
             for (int k = tid; k < m * 8; k += DTQN_THREADS) dst[k] = src[k];
+            if (rows_in_lds)
+                for (int k = tid; k < m * O; k += DTQN_THREADS) obs_l[k] = a.obs_rows[(size_t)c0 * O + k];
         }
         __syncthreads();
+        // (a row outside the chunk's block -- a producer that numbers its rows differently -- is read from the staging as before)
+        auto row = [&](int obs_index, int k) -> float {
+            const int rel = obs_index - c0;
+            return rows_in_lds && rel >= 0 && rel < m ? obs_l[rel * O + k] : a.obs_rows[(size_t)obs_index * O + k];
+        };
         int i = 0;
         while (i < m) {                                   // uniform control flow: every thread walks the same LDS records
             const DtqnReplayRecord r = recs[i];
@@ -44,13 +57,12 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 uint8_t* act = a.rp.actions + (size_t)ep * (T + 1);
                 float* rew = a.rp.rewards + (size_t)ep * T;
                 uint8_t* don = a.rp.dones + (size_t)ep * T;
-                const float* src = a.obs_rows + (size_t)r.obs_index * O;
                 if (a.rp.obs_u8 != nullptr) {      // image observations: uint8 rows (replay_buffer.py:36-45), staged as bytes
                     uint8_t* o8 = a.rp.obs_u8 + (size_t)ep * (T + 1) * O;
                     const uint8_t* s8 = reinterpret_cast<const uint8_t*>(a.obs_rows) + (size_t)r.obs_index * O;
                     for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) o8[k] = k < O ? s8[k] : (uint8_t)a.rp.obs_mask;
                 } else
-                for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? src[k] : a.rp.obs_mask;
+                for (int k = tid; k < (T + 1) * O; k += DTQN_THREADS) obs[k] = k < O ? row(r.obs_index, k) : a.rp.obs_mask;
                 for (int k = tid; k < T + 1; k += DTQN_THREADS) act[k] = 0;
                 for (int k = tid; k < T; k += DTQN_THREADS) { rew[k] = 0.f; don[k] = 1; }
                 if (tid == 0) a.rp.ep_len[ep] = 0;
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
             for (int q = tid; q < cnt * O; q += DTQN_THREADS) {
                 const int ri = i + q / O, k = q - (q / O) * O;
                 const DtqnReplayRecord s = recs[ri];
-                a.rp.obs[((size_t)s.ep * (T + 1) + (s.t + 1)) * O + k] = a.obs_rows[(size_t)s.obs_index * O + k];
+                a.rp.obs[((size_t)s.ep * (T + 1) + (s.t + 1)) * O + k] = row(s.obs_index, k);
             }
             for (int ri = i + tid; ri < j; ri += DTQN_THREADS) {
                 const DtqnReplayRecord s = recs[ri];
@@ -82,10 +94,12 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 a.rp.dones[(size_t)s.ep * T + s.t] = s.done ? 1 : 0;
                 // episode length: the LAST store of that slot inside the run wins (the serial order of replay_buffer.py:71-86),
                 // also when a producer interleaves the stores of two slots
-                bool last = true;
-                for (int rj = ri + 1; rj < j; ++rj)
-                    if (recs[rj].ep == s.ep) { last = false; break; }
-                if (last) a.rp.ep_len[s.ep] = s.ep_len;
+                if (ri + 1 >= j || recs[ri + 1].ep != s.ep) {         // end of a stretch of one slot's stores (the common producer: one stretch)
+                    bool last = true;
+                    for (int rj = ri + 2; rj < j; ++rj)
+                        if (recs[rj].ep == s.ep) { last = false; break; }
+                    if (last) a.rp.ep_len[s.ep] = s.ep_len;
+                }
             }
             __syncthreads();
             i = j;

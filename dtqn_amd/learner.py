@@ -285,85 +285,87 @@ class TdEngine:
                                                 _p(self.ep_idx), _p(self.start), stream if stream is not None else self._stream()),
                     "dtqn_replay_sample")
 
-    # -- pipelined forward (latency mode; include/dtqn_hip.h, dtqn_td_forward_part) ---------------------------------------------
+    # -- pipelined update (latency mode; include/dtqn_hip.h: dtqn_td_forward_part, dtqn_td_backward_ahead) -------------------------
     # At batch 32 the forward is bound by the length of one workgroup's stage chain, and 3 B 2 = 192 workgroups leave a quarter of
     # the chip idle.  The target pass of update k + 1 depends on nothing update k computes (theta_tgt only moves at a hard sync, the
-    # window draw is a pure function of (seed, step, episode lengths)), so it is launched AHEAD on a second stream, where it runs
-    # beside update k's backward (128 workgroups on 256 compute units); the forward of update k + 1 is then the two policy passes as
-    # 2 B 4 = 256 workgroups of 16 rows -- every compute unit busy, half the rows per workgroup: 45.6 -> 34.1 us per launch.  A
-    # pass launched ahead is only USED if what it read is still what the update would read: same (n_valid, exclude, seed), same
-    # draw step, no replay write and no target sync since; otherwise the target pass runs inline (same kernel, same slices: the
-    # numbers do not depend on which way it went).
+    # window draw is a pure function of (seed, step, episode lengths)), so update k's BACKWARD LAUNCH carries it as 4 B extra
+    # workgroups next to its own 4 B (the chain leaves half the compute units idle), and the forward of update k + 1 is the two
+    # policy passes as 2 B 4 = 256 workgroups of 16 rows -- every compute unit busy, half the rows per workgroup: 41.8 -> 30.1 us
+    # per launch (rocprofv3), the backward launch unchanged.  (First built with the pass on a second stream: the two event operations
+    # that needs on the update's stream cost 11.6 us per update -- more than the gain.)  A pass computed ahead is only USED if what it
+    # read is still what the update would read: same (n_valid, exclude, seed), same draw step, no replay write and no target sync
+    # since; otherwise the target pass runs inline (same kernel, same slices: the numbers do not depend on which way it went).
     def enable_pipeline(self, replay_version=lambda: 0) -> bool:
-        """Switch the forward stage to {target pass ahead on a side stream, policy passes as four row slices}.  Returns False
-        (and changes nothing) where the shape is not covered.  `replay_version`: callable that changes whenever the replay arrays are
-        written (ReplayBuffer.version)."""
+        """Switch the update to {policy passes as four row slices, next update's target pass inside the backward launch}.  Returns
+        False (and changes nothing) where the shape is not covered.  `replay_version`: callable that changes whenever the replay arrays
+        are written (ReplayBuffer.version)."""
         import os
         if (self.device.type != "cuda" or self.net.tiled or self.net.bag_size > 0 or self.img is not None or self.row_split != 4
-                or not self.lib.dtqn_td_fwd_slices4_ok(self._net_ref) or os.environ.get("DTQN_PIPELINE", "1") == "0"):
+                or self.wgrad_fused or not self.lib.dtqn_td_fwd_slices4_ok(self._net_ref) or os.environ.get("DTQN_PIPELINE", "1") == "0"):
             return False
-        dev, Bn, net = self.device, self.batch, self.net
         self._qbuf = [self.q3, torch.zeros_like(self.q3)]
-        side = B.DtqnTd()
-        ctypes.memmove(ctypes.byref(side), ctypes.byref(self.td), ctypes.sizeof(B.DtqnTd))
-        self._side_xch = torch.zeros_like(self.xch)
-        self._side_xflags = torch.zeros_like(self.xflags)
-        side.xch, side.xflags = self._side_xch.data_ptr(), self._side_xflags.data_ptr()
-        self._pipe = dict(side=side, side_ref=ctypes.byref(side), stream=torch.cuda.Stream(dev), ev_fwd=torch.cuda.Event(), ev_side=torch.cuda.Event(),
-                          ahead=None, steps=int(self.step_counter[1].item()), tgt_version=0, replay_version=replay_version,
+        nxt = B.DtqnTd()
+        ctypes.memmove(ctypes.byref(nxt), ctypes.byref(self.td), ctypes.sizeof(B.DtqnTd))
+        # the pass ahead runs WHILE the chain of the current update uses td.xch / td.xflags: it gets its own
+        self._next_xch = torch.zeros_like(self.xch)
+        self._next_xflags = torch.zeros_like(self.xflags)
+        nxt.xch, nxt.xflags = self._next_xch.data_ptr(), self._next_xflags.data_ptr()
+        self._pipe = dict(nxt=nxt, nxt_ref=ctypes.byref(nxt), ahead=None, steps=int(self.step_counter[1].item()), tgt_version=0,
+                          replay_version=replay_version,
                           launch_ahead=os.environ.get("DTQN_PIPELINE", "1") != "inline",     # inline: same kernels, target pass never ahead (A/B, tests)
                           used=0, inline=0)
-        self._pipe["stream_ptr"] = ctypes.c_void_p(self._pipe["stream"].cuda_stream)
         return True
 
     def pipeline_reset(self) -> None:
-        """The optimizer state was replaced (checkpoint load): re-read the step count, drop what was launched ahead."""
+        """The optimizer state was replaced (checkpoint load) or stepped behind this object's back: re-read the step count, drop
+        what was computed ahead."""
         if getattr(self, "_pipe", None) is not None:
             torch.cuda.synchronize(self.device)
             self._pipe.update(ahead=None, steps=int(self.step_counter[1].item()))
 
-    def _main_torch_stream(self):
-        return self._bound_torch_stream if self._bound_torch_stream is not None else torch.cuda.current_stream(self.device)
-
-    def _forward_stage(self, replay: DeviceReplay, s) -> None:
-        """The three forwards of this update.  Pipelined: policy passes now (four slices), target pass taken from the launch ahead
-        or run inline; then the target pass of the NEXT update goes onto the side stream."""
-        pipe = getattr(self, "_pipe", None)
-        td = self.td
-        if pipe is None or not td.sample_in_kernel:
-            self._check(self.lib.dtqn_td_forward(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_forward")
-            return
-        lib, n, r, t = self.lib, self._net_ref, replay.view_ref, self._td_ref
-        main = self._main_torch_stream()
+    def _pipe_begin(self, replay: DeviceReplay):
+        """(draw step d, have_target, td_next reference or None) of the update about to be launched; books the pass it launches."""
+        pipe, td = self._pipe, self.td
         d = pipe["steps"]                                  # step_counter[1] when this update's kernels run: the key of its draw
         key = (d, td.sample_n_valid, td.sample_exclude, td.sample_seed, pipe["replay_version"](), pipe["tgt_version"], replay.view.obs)
         td.q3 = self._qbuf[d & 1].data_ptr()
         self.q3 = self._qbuf[d & 1]
-        ahead, pipe["ahead"] = pipe["ahead"], None
-        # every pass of an update is keyed by the same explicit step: the three draws agree whatever the device counter holds
-        self._check(lib.dtqn_td_forward_part(n, r, t, 0, 2, 4, d, s), "dtqn_td_forward_part")
-        if ahead is not None:
-            main.wait_event(pipe["ev_side"])               # the pass launched ahead has left the buffers (used or not): it ran beside
-        if ahead != key:                                   # the previous backward, so this wait is over before it is reached
-            self._check(lib.dtqn_td_forward_part(n, r, t, 2, 1, 4, d, s), "dtqn_td_forward_part")
-            pipe["inline"] += 1
-        else:
-            pipe["used"] += 1
-        if not pipe["launch_ahead"]:
-            return
-        pipe["ev_fwd"].record(main)
+        have = pipe["ahead"] == key
+        pipe["used" if have else "inline"] += 1
+        pipe["ahead"] = None
         # ahead for the next update: not across a hard target sync (the optimizer launch of THIS update writes theta_tgt then)
         tuf = td.target_update_frequency
         if tuf > 0 and (d + 1) % tuf == 0:
             pipe["tgt_version"] += 1
-            return
-        side, st = pipe["side"], pipe["stream"]
-        side.sample_in_kernel, side.sample_n_valid, side.sample_exclude, side.sample_seed = 1, td.sample_n_valid, td.sample_exclude, td.sample_seed
-        side.q3 = self._qbuf[(d + 1) & 1].data_ptr()
-        st.wait_event(pipe["ev_fwd"])                      # beside this update's backward; the buffer's last reader (backward d - 1) is long gone
-        self._check(lib.dtqn_td_forward_part(n, r, pipe["side_ref"], 2, 1, 4, d + 1, pipe["stream_ptr"]), "dtqn_td_forward_part")
-        pipe["ev_side"].record(st)
+            return d, have, None
+        if not pipe["launch_ahead"]:
+            return d, have, None
+        nxt = pipe["nxt"]
+        nxt.sample_in_kernel, nxt.sample_n_valid, nxt.sample_exclude, nxt.sample_seed = 1, td.sample_n_valid, td.sample_exclude, td.sample_seed
+        nxt.q3 = self._qbuf[(d + 1) & 1].data_ptr()        # its last reader, the backward of update d - 1, is behind us on the stream
         pipe["ahead"] = (d + 1,) + key[1:]
+        return d, have, pipe["nxt_ref"]
+
+    def _forward_stage(self, replay: DeviceReplay, s) -> None:
+        """The three forwards of this update (staged callers: data parallel, overlapped actor)."""
+        if getattr(self, "_pipe", None) is None or not self.td.sample_in_kernel:
+            self._pipe_next = None
+            self._check(self.lib.dtqn_td_forward(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_forward")
+            return
+        lib, n, r, t = self.lib, self._net_ref, replay.view_ref, self._td_ref
+        d, have, nxt = self._pipe_begin(replay)
+        # every pass of an update is keyed by the same explicit step: the three draws agree whatever the device counter holds
+        self._check(lib.dtqn_td_forward_part(n, r, t, 0, 2, 4, d, s), "dtqn_td_forward_part")
+        if not have:
+            self._check(lib.dtqn_td_forward_part(n, r, t, 2, 1, 4, d, s), "dtqn_td_forward_part")
+        self._pipe_next = (nxt, d + 1)
+
+    def _backward_stage(self, replay: DeviceReplay, s) -> None:
+        nxt = getattr(self, "_pipe_next", None)
+        if nxt is not None and nxt[0] is not None:
+            self._check(self.lib.dtqn_td_backward_ahead(self._net_ref, replay.view_ref, self._td_ref, nxt[0], nxt[1], s), "dtqn_td_backward_ahead")
+        else:
+            self._check(self.lib.dtqn_td_backward(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_backward")
 
     # -- the update, whole or in stages (stages are what the data-parallel wrapper interleaves) --
     def update(self, replay: DeviceReplay, stream=None):
@@ -373,8 +375,9 @@ class TdEngine:
             return
         s = stream if stream is not None else self._stream()
         if getattr(self, "_pipe", None) is not None and self.td.sample_in_kernel:
-            self._forward_stage(replay, s)
-            self._check(self.lib.dtqn_td_update_tail(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_update_tail")
+            d, have, nxt = self._pipe_begin(replay)
+            self._check(self.lib.dtqn_td_update_pipelined(self._net_ref, replay.view_ref, self._td_ref, nxt, 1 if have else 0, d, s),
+                        "dtqn_td_update_pipelined")
             self._pipe["steps"] += 1
             return
         self._check(self.lib.dtqn_td_update(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_update")
@@ -409,7 +412,7 @@ class TdEngine:
         if self.img is not None:
             self._img_encode_windows(replay, s)
         self._forward_stage(replay, s)
-        self._check(self.lib.dtqn_td_backward(n, r, t, s), "dtqn_td_backward")
+        self._backward_stage(replay, s)
         if self.img is not None:
             self._img_backward(replay, s)
         self._check(self.lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad")

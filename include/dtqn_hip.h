@@ -365,16 +365,25 @@ int dtqn_td_xch_flags(const DtqnNet* net, int batch);
 int dtqn_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* A PART of the same launch (whole-sequence kernels, td->sample_in_kernel == 1): passes [pass0, pass0 + npasses) of
  * {0 policy(o), 1 policy(o'), 2 target(o')} with `slices` workgroups per sequence (1, 2, or 4 where dtqn_td_fwd_slices4_ok).
- * The target pass of update k + 1 depends on nothing update k produces (theta_tgt only moves at a hard sync), so a caller may
- * launch it AHEAD on a second stream while update k's backward leaves half the chip idle -- with its own q3 / xch / xflags in
- * `td` and draw_step = the optimizer step update k + 1 will carry (>= 0; -1 = read step_counter[1]) -- and run passes 0 - 1 of
- * update k + 1 as 2 B 4 = 256 workgroups of 16 rows: every compute unit busy, half the rows per workgroup.  Same dtqn.py:215-230. */
+ * The target pass of update k + 1 depends on nothing update k produces (theta_tgt only moves at a hard sync), so it can run AHEAD,
+ * beside update k's backward, which leaves half the chip idle (dtqn_td_backward_ahead carries it in the same launch) -- and passes
+ * 0 - 1 of update k + 1 then run as 2 B 4 = 256 workgroups of 16 rows: every compute unit busy, half the rows per workgroup.
+ * draw_step >= 0: key of the in-kernel window draw (the optimizer step the update carries); -1 = read step_counter[1].
+ * Same dtqn.py:215-230. */
 int dtqn_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, int slices, int draw_step,
                          void* stream);
 int dtqn_td_fwd_slices4_ok(const DtqnNet* net);
 /* Double-DQN target, MSE, dL/dQ (dtqn.py:219-243) and the data-gradient chain of loss.backward()
  * (dtqn.py:256).  Writes the grd / small records and stats_partial. */
 int dtqn_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* dtqn_td_backward whose launch also carries the TARGET pass of the NEXT update (dtqn.py:230 of update k + 1) as 4 * batch more
+ * workgroups: that pass depends on nothing update k computes, and the chain of dtqn_td_backward leaves half the compute units idle at
+ * batch 32.  td_next: a DtqnTd whose q3 (where the pass leaves Q_tgt(o')), xch / xflags (its own hand-over buffers: the chain uses
+ * td's at the same time) and sample_* fields describe update k + 1; draw_step_next: the optimizer step update k + 1 will carry.  The
+ * caller runs update k + 1 as dtqn_td_forward_part(.., 0, 2, 4, draw_step_next, ..) + this function again, and uses the pass only if
+ * nothing it read has changed since (replay writes, sampling range, hard target sync); otherwise dtqn_td_forward_part(.., 2, 1, 4, ..)
+ * recomputes it.  Covered where dtqn_td_fwd_slices4_ok(net) and td->row_split == 4; DTQN_ERR_CONFIG elsewhere. */
+int dtqn_td_backward_ahead(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int draw_step_next, void* stream);
 /* Weight gradients (the parameter half of loss.backward(), dtqn.py:256): token-contraction GEMMs over act x grd.
  * Large batches: split over the batch into gsplit, summed by dtqn_td_reduce.  Small batches
  * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
@@ -419,8 +428,11 @@ int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_
                     int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream);
 /* Convenience: forward, backward, wgrad, reduce, clip_adam back to back (single GPU). */
 int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
-/* dtqn_td_update without its forward (launched in parts by the caller, dtqn_td_forward_part): backward, wgrad, reduce, clip_adam. */
-int dtqn_td_update_tail(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
+/* dtqn_td_update in its pipelined form (latency mode; dtqn_td_forward_part, dtqn_td_backward_ahead): policy passes as four row
+ * slices, target pass inline unless have_target (the previous call's backward launch carried it into td->q3), the backward launch
+ * carrying update k + 1's target pass when td_next != NULL, wgrad, reduce, clip_adam.  draw_step = optimizer steps taken so far. */
+int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
+                             int draw_step, void* stream);
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
 int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
 
