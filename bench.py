@@ -71,8 +71,9 @@ class SyntheticEnv:
         self.action_space = spaces.Discrete(c["A"])
         self._max_episode_steps = c["T"]
 
-    def reset(self):          # image envs: get_env_obs_length reads the observation's shape off a reset (utils/env_processing.py:86-87)
-        return np.zeros(self._shape, dtype=np.uint8)
+    def reset(self):          # get_agent probes a sample observation like the reference does (utils/env_processing.py:63-66, 86-87)
+        shape = getattr(self, "_shape", None)
+        return np.zeros(shape, dtype=np.uint8) if shape is not None else np.zeros(getattr(self.observation_space, "shape", None) or (1,))
 
 
 def f_tok(c):
@@ -604,6 +605,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's; BASELINE.json metric: 32)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 2-5")
     ap.add_argument("--sampler", default="device", choices=["device", "reference"])
+    ap.add_argument("--prewarm", type=int, default=3000, help="untimed updates on a scratch learner before the W warm-up steps (clock ramp, code loading)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-rate", action="store_true", help="skip the live env-steps/s loops (cleaner rocprofv3 traces)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
@@ -621,8 +623,24 @@ def main():
     if args.batch is None:
         args.batch = c["B"]
     agent = make_agent(c, args.batch, device, rank, args.sampler)
+    # Device pre-warm, untimed and on a scratch learner of the same shape: a fresh box idles at low clocks and loads every code object
+    # on first use; W warm-up steps of 0.1 ms each are over before either has settled.  The measured agent still takes its W steps.
+    if args.prewarm > 0:
+        scratch = make_agent(c, args.batch, device, rank, args.sampler, data_parallel=False)
+        for _ in range(args.prewarm):
+            scratch.train()
+        torch.cuda.synchronize()
+        scratch._drain_stats(block=True)
+        del scratch
+
+    done_ev = torch.cuda.Event()
 
     def sync_all():
+        # a blocking synchronise wakes the host tens of microseconds after the GPU went idle -- a visible share of a 20-step (2 ms) timed
+        # region; polling an event first makes the synchronise below return as soon as the last kernel has retired
+        done_ev.record(torch.cuda.current_stream(device))
+        while not done_ev.query():
+            pass
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -707,7 +725,7 @@ def main():
             "metric": "env-steps/sec + TD-updates/sec, DiscreteCarFlag-v0 ctx=50 b=32, 1/2/4/8 GPU",
             "value": ups, "unit": "TD-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic replay (SURVEY.md 8d shapes), random-init weights",
+            "data": "synthetic replay (SURVEY.md 8d shapes), random-init weights", "prewarm_updates": args.prewarm,
             "config": {"workload": f"{c['name']} shapes (BASELINE config {args.config}): ctx={c['L']}, d_model={c['D']}, {c['H']} heads, "
                                    f"{c['NL']} layers, obs {c['O']} {'f32' if c['kind'] == 'box' else 'tokens'}, {c['A']} actions, "
                                    f"batch {args.batch} per GPU, history {c['L']}, device replay {500_000 // c['T']} x {c['T']} steps",

@@ -128,7 +128,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_img_td_lists": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp, vp, vp, vp, vp, vp, vp],
         "dtqn_forward_tiled_pre": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, i32, u32, u32, vp],
         "dtqn_xch_publish": [vp, i32, vp],
-        "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp],
+        "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp, vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_update_pipelined": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, i32, vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],

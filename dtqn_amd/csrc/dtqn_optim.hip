@@ -95,6 +95,7 @@ struct XreduceArgs {
     int n, n_parts, world;
     int32_t gen;
     long long timeout_ticks;       // bounded wait, in ticks of the 100 MHz wall clock
+    int32_t* own_flag;             // this rank's flag word: raised to `gen` by the launch itself (NULL: dtqn_xch_publish did it)
 };
 // Block b owns parameters [1024 b, 1024 b + 1024): wait for the `world` flag words, then one pass over the `world` buffers in rank
 // order.  Peer buffers are read with system-scope loads (they were written by another GPU / process: nothing of them may come
@@ -104,6 +105,9 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_xreduce_kernel(XreduceArgs a
     const int tid = (int)threadIdx.x;
     if (blockIdx.x == 0)
         for (int i = (int)gridDim.x + tid; i < a.n_parts; i += kOptThreads) a.norm_partial[i] = 0.f;
+    // publish: the kernel boundary in front of THIS launch has made the rank's gradient visible; the first thing the launch does
+    // is say so (every rank does, before it waits for anybody: no cycle) -- the one-thread publish launch of round 3 is gone
+    if (a.own_flag != nullptr && blockIdx.x == 0 && tid == 0) DTQN_SYSTEM_STORE(a.own_flag, a.gen);
     if (tid < a.world) {
         const int32_t* f = a.peer_flag[tid];
         const long long t0 = wall_clock64();
@@ -303,7 +307,7 @@ extern "C" int dtqn_xch_publish(int32_t* own_flag_dev, int32_t gen, void* stream
 }
 
 extern "C" int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_ptrs_dev, const void* peer_flag_ptrs_dev, int world,
-                               int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream) {
+                               int32_t gen, float* gsum_dev, int32_t* status_dev, int32_t* own_flag_dev, void* stream) {
     if (!net || !td || !peer_grad_ptrs_dev || !peer_flag_ptrs_dev || !gsum_dev || !status_dev) return DTQN_ERR_ARG;
     if (world < 1 || world > kOptThreads) return DTQN_ERR_ARG;
     if (td->n_norm_blocks != opt_blocks(net->n_trainable)) return DTQN_ERR_ARG;
@@ -311,7 +315,7 @@ extern "C" int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void*
     a.peer_grad = static_cast<const float* const*>(peer_grad_ptrs_dev);
     a.peer_flag = static_cast<int32_t* const*>(peer_flag_ptrs_dev);
     a.gsum = gsum_dev; a.norm_partial = td->norm_partial; a.status = status_dev;
-    a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net); a.world = world; a.gen = gen;
+    a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net); a.world = world; a.gen = gen; a.own_flag = own_flag_dev;
     // DTQN_XCH_TIMEOUT_MS: how long a block waits for a peer's flag before it sets *status_dev (default 5000; tests use less)
     const char* tmo = getenv("DTQN_XCH_TIMEOUT_MS");
     const long long ms = tmo != nullptr && atoll(tmo) > 0 ? atoll(tmo) : 5000ll;

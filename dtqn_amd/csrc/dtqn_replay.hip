@@ -25,6 +25,7 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
     constexpr int OBS_LDS = 4096;                         // floats: the chunk's observation rows ride along when they fit (vector observations)
     __shared__ DtqnReplayRecord recs[CH];
     __shared__ float obs_l[OBS_LDS];
+    __shared__ int next_obs;
     static_assert(sizeof(DtqnReplayRecord) == 32, "eight dwords per record");
     const int tid = (int)threadIdx.x;
     const int T = a.rp.max_steps, O = a.rp.obs_dim;
@@ -71,8 +72,14 @@ __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_apply_kernel(ApplyAr
                 continue;
             }
             // store (:71-86) x run: obs at row t+1, action / reward / done at row t, episode length (the last store of a slot wins)
-            int j = i + 1;
-            while (j < m && recs[j].kind != 0) ++j;
+            // the run ends at the next store_obs: found by all threads at once (a serial walk over the LDS records -- one dependent
+            // read and branch per record -- was 10 us of a 256-record commit)
+            if (tid == 0) next_obs = -m;
+            __syncthreads();
+            for (int k = i + 1 + tid; k < m; k += DTQN_THREADS)
+                if (recs[k].kind == 0) atomicMax(&next_obs, -k);
+            __syncthreads();
+            const int j = -next_obs;
             const int cnt = j - i;
             if (a.rp.obs_u8 != nullptr) {
                 const uint8_t* s8 = reinterpret_cast<const uint8_t*>(a.obs_rows);

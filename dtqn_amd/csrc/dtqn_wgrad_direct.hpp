@@ -22,7 +22,10 @@ constexpr int kDirectThreads = kDirectWaves * 64;
 constexpr int kDirectMaxTokens = 2048;
 constexpr int kDTN = 16, kDTK = 32;         // tile: dY columns x X columns
 constexpr int kDGroup = 8;                  // 16-token units in flight per wave and buffer
-constexpr int kDSmall = 128;                // per-sequence-partial elements per workgroup (own launch)
+#ifndef DTQN_DSMALL
+#define DTQN_DSMALL 128
+#endif
+constexpr int kDSmall = DTQN_DSMALL;        // per-sequence-partial elements per workgroup (own launch)
 constexpr int kDSmallFused = 256;           //   ... in the backward launch (fewer, larger blocks: at most one late item per workgroup)
 constexpr size_t direct_lds_floats(int waves) { return waves + (size_t)waves * (kDTN + 1) * (kDTK + 4); }
 constexpr size_t kDirectLdsFloats = direct_lds_floats(kDirectWaves);

@@ -69,7 +69,7 @@ def agree_any(flag: bool, device) -> bool:
 class P2PExchange:
     """Device-side gradient exchange (include/dtqn_hip.h, dtqn_td_xreduce): every rank exports one allocation
     [gx generation 0 | gx generation 1 | flag word] to its peers and maps theirs; an update then needs no library call --
-    one 1-thread publish launch and one reduce launch that reads all peers directly (7 xGMI links per GPU on an MI355X node: a
+    ONE launch that raises the rank's flag and reads all peers directly (7 xGMI links per GPU on an MI355X node: a
     rank reads its 7 peers at once).  The handles travel through torch's own IPC reductions (hipIpcGetMemHandle over dmabuf:
     HSA_ENABLE_IPC_MODE_LEGACY=0) and `all_gather_object`; on a CPU test build the buffer is POSIX shared memory."""
 
@@ -116,9 +116,9 @@ class P2PExchange:
         e = self.engine
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
         s = e._stream()
-        e._check(e.lib.dtqn_xch_publish(vp(self.own_flag), self.k, s), "dtqn_xch_publish")
+        # one launch: it raises this rank's flag (the kernel boundary in front of it has made the gradient visible), then waits and sums
         e._check(e.lib.dtqn_td_xreduce(e._net_ref, e._td_ref, vp(self.grad_ptrs[self.k & 1]), vp(self.flag_ptrs), self.world, self.k,
-                                       vp(e.grad), vp(self.status), s), "dtqn_td_xreduce")
+                                       vp(e.grad), vp(self.status), vp(self.own_flag), s), "dtqn_td_xreduce")
         e.td.grad = e.grad.data_ptr()
 
     def check(self) -> None:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 13
+#define DTQN_ABI_VERSION 14
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -421,11 +421,13 @@ int dtqn_td_clip_adam(const DtqnNet* net, const DtqnTd* td, void* stream);
  * safe: a rank gets past step 3 of update k + 1 only after every peer published k + 1, i.e. finished reading generation k.
  *   peer_grad_ptrs_dev  device array of `world` pointers (const float*): generation (gen & 1) of every rank's buffer, own included
  *   peer_flag_ptrs_dev  device array of `world` pointers (int32_t*): every rank's flag word
+ *   own_flag_dev        this rank's flag word, or NULL.  Not NULL: the launch raises it to `gen` itself before it waits (step 2 folded
+ *                       into step 3: the kernel boundary in front of this launch is the same one dtqn_xch_publish relied on)
  *   status_dev          int32: set to 1 by a block whose wait ran out (5 s; DTQN_XCH_TIMEOUT_MS overrides): the caller raises instead of
  *                       hanging the GPU.  The sum is then stale: point DtqnTd.xstatus at this word and dtqn_td_clip_adam skips the update */
 int dtqn_xch_publish(int32_t* own_flag_dev, int32_t gen, void* stream);
 int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void* peer_grad_ptrs_dev, const void* peer_flag_ptrs_dev, int world,
-                    int32_t gen, float* gsum_dev, int32_t* status_dev, void* stream);
+                    int32_t gen, float* gsum_dev, int32_t* status_dev, int32_t* own_flag_dev, void* stream);
 /* Convenience: forward, backward, wgrad, reduce, clip_adam back to back (single GPU). */
 int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, void* stream);
 /* dtqn_td_update in its pipelined form (latency mode; dtqn_td_forward_part, dtqn_td_backward_ahead): policy passes as four row

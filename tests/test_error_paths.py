@@ -83,7 +83,7 @@ def run_dead_peer_case(lib, eng, rep, device):
     try:
         import time
         t0 = time.time()
-        assert lib.dtqn_td_xreduce(eng._net_ref, eng._td_ref, vp(gptr), vp(fptr), 2, 1, vp(gsum), vp(status), eng._stream()) == 0
+        assert lib.dtqn_td_xreduce(eng._net_ref, eng._td_ref, vp(gptr), vp(fptr), 2, 1, vp(gsum), vp(status), None, eng._stream()) == 0
         assert int(status.item()) == 1, "the bounded wait did not report the missing peer"
         assert time.time() - t0 < 20.0
     finally:

@@ -10,11 +10,12 @@ run_one() {
     serial) flags="" ;;
     overlap) flags="--overlap" ;;
     vector8) flags="--num-envs 8" ;;
+    refq) flags="--overlap --sampler reference --ref-quirks" ;;     # the reference's data stream: Python `random` window draws, int-truncated actor context
   esac
   d=$(mktemp -d)
   ( cd $d && cp -r "$GRAFT_REPO_ROOT"/{run.py,dtqn_amd,include} . 2>/dev/null
     t0=$(date +%s)
-    timeout 900 python run.py --disable-wandb --num-steps 1500000 --in-embed 64 $flags --sampler device --eval-frequency 50000 --eval-episodes 20 --seed $seed > log.txt 2>&1
+    timeout 900 python run.py --disable-wandb --num-steps 1500000 --in-embed 64 $( [[ "$flags" == *--sampler* ]] || echo --sampler device ) $flags --eval-frequency 50000 --eval-episodes 20 --seed $seed > log.txt 2>&1
     echo "$mode seed $seed rc=$? wall=$(( $(date +%s) - t0 ))s" )
   for f in $(find $d -name '*results.csv' -o -name '*losses.csv'); do
     k=results; [[ $f == *losses* ]] && k=losses
