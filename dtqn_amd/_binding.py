@@ -131,6 +131,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_xreduce": [P(DtqnNet), P(DtqnTd), vp, vp, i32, i32, vp, vp, vp, vp],
         "dtqn_td_update": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), vp],
         "dtqn_td_update_pipelined": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, i32, vp],
+        "dtqn_td_gradients_pipelined": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, i32, vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
         "dtqn_debug_set_profile_buffer": [vp],
         "dtqn_abi_version": [],

@@ -75,8 +75,8 @@ extern "C" int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const Dt
 // target pass inline unless the previous update's backward launch already carried it (have_target), the backward launch carrying the
 // NEXT update's target pass when td_next is given, weight gradients, reduce, clip + Adam.  draw_step: the optimizer step this
 // update carries (key of its window draw); the next update's is draw_step + 1.
-extern "C" int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
-                                        int draw_step, void* stream) {
+extern "C" int dtqn_td_gradients_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
+                                           int draw_step, void* stream) {
     int rc;
     if (draw_step < 0) return DTQN_ERR_ARG;
     if ((rc = dtqn_td_forward_part(net, rp, td, 0, 2, 4, draw_step, stream)) != DTQN_OK) return rc;
@@ -84,8 +84,12 @@ extern "C" int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp
     rc = td_next != nullptr ? dtqn_td_backward_ahead(net, rp, td, td_next, draw_step + 1, stream) : dtqn_td_backward(net, rp, td, stream);
     if (rc != DTQN_OK) return rc;
     if ((rc = dtqn_td_wgrad(net, td, stream)) != DTQN_OK) return rc;
-    if ((rc = dtqn_td_reduce(net, td, stream)) != DTQN_OK) return rc;
-    return dtqn_td_clip_adam(net, td, stream);
+    return dtqn_td_reduce(net, td, stream);
+}
+extern "C" int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
+                                        int draw_step, void* stream) {
+    const int rc = dtqn_td_gradients_pipelined(net, rp, td, td_next, have_target, draw_step, stream);
+    return rc != DTQN_OK ? rc : dtqn_td_clip_adam(net, td, stream);
 }
 
 // Rollout staging (north_star: "pinned hipMemcpyAsync into the device buffer").  Every HIP API call costs the host

@@ -74,25 +74,42 @@ class P2PExchange:
     HSA_ENABLE_IPC_MODE_LEGACY=0) and `all_gather_object`; on a CPU test build the buffer is POSIX shared memory."""
 
     def __init__(self, engine, group=None):
+        """Collective: every rank of `group` must construct one.  The ONLY collective inside is one all_gather_object that every rank
+        reaches whatever happens locally; a rank whose export or mapping fails records it in `self.error` (the caller votes on it,
+        DataParallel.__init__) instead of leaving the others alone in a later collective."""
         from torch.multiprocessing import reductions  # noqa: F401  (registers the reducers with ForkingPickler)
         self.engine, self.group = engine, group
         self.world, self.rank = td.get_world_size(group), td.get_rank(group)
         n = self.n = engine.net.n_trainable
         dev = engine.device
+        self.error = None
         self.buf = torch.zeros(2 * n + 16, dtype=torch.float32, device=dev)
-        if dev.type != "cuda":
-            torch.multiprocessing.set_sharing_strategy("file_system")      # handles that survive pickling through a collective
-            self.buf.share_memory_()
         # ForkingPickler carries torch's IPC reducers (a storage travels as its shared-memory / IPC handle, not as a copy of its bytes)
         import pickle
         from multiprocessing.reduction import ForkingPickler
+        payload = None
+        try:
+            if dev.type != "cuda":
+                torch.multiprocessing.set_sharing_strategy("file_system")      # handles that survive pickling through a collective
+                self.buf.share_memory_()
+            payload = bytes(ForkingPickler.dumps(self.buf))
+        except Exception as exc:
+            self.error = f"export: {type(exc).__name__}: {exc}"[:200]
         handles = [None] * self.world
-        td.all_gather_object(handles, bytes(ForkingPickler.dumps(self.buf)), group=group)
-        self.peers = [self.buf if r == self.rank else pickle.loads(h) for r, h in enumerate(handles)]
-        if dev.type == "cuda":
-            for r, p in enumerate(self.peers):          # a first copy makes torch enable peer access to that device
-                if r != self.rank and p.device != dev:
-                    p[:1].to(dev)
+        td.all_gather_object(handles, payload, group=group)
+        self.peers = [self.buf] * self.world
+        try:
+            if self.error is None and any(h is None for h in handles):
+                raise RuntimeError("a peer could not export its exchange buffer")
+            if self.error is None:
+                self.peers = [self.buf if r == self.rank else pickle.loads(h) for r, h in enumerate(handles)]
+                if dev.type == "cuda":
+                    for r, p in enumerate(self.peers):          # a first copy makes torch enable peer access to that device
+                        if r != self.rank and p.device != dev:
+                            p[:1].to(dev)
+        except Exception as exc:
+            self.error = f"mapping: {type(exc).__name__}: {exc}"[:200]
+            self.peers = [self.buf] * self.world
         esz = 4
         ptrs = lambda off: torch.tensor([p.data_ptr() + off * esz for p in self.peers], dtype=torch.int64, device=dev)
         self.grad_ptrs = [ptrs(0), ptrs(n)]
@@ -104,7 +121,7 @@ class P2PExchange:
         # applying a stale sum, and the host raises when it drains that update's statistics (DtqnAgent._drain_stats)
         engine.td.xstatus = self.status.data_ptr()
         self.k = 0
-        td.barrier(group=group)                         # every rank has mapped every buffer before anyone publishes
+        # (no barrier here: the caller's vote on `error` is the point every rank has mapped every buffer before anyone publishes)
 
     def begin(self) -> None:
         """Point the gradient kernels of the next update at this generation's exchange buffer."""
@@ -149,12 +166,9 @@ class DataParallel:
         self.selection = {"kind": "rccl", "validated": False, "reason": "requested"}
         if kind == "rccl":
             return
-        err = None
-        try:
-            self.p2p = P2PExchange(engine, group)
-        except Exception as exc:                          # IPC export / mapping refused on this node
-            err = f"{type(exc).__name__}: {exc}"[:200]
-        mapped = agree_all(self.p2p is not None, self._vote_device())
+        self.p2p = P2PExchange(engine, group)             # one collective inside, reached by every rank; failures land in .error
+        err = self.p2p.error
+        mapped = agree_all(err is None, self._vote_device())
         if not mapped:
             if kind == "p2p":
                 raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p but the peers' exchange buffers could not be mapped on every rank ({err})")

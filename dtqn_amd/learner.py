@@ -409,6 +409,11 @@ class TdEngine:
 
     def forward_backward(self, replay: DeviceReplay):
         s, n, r, t = self._stream(), self._net_ref, replay.view_ref, self._td_ref
+        if getattr(self, "_pipe", None) is not None and self.td.sample_in_kernel and self.img is None:
+            # one library call for the five launches in front of the optimizer (host time matters in the step loops)
+            d, have, nxt = self._pipe_begin(replay)
+            self._check(self.lib.dtqn_td_gradients_pipelined(n, r, t, nxt, 1 if have else 0, d, s), "dtqn_td_gradients_pipelined")
+            return
         if self.img is not None:
             self._img_encode_windows(replay, s)
         self._forward_stage(replay, s)

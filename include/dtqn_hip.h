@@ -435,6 +435,10 @@ int dtqn_td_update(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, v
  * carrying update k + 1's target pass when td_next != NULL, wgrad, reduce, clip_adam.  draw_step = optimizer steps taken so far. */
 int dtqn_td_update_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
                              int draw_step, void* stream);
+/* ... the same up to the gradient (forward parts, backward, wgrad, reduce), for callers that put something between the gradient and the
+ * optimizer launch: the data-parallel exchange, or the wait for an actor forward that still reads theta (two-stream rollout). */
+int dtqn_td_gradients_pipelined(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, const DtqnTd* td_next, int have_target,
+                                int draw_step, void* stream);
 /* Hard target update theta_tgt <- theta_pol (dqn.py:208-210). */
 int dtqn_target_sync(const DtqnNet* net, const float* theta_pol, float* theta_tgt, void* stream);
 
