@@ -684,9 +684,10 @@ def main():
         solo_rate = args.steps / (time.perf_counter() - t1)
         solo._drain_stats(block=True)
         # per-rank kernel sums (HIP events, one launch at a time): the slowest rank's kernels bound the data-parallel step
-        ksum = torch.tensor([float(sum(v for k, v in time_kernels(solo, 20).items() if not k.startswith("_") and not k.endswith("_target_inline")))], dtype=torch.float64)
+        ksum = torch.tensor([float(sum(v for k, v in time_kernels(solo, 20).items() if not k.startswith("_") and not k.endswith("_target_inline")))],
+                            dtype=torch.float64, device="cpu" if ddp.same_device() else device)      # gloo (same-device smoke mode) moves host tensors
         allk = [torch.zeros_like(ksum) for _ in range(world)]
-        torch.distributed.all_gather(allk, ksum.to(device) if not ddp.same_device() else ksum)
+        torch.distributed.all_gather(allk, ksum)
         exchange["solo_updates_per_s_rank0"] = solo_rate
         exchange["kernels_us_sum_per_rank"] = [float(k.item()) for k in allk]
         del solo

@@ -92,6 +92,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_lds_bytes_backward": [P(DtqnNet)],
         "dtqn_replay_apply": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_replay_sample": [P(DtqnReplay), i32, i32, i32, i32, u32, vp, vp, vp, vp],
+        "dtqn_replay_sample_at": [P(DtqnReplay), i32, i32, i32, i32, u32, i32, vp, vp, vp, vp],
         "dtqn_replay_push": [P(DtqnReplay), vp, vp, i32, vp],
         "dtqn_td_prefers_tiled": [P(DtqnNet), i32],
         "dtqn_net_tiled_twin": [P(DtqnNet), P(DtqnNet)],

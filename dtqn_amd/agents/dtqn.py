@@ -158,9 +158,9 @@ class DtqnAgent:
         if cuda:
             self.engine.bind_stream(self._main_stream)
             self.replay_buffer.bind_stream(self._main_ptr, self._main_stream)
-            if self.sampler == "device" and not self._separate_sample_launch:
-                # latency mode: target pass of the next update launched ahead, policy passes as four row slices (learner.py)
-                self.pipelined = self.engine.enable_pipeline(lambda rb=self.replay_buffer: rb.version)
+        if self.sampler == "device" and not self._separate_sample_launch:
+            # latency mode: the next update's target pass inside the backward launch, policy passes as four row slices (learner.py)
+            self.pipelined = self.engine.enable_pipeline(lambda rb=self.replay_buffer: rb.version)
         self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
         self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream) if cuda else None
         self._ev_update_done = torch.cuda.Event() if cuda else None

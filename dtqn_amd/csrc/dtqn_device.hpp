@@ -24,6 +24,7 @@ extern "C" void* dtqn_debug_profile_buffer(void);
 namespace dtqn {
 // row-block tiled TD passes (dtqn_tiled.hip), dispatched to by dtqn_td_forward / dtqn_td_backward when net->tiled
 int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
+int tiled_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, hipStream_t stream);
 int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream);
 int tiled_forward_actor(const DtqnNet* net, const float* theta, const float* obs, const uint8_t* actions, int batch, int n, int in_rows,
                         float* q_out, float* workspace, int train_mode, uint32_t drop_seed, uint32_t drop_step, hipStream_t stream, const int32_t* lens = nullptr);

@@ -170,10 +170,10 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     // image nets: the windows must exist before dtqn_img_encode, which fills td->xemb in front of this call
     if (net->img_c > 0 && (draw || !td->xemb)) return DTQN_ERR_ARG;
     if (net->tiled) {       // the multi-kernel path reads the windows from td->ep_idx / td->start: draw them first
-        if (!whole) return DTQN_ERR_CONFIG;
+        if (!whole && !draw) return DTQN_ERR_ARG;
         if (draw) {
-            const int rc = dtqn_replay_sample(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed,
-                                              td->step_counter, td->ep_idx, td->start, stream);
+            const int rc = dtqn_replay_sample_at(rp, td->sample_n_valid, td->sample_exclude, net->ctx_len, td->batch, td->sample_seed, draw_step,
+                                                 td->step_counter, td->ep_idx, td->start, stream);
             if (rc != DTQN_OK) return rc;
             if (net->bag_size > 0) {      // ... and the bags of those windows
                 const int rb = dtqn_replay_gather_bag(rp, td->ep_idx, td->start, nullptr, td->batch, net->bag_size, td->sample_seed,
@@ -181,7 +181,7 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
                 if (rb != DTQN_OK) return rb;
             }
         }
-        return tiled_td_forward(net, rp, td, (hipStream_t)stream);
+        return tiled_td_forward_part(net, rp, td, pass0, npasses, (hipStream_t)stream);
     }
     if (!whole && !draw) return DTQN_ERR_ARG;      // a partial launch re-derives its windows from the counter-based draw
     FwdArgs a;

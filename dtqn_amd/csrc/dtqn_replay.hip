@@ -119,6 +119,7 @@ struct SampleArgs {
     const int32_t* ep_len;
     int n_valid, exclude, ctx_len, batch;
     uint32_t seed;
+    int step;                          // >= 0: the draw's step; else step_counter[1]
     const int32_t* step_counter;
     int32_t* ep_idx;
     int32_t* start;
@@ -127,7 +128,7 @@ struct SampleArgs {
 __global__ __launch_bounds__(DTQN_THREADS) void dtqn_replay_sample_kernel(SampleArgs a) {
     const int b = (int)blockIdx.x * DTQN_THREADS + (int)threadIdx.x;
     if (b >= a.batch) return;
-    const uint32_t step = a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : 0u;
+    const uint32_t step = a.step >= 0 ? (uint32_t)a.step : a.step_counter != nullptr ? (uint32_t)a.step_counter[1] : 0u;
     int e, s;
     replay_draw(a.ep_len, a.n_valid, a.exclude, a.ctx_len, a.seed, step, b, e, s);
     a.ep_idx[b] = (int32_t)e;
@@ -205,12 +206,16 @@ extern "C" int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* r
 
 extern "C" int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed,
                                   const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream) {
+    return dtqn_replay_sample_at(rp, n_valid, exclude, ctx_len, batch, seed, -1, step_counter_dev, ep_idx_dev, start_dev, stream);
+}
+extern "C" int dtqn_replay_sample_at(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed, int step,
+                                     const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream) {
     if (!rp || batch < 1 || !ep_idx_dev || !start_dev) return DTQN_ERR_ARG;
     const bool skip = exclude >= 0 && exclude < n_valid;
     if (n_valid - (skip ? 1 : 0) < 1) return DTQN_ERR_ARG;
     SampleArgs a;
     a.ep_len = rp->ep_len; a.n_valid = n_valid; a.exclude = exclude; a.ctx_len = ctx_len; a.batch = batch;
-    a.seed = seed; a.step_counter = step_counter_dev; a.ep_idx = ep_idx_dev; a.start = start_dev;
+    a.seed = seed; a.step = step; a.step_counter = step_counter_dev; a.ep_idx = ep_idx_dev; a.start = start_dev;
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
     hipLaunchKernelGGL(dtqn_replay_sample_kernel, dim3((batch + DTQN_THREADS - 1) / DTQN_THREADS), dim3(DTQN_THREADS), 0,
                        (hipStream_t)stream, a);

@@ -76,6 +76,7 @@ struct TlEmbedArgs {
     const int32_t* ep_idx;             // replay mode (TD): sequence s = which * batch + b reads episode ep_idx[b]
     const int32_t* start;              //   from row start[b] + (which > 0); nullptr: sequence s reads "episode" s from row 0
     int batch;
+    int seq0;                          // replay mode: the launch's sequence 0 is sequence seq0 of the update (a launch of some of the passes)
     int n, rpb;
     Fld x;                             // [LPB][D] embedded tokens + positions
     Fld ein;                           // [LPB][KEP] input of the embedding linear (training only; base may be null)
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
     const float* __restrict__ theta = s >= a.split ? a.theta_b : a.theta_a;
     int ep = a.src_mod > 0 ? s % a.src_mod : s, row_first = 0;
     if (a.ep_idx != nullptr) {
-        const int which = s / a.batch, b = s - which * a.batch;
+        const int sg = s + a.seq0;
+        const int which = sg / a.batch, b = sg - which * a.batch;
         ep = a.ep_idx[b];
         row_first = a.start[b] + (which > 0 ? 1 : 0);
     }
@@ -1659,9 +1661,13 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
 // the MFMAs: measured cfg 4 787 -> 748, cfg 5 445 -> 408 updates/s, so they stay an experiment switch.  (The fused feed-forward
 // kernel, whose workgroups run 8-16 weight fragments deep, gains from 32 rows: launch_ffn.)
 static bool tl_half_rows(int blocks64, int slots) {
-    (void)blocks64; (void)slots;
     const char* e = getenv("DTQN_GEMM_ROWS");
-    return e != nullptr && atoi(e) == 32;
+    if (e == nullptr) return false;
+    if (e[0] == 'a') {                 // "auto" (experiment): 32 rows only for launches that would leave more than 40 % of their slots idle
+        const int rounds = (blocks64 + slots - 1) / slots;
+        return (rounds * slots - blocks64) * 100 > 40 * rounds * slots;
+    }
+    return atoi(e) == 32;
 }
 template <int D>
 static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
@@ -1823,6 +1829,7 @@ struct EmbedSrc {
     const int32_t* ep_idx;
     const int32_t* start;
     int batch;
+    int seq0 = 0;
     // bag_size > 0: [bag_batch][bag_size][O] observations / [bag_batch][bag_size] actions; sequence s uses bag s % bag_batch
     const float* bag_obs = nullptr;
     const uint8_t* bag_actions = nullptr;
@@ -1847,7 +1854,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         TlEmbedArgs e;
         e.net = net; e.theta_a = theta_a; e.theta_b = theta_b; e.split = split;
         e.obs = src.obs; e.actions = src.actions; e.obs_ep_stride = src.obs_ep_stride; e.act_ep_stride = src.act_ep_stride;
-        e.ep_idx = src.ep_idx; e.start = src.start; e.batch = src.batch;
+        e.ep_idx = src.ep_idx; e.start = src.start; e.batch = src.batch; e.seq0 = src.seq0;
         e.n = n; e.rpb = rpb;
         e.x = ident ? F(net.ao_x0, D) : F(L0(0) + net.al_u1, D);
         e.ein = training ? F(net.ao_ein, net.kep) : nofld();
@@ -1995,7 +2002,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.net = net; e.theta_a = theta_a; e.theta_b = theta_b; e.split = split;
             e.obs = src.bag_obs; e.actions = src.bag_actions;
             e.obs_ep_stride = (long long)bag * net.obs_dim; e.act_ep_stride = bag;
-            e.ep_idx = nullptr; e.start = nullptr; e.batch = src.bag_batch;
+            e.ep_idx = nullptr; e.start = nullptr; e.batch = src.bag_batch; e.seq0 = 0;
             e.n = bag; e.rpb = rpb;
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
@@ -2212,18 +2219,32 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
 }
 
 int tiled_td_forward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, hipStream_t stream) {
+    return tiled_td_forward_part(net, rp, td, 0, 3, stream);
+}
+
+// Passes [pass0, pass0 + npasses) of {policy(o), policy(o'), target(o')} (dtqn_td_forward_part): the same kernels over the sequences
+// of those passes only -- records, Q rows and the parameter split are addressed from the first sequence of the launch, the window
+// lookup of the embedding kernel knows where in the update it sits (EmbedSrc::seq0).
+int tiled_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td, int pass0, int npasses, hipStream_t stream) {
+    const bool whole = pass0 == 0 && npasses == 3;
+    if (!whole && (net->bag_size > 0 || net->img_c > 0 || net->dropout > 0.f)) return DTQN_ERR_CONFIG;
     EmbedSrc src;
     src.obs = rp->obs; src.actions = rp->actions;
     src.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim; src.act_ep_stride = rp->max_steps + 1;
     src.ep_idx = td->ep_idx; src.start = td->start; src.batch = td->batch;
     src.bag_obs = td->bag_obs; src.bag_actions = td->bag_actions; src.bag_batch = td->batch;
     src.pre = td->xemb; src.pre_rows = net->lp;
-    const int S = 3 * td->batch;
+    src.seq0 = pass0 * td->batch;
+    const int S = npasses * td->batch;
     const long long qs = (long long)net->lp * net->ap;
+    const size_t rstride = rec_map(*net, true).stride;
+    float* rec0 = td->act + (size_t)src.seq0 * rstride;
+    float* q0 = td->q3 + (size_t)src.seq0 * qs;
+    const int split = 2 * td->batch - src.seq0 > 0 ? 2 * td->batch - src.seq0 : 0;     // sequences of passes 0 - 1 use theta_pol
     // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230); step = optimizer steps so far
     const TlDrop drop = tl_drop_make(*net, td->dropout_seed, 0u, td->step_counter, td->batch, 0x3);
 #define DTQN_TL_CASE(d) \
-    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, 2 * td->batch, src, S, net->ctx_len, td->act, true, td->q3, qs, net->ap, stream, drop);
+    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, split, src, S, net->ctx_len, rec0, true, q0, qs, net->ap, stream, drop);
     switch (net->d_model) {
         DTQN_TL_CASE(64)
         DTQN_TL_CASE(128)

@@ -300,8 +300,15 @@ class TdEngine:
         False (and changes nothing) where the shape is not covered.  `replay_version`: callable that changes whenever the replay arrays
         are written (ReplayBuffer.version)."""
         import os
-        if (self.device.type != "cuda" or self.net.tiled or self.net.bag_size > 0 or self.img is not None or self.row_split != 4
-                or self.wgrad_fused or not self.lib.dtqn_td_fwd_slices4_ok(self._net_ref) or os.environ.get("DTQN_PIPELINE", "1") == "0"):
+        if self.net.bag_size > 0 or self.img is not None or self.net.dropout > 0 or os.environ.get("DTQN_PIPELINE", "1") == "0":
+            return False
+        ride = (not self.net.tiled and self.row_split == 4 and not self.wgrad_fused and bool(self.lib.dtqn_td_fwd_slices4_ok(self._net_ref)))
+        # Row-block tiled nets at small batches (BASELINE config 5: 32 sequences x 4 row blocks = 128 workgroups per pass and per
+        # launch of the backward -- half the chip): the same idea on a SECOND STREAM.  The target pass of update k + 1 runs its
+        # kernels beside update k's backward kernels; update k + 1's forward launches cover two passes (one round of 256 workgroups
+        # instead of one and a half).  The two event operations per update that cost 11.6 us are 0.5 % of a 2 ms update here.
+        stream_flavour = (self.net.tiled == 1 and self.device.type == "cuda" and self.batch * (self.net.lp // 64) <= 128)
+        if not ride and not stream_flavour:
             return False
         self._qbuf = [self.q3, torch.zeros_like(self.q3)]
         nxt = B.DtqnTd()
@@ -310,8 +317,13 @@ class TdEngine:
         self._next_xch = torch.zeros_like(self.xch)
         self._next_xflags = torch.zeros_like(self.xflags)
         nxt.xch, nxt.xflags = self._next_xch.data_ptr(), self._next_xflags.data_ptr()
+        if not ride:       # its own window indices (the multi-kernel path keeps them in memory) and stream / events
+            self._next_idx = torch.zeros_like(self._idx_dev)
+            nxt.ep_idx, nxt.start = self._next_idx[0].data_ptr(), self._next_idx[1].data_ptr()
         self._pipe = dict(nxt=nxt, nxt_ref=ctypes.byref(nxt), ahead=None, steps=int(self.step_counter[1].item()), tgt_version=0,
-                          replay_version=replay_version,
+                          replay_version=replay_version, ride=ride,
+                          stream=None if ride else torch.cuda.Stream(self.device), ev_fwd=None if ride else torch.cuda.Event(),
+                          ev_side=None if ride else torch.cuda.Event(), side_busy=False,
                           launch_ahead=os.environ.get("DTQN_PIPELINE", "1") != "inline",     # inline: same kernels, target pass never ahead (A/B, tests)
                           used=0, inline=0)
         return True
@@ -320,8 +332,9 @@ class TdEngine:
         """The optimizer state was replaced (checkpoint load) or stepped behind this object's back: re-read the step count, drop
         what was computed ahead."""
         if getattr(self, "_pipe", None) is not None:
-            torch.cuda.synchronize(self.device)
-            self._pipe.update(ahead=None, steps=int(self.step_counter[1].item()))
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self._pipe.update(ahead=None, steps=int(self.step_counter[1].item()), side_busy=False)
 
     def _pipe_begin(self, replay: DeviceReplay):
         """(draw step d, have_target, td_next reference or None) of the update about to be launched; books the pass it launches."""
@@ -354,11 +367,38 @@ class TdEngine:
             return
         lib, n, r, t = self.lib, self._net_ref, replay.view_ref, self._td_ref
         d, have, nxt = self._pipe_begin(replay)
+        if not self._pipe["ride"]:
+            self._forward_stage_streams(replay, s, d, have, nxt)
+            return
         # every pass of an update is keyed by the same explicit step: the three draws agree whatever the device counter holds
         self._check(lib.dtqn_td_forward_part(n, r, t, 0, 2, 4, d, s), "dtqn_td_forward_part")
         if not have:
             self._check(lib.dtqn_td_forward_part(n, r, t, 2, 1, 4, d, s), "dtqn_td_forward_part")
         self._pipe_next = (nxt, d + 1)
+
+    def _forward_stage_streams(self, replay: DeviceReplay, s, d, have, nxt) -> None:
+        """Second-stream flavour (row-block nets): policy passes on the update's stream, the NEXT update's target pass on the side
+        stream, gated behind them (its kernels then run beside this update's backward kernels)."""
+        lib, n, r, t, pipe = self.lib, self._net_ref, replay.view_ref, self._td_ref, self._pipe
+        main = self._main_torch_stream()
+        self._check(lib.dtqn_td_forward_part(n, r, t, 0, 2, 1, d, s), "dtqn_td_forward_part")
+        if pipe["side_busy"]:
+            main.wait_event(pipe["ev_side"])               # the pass launched ahead has left the buffers, used or not; it ran beside the
+            pipe["side_busy"] = False                      # previous backward, so the wait is over before the stream gets here
+        if not have:
+            self._check(lib.dtqn_td_forward_part(n, r, t, 2, 1, 1, d, s), "dtqn_td_forward_part")
+        self._pipe_next = None                             # the backward launch of this flavour carries nothing
+        if nxt is None:
+            return
+        st = pipe["stream"]
+        pipe["ev_fwd"].record(main)
+        st.wait_event(pipe["ev_fwd"])
+        self._check(lib.dtqn_td_forward_part(n, r, nxt, 2, 1, 1, d + 1, ctypes.c_void_p(st.cuda_stream)), "dtqn_td_forward_part")
+        pipe["ev_side"].record(st)
+        pipe["side_busy"] = True
+
+    def _main_torch_stream(self):
+        return self._bound_torch_stream if self._bound_torch_stream is not None else torch.cuda.current_stream(self.device)
 
     def _backward_stage(self, replay: DeviceReplay, s) -> None:
         nxt = getattr(self, "_pipe_next", None)
@@ -375,6 +415,10 @@ class TdEngine:
             return
         s = stream if stream is not None else self._stream()
         if getattr(self, "_pipe", None) is not None and self.td.sample_in_kernel:
+            if not self._pipe["ride"]:
+                self.forward_backward(replay)
+                self.clip_adam()
+                return
             d, have, nxt = self._pipe_begin(replay)
             self._check(self.lib.dtqn_td_update_pipelined(self._net_ref, replay.view_ref, self._td_ref, nxt, 1 if have else 0, d, s),
                         "dtqn_td_update_pipelined")
@@ -409,7 +453,7 @@ class TdEngine:
 
     def forward_backward(self, replay: DeviceReplay):
         s, n, r, t = self._stream(), self._net_ref, replay.view_ref, self._td_ref
-        if getattr(self, "_pipe", None) is not None and self.td.sample_in_kernel and self.img is None:
+        if getattr(self, "_pipe", None) is not None and self.td.sample_in_kernel and self.img is None and self._pipe["ride"]:
             # one library call for the five launches in front of the optimizer (host time matters in the step loops)
             d, have, nxt = self._pipe_begin(replay)
             self._check(self.lib.dtqn_td_gradients_pipelined(n, r, t, nxt, 1 if have else 0, d, s), "dtqn_td_gradients_pipelined")

@@ -216,6 +216,10 @@ int dtqn_replay_gather_bag(const DtqnReplay* rp, const int32_t* ep_idx_dev, cons
                            uint8_t* bag_actions_dev, void* stream);
 int dtqn_replay_sample(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed,
                        const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream);
+/* ... keyed by an explicit optimizer step (>= 0) instead of step_counter_dev[1]: the draw of an update other than the one in
+ * flight (dtqn_td_forward_part with draw_step) */
+int dtqn_replay_sample_at(const DtqnReplay* rp, int n_valid, int exclude, int ctx_len, int batch, uint32_t seed, int step,
+                          const int32_t* step_counter_dev, int32_t* ep_idx_dev, int32_t* start_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Inference / actor forward.  Replaces DTQN.forward (dtqn/networks/dtqn.py:158-218) for the

@@ -487,3 +487,43 @@ def test_time_limit_vote_happens_at_vector_step_boundaries(emu, monkeypatch):
     # votes at the first boundary of period 0 (timestep 7) and of period 1 (timestep 263); the second one stops the loop
     assert len(votes) == 2
     assert saved == [264] and agent.num_train_steps == 264
+
+
+@pytest.mark.parametrize("mode", ["serial", "overlap"])
+def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypatch, mode):
+    """The pipelined update of latency mode (learner.py: next update's target pass inside the backward launch, policy passes as four
+    16-row slices) on the emulation, cfg-1 network at batch 2: a pass computed ahead is only used while what it read is what the
+    update would read; episode ends (replay commit, new sampling range) and hard target syncs must send the update to the inline
+    pass, and the parameters must be BIT-equal to the same kernels with the target pass always inline (DTQN_PIPELINE=inline)."""
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import LinearAnneal
+    from dtqn_amd.utils.random import set_global_seed
+
+    def go(pipe):
+        monkeypatch.setenv("DTQN_PIPELINE", pipe)
+        env = envs.make("DiscreteCarFlag-v0")
+        set_global_seed(8, env)
+        agent = make_agent(emu, env, batch=2, L=50, D=64, H=8, tuf=5, sampler="device", sample_seed=8)
+        assert agent.pipelined and agent.engine.row_split == 4
+        runpy.prepopulate(agent, 700, [env])
+        eps = LinearAnneal(1.0, 1.0, 10)                     # random actions: both runs walk the same trajectory
+        agent.context_reset(env.reset())
+        for _ in range(36):
+            if mode == "overlap":
+                done = runpy.step_overlapped(agent, env, eps)
+            else:
+                done = runpy.step(agent, env, eps)
+                agent.train()
+            if done or agent.context.timestep >= 11:         # short episodes: several commits inside the run
+                agent.replay_buffer.flush()
+                agent.context_reset(env.reset())
+        agent._drain_stats(block=True)
+        e = agent.engine
+        return e.theta_pol.clone(), e.theta_tgt.clone(), e.adam_v.clone(), list(agent.td_errors.q), (e._pipe["used"], e._pipe["inline"])
+    a, b = go("1"), go("inline")
+    used, inline = a[4]
+    assert used >= 15 and inline >= 8 and b[4][0] == 0, (a[4], b[4])
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3] and len(a[3]) == 36

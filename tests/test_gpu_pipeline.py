@@ -62,3 +62,29 @@ def test_pipelined_update_matches_the_whole_launch(monkeypatch):
     assert c[6] is None
     ea, ec = np.array(a[4]), np.array(c[4])
     assert ea.shape == ec.shape and np.abs(ea[:10] - ec[:10]).max() <= 1e-4 * max(1.0, np.abs(ec[:10]).max())
+
+
+def test_row_block_net_target_pass_on_the_side_stream_equals_inline(monkeypatch):
+    """BASELINE config 5 shapes (ctx 256, d_model 256, batch 32: row-block kernels, 128 workgroups per pass): the second-stream
+    flavour of the pipelined update -- the next update's target pass launched on a side stream beside this update's backward kernels --
+    against the same kernels with the target pass inline: bit-equal parameters and statistics."""
+    import bench
+
+    def go(mode, n=24):
+        monkeypatch.setenv("DTQN_PIPELINE", mode)
+        c = bench.CONFIGS[5]
+        torch.manual_seed(5)                  # the synthetic env is not seeded: same initial parameters for both runs
+        agent = bench.make_agent(c, c["B"], torch.device("cuda:0"), 0, "device")
+        pipe = getattr(agent.engine, "_pipe", None)
+        assert pipe is not None and not pipe["ride"]
+        for i in range(n):
+            if i == 9:                        # a replay write in between: the pass launched ahead must be dropped once
+                agent.replay_buffer.version += 1
+            agent.train()
+        agent._drain_stats(block=True)
+        torch.cuda.synchronize()
+        e = agent.engine
+        return e.theta_pol.clone(), e.adam_v.clone(), list(agent.td_errors.q), (pipe["used"], pipe["inline"])
+    a, b = go("1"), go("inline")
+    assert a[3][0] >= 20 and a[3][1] == 2 and b[3][0] == 0, (a[3], b[3])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
