@@ -1663,7 +1663,8 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
 static bool tl_half_rows(int blocks64, int slots) {
     const char* e = getenv("DTQN_GEMM_ROWS");
     if (e == nullptr) return false;
-    if (e[0] == 'a') {                 // "auto" (experiment): 32 rows only for launches that would leave more than 40 % of their slots idle
+    if (e[0] == 'a') {                 // "auto" (experiment, round 4: cfg 5 485.5 -> 476.3, cfg 4 847.5 -> 840.0, cfg 3 508.2 -> 507.4: stays off):
+                                       // 32 rows only for launches that would leave more than 40 % of their slots idle
         const int rounds = (blocks64 + slots - 1) / slots;
         return (rounds * slots - blocks64) * 100 > 40 * rounds * slots;
     }
