@@ -358,3 +358,38 @@ def test_bag_network_counts_both_token_sets_for_the_one_launch_weight_gradients(
     # B = 16: 2 * 16 * 64 tokens = exactly what a one-launch tile holds (eight units per wave on all 16 waves)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=36, batch=16, T=80, n_eps=24, mask=-5)
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+@pytest.mark.parametrize("heads", [8, 4])
+def test_forward_in_parts_and_four_row_slices(emu, heads, monkeypatch):
+    """dtqn_td_forward_part (round 4): the three passes launched in parts leave exactly what the one launch leaves, and the four
+    16-row slices per sequence of the pipelined update (K | V of the lower rows handed from every slice to every slice above it)
+    pass the same oracle parity as the two-slice forward -- cfg-1 network, in-kernel window draw with an explicit step."""
+    import ctypes
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=heads, num_layers=2, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=6, batch=3, T=120, n_eps=8, mask=-5)
+    assert eng.row_split == 4 and emu.dtqn_td_fwd_slices4_ok(eng._net_ref) == 1
+    n, r, t = eng._net_ref, rep.view_ref, eng._td_ref
+    eng.sample_in_forward(8, 3, 99)
+    eng.step_counter[1] = 4
+    assert emu.dtqn_td_forward(n, r, t, None) == 0
+    q_whole, idx_whole = eng.q3.clone(), eng._idx_dev.clone()      # (the activation records also hold pad rows nobody reads: not compared)
+    for slices in (2, 4):
+        for parts in (((0, 3),), ((0, 2), (2, 1)), ((2, 1), (1, 1), (0, 1))):
+            eng.q3.zero_(); eng._idx_dev.zero_()
+            for p0, np_ in parts:
+                assert emu.dtqn_td_forward_part(n, r, t, p0, np_, slices, 4, None) == 0      # explicit draw step = the counter's value
+            assert torch.equal(eng._idx_dev, idx_whole)
+            if slices == 2:
+                assert torch.equal(eng.q3, q_whole), (slices, parts)
+            else:       # four slices: same numbers up to the summation order of the 16-row items
+                assert (eng.q3 - q_whole).abs().max() <= 2e-5 * max(1.0, float(q_whole.abs().max()))
+    # a different explicit step draws different windows
+    assert emu.dtqn_td_forward_part(n, r, t, 0, 3, 4, 5, None) == 0
+    assert not torch.equal(eng._idx_dev, idx_whole)
+    # pass ranges are validated
+    assert emu.dtqn_td_forward_part(n, r, t, 2, 2, 4, 4, None) != 0 and emu.dtqn_td_forward_part(n, r, t, 0, 1, 3, 4, None) != 0
+    # the whole update on the four-slice forward against the oracle (DTQN_FWD_SLICES=4 routes dtqn_td_forward there)
+    monkeypatch.setenv("DTQN_FWD_SLICES", "4")
+    eng.step_counter[1] = 0
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
