@@ -23,6 +23,9 @@ def main(cfg_dir, out):
         v = dict(v)
         v.pop("mfma_busy_frac", None)
         lu = us.get(k)
+        if lu is None:       # the kernel-trace table truncates long (templated) names: match on the common prefix
+            cands = [v_ for n_, v_ in us.items() if k.startswith(n_) or n_.startswith(k)]
+            lu = cands[0] if len(cands) == 1 else None
         per = (v.get("SQ_VALU_MFMA_BUSY_CYCLES") or 0.0) / 32.0
         v["launch_us"] = lu
         v["mfma_busy_cycles_per_simd"] = per
