@@ -112,8 +112,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
             return;
         }
     }
-    const int b = (int)blockIdx.x / RS;
-    const int slice = RS - 1 - ((int)blockIdx.x - b * RS);     // the upper slice (the producer of this kernel) first
+    int b, pos;                                    // the upper slice (the producer of this kernel) first; a sequence's slices on one XCD
+    slice_block_map((int)blockIdx.x, a.batch, RS, b, pos);
+    const int slice = RS - 1 - pos;
     const int R0 = slice * LP;
     const int Lfull = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
     const int L = Lfull - R0 < LP ? Lfull - R0 : LP;   // live rows of this slice (may be <= 0)
@@ -806,6 +807,7 @@ static int td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* t
                 return DTQN_ERR_CONFIG;
             FwdArgs f;
             td_forward_args(net, rp, td_next, 2, draw_step_next, &f);
+            f.nseq = td_next->batch;
             f.prof = nullptr;
             if (D == 64 && HD == 8) return launch_bwd_ahead<8>(a, f, s);
             if (D == 64 && HD == 16) return launch_bwd_ahead<16>(a, f, s);

@@ -873,6 +873,24 @@ __device__ __forceinline__ void tile_load(float* s, int ld, const float* __restr
     }
 }
 
+// Workgroup -> (sequence, position in the sequence's hand-over order) for launches with RS workgroups per sequence that WAIT for each
+// other (row slices: a slice spins until the slices it depends on have published their tiles).  Position 0 waits for nobody, position
+// k only for positions < k of the same sequence.  Blocks of a launch go to the eight XCDs round-robin, and every XCD places its share
+// in order when it has room.  If the RS workgroups of a sequence sat on RS different XCDs (block = sequence * RS + position), an XCD
+// could fill up with WAITING workgroups whose producers belong to another XCD -- harmless while one launch owns the chip (everything is
+// resident), a deadlock as soon as a second process's launch of the same kind shares the GPU: found with two ranks on one MI355X once
+// the forward was 2 B 4 = 256 workgroups (64 per position = two full XCDs; round 4).  So the RS workgroups of a sequence are blocks
+// x, x + 8, ..., x + 8 (RS - 1) of a group of 8 sequences: the same XCD whatever the round-robin offset of the launch, in hand-over
+// order -- every resident waiter has its producers resident or done, on every XCD, under any mix of launches.  (A last group of fewer
+// than 8 sequences keeps the order, not the XCD.)
+__device__ __forceinline__ void slice_block_map(int bid, int nseq, int RS, int& seq, int& pos) {
+    if (RS == 1) { seq = bid; pos = 0; return; }
+    const int g = bid / (8 * RS), u = bid - g * 8 * RS;
+    const int rem = nseq - g * 8, w = rem < 8 ? rem : 8;
+    pos = u / w;
+    seq = g * 8 + (u - pos * w);
+}
+
 // splitmix64-style counter hash -> 32 random bits per (seed, step, element, draw)
 __device__ __forceinline__ uint32_t hash_u32(uint32_t seed, uint32_t step, uint32_t elem, uint32_t draw) {
     unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^

@@ -99,7 +99,7 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.obs_ep_stride = (long long)in_rows * net->obs_dim;
     a.act_ep_stride = in_rows;
     a.ep_idx = nullptr; a.start = nullptr;
-    a.n = n; a.batch = batch; a.block0 = 0; a.pass0 = 0; a.draw_step = -1;
+    a.n = n; a.batch = batch; a.nseq = batch; a.block0 = 0; a.pass0 = 0; a.draw_step = -1;
     a.q_out = q_out;
     a.q_which_stride = 0;
     a.q_seq_stride = (long long)n * net->num_actions;
@@ -116,7 +116,8 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     if (xch != nullptr && xflags != nullptr) {
         // latency mode of the actor: four 16-row workgroups per sequence where that body exists and all of them are resident at
         // once (one forward of 50 rows: 38 -> 29 us per launch of the stage chain), else two 32-row ones
-        const bool four = batch * 4 <= 256 && dtqn_td_fwd_slices4_ok(net) != 0 && a.drop_thresh == 0u;
+        const char* es = getenv("DTQN_ACTOR_SLICES");      // A/B knob: 2 = the two-slice actor of round 3
+        const bool four = batch * 4 <= 256 && dtqn_td_fwd_slices4_ok(net) != 0 && a.drop_thresh == 0u && !(es != nullptr && atoi(es) == 2);
         return dispatch_fwd(a, batch, four ? 4 : 2, (hipStream_t)stream);
     }
     // short prefix of a 64-row context: 16- or 32-row instantiation (same kernel, fewer row tiles), else the full tile
@@ -141,7 +142,7 @@ void dtqn::td_forward_args(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
     a.ep_out = td->ep_idx; a.start_out = td->start;
     a.s_n_valid = td->sample_n_valid; a.s_exclude = td->sample_exclude; a.s_seed = td->sample_seed;
-    a.n = net->ctx_len; a.batch = td->batch; a.block0 = 0; a.pass0 = pass0; a.draw_step = draw_step;
+    a.n = net->ctx_len; a.batch = td->batch; a.nseq = 3 * td->batch; a.block0 = 0; a.pass0 = pass0; a.draw_step = draw_step;
     a.q_out = td->q3;
     a.q_which_stride = (long long)td->batch * net->lp * net->ap;
     a.q_seq_stride = (long long)net->lp * net->ap;
@@ -192,6 +193,7 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
         if (e != nullptr && atoi(e) == 4 && td->row_split >= 2 && dtqn_td_fwd_slices4_ok(net)) slices = 4;
     }
     if (slices == 4 && !dtqn_td_fwd_slices4_ok(net)) return DTQN_ERR_CONFIG;
+    a.nseq = npasses * td->batch;
     return dispatch_fwd(a, npasses * td->batch, slices, (hipStream_t)stream);
 }
 

@@ -29,6 +29,7 @@ struct FwdArgs {
     const int32_t* start;
     int n;                      // real sequence length (<= ctx_len)
     int batch;                  // sequences per `which`
+    int nseq;                   // sequences of this launch (passes x batch, or the actors of a batched actor forward)
     int block0;                 // first workgroup of this forward inside its launch (> 0: the passes ride behind another kernel's workgroups,
                                 // dtqn_backward.hip AHEAD)
     int pass0;                  // first pass of this launch: which = pass0 + sequence / batch (TD update: 0 policy(o), 1 policy(o'), 2 target(o'))
@@ -65,7 +66,8 @@ __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 // Sender s < RS - 1 publishes its [LP][2 D] K | V tile once (16-byte write-through stores) into segment s of the (sequence, layer)
 // buffer and raises one flag per receiver above it; receiver r > 0 waits for the flags of all senders below it, pulls their
 // segments into rows [s LP, (s + 1) LP) of its own LDS tile and lowers its flags again (the next launch starts from 0).  A middle
-// slice sends first, then receives.  Senders always have the lower blockIdx of a pair.  Pair (s, r), s < r: flag r (r - 1) / 2 + s.
+// slice sends first, then receives.  Senders always have the lower blockIdx of a pair, on the receiver's XCD (slice_block_map).
+// Pair (s, r), s < r: flag r (r - 1) / 2 + s.
 template <int NW, int RS>
 __device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
     const int cols = 2 * D, c4 = cols >> 2;
@@ -119,7 +121,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     constexpr int NC = D >= 128 ? D : 2 * D;       // FFN hidden columns per pass (D = 128: two 2D-wide FFN-2 fragments alone would be 128 VGPRs)
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
-    const int seq = (int)blockIdx.x / RS, slice = (int)blockIdx.x - seq * RS;     // slice 0 (the producer) first
+    int seq, slice;                                // slice 0 (the producer) first, a sequence's slices on one XCD (slice_block_map)
+    slice_block_map((int)blockIdx.x - a.block0, a.nseq, RS, seq, slice);
     const int R0 = slice * LP;
     const int which = a.pass0 + seq / a.batch;
     const int b = seq - (which - a.pass0) * a.batch;
@@ -451,8 +454,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     static_assert(PSN / 4 <= NT, "one float4 of the parameter block per thread");
     const DtqnNet& net = a.net;
     const Thr t = make_thr();
-    const int bid = (int)blockIdx.x - a.block0;
-    const int seq = bid / RS, slice = bid - seq * RS;
+    int seq, slice;                                // slice 0 (the producer) first, a sequence's slices on one XCD (slice_block_map)
+    slice_block_map((int)blockIdx.x - a.block0, a.nseq, RS, seq, slice);
     const int R0 = slice * LP;
     const int which = a.pass0 + seq / a.batch;
     const int b = seq - (which - a.pass0) * a.batch;
@@ -744,7 +747,9 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
 template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     static_assert(!(WL && DROP), "dropout runs on the register-direct stages");
-    const int which = a.pass0 + ((int)blockIdx.x / RS) / a.batch;            // workgroup-uniform
+    int seq_, slice_;
+    slice_block_map((int)blockIdx.x - a.block0, a.nseq, RS, seq_, slice_);
+    const int which = a.pass0 + seq_ / a.batch;                               // workgroup-uniform
     if constexpr (WL) {
         if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true>(a);
         else forward_body_wl<D, MT, HD, NW, RS, false>(a);

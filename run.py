@@ -212,6 +212,9 @@ def train(agent, envs, eval_envs, env_strs, total_steps, eps, eval_frequency, ev
 
 def run_experiment(args):
     start = time()
+    if os.environ.get("DTQN_DEBUG_HANG_DUMP"):       # debugging aid: dump every thread's Python stack after N seconds (a rank stuck in a collective)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DTQN_DEBUG_HANG_DUMP"]), repeat=False)
     rank, world, local = ddp.init_from_env("cuda" if args.device.startswith("cuda") else "cpu")
     is_main = rank == 0
     device = torch.device(args.device if world == 1 or not args.device.startswith("cuda") else f"cuda:{local}")
