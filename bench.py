@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# This one process builds a learner per BASELINE config, each with its own streams; HIP multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue do not overlap.  A training process has three
+# streams (update, actor, the row-block path's side stream); give the benchmark process room for all of its learners'.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

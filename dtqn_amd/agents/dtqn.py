@@ -161,10 +161,10 @@ class DtqnAgent:
         if self.sampler == "device" and not self._separate_sample_launch:
             # latency mode: the next update's target pass inside the backward launch, policy passes as four row slices (learner.py)
             self.pipelined = self.engine.enable_pipeline(lambda rb=self.replay_buffer: rb.version)
-        self._actor_stream = torch.cuda.Stream(self.device) if cuda else None
-        self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream) if cuda else None
-        self._ev_update_done = torch.cuda.Event() if cuda else None
-        self._ev_actor_done = torch.cuda.Event() if cuda else None
+        # the actor's stream and its two events are created by the first begin_action(): agents that never act in pipelined mode
+        # (benchmarks of the update alone, evaluation) leave the process's hardware queues to the streams that are in use
+        self._actor_stream, self._actor_ptr, self._ev_update_done, self._ev_actor_done = None, None, None, None
+        self._actor_stream_ok = cuda
         self._actor_inflight = False
         self._actor_calls = 0
         self.pipelined = getattr(self, "pipelined", False)
@@ -270,8 +270,12 @@ class DtqnAgent:
             return self._bag_action()
         if self.image is not None:
             return self._image_action()
-        if self._actor_stream is None:            # CPU kernel-emulation tests: no streams, same result
+        if not self._actor_stream_ok:             # CPU kernel-emulation tests: no streams, same result
             return self._sync_forward_action()
+        if self._actor_stream is None:
+            self._actor_stream = torch.cuda.Stream(self.device)
+            self._actor_ptr = ctypes.c_void_p(self._actor_stream.cuda_stream)
+            self._ev_update_done, self._ev_actor_done = torch.cuda.Event(), torch.cuda.Event()
         if not getattr(self, "_update_recorded", True):       # order the actor behind the last TD update (pipelined mode only)
             self._ev_update_done.record(self._main_stream)
             self._update_recorded = True

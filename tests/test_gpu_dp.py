@@ -45,3 +45,20 @@ def test_run_py_two_ranks_on_one_gpu(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=str(tmp_path), env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert out.stdout.count("Training Steps: 2000") == 1          # rank 0 alone reports
+
+
+def test_run_py_two_ranks_overlapped_on_one_gpu(tmp_path):
+    """Two PROCESSES on one GPU, each with the pipelined update (2 B 4 = 256-workgroup forward and backward launches whose row slices
+    spin on each other's hand-overs) and an actor forward on a second stream: the combination that deadlocked the GPU in round 4 until
+    a sequence's row slices were kept on ONE XCD in hand-over order (dtqn_device.hpp, slice_block_map) -- with block = sequence * RS +
+    slice, one process's waiting slices could fill the XCD another process's producers needed.  The subprocess timeout is the assertion."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DTQN_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", os.path.join(REPO, "run.py"), "--disable-wandb", "--in-embed", "64", "--num-steps", "2500",
+           "--prepopulate", "4000", "--eval-frequency", "1000", "--eval-episodes", "2", "--sampler", "device", "--verbose", "--overlap"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert out.stdout.count("Training Steps: 2000") == 1

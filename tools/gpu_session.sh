@@ -1,11 +1,17 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
-export DTQN_DIST_SAME_DEVICE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-run() { name=$1; shift
-  d=gpurun_out/s16/$name; rm -rf $d; mkdir -p $d
-  (cd $d && env "$@" timeout 45 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port $PORT $GRAFT_REPO_ROOT/run.py --disable-wandb --in-embed 64 --num-steps 2500 --prepopulate 4000 --eval-frequency 1000 --eval-episodes 2 --sampler device --verbose --overlap > log.txt 2>&1; echo "$name rc=$? steps2000=$(grep -c 'Training Steps: 2000' log.txt)")
-}
-PORT=29721 run base X=1
-PORT=29722 run nopipe DTQN_PIPELINE=0
-PORT=29723 run actor2 DTQN_ACTOR_SLICES=2
-PORT=29724 run rccl DTQN_DP_EXCHANGE=rccl
-PORT=29725 run inline DTQN_PIPELINE=inline
+mkdir -p gpurun_out/s17
+timeout 700 bash tools/dp_modes_one_gpu.sh 2>&1 | grep -E "^OK|^FAIL"
+timeout 300 python bench.py --steps 2000 --warmup 200 --no-other-configs --no-env-rate --no-cpu-baseline > gpurun_out/s17/bench2000.json 2> gpurun_out/s17/bench2000.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-other-configs --no-env-rate --no-cpu-baseline > gpurun_out/s17/bench20.json 2> gpurun_out/s17/bench20.err
+python - <<PY
+import json
+for f in ('bench2000','bench20'):
+    try:
+        d=json.loads([l for l in open(f'gpurun_out/s17/{f}.json') if l.startswith('{')][0])
+        print(f, round(d['value'],1), round(d['ms_per_step']*1e3,2), d['kernels_us'])
+    except Exception as e:
+        print(f, 'failed', e); print(open(f'gpurun_out/s17/{f}.err').read()[-1500:])
+PY
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/s17/all_tests.log 2>&1
+echo "all tests rc=$?" >> gpurun_out/s17/all_tests.log
+tail -5 gpurun_out/s17/all_tests.log
