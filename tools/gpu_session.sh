@@ -1,15 +1,17 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
-GIT_HEAD=07d60d6 bash tools/profile_round4.sh r04b "1 5" > gpurun_out/r04b_profile.log 2>&1
-tail -3 gpurun_out/r04b_profile.log
-mkdir -p gpurun_out/s18
-timeout 300 python -m pytest tests/test_gpu_dp.py tests/test_gpu_agent.py tests/test_gpu_pipeline.py -q -m gpu > gpurun_out/s18/tests.log 2>&1
-tail -3 gpurun_out/s18/tests.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/s18/bench_full.json 2> gpurun_out/s18/bench_full.err
-python - <<PY
+mkdir -p gpurun_out/s19
+for v in product l2scope product l2scope; do
+  if [ $v = product ]; then unset DTQN_HIP_LIB; else export DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_$v.so; fi
+  timeout 300 python bench.py --steps 2000 --warmup 200 --no-other-configs --no-env-rate --no-cpu-baseline > gpurun_out/s19/bench_$v.json 2> gpurun_out/s19/bench_$v.err
+  python - <<PY
 import json
 try:
-    d=json.loads([l for l in open('gpurun_out/s18/bench_full.json') if l.startswith('{')][0])
-    print(round(d['value'],1), round(d['ms_per_step']*1e3,2), d['roofline']['traffic_src'], d['other_configs'], d['env_steps_per_sec'])
+    d=json.loads([l for l in open('gpurun_out/s19/bench_$v.json') if l.startswith('{')][0])
+    print('$v', round(d['value'],1), round(d['ms_per_step']*1e3,2), d['kernels_us'])
 except Exception as e:
-    print('failed', e); print(open('gpurun_out/s18/bench_full.err').read()[-1500:])
+    print('$v failed', e); print(open('gpurun_out/s19/bench_$v.err').read()[-800:])
 PY
+done
+export DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_l2scope.so
+timeout 600 python -m pytest tests/test_gpu_td.py tests/test_gpu_pipeline.py tests/test_gpu_loop_golden.py -q -m gpu -x > gpurun_out/s19/tests_l2.log 2>&1
+tail -4 gpurun_out/s19/tests_l2.log
