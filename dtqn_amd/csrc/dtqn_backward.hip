@@ -826,18 +826,7 @@ static int td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* t
     }
 #define DTQN_BWD_CASE(d, mt, hd, nw) \
     if (D == d && MT == mt && HD == hd && NW == nw) return launch_bwd<d, mt, hd, nw>(a, s);
-    DTQN_BWD_CASE(64, 4, 8, 4)
-    DTQN_BWD_CASE(64, 4, 8, 8)
-    DTQN_BWD_CASE(64, 4, 8, 16)
-    DTQN_BWD_CASE(128, 4, 16, 4)
-    DTQN_BWD_CASE(128, 4, 16, 8)
-    DTQN_BWD_CASE(64, 4, 16, 8)
-    DTQN_BWD_CASE(64, 2, 8, 8)
-    DTQN_BWD_CASE(64, 1, 8, 8)
-    DTQN_BWD_CASE(16, 1, 8, 4)
-    DTQN_BWD_CASE(16, 1, 8, 8)
-    DTQN_BWD_CASE(32, 2, 8, 4)
-    DTQN_BWD_CASE(32, 1, 16, 4)
+    DTQN_WS_TRAIN_INSTANCES(DTQN_BWD_CASE)
 #undef DTQN_BWD_CASE
     return DTQN_ERR_CONFIG;
 }

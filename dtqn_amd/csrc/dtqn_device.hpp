@@ -957,8 +957,9 @@ __device__ __forceinline__ void xch_recv(float* s, int ld, const float* g, int r
 // sequence a workgroup owns (the small-batch regime is latency-bound), fewer = more registers per wave.
 // DTQN_WAVES in the environment overrides the default (tuning / tests).
 static inline int waves_for(const DtqnNet& net) {
-    int nw = net.d_model <= 64 ? (net.lp >= 64 ? 8 : 4) : (net.lp >= 64 ? 8 : 4);
-    if (net.d_model == 32 || net.d_model == 16) nw = 4;
+    int nw = 8;                        // the default wave count of the network's instantiation (dtqn_limits.h)
+    dtqn_ws_pick(net.d_model, net.head_dim, net.lp / 16, &nw);
+    if (nw == 0) nw = 8;
     const char* e = getenv("DTQN_WAVES");
     if (e != nullptr) {
         const int v = atoi(e);

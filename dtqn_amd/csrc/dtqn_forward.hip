@@ -43,22 +43,8 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     }
 #define DTQN_FWD_CASE(d, mt, hd, nw) \
     if (D == d && MT == mt && HD == hd && NW == nw) return launch_fwd<d, mt, hd, nw>(a, nseq, stream);
-    DTQN_FWD_CASE(64, 4, 8, 4)
-    DTQN_FWD_CASE(64, 4, 8, 8)
-    DTQN_FWD_CASE(64, 4, 8, 16)
-    DTQN_FWD_CASE(128, 4, 16, 4)
-    DTQN_FWD_CASE(128, 4, 16, 8)
-    DTQN_FWD_CASE(64, 4, 16, 8)
-    DTQN_FWD_CASE(64, 2, 8, 8)
-    DTQN_FWD_CASE(64, 1, 8, 8)
-    DTQN_FWD_CASE(64, 2, 16, 8)
-    DTQN_FWD_CASE(64, 1, 16, 8)
-    DTQN_FWD_CASE(128, 2, 16, 8)
-    DTQN_FWD_CASE(128, 1, 16, 8)
-    DTQN_FWD_CASE(16, 1, 8, 4)
-    DTQN_FWD_CASE(16, 1, 8, 8)
-    DTQN_FWD_CASE(32, 2, 8, 4)
-    DTQN_FWD_CASE(32, 1, 16, 4)
+    DTQN_WS_TRAIN_INSTANCES(DTQN_FWD_CASE)
+    DTQN_WS_FWD_ONLY_INSTANCES(DTQN_FWD_CASE)
 #undef DTQN_FWD_CASE
     return DTQN_ERR_CONFIG;
 }

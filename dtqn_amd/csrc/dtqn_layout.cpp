@@ -73,11 +73,18 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->ffn_chunk = 2 * D;
     // kernels cover what fits the per-sequence LDS tile (DESIGN.md "coverage")
     if (net->head_dim > DTQN_MAX_HEAD_DIM || (net->head_dim % 4) != 0) return DTQN_ERR_CONFIG;
-    if (!net->tiled && (D == 128 || D == 256) && (dtqn_lds_bytes_backward(net) == 0 || net->gate == DTQN_GATE_GRU)) {
-        // the whole-sequence tile set of this variant (identity-reordered layers or the GRU gate at D = 128) exceeds
-        // 160 KB of LDS
-        net->tiled = 1;
-        net->lp = (L + 63) / 64 * 64;
+    if (!net->tiled) {
+        // whole-sequence kernels are explicit instantiations (dtqn_limits.h): the smallest row-tile count of this (d_model, head_dim)
+        // that holds the context (a context of 8 at d_model 64 runs the 16-row kernels, head_dim 16 at d_model 64 the 64-row
+        // ones: rows past the context are masked like rows 50..63 of BASELINE config 1); none -> the row-block tiled path
+        const int mt = dtqn_ws_pick(D, net->head_dim, net->lp / 16, nullptr);
+        if (mt > 0) net->lp = 16 * mt;
+        if (mt == 0 || ((D == 128 || D == 256) && (dtqn_lds_bytes_backward(net) == 0 || net->gate == DTQN_GATE_GRU))) {
+            // ... or the whole-sequence tile set of this variant (identity-reordered layers or the GRU gate at D = 128) exceeds
+            // 160 KB of LDS
+            net->tiled = 1;
+            net->lp = (L + 63) / 64 * 64;
+        }
     }
     const int LP = net->lp;
     // the bag branch is composed from the row-block kernels: as many bag entries as the records have rows
@@ -85,6 +92,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (net->tiled) {
         // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
         if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;
+        const int hd = net->head_dim;                    // tl_attn_kernel / tl_attn_bwd_kernel instantiations
+        if (!(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64)) return DTQN_ERR_CONFIG;
         if (((size_t)LP * (4 * net->head_dim + 4) + 2 * (size_t)LP) * sizeof(float) > 160 * 1024) return DTQN_ERR_CONFIG;
     }
     if (A > DTQN_MAX_ACTIONS || (!net->tiled && net->kep > 3 * D)) return DTQN_ERR_CONFIG;

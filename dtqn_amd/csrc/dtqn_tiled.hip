@@ -1762,35 +1762,31 @@ static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
     TL_LAUNCH((tl_layernorm_bwd_kernel<D>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
+// head_dim instantiations of the attention kernels (dtqn_net_init admits exactly these on the row-block path)
+#define TL_ATTN_HEAD_DIMS(X) X(4) X(8) X(16) X(32) X(64)
 static int launch_attn(const TlAttnArgs& a, int S, int H, int HD, hipStream_t stream) {
     const size_t lds = (size_t)a.lpb * (3 * HD + 4) * sizeof(float);
-    if (a.drop.thresh != 0u) {
-        if (HD == 8) TL_LAUNCH((tl_attn_kernel<8, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else return DTQN_ERR_CONFIG;
-        return DTQN_OK;
+#define TL_ATTN_CASE(hd)                                                                                             \
+    if (HD == hd) {                                                                                                  \
+        if (a.drop.thresh != 0u) TL_LAUNCH((tl_attn_kernel<hd, true>), dim3(S, H), dim3(256), lds, stream, a);       \
+        else TL_LAUNCH((tl_attn_kernel<hd, false>), dim3(S, H), dim3(256), lds, stream, a);                          \
+        return DTQN_OK;                                                                                              \
     }
-    if (HD == 8) TL_LAUNCH((tl_attn_kernel<8, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 16) TL_LAUNCH((tl_attn_kernel<16, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 32) TL_LAUNCH((tl_attn_kernel<32, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else return DTQN_ERR_CONFIG;
-    return DTQN_OK;
+    TL_ATTN_HEAD_DIMS(TL_ATTN_CASE)
+#undef TL_ATTN_CASE
+    return DTQN_ERR_CONFIG;
 }
 static int launch_attn_bwd(const TlAttnBwdArgs& a, int S, int H, int HD, hipStream_t stream) {
     const size_t lds = ((size_t)a.lpb * (4 * HD + 4) + 2 * (size_t)a.lpb) * sizeof(float);
-    if (a.drop.thresh != 0u) {
-        if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32, true>), dim3(S, H), dim3(256), lds, stream, a);
-        else return DTQN_ERR_CONFIG;
-        return DTQN_OK;
+#define TL_ATTN_CASE(hd)                                                                                             \
+    if (HD == hd) {                                                                                                  \
+        if (a.drop.thresh != 0u) TL_LAUNCH((tl_attn_bwd_kernel<hd, true>), dim3(S, H), dim3(256), lds, stream, a);   \
+        else TL_LAUNCH((tl_attn_bwd_kernel<hd, false>), dim3(S, H), dim3(256), lds, stream, a);                      \
+        return DTQN_OK;                                                                                              \
     }
-    if (HD == 8) TL_LAUNCH((tl_attn_bwd_kernel<8, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 16) TL_LAUNCH((tl_attn_bwd_kernel<16, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else if (HD == 32) TL_LAUNCH((tl_attn_bwd_kernel<32, false>), dim3(S, H), dim3(256), lds, stream, a);
-    else return DTQN_ERR_CONFIG;
-    return DTQN_OK;
+    TL_ATTN_HEAD_DIMS(TL_ATTN_CASE)
+#undef TL_ATTN_CASE
+    return DTQN_ERR_CONFIG;
 }
 
 // Where the forward keeps its tensors.  Training: the DtqnNet activation record (every layer saved).

@@ -118,16 +118,20 @@ def test_train_loop_statistics_and_target_sync(emu):
     assert torch.equal(agent.target_network.flat, agent.policy_network.flat)
 
 
-def test_agent_on_the_tiled_path(emu, monkeypatch):
-    """Acting and training through the row-block tiled kernels (forced on a small width) behind the agent surface."""
+@pytest.mark.parametrize("heads", [8, 1])
+def test_agent_on_the_tiled_path(emu, monkeypatch, heads):
+    """Acting and training through the row-block tiled kernels behind the agent surface: forced on a small width (8 heads), and where
+    dtqn_net_init sends a shape by itself (one head of width 64 -- utils/agent_utils.py:36-58 defaults num_heads=1 -- has no
+    whole-sequence instantiation)."""
     import run as runpy
     from dtqn_amd import envs
     from dtqn_amd.utils.epsilon_anneal import Constant
     from dtqn_amd.utils.random import set_global_seed
-    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    if heads == 8:
+        monkeypatch.setenv("DTQN_FORCE_TILED", "1")
     env = envs.make("DiscreteCarFlag-v0")
     set_global_seed(2, env)
-    agent = make_agent(emu, env, batch=2, L=8, D=64, H=8, tuf=2)
+    agent = make_agent(emu, env, batch=2, L=8, D=64, H=heads, tuf=2)
     assert agent.policy_network.net.tiled == 1
     runpy.prepopulate(agent, 600, [env])
     theta0 = agent.policy_network.flat.clone()
@@ -489,8 +493,8 @@ def test_time_limit_vote_happens_at_vector_step_boundaries(emu, monkeypatch):
     assert saved == [264] and agent.num_train_steps == 264
 
 
-@pytest.mark.parametrize("mode", ["serial", "overlap"])
-def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypatch, mode):
+@pytest.mark.parametrize("mode,shape", [("serial", (50, 8)), ("overlap", (50, 8)), ("serial", (8, 4))])
+def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypatch, mode, shape):
     """The pipelined update of latency mode (learner.py: next update's target pass inside the backward launch, policy passes as four
     16-row slices) on the emulation, cfg-1 network at batch 2: a pass computed ahead is only used while what it read is what the
     update would read; episode ends (replay commit, new sampling range) and hard target syncs must send the update to the inline
@@ -504,8 +508,10 @@ def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypa
         monkeypatch.setenv("DTQN_PIPELINE", pipe)
         env = envs.make("DiscreteCarFlag-v0")
         set_global_seed(8, env)
-        agent = make_agent(emu, env, batch=2, L=50, D=64, H=8, tuf=5, sampler="device", sample_seed=8)
-        assert agent.pipelined and agent.engine.row_split == 4
+        # (8, 4): a context of 8 at head_dim 16 sits on the 64-row instantiation (dtqn_limits.h) -- three of the four row slices hold
+        # no valid row at all
+        agent = make_agent(emu, env, batch=2, L=shape[0], D=64, H=shape[1], tuf=5, sampler="device", sample_seed=8)
+        assert agent.pipelined and agent.engine.row_split == 4 and agent.policy_network.net.lp == 64
         runpy.prepopulate(agent, 700, [env])
         eps = LinearAnneal(1.0, 1.0, 10)                     # random actions: both runs walk the same trajectory
         agent.context_reset(env.reset())

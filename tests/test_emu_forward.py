@@ -40,6 +40,10 @@ CASES = [
          action_dim=8, pos="none"),
     dict(obs_dim=3, num_actions=3, inner_embed_size=16, num_heads=2, history_len=8, gate="gru"),
     dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, gate="gru", identity=True),
+    # contexts shorter than the smallest instantiated row-tile count of their (d_model, head_dim): dtqn_limits.h
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=10, num_layers=1),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, history_len=20, num_layers=1, gate="gru"),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=20, num_layers=1),
 ]
 
 

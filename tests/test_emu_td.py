@@ -393,3 +393,61 @@ def test_forward_in_parts_and_four_row_slices(emu, heads, monkeypatch):
     monkeypatch.setenv("DTQN_FWD_SLICES", "4")
     eng.step_counter[1] = 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+# Shapes that dtqn_net_init used to accept and the first launch then refused (no whole-sequence instantiation), or that it refused
+# outright (head_dim 4 / 64): they now run on the smallest instantiated row-tile count, or on the row-block tiled path.
+# (kw, run, expected (tiled, lp))
+ROUTED = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=8), dict(batch=3, T=14, mask=-5), (0, 16)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (0, 32)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=8, action_dim=4), dict(batch=3, T=14, mask=-5), (0, 64)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=8, gate="gru"), dict(batch=2, T=14, mask=-5), (0, 16)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=10, discrete=True, vocab_sizes=9), dict(batch=2, T=16, mask=8), (0, 64)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, num_layers=1, history_len=20), dict(batch=2, T=30, mask=-5), (1, 64)),       # head_dim 32
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (1, 64)),  # head_dim 64: agent_utils.py's default num_heads=1
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, num_layers=1, history_len=12, pos="sin"), dict(batch=2, T=20, mask=-5), (1, 64)),  # head_dim 4
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=2, num_layers=1, history_len=70, gate="gru", action_dim=8), dict(batch=2, T=90, mask=-5), (1, 128)),  # head_dim 64
+]
+
+
+@pytest.mark.parametrize("kw,run,where", ROUTED)
+def test_td_update_routed_shapes(emu, kw, run, where):
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=17, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
+    assert (net.tiled, net.lp) == where
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
+def test_every_accepted_shape_has_kernels(emu):
+    """dtqn_net_init is the one place that says what is covered: every (d_model, heads, context) it accepts runs a forward that
+    matches the oracle; what it refuses, it refuses there (DTQN_ERR_CONFIG), not at the first launch."""
+    import itertools
+    from helpers import net_from_cfg, pack_theta, ptr
+    accepted = 0
+    for D, H, L in itertools.product((16, 32, 48, 64, 128, 256), (1, 2, 4, 8, 16), (8, 40, 100)):
+        if D % H:
+            continue
+        cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=D, num_heads=H, history_len=L, num_layers=1)
+        try:
+            net = net_from_cfg(emu, cfg)
+        except Exception as e:
+            assert "rc=1" in str(e)
+            continue
+        accepted += 1
+        params = O.init_params(cfg, seed=3, perturb=True)
+        theta = torch.from_numpy(pack_theta(net, params))
+        rng = np.random.default_rng(D + H + L)
+        obs = torch.tensor(rng.uniform(-1, 1, (2, L, 3)).astype(np.float32))
+        act = torch.tensor(rng.integers(0, 3, (2, L)).astype(np.uint8))
+        q = torch.full((2, L, 3), float("nan"))
+        if net.tiled:
+            ws = torch.empty(emu.dtqn_forward_workspace_floats(ctypes.byref(net), 2))
+            rc = emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 2, L, ptr(q), ptr(ws), None)
+        else:
+            rc = emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 2, L, ptr(q), None)
+        assert rc == 0, (D, H, L, net.tiled, net.lp)
+        with torch.no_grad():
+            ref = O.forward(params, cfg, obs, act.long().unsqueeze(-1)).numpy()
+        assert np.abs(q.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (D, H, L)
+    assert accepted >= 35

@@ -102,6 +102,13 @@ VARIANTS = [
     dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, history_len=128, discrete=True, vocab_sizes=12),
     dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=8, history_len=256, discrete=True, vocab_sizes=22, identity=True, pos="sin"),
     dict(obs_dim=3, num_actions=3, inner_embed_size=256, num_heads=8, history_len=100, action_dim=8),
+    # placed by dtqn_net_init on a larger row-tile count / the tiled path (dtqn_limits.h): short contexts, head_dim 32, 64, 4
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=10),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=20),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, history_len=50),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, history_len=50),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, history_len=30),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=256, num_heads=4, history_len=128),
 ]
 
 

@@ -55,6 +55,20 @@ CASES = [
 ]
 
 
+# shapes dtqn_net_init places on a larger instantiated row-tile count or sends to the row-block path (dtqn_limits.h): short contexts,
+# head_dim 32 / 64 / 4 (round 4; the same list runs on the emulation, tests/test_emu_td.py ROUTED)
+CASES += [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=8), dict(batch=32, T=14, mask=-5, n_eps=40)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=2, history_len=8, action_dim=4), dict(batch=16, T=14, mask=-5, n_eps=30, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=10, discrete=True, vocab_sizes=9), dict(batch=8, T=16, mask=8, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, num_layers=2, history_len=50), dict(batch=8, T=200, mask=-5, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, num_layers=2, history_len=50), dict(batch=8, T=200, mask=-5, n_eps=20, tuf=2)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, num_layers=1, history_len=50, pos="sin"), dict(batch=4, T=200, mask=-5, n_eps=12)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=2, num_layers=1, history_len=100, gate="gru", action_dim=8), dict(batch=3, T=120, mask=-5, n_eps=8)),
+    (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=4, num_layers=1, history_len=128, discrete=True, vocab_sizes=22), dict(batch=2, T=140, mask=21, n_eps=5)),
+]
+
+
 @pytest.mark.parametrize("kw,run", CASES)
 def test_td_update_vs_oracle(lib, kw, run):
     cfg = O.NetCfg(**kw)

@@ -65,6 +65,9 @@ EMU_CASES = [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, history_len=50, num_layers=1), (2,)),
     (dict(obs_dim=3, num_actions=4, inner_embed_size=32, num_heads=4, history_len=20, gate="gru", action_dim=4), (3,)),
     (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=4, num_layers=1, history_len=70, discrete=True, vocab_sizes=9, action_dim=8), (2,)),
+    # a context of 10 on the 64-row instantiation of head_dim 16 (dtqn_limits.h), and one head of width 64 on the row-block path
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, history_len=10, num_layers=1), (3,)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, history_len=12, num_layers=1), (2,)),
 ]
 
 
