@@ -118,7 +118,7 @@ STAMP = {"torch": torch.__version__, "numpy": np.__version__,
 
 
 def checksum(params):
-    return float(sum(float(v.double().abs().sum()) for k, v in sorted(params.items())))
+    return O.param_checksum(params)          # finite entries only (the causal masks are -inf)
 
 
 def make_ref_net(cfg: O.NetCfg, params):

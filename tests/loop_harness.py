@@ -52,6 +52,8 @@ def run_loop(fx, name, device, test_lib=None):
             agent_utils.MODEL_MAP["DTQN"] = orig
     ocfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=D, num_heads=H, num_layers=NL, history_len=L)
     pol = O.init_params(ocfg, seed=int(g("pol_seed")), perturb=True)
+    cs = O.param_checksum(pol)                 # the weights the reference run started from (generator drift guard)
+    assert np.isfinite(cs) and abs(cs - float(g("pol_checksum"))) <= 1e-12 * cs
     agent.policy_network.load_state_dict({k: v.clone() for k, v in pol.items()})
     agent.target_update()
     runpy.prepopulate(agent, int(g("prepop")), train_envs)

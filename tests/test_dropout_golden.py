@@ -27,7 +27,8 @@ def load_case(name):
     meta = json.loads(str(z[f"{name}_meta"]))
     pol = O.init_params(cfg, seed=meta["seed"], perturb=True)
     tgt = O.init_params(cfg, seed=meta["seed"] + 1, perturb=True)
-    cs = float(sum(float(v.double().abs().sum()) for k, v in sorted(pol.items())))
+    cs = O.param_checksum(pol)
+    assert np.isfinite(cs) and cs > 0
     assert cs == pytest.approx(float(z[f"{name}_pol_checksum"]), rel=1e-12)
     return z, cfg, meta, pol, tgt
 
