@@ -340,7 +340,10 @@ class TdEngine:
         """(draw step d, have_target, td_next reference or None) of the update about to be launched; books the pass it launches."""
         pipe, td = self._pipe, self.td
         d = pipe["steps"]                                  # step_counter[1] when this update's kernels run: the key of its draw
-        key = (d, td.sample_n_valid, td.sample_exclude, td.sample_seed, pipe["replay_version"](), pipe["tgt_version"], replay.view.obs)
+        # theta_tgt._version: host-side writes to the target parameters that do not come through target_sync (load_state_dict on the
+        # target module, an in-place torch op on one of its views) bump torch's version counter of the flat buffer
+        key = (d, td.sample_n_valid, td.sample_exclude, td.sample_seed, pipe["replay_version"](), pipe["tgt_version"], replay.view.obs,
+               self.theta_tgt._version)
         td.q3 = self._qbuf[d & 1].data_ptr()
         self.q3 = self._qbuf[d & 1]
         have = pipe["ahead"] == key

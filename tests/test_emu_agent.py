@@ -515,7 +515,9 @@ def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypa
         runpy.prepopulate(agent, 700, [env])
         eps = LinearAnneal(1.0, 1.0, 10)                     # random actions: both runs walk the same trajectory
         agent.context_reset(env.reset())
-        for _ in range(36):
+        for it in range(36):
+            if it == 21:            # a host-side write to the target parameters behind the engine's back: the pass computed ahead is stale
+                agent.target_network.load_state_dict(agent.policy_network.state_dict())
             if mode == "overlap":
                 done = runpy.step_overlapped(agent, env, eps)
             else:
