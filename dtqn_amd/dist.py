@@ -106,6 +106,11 @@ class P2PExchange:
                 if dev.type == "cuda":
                     for r, p in enumerate(self.peers):          # a first copy makes torch enable peer access to that device
                         if r != self.rank and p.device != dev:
+                            # a kernel that reads a buffer its device cannot reach faults the whole process: ask first, and let
+                            # the vote send every rank to the collective instead
+                            mine = dev.index if dev.index is not None else torch.cuda.current_device()
+                            if not torch.cuda.can_device_access_peer(mine, p.device.index):
+                                raise RuntimeError(f"device {mine} has no peer access to device {p.device.index}")
                             p[:1].to(dev)
         except Exception as exc:
             self.error = f"mapping: {type(exc).__name__}: {exc}"[:200]
@@ -198,8 +203,8 @@ class DataParallel:
         (r + 1) * (i mod 7 + g) -- small integers --, so the rank-ordered device-side sum must EQUAL the collective's."""
         e, p = self.engine, self.p2p
         n = p.n
+        had = "DTQN_XCH_TIMEOUT_MS" in os.environ                 # the user's own bound, if any, stays
         os.environ.setdefault("DTQN_XCH_TIMEOUT_MS", "2000")      # a start-up check must not sit out the 5 s of a training run
-        had = "DTQN_XCH_TIMEOUT_MS" in os.environ and os.environ["DTQN_XCH_TIMEOUT_MS"] != "2000"
         ok, why = True, "two generations equal to all_reduce on every rank"
         try:
             base = torch.arange(n, dtype=torch.float32, device=e.device) % 7

@@ -318,9 +318,12 @@ def test_training_on_the_row_block_twin(emu, monkeypatch):
     cfg = O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, action_dim=8)
     net = B.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50, action_dim=8)
     assert net.tiled == 0 and emu.dtqn_td_prefers_tiled(ctypes.byref(net), 2) == 0 and emu.dtqn_td_prefers_tiled(ctypes.byref(net), 64) == 1
-    for kw in (dict(inner_embed_size=64), dict(gate="gru"), dict(identity=True), dict(history_len=20)):     # shapes the policy leaves alone
+    for kw in (dict(inner_embed_size=64), dict(gate="gru"), dict(identity=True)):     # shapes the policy leaves alone
         other = B.make_net(emu, **{**dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50), **kw})
         assert emu.dtqn_td_prefers_tiled(ctypes.byref(other), 64) == 0, kw
+    # a short context at this width sits on the same 64-row instantiation (dtqn_limits.h) and gets the same answer
+    short = B.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, num_layers=1, history_len=20)
+    assert short.lp == 64 and emu.dtqn_td_prefers_tiled(ctypes.byref(short), 64) == 1
     monkeypatch.setenv("DTQN_TRAIN_TILED", "1")
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=41, batch=2, T=60, n_eps=5, mask=-5, tuf=2)
     assert net.tiled == 0 and eng.net.tiled == 1 and eng.actor_net.tiled == 0
