@@ -70,10 +70,12 @@ typedef struct DtqnNet {
                                * 128->128 s2; padding 1; ReLU after each) + Flatten + Linear(128 h5 w5, D - a).  obs_dim must be C*H*W (uint8
                                * pixels, fed to the network as their float values like the reference).  Row-block tiled path; (D - a) % 16 == 0 */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
-                               * forwards only; 0 = off.  Whole-sequence kernels only (DTQN_ERR_CONFIG on the row-block tiled path) */
+                               * forwards only; 0 = off.  Both kernel families (counter-based keep masks, recomputed in the backward) */
     /* ---- derived: geometry ---- */
     int32_t abi_version;
-    int32_t lp;               /* L padded to the MFMA row tile (multiple of 16) */
+    int32_t lp;               /* rows of the per-sequence records: L padded to the row count of the kernels the network runs on -- the smallest
+                               * instantiated multiple of 16 of its (d_model, head_dim) on the whole-sequence kernels (dtqn_limits.h; 64 for
+                               * ctx_len 50 at d_model 64), a multiple of 64 on the row-block tiled path.  Rows >= ctx_len are masked */
     int32_t ke;               /* embedding-linear fan-in: O (continuous) or O*e (discrete) */
     int32_t kep;              /* ke padded to 4 */
     int32_t ap;               /* A padded to 4 */
@@ -149,8 +151,9 @@ typedef struct DtqnWJob {
     int32_t dy_lstride;      /*      summed over l                                                               */
 } DtqnWJob;
 
-/* Fills every derived field of `net` from its inputs.  Returns DTQN_ERR_CONFIG when the variant
- * is outside what the gfx950 kernels cover (see DESIGN.md "coverage"). */
+/* Fills every derived field of `net` from its inputs and decides which kernel family the network runs on (`tiled`, `lp`).  Returns
+ * DTQN_ERR_CONFIG when the variant is outside what the gfx950 kernels cover; a network it accepts has a kernel
+ * instantiation behind every entry point below. */
 int dtqn_net_init(DtqnNet* net);
 /* Writes net->n_wjobs jobs (host memory). */
 int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs);

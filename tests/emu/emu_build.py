@@ -30,6 +30,17 @@ def build(verbose=False) -> str:
         return lib
     if not os.path.exists(CLANG):
         raise RuntimeError("host clang++ not found")
+    # one builder at a time (pytest-xdist workers reach this together after a source change and would compile into the same object
+    # files); whoever gets the lock second finds the library built
+    import fcntl
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(lib):
+            return lib
+        return _build_locked(srcs, lib, verbose)
+
+
+def _build_locked(srcs, lib, verbose):
     for f in os.listdir(OUT):
         if f.startswith("libdtqn_emu_"):
             os.remove(os.path.join(OUT, f))
@@ -47,7 +58,8 @@ def build(verbose=False) -> str:
             raise RuntimeError(f"emu compile failed for {s}:\n{out.decode()}")
         if verbose and out:
             print(out.decode())
-    subprocess.check_call([CLANG, "-shared", "-o", lib] + objs + ["-lpthread"])
+    subprocess.check_call([CLANG, "-shared", "-o", lib + ".tmp"] + objs + ["-lpthread"])
+    os.replace(lib + ".tmp", lib)           # the library appears complete or not at all
     for o in objs:
         os.remove(o)
     return lib
