@@ -178,10 +178,12 @@ def make_net(lib, *, obs_dim, num_actions, embed_per_obs_dim=8, action_dim=0, in
     return net
 
 
-def param_table(net: DtqnNet) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
+def param_table(net: DtqnNet, width: int = 0) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
     """state_dict key -> (offset into theta, shape), using the reference's key names
-    (SURVEY.md section 8b).  Shared GRU gates appear under every layer prefix with the same offset."""
-    D, L, A, a = net.d_model, net.ctx_len, net.num_actions, net.action_dim
+    (SURVEY.md section 8b).  Shared GRU gates appear under every layer prefix with the same offset.
+    The shapes are those of the buffer (d_model wide; for a width-padded network that is the padded width); `width` = net.d_real
+    gives the shapes the reference's state_dict has for the same keys (same offsets: see pad_param / unpad_param)."""
+    D, L, A, a = (width or net.d_model), net.ctx_len, net.num_actions, net.action_dim
     tab: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
     if a > 0:
         tab["action_embedding.embedding.0.weight"] = (net.off_act_emb, (A, a))
@@ -234,3 +236,39 @@ def param_table(net: DtqnNet) -> Dict[str, Tuple[int, Tuple[int, ...]]]:
     tab["ffn.2.weight"] = (net.off_head2_w, (A, D))
     tab["ffn.2.bias"] = (net.off_head2_b, (A,))
     return tab
+
+
+# ---- width-padded networks (include/dtqn_hip.h, DtqnNet.d_real) ---------------------------------------------------------------
+# theta holds every tensor at the padded width with the real entries in front; attention.in_proj_* are three stacked blocks
+# (q | k | v), each with its real rows in front.  The two functions below move one tensor between the reference's shape and that layout.
+def _blocks(key: str) -> int:
+    return 3 if key.endswith("in_proj_weight") or key.endswith("in_proj_bias") else 1
+
+
+def unpad_param(net: DtqnNet, key: str, padded, real_shape):
+    """The reference-shaped part of a buffer-shaped tensor (torch or numpy; a view where the layout allows, else a copy)."""
+    if not net.d_real or tuple(padded.shape) == tuple(real_shape):
+        return padded
+    nb = _blocks(key)
+    if nb == 1:
+        return padded[tuple(slice(0, r) for r in real_shape)]
+    rows_p, rows_r = padded.shape[0] // nb, real_shape[0] // nb
+    blk = padded.reshape((nb, rows_p) + tuple(padded.shape[1:]))
+    blk = blk[(slice(None), slice(0, rows_r)) + tuple(slice(0, r) for r in real_shape[1:])]
+    return blk.reshape(tuple(real_shape))
+
+
+def pad_param(net: DtqnNet, key: str, real, padded_shape):
+    """A reference-shaped tensor laid out at the buffer's shape, zeros in the padding (numpy in, numpy out; torch in, torch out)."""
+    if not net.d_real or tuple(real.shape) == tuple(padded_shape):
+        return real
+    import numpy as _np
+    out = _np.zeros(padded_shape, dtype=real.dtype) if isinstance(real, _np.ndarray) else real.new_zeros(padded_shape)
+    nb = _blocks(key)
+    if nb == 1:
+        out[tuple(slice(0, r) for r in real.shape)] = real
+        return out
+    rows_p, rows_r = padded_shape[0] // nb, real.shape[0] // nb
+    view = out.reshape((nb, rows_p) + tuple(padded_shape[1:]))          # a view of `out` for both array types (contiguous)
+    view[(slice(None), slice(0, rows_r)) + tuple(slice(0, r) for r in real.shape[1:])] = real.reshape((nb, rows_r) + tuple(real.shape[1:]))
+    return out

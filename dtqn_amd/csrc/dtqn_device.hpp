@@ -497,12 +497,15 @@ struct StageDyW {
 // LPT: compile-time upper bound of LP (rows): with fewer rows more lanes share a row, every lane stays busy and the
 // stores of the pass are unconditional (the compiler can then count them for later s_waitcnt's)
 // SAVE = false: st_out / save_in / save_out are ignored at compile time (no conditional stores in the instruction stream)
-template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true>
+// PAD (width-padded networks, DtqnNet.d_real): the statistics run over the first d_real columns; the columns behind them hold zeros
+// (and get zeros back: their gamma / beta are zero).
+template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true, bool PAD = false>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t,
                                                float* __restrict__ save_in = nullptr, float* __restrict__ save_out = nullptr,
-                                               int ld_dst = 0) {                 // ld_dst: leading dim of dst when it differs from src's
+                                               int ld_dst = 0, int d_real = D) {  // ld_dst: leading dim of dst when it differs from src's
+    const float inv_d = PAD ? 1.0f / (float)d_real : (1.0f / D);
     constexpr int THREADS = NW * 64;
     if (ld_dst == 0) ld_dst = ld;
     constexpr int LPR = (THREADS / LPT) < (D / 4) ? (THREADS / LPT) : (D / 4);                  // lanes per row (4, 8 or 16)
@@ -525,16 +528,20 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
-        const float mean = sum * (1.0f / D);
+        const float mean = sum * inv_d;
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            if constexpr (PAD) {
+                const int c0 = part * 4 + 4 * LPR * j;
+                a = c0 < d_real ? a : 0.f; b = c0 + 1 < d_real ? b : 0.f; c = c0 + 2 < d_real ? c : 0.f; d = c0 + 3 < d_real ? d : 0.f;
+            }
             sq += (a * a + b * b) + (c * c + d * d);
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        const float rstd = 1.0f / sqrtf(sq * inv_d + 1e-5f);
         if (valid) {
             float* dp = dst + row * ld_dst + part * 4;
 #pragma unroll

@@ -33,9 +33,32 @@ extern "C" int dtqn_net_tiled_twin(const DtqnNet* src, DtqnNet* dst) {
 extern "C" int dtqn_net_init(DtqnNet* net) {
     if (!net) return DTQN_ERR_ARG;
     const int O = net->obs_dim, A = net->num_actions, e = net->embed_per_obs, a = net->action_dim;
-    const int D = net->d_model, H = net->num_heads, NL = net->num_layers, L = net->ctx_len, V = net->vocab;
-    if (O < 1 || A < 1 || D < 16 || H < 1 || NL < 1 || NL > DTQN_MAX_LAYERS || L < 1) return DTQN_ERR_CONFIG;
-    if (D % 16 != 0 || D % H != 0 || a < 0 || a >= D || (a % 4) != 0) return DTQN_ERR_CONFIG;
+    const int NL = net->num_layers, L = net->ctx_len, V = net->vocab;
+    if (net->d_real > 0) {            // a padded network initialised again (dtqn_net_tiled_twin, a copy): back to the caller's width first
+        net->d_model = net->d_real;
+        net->num_heads = net->heads_real;
+    }
+    net->d_real = net->heads_real = 0;
+    if (O < 1 || A < 1 || net->d_model < 16 || net->num_heads < 1 || NL < 1 || NL > DTQN_MAX_LAYERS || L < 1) return DTQN_ERR_CONFIG;
+    if (net->d_model % net->num_heads != 0 || a < 0 || a >= net->d_model || (a % 4) != 0) return DTQN_ERR_CONFIG;
+    {
+        // Width padding (include/dtqn_hip.h, d_real): a width the kernels are not instantiated for runs as the next one that is, with
+        // whole extra heads of the caller's head width -- all-zero heads attend uniformly over zero values and contribute nothing.
+        const int d = net->d_model, hd = d / net->num_heads;
+        const bool native = d == 16 || d == 32 || d == 64 || d == 128 || d == 256;
+        if (!native) {
+            const int dp = d < 64 ? 64 : d < 128 ? 128 : 256;
+            if (d > 256 || !(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64) || a != 0 || net->bag_size != 0 || net->img_c > 0 ||
+                net->dropout != 0.f)
+                return DTQN_ERR_CONFIG;
+            net->d_real = d;
+            net->heads_real = net->num_heads;
+            net->d_model = dp;
+            net->num_heads = dp / hd;
+        }
+    }
+    const int D = net->d_model, H = net->num_heads;
+    if (D % 16 != 0 || D % H != 0) return DTQN_ERR_CONFIG;
     if (net->discrete && (V < 1 || e < 1)) return DTQN_ERR_CONFIG;
     if (net->gate != DTQN_GATE_RES && net->gate != DTQN_GATE_GRU) return DTQN_ERR_CONFIG;
     if (net->pos < DTQN_POS_LEARNED || net->pos > DTQN_POS_NONE) return DTQN_ERR_CONFIG;
@@ -61,7 +84,8 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
-    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0 || img) {
+    if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0 || img ||
+        net->d_real > 0) {
         // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
         net->tiled = 1;
         net->lp = (L + 63) / 64 * 64;
@@ -336,16 +360,19 @@ extern "C" int dtqn_net_wjobs(const DtqnNet* net, DtqnWJob* jobs) {
 extern "C" int dtqn_net_fill_frozen(const DtqnNet* net, float* theta) {
     if (!net || !theta) return DTQN_ERR_ARG;
     const int L = net->ctx_len, D = net->d_model;
+    const int DR = net->d_real > 0 ? net->d_real : D;        // the table of the caller's width in front of each padded row, zeros behind
     if (net->pos == DTQN_POS_SIN) {
         // position_encodings.py:23-35: P[t,2i] = sin(t * exp(2i * -ln(1e4)/D)), P[t,2i+1] = cos(same);
         // the reference evaluates it in fp32 torch ops: exp in fp32, product in fp32, sin/cos in fp32.
-        for (int t = 0; t < L; ++t)
-            for (int i = 0; i < D; i += 2) {
-                const float div = std::exp((float)i * (float)(-std::log(10000.0) / D));
+        for (int t = 0; t < L; ++t) {
+            for (int i = 0; i < DR; i += 2) {
+                const float div = std::exp((float)i * (float)(-std::log(10000.0) / DR));
                 const float ang = (float)t * div;
                 theta[net->off_pos + t * D + i] = std::sin(ang);
-                if (i + 1 < D) theta[net->off_pos + t * D + i + 1] = std::cos(ang);
+                if (i + 1 < DR) theta[net->off_pos + t * D + i + 1] = std::cos(ang);
             }
+            for (int i = DR; i < D; ++i) theta[net->off_pos + t * D + i] = 0.f;
+        }
     } else if (net->pos == DTQN_POS_NONE) {
         std::memset(theta + net->off_pos, 0, sizeof(float) * (size_t)L * D);
     }

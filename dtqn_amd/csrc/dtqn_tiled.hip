@@ -1099,14 +1099,15 @@ struct TlLnArgs {
     Fld src, dst, st;                  // st: (mean, rstd) per row, base may be null
     const float *ga, *gb, *ba, *bb;    // gamma / beta, sequences >= split use the second set
     int split, rpb;
+    int d_real;                        // width-padded network (DtqnNet.d_real): statistics over the first d_real columns; 0 = all D
 };
-template <int D>
+template <int D, bool PAD>
 __global__ __launch_bounds__(TNT) void tl_layernorm_kernel(TlLnArgs a) {
     const Thr t = make_thr();
     const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * TROWS;
     float* st = a.st.base != nullptr ? a.st.base + (size_t)s * a.st.stride + (size_t)row0 * 2 : nullptr;
-    layernorm_rows<D, TNW>(frow(a.src, s, row0), frow(a.dst, s, row0), a.src.ld, TROWS, s >= a.split ? a.gb : a.ga,
-                           s >= a.split ? a.bb : a.ba, st, t, nullptr, nullptr, a.dst.ld);
+    layernorm_rows<D, TNW, DTQN_MAX_LP, true, PAD>(frow(a.src, s, row0), frow(a.dst, s, row0), a.src.ld, TROWS, s >= a.split ? a.gb : a.ga,
+                                                   s >= a.split ? a.bb : a.ba, st, t, nullptr, nullptr, a.dst.ld, PAD ? a.d_real : D);
 }
 
 // backward, one workgroup per (sequence, 64-row block): 8 lanes per row, each with D / 32 float4 of the row in registers.
@@ -1123,8 +1124,11 @@ struct TlLnBwdArgs {
     int dgb_off;
     int rpb;
     int accumulate;
+    int d_real;                        // DtqnNet.d_real (0 = not padded)
 };
-template <int D>
+// PAD: width-padded network -- the two row means run over the d_real real columns, and the padded columns of dx are 0 (their dy and gamma
+// are zero, but -c1 - xhat c2 is not: left in, it would reach the padded rows of every weight gradient below)
+template <int D, bool PAD>
 __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
     constexpr int NV = D / 32;                                         // float4 per lane: columns part * 4 + 32 * j
     float* red = reinterpret_cast<float*>(dtqn_smem);                  // [TNW][2][D]
@@ -1148,8 +1152,9 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
     }
 #pragma unroll
     for (int m = 1; m < 8; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
-    c1 *= (1.0f / D);
-    c2 *= (1.0f / D);
+    const float inv_d = PAD ? 1.0f / (float)a.d_real : (1.0f / D);
+    c1 *= inv_d;
+    c2 *= inv_d;
     // column sums over the 8 rows of this wave
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -1174,6 +1179,10 @@ __global__ __launch_bounds__(TNT) void tl_layernorm_bwd_kernel(TlLnBwdArgs a) {
         o.y = rstd * (y[j].y * gm.y - c1 - xh[j].y * c2);
         o.z = rstd * (y[j].z * gm.z - c1 - xh[j].z * c2);
         o.w = rstd * (y[j].w * gm.w - c1 - xh[j].w * c2);
+        if constexpr (PAD) {
+            const int c0 = part * 4 + 32 * j;
+            o.x = c0 < a.d_real ? o.x : 0.f; o.y = c0 + 1 < a.d_real ? o.y : 0.f; o.z = c0 + 2 < a.d_real ? o.z : 0.f; o.w = c0 + 3 < a.d_real ? o.w : 0.f;
+        }
         if (a.accumulate) {
             const float4 p = ld4(dp + 32 * j);
             o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
@@ -1753,13 +1762,15 @@ static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
 }
 template <int D>
 static int launch_ln(const TlLnArgs& a, int S, hipStream_t stream) {
-    TL_LAUNCH((tl_layernorm_kernel<D>), dim3(S * a.rpb), dim3(TNT), 0, stream, a);
+    if (a.d_real > 0) TL_LAUNCH((tl_layernorm_kernel<D, true>), dim3(S * a.rpb), dim3(TNT), 0, stream, a);
+    else TL_LAUNCH((tl_layernorm_kernel<D, false>), dim3(S * a.rpb), dim3(TNT), 0, stream, a);
     return DTQN_OK;
 }
 template <int D>
 static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
     const size_t lds = (size_t)TNW * 2 * D * sizeof(float);
-    TL_LAUNCH((tl_layernorm_bwd_kernel<D>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    if (a.d_real > 0) TL_LAUNCH((tl_layernorm_bwd_kernel<D, true>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+    else TL_LAUNCH((tl_layernorm_bwd_kernel<D, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
 // head_dim instantiations of the attention kernels (dtqn_net_init admits exactly these on the row-block path)
@@ -1898,9 +1909,11 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         TlLnArgs a;
         a.src = s_; a.dst = d_; a.st = st;
         a.ga = theta_a + w_off; a.gb = theta_b + w_off; a.ba = theta_a + b_off; a.bb = theta_b + b_off;
-        a.split = split; a.rpb = rpb;
+        a.split = split; a.rpb = rpb; a.d_real = net.d_real;
         return launch_ln<D>(a, S, stream);
     };
+    // width-padded networks keep their LayerNorms in launches of their own (the fused epilogues below take the statistics over all D columns)
+    const bool padded = net.d_real > 0;
     for (int l = 0; l < net.num_layers; ++l) {
         const int tb = net.off_layer0 + l * net.layer_stride, ab = L0(l);
         const bool last = l + 1 == net.num_layers;
@@ -1927,7 +1940,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
-        if (!gru && !ident && getenv("DTQN_NO_WIDE") == nullptr) {
+        if (!gru && !ident && !padded && getenv("DTQN_NO_WIDE") == nullptr) {
             // post-LN residual layer: out-projection, residual add and LayerNorm-1 in one launch (s1 kept for the backward only)
             TlWideArgs wa = {};
             wa.in = F(ab + net.al_o, D); wa.out = s1; wa.N = D;
@@ -1966,7 +1979,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
             if (!gru) { fa.mode = 2; fa.out = s2; fa.res = ident ? s1 : u2; }
             else { fa.mode = 1; fa.out = F(ab + net.al_gate2 + 5 * LPD, D); fa.res = nofld(); }
-            ln2_folded = !gru && !ident;
+            ln2_folded = !gru && !ident && !padded;
             if (ln2_folded) {            // post-LN residual layer: the LayerNorm that closes it rides in the kernel's epilogue
                 fa.ln_out = last ? (net.bag_size > 0 ? F(rm.xcat, 2 * D) : F(rm.xf, D)) : F(L0(l + 1) + net.al_u1, D);
                 fa.ln_st = st2;
@@ -2070,6 +2083,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         TlLnBwdArgs a;
         a.dy = dy; a.xin = xin; a.st = st; a.dst = G; a.gamma = theta + gamma_off;
         a.small = td.small; a.small_stride = net.sp_stride; a.dgb_off = dgb_off; a.rpb = rpb; a.accumulate = accumulate ? 1 : 0;
+        a.d_real = net.d_real;
         return launch_ln_bwd<D>(a, B, stream);
     };
     auto mask = [&](Fld m, Fld dst) -> int {

@@ -68,6 +68,9 @@ class DTQN(nn.Module):
         self._lib.dtqn_net_fill_frozen(ctypes.byref(net), flat.ctypes.data_as(ctypes.c_void_p))
         self.flat = torch.from_numpy(flat)
         self._table = B.param_table(net)
+        # width-padded network (DtqnNet.d_real): the buffer holds every tensor at the padded width; state_dict() / load_state_dict()
+        # speak the reference's shapes (`_real_shapes`), parameters() are the buffer's own views
+        self._real_shapes = {k: shp for k, (_, shp) in B.param_table(net, net.d_real).items()} if net.d_real else None
         self._views = {}
         seen = {}
         for key, (off, shape) in self._table.items():
@@ -108,6 +111,38 @@ class DTQN(nn.Module):
                 p.zero_()
             else:
                 p.normal_(mean=0.0, std=0.02)
+        self._zero_padding()
+
+    @torch.no_grad()
+    def _zero_padding(self) -> None:
+        """Width-padded network: everything outside the reference-shaped part of each tensor is zero (and stays zero under training:
+        include/dtqn_hip.h, d_real)."""
+        if self._real_shapes is None:
+            return
+        for key, (p, off, shape) in self._views.items():
+            real_shape = self._real_shapes[key]
+            if tuple(real_shape) != tuple(shape):
+                real = B.unpad_param(self.net, key, p.data, real_shape).clone()
+                p.data.zero_()
+                p.data.copy_(B.pad_param(self.net, key, real, tuple(shape)))
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if self._real_shapes is not None:           # the reference's shapes (slices of the buffer; the stacked in_proj tensors as copies)
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for key, real_shape in self._real_shapes.items():
+                if prefix + key in sd:
+                    sd[prefix + key] = B.unpad_param(self.net, key, sd[prefix + key], real_shape)
+        return sd
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        if self._real_shapes is not None:
+            state_dict = dict(state_dict)
+            for key, (off, shape) in self._table.items():
+                v = state_dict.get(key)
+                if v is not None and tuple(v.shape) == tuple(self._real_shapes[key]) and tuple(v.shape) != tuple(shape):
+                    state_dict[key] = B.pad_param(self.net, key, v.detach(), tuple(shape))
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     def _apply(self, fn, recurse=True):
         """Module.to()/cuda()/float(): move the flat buffer once and re-point every view at it."""

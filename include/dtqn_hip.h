@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 14
+#define DTQN_ABI_VERSION 15
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -71,6 +71,15 @@ typedef struct DtqnNet {
                                * pixels, fed to the network as their float values like the reference).  Row-block tiled path; (D - a) % 16 == 0 */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
                                * forwards only; 0 = off.  Both kernel families (counter-based keep masks, recomputed in the backward) */
+    int32_t d_real, heads_real; /* width padding (0 on a fresh struct = none).  A d_model outside the kernels' widths whose head width they cover
+                               * (d_model / num_heads in {4, 8, 16, 32, 64}; no action embedding, bag, image or dropout) is padded by dtqn_net_init
+                               * to the next of 64 / 128 / 256: d_real / heads_real keep the caller's values, d_model / num_heads become the
+                               * padded ones (whole extra heads of the same width), and every tensor of theta has the padded shape with the
+                               * real entries in front (in_proj: in front of each of its q | k | v blocks).  Padded entries are zero and stay
+                               * zero: zero weights and LayerNorm affines make the padded columns 0 in every activation, the LayerNorm
+                               * statistics run over the d_real real columns, its backward writes 0 into the padded ones, so every padded
+                               * gradient entry is exactly 0 and Adam leaves the entry alone.  Row-block tiled path.  A struct that is
+                               * initialised again keeps its padding (the fields are read as inputs when d_real > 0) */
     /* ---- derived: geometry ---- */
     int32_t abi_version;
     int32_t lp;               /* rows of the per-sequence records: L padded to the row count of the kernels the network runs on -- the smallest

@@ -18,9 +18,10 @@ def net_from_cfg(lib, cfg: O.NetCfg):
 
 
 def pack_theta(net, params) -> np.ndarray:
+    """Oracle / reference-shaped tensors -> the engine's flat buffer (width-padded networks: zeros in the padding, DtqnNet.d_real)."""
     theta = np.zeros(net.n_theta, dtype=np.float32)
     for key, (off, shape) in B.param_table(net).items():
-        v = params[key].detach().numpy().astype(np.float32).reshape(-1)
+        v = B.pad_param(net, key, params[key].detach().numpy().astype(np.float32), tuple(shape)).reshape(-1)
         assert v.size == int(np.prod(shape)), key
         theta[off:off + v.size] = v
     return theta
@@ -28,11 +29,24 @@ def pack_theta(net, params) -> np.ndarray:
 
 def unpack_flat(net, flat: np.ndarray, keys):
     tab = B.param_table(net)
+    real = B.param_table(net, net.d_real) if net.d_real else tab
     out = {}
     for k in keys:
         off, shape = tab[k]
-        out[k] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
+        out[k] = np.ascontiguousarray(B.unpad_param(net, k, flat[off:off + int(np.prod(shape))].reshape(shape), real[k][1])).copy()
     return out
+
+
+def padding_mask(net) -> np.ndarray:
+    """True at the trainable entries of the flat buffer that are PADDING of a width-padded network (all False otherwise)."""
+    m = np.zeros(net.n_trainable, dtype=bool)
+    if net.d_real:
+        real = B.param_table(net, net.d_real)
+        for k, (off, shape) in B.param_table(net).items():
+            if off < net.n_trainable:
+                n = int(np.prod(shape))
+                m[off:off + n] = B.pad_param(net, k, np.ones(real[k][1], dtype=np.float32), tuple(shape)).reshape(-1) == 0
+    return m
 
 
 def ptr(a):
@@ -69,7 +83,7 @@ def flat_from_params(net, params, keys):
     flat = np.zeros(net.n_trainable, dtype=np.float32)
     for k in keys:
         off, shape = tab[k]
-        v = params[k].detach().numpy().reshape(-1)
+        v = B.pad_param(net, k, params[k].detach().numpy(), tuple(shape)).reshape(-1)
         flat[off:off + v.size] = v
     return flat
 
@@ -115,12 +129,17 @@ def engine_probe(cfg, net, eng):
         bit = (((rows >> 2) & 3) << 4) + (cols & 15)
         return torch.from_numpy(((words[:, widx] >> bit.astype(np.uint64)) & np.uint64(1)).astype(bool))
     masks = []
+    Dp = net.d_model                  # the records are d_model wide; a width-padded network's real columns are the first D of them
     for l in range(cfg.num_layers):
         base = net.ao_layer0 + l * net.act_layer_stride
-        m_h = ballots(base + net.al_mh, 4 * D)
-        assert torch.equal(m_h, fld(base + net.al_h, 4 * D)), "hidden ballot disagrees with the saved hidden"
-        masks += [ballots(base + net.al_m1, D), m_h, ballots(base + net.al_m2, D)]
-    masks.append(fld(net.ao_hh, D))
+        m_h = ballots(base + net.al_mh, 4 * Dp)
+        assert torch.equal(m_h, fld(base + net.al_h, 4 * Dp)), "hidden ballot disagrees with the saved hidden"
+        m1, m2 = ballots(base + net.al_m1, Dp), ballots(base + net.al_m2, Dp)
+        assert not m_h[..., 4 * D:].any() and not m1[..., D:].any() and not m2[..., D:].any(), "a padded unit is active"
+        masks += [m1[..., :D], m_h[..., :4 * D], m2[..., :D]]
+    hh = fld(net.ao_hh, Dp)
+    assert not hh[..., D:].any()
+    masks.append(hh[..., :D])
     return {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
 
 
@@ -180,6 +199,9 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         got = eng.grad.cpu().numpy().copy()
         gerr = np.abs(got - ref_flat).max()
         assert gerr <= grad_rtol * np.abs(ref_flat).max(), (it, gerr, np.abs(ref_flat).max(), probe)
+        pad = padding_mask(net)
+        if pad.any():                  # width-padded network: the padding takes no gradient at all
+            assert not got[:net.n_trainable][pad].any(), (it, int(np.count_nonzero(got[:net.n_trainable][pad])))
         # --- optimizer step + statistics
         if not one_call:
             eng.clip_adam()
@@ -192,6 +214,7 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         for k in ("td_error", "grad_norm", "qvalue_max", "qvalue_mean", "qvalue_min", "target_max", "target_mean", "target_min"):
             assert st[k] == ref_stats[k] or abs(st[k] - ref_stats[k]) <= 2e-4 * max(1.0, abs(ref_stats[k])), (it, k, st[k], ref_stats[k])
         post = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+        assert not post[pad].any()     # ... and stays zero through the optimizer step
         ref_post = flat_from_params(net, oracle.pol, keys)
         d = np.abs(post - ref_post)
         solid = np.abs(ref_flat) >= 1e-3 * np.abs(ref_flat).max()
@@ -207,8 +230,8 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         for k in keys:
             off, shape = tab[k]
             n = int(np.prod(shape))
-            eng.adam_m[off:off + n].copy_(oracle.opt.m[k].reshape(-1))
-            eng.adam_v[off:off + n].copy_(oracle.opt.v[k].reshape(-1))
+            eng.adam_m[off:off + n].copy_(B.pad_param(net, k, oracle.opt.m[k], tuple(shape)).reshape(-1))
+            eng.adam_v[off:off + n].copy_(B.pad_param(net, k, oracle.opt.v[k], tuple(shape)).reshape(-1))
         # target sync parity
         tgt_ref = pack_theta(net, oracle.tgt)[:net.n_trainable]
         tgt_got = eng.theta_tgt.cpu().numpy()[:net.n_trainable].copy()

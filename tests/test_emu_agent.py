@@ -183,7 +183,8 @@ def test_overlapped_step_matches_serial_step(emu):
     assert torch.equal(results[0][1], results[1][1])
 
 
-def test_checkpoint_round_trip(emu, tmp_path):
+@pytest.mark.parametrize("width", [(32, 2), (48, 6)])       # (48, 6): a width-padded network -- its state_dicts travel in the reference's shapes
+def test_checkpoint_round_trip(emu, tmp_path, width):
     import run as runpy
     from dtqn_amd import envs
     from dtqn_amd.utils.epsilon_anneal import LinearAnneal
@@ -191,7 +192,7 @@ def test_checkpoint_round_trip(emu, tmp_path):
     from dtqn_amd.utils.random import set_global_seed
     env = envs.make("Memory-5-v0")
     set_global_seed(2, env)
-    a = make_agent(emu, env, D=32)
+    a = make_agent(emu, env, D=width[0], H=width[1])
     runpy.prepopulate(a, 400, [env])
     for _ in range(3):
         a.train()
@@ -201,7 +202,7 @@ def test_checkpoint_round_trip(emu, tmp_path):
     ras[0].add(0.5)
     path = str(tmp_path / "ck")
     a.save_checkpoint(path, "wid", ras[0], ras[1], ras[2], eps)
-    b = make_agent(emu, env, D=32)
+    b = make_agent(emu, env, D=width[0], H=width[1])
     wid, s, r, l, ev = b.load_checkpoint(path)
     assert wid == "wid" and ev == eps.val and s.mean() == 0.5 and b.num_train_steps == 3
     assert torch.equal(a.policy_network.flat, b.policy_network.flat) and torch.equal(a.engine.adam_v, b.engine.adam_v)

@@ -109,6 +109,9 @@ VARIANTS = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, history_len=50),
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, history_len=30),
     dict(obs_dim=3, num_actions=3, inner_embed_size=256, num_heads=4, history_len=128),
+    # width-padded (DtqnNet.d_real): 48 -> 64 with two all-zero heads, 96 -> 128
+    dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, history_len=50),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=96, num_heads=6, history_len=100, pos="sin", gate="gru"),
 ]
 
 

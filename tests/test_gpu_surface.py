@@ -144,3 +144,29 @@ def test_loading_a_checkpoint_into_an_agent_that_already_trained(tmp_path):
     m = a.td_errors.mean()
     assert np.isfinite(m) and len(a.td_errors.q) == 8 and a.num_train_steps == 8
     assert int(a.engine.step_counter[1].item()) == 8
+
+
+def test_module_at_a_padded_width_speaks_the_reference_shapes():
+    """DTQN(inner_embed_size=48, num_heads=6) on the device (DtqnNet.d_real: runs at width 64 with two all-zero heads): reference-shaped
+    state_dict in and out, forward == the oracle at width 48 on full contexts and prefixes, policy -> target copy."""
+    from helpers import padding_mask
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=50, pos="sin")
+    m = _module(cfg)
+    assert (m.net.d_real, m.net.d_model, m.net.num_heads) == (48, 64, 8)
+    params = O.init_params(cfg, seed=11, perturb=True)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in params.items()}
+    m.load_state_dict({k: v.clone() for k, v in params.items()})
+    pad = torch.from_numpy(padding_mask(m.net)).cuda()
+    assert pad.any() and not m.flat[:m.net.n_trainable][pad].any()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), params[k]), k
+    rng = np.random.default_rng(3)
+    for n in (1, 17, 50):
+        obs = rng.uniform(-1, 1, (4, n, 3)).astype(np.float32)
+        act = np.zeros((4, n, 1), dtype=np.int64)
+        with torch.no_grad():
+            ref = O.forward(params, cfg, torch.as_tensor(obs), torch.as_tensor(act)).numpy()
+        assert np.abs(_q(m, cfg, obs, act) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), n
+    tgt = _module(cfg)
+    tgt.load_state_dict(m.state_dict())
+    assert torch.equal(tgt.flat, m.flat)

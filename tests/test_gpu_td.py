@@ -66,6 +66,13 @@ CASES += [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, num_layers=1, history_len=50, pos="sin"), dict(batch=4, T=200, mask=-5, n_eps=12)),
     (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=2, num_layers=1, history_len=100, gate="gru", action_dim=8), dict(batch=3, T=120, mask=-5, n_eps=8)),
     (dict(obs_dim=1, num_actions=5, inner_embed_size=256, num_heads=4, num_layers=1, history_len=128, discrete=True, vocab_sizes=22), dict(batch=2, T=140, mask=21, n_eps=5)),
+    # width-padded networks (DtqnNet.d_real; the same mechanism on the emulation: tests/test_padded_width.py): 48 -> 64, 96 -> 128, 80 -> 128 (GRU),
+    # 160 -> 256; check_td_updates also demands that no padded entry takes a gradient or moves
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=50), dict(batch=16, T=200, mask=-5, n_eps=30, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=6, num_layers=2, history_len=50, discrete=True, vocab_sizes=9, pos="sin"),
+     dict(batch=8, T=60, mask=8, n_eps=20)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=80, num_heads=5, num_layers=1, history_len=100, gate="gru", identity=True), dict(batch=4, T=120, mask=-5, n_eps=10)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=160, num_heads=5, num_layers=1, history_len=50), dict(batch=4, T=200, mask=-5, n_eps=12)),
 ]
 
 

@@ -1,0 +1,131 @@
+"""Width-padded networks (include/dtqn_hip.h, DtqnNet.d_real): a d_model the kernels are not instantiated for (48, 80, 96, 160 ...) runs at
+the next width that is, with whole extra heads; padded entries are zero and stay zero.  On the test-only emulation: the TD update against
+the oracle at the REAL width, the reference-shaped state_dict of the module, an agent that trains.  (`-m gpu` twins: tests/test_gpu_td.py,
+tests/test_gpu_surface.py.)"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dtqn_amd import _binding as B
+from oracle import dtqn_oracle as O
+
+from helpers import make_td_case, check_td_updates, net_from_cfg, pack_theta, padding_mask
+
+# (reference constructor arguments, run, (padded d_model, padded heads))
+PADDED = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (64, 8)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=6, num_layers=1, history_len=30, discrete=True, vocab_sizes=9, pos="sin"),
+     dict(batch=2, T=40, mask=8), (128, 8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=80, num_heads=5, num_layers=1, history_len=12, gate="gru"), dict(batch=2, T=20, mask=-5), (128, 8)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=40, num_heads=5, num_layers=1, history_len=70, identity=True), dict(batch=2, T=90, mask=-5), (64, 8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=160, num_heads=5, num_layers=1, history_len=16), dict(batch=2, T=24, mask=-5), (256, 8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=12, num_layers=1, history_len=10, gate="gru", identity=True, pos="none"),
+     dict(batch=2, T=16, mask=-5), (64, 16)),
+]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import emu_build
+    return B.load_library(emu_build.build())
+
+
+@pytest.mark.parametrize("kw,run,padded", PADDED)
+def test_td_update_of_a_width_padded_network(emu, kw, run, padded):
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=19, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
+    assert (net.d_real, net.heads_real) == (cfg.inner_embed_size, cfg.num_heads) and (net.d_model, net.num_heads) == padded
+    assert net.tiled == 1 and net.head_dim == cfg.inner_embed_size // cfg.num_heads
+    assert padding_mask(net).sum() > 0
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)      # incl.: padded gradient entries == 0, padded parameters stay 0
+
+
+def test_forward_on_context_prefixes(emu):
+    from helpers import ptr
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=20, pos="sin")
+    net = net_from_cfg(emu, cfg)
+    params = O.init_params(cfg, seed=3, perturb=True)
+    theta = torch.from_numpy(pack_theta(net, params))
+    rng = np.random.default_rng(1)
+    ws = torch.empty(emu.dtqn_forward_workspace_floats(ctypes.byref(net), 3))
+    for n in (1, 2, 10, 20):
+        obs = torch.tensor(rng.uniform(-1, 1, (3, n, 3)).astype(np.float32))
+        act = torch.tensor(rng.integers(0, 3, (3, n)).astype(np.uint8))
+        q = torch.full((3, n, 3), float("nan"))
+        assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 3, n, ptr(q), ptr(ws), None) == 0
+        with torch.no_grad():
+            ref = O.forward(params, cfg, obs, act.long().unsqueeze(-1)).numpy()
+        assert np.abs(q.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), n
+
+
+def test_what_padding_does_not_cover_is_refused(emu):
+    ok = dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=1, history_len=10)
+    assert B.make_net(emu, **ok).d_real == 48
+    for bad in (dict(num_heads=4),                    # head width 12: no attention instantiation
+                dict(action_dim=4),                   # the action embedding's columns sit at the END of a token: not a prefix of the padded row
+                dict(dropout=0.1),                    # keep masks are keyed by the element index at the buffer's width
+                dict(bag_size=4),
+                dict(inner_embed_size=272, num_heads=17)):
+        with pytest.raises(NotImplementedError):
+            B.make_net(emu, **{**ok, **bad})
+    again = B.make_net(emu, **ok)                     # a padded struct initialised again keeps the caller's width
+    assert emu.dtqn_net_init(ctypes.byref(again)) == 0 and (again.d_real, again.d_model, again.heads_real, again.num_heads) == (48, 64, 6, 8)
+
+
+def test_module_speaks_the_reference_shapes(emu):
+    """DTQN(inner_embed_size=48, num_heads=6): state_dict() has the reference's shapes, a reference-shaped state_dict loads, the forward
+    equals the oracle at width 48, and everything outside the real entries of the flat buffer is zero."""
+    from dtqn_amd.networks.dtqn import DTQN
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=12, gate="gru")
+    m = DTQN(3, 3, 8, 0, 48, 6, 2, 12, gate="gru", _test_lib=emu)
+    m._allow_cpu = True
+    params = O.init_params(cfg, seed=7, perturb=True)
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v.shape) for k, v in params.items()}
+    pad = padding_mask(m.net)
+    assert pad.any() and not m.flat[:m.net.n_trainable][torch.from_numpy(pad)].any()       # fresh module: zero padding (LayerNorm gammas included)
+    real = ~pad
+    assert m.flat[:m.net.n_trainable][torch.from_numpy(real)].abs().sum() > 0
+    m.load_state_dict(params)
+    assert not m.flat[:m.net.n_trainable][torch.from_numpy(pad)].any()
+    back = m.state_dict()
+    for k, v in params.items():
+        assert torch.equal(back[k], v), k
+    rng = np.random.default_rng(2)
+    obs = torch.tensor(rng.uniform(-1, 1, (2, 9, 3)).astype(np.float32))
+    act = torch.zeros(2, 9, 1, dtype=torch.long)
+    with torch.no_grad():
+        ref = O.forward(params, cfg, obs, act)
+    assert (m(obs, act) - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+    # a second module takes the first one's state_dict (DqnAgent.target_update, dqn.py:208-210)
+    m2 = DTQN(3, 3, 8, 0, 48, 6, 2, 12, gate="gru", _test_lib=emu)
+    m2.load_state_dict(m.state_dict())
+    assert torch.equal(m2.flat, m.flat)
+
+
+def test_agent_trains_at_a_padded_width(emu):
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import Constant
+    from dtqn_amd.utils.random import set_global_seed
+    from test_emu_agent import make_agent
+    env = envs.make("DiscreteCarFlag-v0")
+    set_global_seed(4, env)
+    agent = make_agent(emu, env, batch=2, L=8, D=48, H=6, tuf=2)
+    net = agent.policy_network.net
+    assert (net.d_real, net.d_model) == (48, 64)
+    runpy.prepopulate(agent, 600, [env])
+    theta0 = agent.policy_network.flat.clone()
+    agent.context_reset(env.reset())
+    for _ in range(3):
+        if runpy.step(agent, env, Constant(0.3)):
+            agent.replay_buffer.flush(); agent.context_reset(env.reset())
+        agent.train()
+    assert agent.num_train_steps == 3 and np.isfinite(agent.td_errors.mean())
+    pad = torch.from_numpy(padding_mask(net))
+    for flat in (agent.policy_network.flat, agent.target_network.flat, agent.engine.adam_m, agent.engine.adam_v):
+        assert not flat[:net.n_trainable][pad].any()
+    assert not torch.equal(theta0, agent.policy_network.flat)
+    assert tuple(agent.policy_network.state_dict()["transformer_layers.0.attention.in_proj_weight"].shape) == (144, 48)

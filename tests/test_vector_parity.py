@@ -68,6 +68,7 @@ EMU_CASES = [
     # a context of 10 on the 64-row instantiation of head_dim 16 (dtqn_limits.h), and one head of width 64 on the row-block path
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=4, history_len=10, num_layers=1), (3,)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, history_len=12, num_layers=1), (2,)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, history_len=12, num_layers=1), (2,)),       # width-padded (DtqnNet.d_real)
 ]
 
 
