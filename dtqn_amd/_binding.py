@@ -239,23 +239,27 @@ def param_table(net: DtqnNet, width: int = 0) -> Dict[str, Tuple[int, Tuple[int,
 
 
 # ---- width-padded networks (include/dtqn_hip.h, DtqnNet.d_real) ---------------------------------------------------------------
-# theta holds every tensor at the padded width with the real entries in front; attention.in_proj_* are three stacked blocks
-# (q | k | v), each with its real rows in front.  The two functions below move one tensor between the reference's shape and that layout.
-def _blocks(key: str) -> int:
-    return 3 if key.endswith("in_proj_weight") or key.endswith("in_proj_bias") else 1
+# theta holds every tensor at the padded shape with the real entries in front -- except along a head-structured axis, where each
+# head's real entries sit in front of that head's block: attention.in_proj_* rows are [q | k | v][head][width], attention.out_proj
+# columns are [head][width].  The two functions below move one tensor between the reference's shape and that layout.
+def _grids(net: DtqnNet, key: str, real_shape, padded_shape):
+    """(real grid, padded grid): the tensor's shape with its head-structured axis split into (blocks, heads, width); the real tensor is
+    the leading corner of the padded one in that form."""
+    H, Hp = net.heads_real or net.num_heads, net.num_heads
+    hd, hdp = net.hd_real or net.head_dim, net.head_dim
+    if key.endswith("attention.in_proj_weight") or key.endswith("attention.in_proj_bias"):
+        return (3, H, hd) + tuple(real_shape[1:]), (3, Hp, hdp) + tuple(padded_shape[1:])
+    if key.endswith("attention.out_proj.weight"):
+        return (real_shape[0], H, hd), (padded_shape[0], Hp, hdp)
+    return tuple(real_shape), tuple(padded_shape)
 
 
 def unpad_param(net: DtqnNet, key: str, padded, real_shape):
     """The reference-shaped part of a buffer-shaped tensor (torch or numpy; a view where the layout allows, else a copy)."""
     if not net.d_real or tuple(padded.shape) == tuple(real_shape):
         return padded
-    nb = _blocks(key)
-    if nb == 1:
-        return padded[tuple(slice(0, r) for r in real_shape)]
-    rows_p, rows_r = padded.shape[0] // nb, real_shape[0] // nb
-    blk = padded.reshape((nb, rows_p) + tuple(padded.shape[1:]))
-    blk = blk[(slice(None), slice(0, rows_r)) + tuple(slice(0, r) for r in real_shape[1:])]
-    return blk.reshape(tuple(real_shape))
+    rg, pg = _grids(net, key, real_shape, padded.shape)
+    return padded.reshape(pg)[tuple(slice(0, r) for r in rg)].reshape(tuple(real_shape))
 
 
 def pad_param(net: DtqnNet, key: str, real, padded_shape):
@@ -263,12 +267,7 @@ def pad_param(net: DtqnNet, key: str, real, padded_shape):
     if not net.d_real or tuple(real.shape) == tuple(padded_shape):
         return real
     import numpy as _np
-    out = _np.zeros(padded_shape, dtype=real.dtype) if isinstance(real, _np.ndarray) else real.new_zeros(padded_shape)
-    nb = _blocks(key)
-    if nb == 1:
-        out[tuple(slice(0, r) for r in real.shape)] = real
-        return out
-    rows_p, rows_r = padded_shape[0] // nb, real.shape[0] // nb
-    view = out.reshape((nb, rows_p) + tuple(padded_shape[1:]))          # a view of `out` for both array types (contiguous)
-    view[(slice(None), slice(0, rows_r)) + tuple(slice(0, r) for r in real.shape[1:])] = real.reshape((nb, rows_r) + tuple(real.shape[1:]))
+    out = _np.zeros(padded_shape, dtype=real.dtype) if isinstance(real, _np.ndarray) else real.new_zeros(tuple(padded_shape))
+    rg, pg = _grids(net, key, real.shape, padded_shape)
+    out.reshape(pg)[tuple(slice(0, r) for r in rg)] = real.reshape(rg)        # reshape of the fresh contiguous `out` is a view
     return out

@@ -116,7 +116,8 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
                                                               const float* delta_s, const float* lse_s, const Thr& t,
                                                               float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
                                                               const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
-                                                              bool p2_own = false, int q_tiles = 0, BT between = BT()) {
+                                                              bool p2_own = false, int q_tiles = 0, BT between = BT(),
+                                                              float hd_eff = (float)HD) {          // hd_eff: see attention_forward
     // dr / layer / head0 (global index of the group's first head): attention-probability dropout of the forward, recomputed:
     // o = (P * M) v with M = keep / (1 - p), so dV takes P * M, and dP = M * (dO v^T) before the softmax backward
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
@@ -128,7 +129,7 @@ __device__ __forceinline__ void attention_backward_group_mfma(float* W5, int ld,
     constexpr float LOG2E = 1.4426950408889634f;
     const int HG = GW / HD, MT = LP / 16, last_tile = (n - 1) / 16;
     const int T0 = row0 / 16, MTK = T0 + MT;                 // first query tile; number of key tiles
-    const float scale = 1.0f / sqrtf((float)HD), scale2 = scale * LOG2E;
+    const float scale = 1.0f / sqrtf(hd_eff), scale2 = scale * LOG2E;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int item = t.wave; item < HG * MT; item += NW) {
         const int h = item % HG, ti = T0 + item / HG;
@@ -279,7 +280,8 @@ template <int HD, int NW>
 __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
                                                          float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
-                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                         float hd_eff = (float)HD) {
     // dq goes to W5's fifth tile by default, or to dq_base (row stride dq_ld; may be global memory) when the
     // caller cannot afford a fifth LDS tile.
     // Row slices: queries [row0, row0 + LP) against keys [0, row0 + LP); all tile rows are GLOBAL rows, delta_s /
@@ -287,7 +289,7 @@ __device__ __forceinline__ void attention_backward_group_valu(float* W5, int ld,
     if (dq_base == nullptr) { dq_base = W5 + 4 * GW; dq_ld = ld; }
     if (sl_ld == 0) sl_ld = LP;
     const int HG = GW / HD;
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = 1.0f / sqrtf(hd_eff);
     const int q_hi = n < row0 + LP ? n : row0 + LP;          // queries of this slice: [row0, q_hi)
     int nblocks = (LP * HG + 63) / 64;
     bool one_round = nblocks <= NW && (64 % HG) == 0;
@@ -406,9 +408,12 @@ template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int GW, int LP, int n,
                                                          const float* delta_s, const float* lse_s, const Thr& t,
                                                          float* dq_base = nullptr, int dq_ld = 0, int row0 = 0, int sl_ld = 0,
-                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
-    if constexpr (MFMA) attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0);
-    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0);
+                                                         const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                         float hd_eff = (float)HD) {
+    if constexpr (MFMA)
+        attention_backward_group_mfma<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0, false, 0,
+                                              AttnNoBetween(), hd_eff);
+    else attention_backward_group_valu<HD, NW>(W5, ld, GW, LP, n, delta_s, lse_s, t, dq_base, dq_ld, row0, sl_ld, dr, layer, head0, hd_eff);
 }
 
 // Double-DQN target, MSE and dL/dQ of ONE sequence, executed by one wave (dtqn/agents/dtqn.py:219-253).

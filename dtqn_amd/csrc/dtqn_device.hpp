@@ -699,11 +699,12 @@ __device__ __forceinline__ void attention_forward_chunk(const float* kbase, cons
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D, int H, int LP, int n,
                                                        float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                       const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+                                                       const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                       float hd_eff = (float)HD) {     // hd_eff: see attention_forward
     if (lse_ld == 0) lse_ld = LP;               // query rows [row0, row0 + LP), row0 a multiple of 16
     constexpr int KS = HD / 4;                  // MFMA steps of the score contraction (4 columns of q/k per step)
     constexpr int CT = (HD + 15) / 16;          // 16-row tiles of O^T (rows = head columns c)
-    const float scale = 1.4426950408889634f / sqrtf((float)HD);        // hd^-0.5 * log2(e)
+    const float scale = 1.4426950408889634f / sqrtf(hd_eff);           // hd^-0.5 * log2(e)
     const int MT = LP / 16;
     const int last_tile = (n - 1) / 16;         // query tiles beyond it hold only pad rows
     for (int item = t.wave; item < H * MT; item += NW) {
@@ -762,10 +763,11 @@ __device__ __forceinline__ void attention_forward_mfma(float* Ws, int ld, int D,
 template <int HD, int NW>
 __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                  float hd_eff = (float)HD) {
     // query rows [row0, row0 + LP) of the tile (a row slice of the sequence when row0 > 0); keys 0 .. row
     if (lse_ld == 0) lse_ld = LP;
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = 1.0f / sqrtf(hd_eff);
     const int nblocks = (LP * H + 63) / 64;
     const bool one_round = nblocks <= NW && (64 % H) == 0;
     const int nloc = n - row0 < 0 ? 0 : (n - row0 > LP ? LP : n - row0);
@@ -854,11 +856,14 @@ constexpr int kAttnMfmaMinHeadDim = 16;
 template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
-                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0) {
+                                                  const Drop& dr = Drop{0u, 1.0f, 0u, 0u, 0u}, int layer = 0, int head0 = 0,
+                                                  float hd_eff = (float)HD) {
     // head0: global index of the tile's first head (the row-block kernels hold one head per workgroup): the keep masks of
     // the attention-probability dropout are keyed by the global head
-    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0);
-    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0);
+    // hd_eff: the head width the softmax scale is taken from -- HD itself (a compile-time constant after inlining), or the caller's real
+    // head width when the heads are zero-padded to HD columns (DtqnNet.hd_real)
+    if constexpr (MFMA) attention_forward_mfma<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0, hd_eff);
+    else attention_forward_valu<HD, NW>(Ws, ld, D, H, LP, n, lse_out, t, row0, lse_ld, dr, layer, head0, hd_eff);
 }
 
 // Cooperative copy of a [rows][cols] LDS tile (leading dim ld) to / from a dense global array.

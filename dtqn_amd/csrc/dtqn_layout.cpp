@@ -34,27 +34,30 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     if (!net) return DTQN_ERR_ARG;
     const int O = net->obs_dim, A = net->num_actions, e = net->embed_per_obs, a = net->action_dim;
     const int NL = net->num_layers, L = net->ctx_len, V = net->vocab;
-    if (net->d_real > 0) {            // a padded network initialised again (dtqn_net_tiled_twin, a copy): back to the caller's width first
+    if (net->d_real > 0) {            // a padded network initialised again (dtqn_net_tiled_twin, a copy): back to the caller's shape first
         net->d_model = net->d_real;
         net->num_heads = net->heads_real;
     }
-    net->d_real = net->heads_real = 0;
+    net->d_real = net->heads_real = net->hd_real = 0;
     if (O < 1 || A < 1 || net->d_model < 16 || net->num_heads < 1 || NL < 1 || NL > DTQN_MAX_LAYERS || L < 1) return DTQN_ERR_CONFIG;
     if (net->d_model % net->num_heads != 0 || a < 0 || a >= net->d_model || (a % 4) != 0) return DTQN_ERR_CONFIG;
     {
-        // Width padding (include/dtqn_hip.h, d_real): a width the kernels are not instantiated for runs as the next one that is, with
-        // whole extra heads of the caller's head width -- all-zero heads attend uniformly over zero values and contribute nothing.
-        const int d = net->d_model, hd = d / net->num_heads;
-        const bool native = d == 16 || d == 32 || d == 64 || d == 128 || d == 256;
+        // Width padding (include/dtqn_hip.h, d_real): a shape the kernels are not instantiated for runs as the next one that is -- every head
+        // at the next instantiated head width, then whole extra heads (all-zero heads attend uniformly over zero values and contribute
+        // nothing) up to the next instantiated d_model.
+        const int d = net->d_model, h = net->num_heads, hd = d / h;
+        const int hdp = hd <= 4 ? 4 : hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
+        bool native = (d == 16 || d == 32 || d == 64 || d == 128 || d == 256) && hd == hdp;
+        // widths 16 / 32 exist on the whole-sequence kernels only (a few row counts): beyond those they run padded to 64 columns
+        if (native && d < 64 && dtqn_ws_pick(d, hd, up16(L) / 16, nullptr) == 0) native = false;
         if (!native) {
-            const int dp = d < 64 ? 64 : d < 128 ? 128 : 256;
-            if (d > 256 || !(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64) || a != 0 || net->bag_size != 0 || net->img_c > 0 ||
-                net->dropout != 0.f)
-                return DTQN_ERR_CONFIG;
+            const int dmin = h * hdp, dp = dmin <= 64 ? 64 : dmin <= 128 ? 128 : 256;
+            if (hd > 64 || dmin > 256 || a != 0 || net->bag_size != 0 || net->img_c > 0 || net->dropout != 0.f) return DTQN_ERR_CONFIG;
             net->d_real = d;
-            net->heads_real = net->num_heads;
+            net->heads_real = h;
+            net->hd_real = hd;
             net->d_model = dp;
-            net->num_heads = dp / hd;
+            net->num_heads = dp / hdp;
         }
     }
     const int D = net->d_model, H = net->num_heads;

@@ -1014,6 +1014,7 @@ struct TlAttnArgs {
     int D, lpb, n;
     TlDrop drop;                       // dropout on the attention probabilities (MultiheadAttention(dropout=p), transformer.py:34)
     int layer;
+    float hd_eff;                      // head width of the softmax scale: HD, or DtqnNet.hd_real when the heads are zero-padded to HD columns
 };
 // DROP: compile-time, so that the default build of the kernel carries no keep-mask code
 template <int HD, bool DROP>
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(256) void tl_attn_kernel(TlAttnArgs a) {
     float* lse = a.lse.base != nullptr ? a.lse.base + (size_t)s * a.lse.stride + (size_t)h * a.lpb : nullptr;
     Drop dr = drop_off();
     if constexpr (DROP) dr = tl_drop(a.drop, s);
-    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, lse, t, 0, 0, dr, a.layer, h);       // one head: "D" = HD, H = 1
+    attention_forward<HD, 4>(T, LDH, HD, 1, a.lpb, a.n, lse, t, 0, 0, dr, a.layer, h, a.hd_eff);       // one head: "D" = HD, H = 1
     __syncthreads();
     float* dst = frow(a.o, s, 0) + h * HD;
     for (int idx = t.tid; idx < a.lpb * (HD / 4); idx += 256) {
@@ -1049,6 +1050,7 @@ struct TlAttnBwdArgs {
     int D, lpb, n;
     TlDrop drop;                       // the forward's attention-probability dropout, recomputed
     int layer;
+    float hd_eff;                      // as in TlAttnArgs
 };
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256) void tl_attn_bwd_kernel(TlAttnBwdArgs a) {
@@ -1085,7 +1087,7 @@ __global__ __launch_bounds__(256) void tl_attn_bwd_kernel(TlAttnBwdArgs a) {
     float* dq = frow(a.dqkv, s, 0) + h * HD;
     Drop dr = drop_off();
     if constexpr (DROP) dr = tl_drop(a.drop, s);
-    attention_backward_group<HD, 4>(T, LDH, HD, a.lpb, a.n, delta_s, lse_s, t, dq, a.dqkv.ld, 0, 0, dr, a.layer, h);
+    attention_backward_group<HD, 4>(T, LDH, HD, a.lpb, a.n, delta_s, lse_s, t, dq, a.dqkv.ld, 0, 0, dr, a.layer, h, a.hd_eff);
     __syncthreads();
     for (int idx = t.tid; idx < a.lpb * 2 * (HD / 4); idx += 256) {
         const int r = idx / (2 * (HD / 4)), rem = idx - r * (2 * (HD / 4));
@@ -1937,6 +1939,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             at.qkv = F(ab + net.al_qkv, 3 * D); at.o = F(ab + net.al_o, D);
             at.lse = training ? F(ab + net.al_lse, lpb) : nofld();
             at.D = D; at.lpb = lpb; at.n = n; at.drop = drop; at.layer = l;
+            at.hd_eff = (float)(net.hd_real > 0 ? net.hd_real : HD);
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
@@ -2196,6 +2199,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             a.qkv = FA(ab + net.al_qkv, 3 * D); a.o = FA(ab + net.al_o, D); a.lse = FA(ab + net.al_lse, lpb);
             a.dO = FG(net.go_do, D); a.dqkv = FG(gb + net.gl_dqkv, 3 * D);
             a.D = D; a.lpb = lpb; a.n = L; a.drop = drop; a.layer = l;
+            a.hd_eff = (float)(net.hd_real > 0 ? net.hd_real : HD);
             if ((rc = launch_attn_bwd(a, B, H, HD, stream)) != DTQN_OK) return rc;
         }
         if (!ident) {

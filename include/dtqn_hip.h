@@ -71,12 +71,16 @@ typedef struct DtqnNet {
                                * pixels, fed to the network as their float values like the reference).  Row-block tiled path; (D - a) % 16 == 0 */
     float dropout;            /* p of nn.Dropout / MultiheadAttention(dropout=p) (dtqn.py:51,105; transformer.py:34,41); train-mode
                                * forwards only; 0 = off.  Both kernel families (counter-based keep masks, recomputed in the backward) */
-    int32_t d_real, heads_real; /* width padding (0 on a fresh struct = none).  A d_model outside the kernels' widths whose head width they cover
-                               * (d_model / num_heads in {4, 8, 16, 32, 64}; no action embedding, bag, image or dropout) is padded by dtqn_net_init
-                               * to the next of 64 / 128 / 256: d_real / heads_real keep the caller's values, d_model / num_heads become the
-                               * padded ones (whole extra heads of the same width), and every tensor of theta has the padded shape with the
-                               * real entries in front (in_proj: in front of each of its q | k | v blocks).  Padded entries are zero and stay
-                               * zero: zero weights and LayerNorm affines make the padded columns 0 in every activation, the LayerNorm
+    int32_t d_real, heads_real, hd_real; /* width padding (0 on a fresh struct = none).  A shape outside the kernels' instantiations -- a d_model
+                               * other than 64 / 128 / 256, a head width (d_model / num_heads) that is not 4, 8, 16, 32 or 64 -- is padded by
+                               * dtqn_net_init (no action embedding, bag, image or dropout; head width <= 64, padded d_model <= 256): every head
+                               * to the next of those widths, then whole extra heads up to the next of 64 / 128 / 256 columns.  d_real /
+                               * heads_real / hd_real keep the caller's d_model / num_heads / head width; d_model / num_heads / head_dim
+                               * become the padded ones.  Every tensor of theta has the padded shape: the real entries in front, except
+                               * along a head-structured axis (in_proj rows: [q | k | v][head][width]; out_proj columns: [head][width]),
+                               * where each head's real entries are in front of that head's block.  The attention scale stays
+                               * 1 / sqrt(hd_real).  Padded entries are zero and stay zero: zero weights and LayerNorm affines make the padded
+                               * columns 0 in every activation (an all-zero head attends uniformly over zero values), the LayerNorm
                                * statistics run over the d_real real columns, its backward writes 0 into the padded ones, so every padded
                                * gradient entry is exactly 0 and Adam leaves the entry alone.  Row-block tiled path.  A struct that is
                                * initialised again keeps its padding (the fields are read as inputs when d_real > 0) */

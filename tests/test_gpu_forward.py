@@ -112,6 +112,8 @@ VARIANTS = [
     # width-padded (DtqnNet.d_real): 48 -> 64 with two all-zero heads, 96 -> 128
     dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, history_len=50),
     dict(obs_dim=3, num_actions=3, inner_embed_size=96, num_heads=6, history_len=100, pos="sin", gate="gru"),
+    dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=4, history_len=50),               # heads of 12 -> 16
+    dict(obs_dim=3, num_actions=3, inner_embed_size=120, num_heads=5, history_len=128),             # heads of 24 -> 32, 160 -> 256 columns
 ]
 
 

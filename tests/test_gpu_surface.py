@@ -146,13 +146,14 @@ def test_loading_a_checkpoint_into_an_agent_that_already_trained(tmp_path):
     assert int(a.engine.step_counter[1].item()) == 8
 
 
-def test_module_at_a_padded_width_speaks_the_reference_shapes():
+@pytest.mark.parametrize("heads,padded", [(6, (64, 8, 8)), (4, (64, 4, 16))])
+def test_module_at_a_padded_width_speaks_the_reference_shapes(heads, padded):
     """DTQN(inner_embed_size=48, num_heads=6) on the device (DtqnNet.d_real: runs at width 64 with two all-zero heads): reference-shaped
     state_dict in and out, forward == the oracle at width 48 on full contexts and prefixes, policy -> target copy."""
     from helpers import padding_mask
-    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=50, pos="sin")
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=heads, num_layers=2, history_len=50, pos="sin")
     m = _module(cfg)
-    assert (m.net.d_real, m.net.d_model, m.net.num_heads) == (48, 64, 8)
+    assert (m.net.d_real, m.net.d_model, m.net.num_heads, m.net.head_dim) == (48,) + padded
     params = O.init_params(cfg, seed=11, perturb=True)
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in params.items()}
     m.load_state_dict({k: v.clone() for k, v in params.items()})

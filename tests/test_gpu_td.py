@@ -73,6 +73,12 @@ CASES += [
      dict(batch=8, T=60, mask=8, n_eps=20)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=80, num_heads=5, num_layers=1, history_len=100, gate="gru", identity=True), dict(batch=4, T=120, mask=-5, n_eps=10)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=160, num_heads=5, num_layers=1, history_len=50), dict(batch=4, T=200, mask=-5, n_eps=12)),
+    # ... and padded head widths (12 -> 16, 24 -> 32, 20 -> 32 plus an extra head), softmax scale of the real width; width 32 beyond 32 rows
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=4, num_layers=2, history_len=50), dict(batch=16, T=200, mask=-5, n_eps=30, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=100, discrete=True, vocab_sizes=9, pos="sin", gate="gru"),
+     dict(batch=4, T=120, mask=8, n_eps=10)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=60, num_heads=3, num_layers=1, history_len=50, identity=True), dict(batch=4, T=200, mask=-5, n_eps=12)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, num_layers=1, history_len=50), dict(batch=8, T=200, mask=-5, n_eps=20)),
 ]
 
 

@@ -23,6 +23,16 @@ PADDED = [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=160, num_heads=5, num_layers=1, history_len=16), dict(batch=2, T=24, mask=-5), (256, 8)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=12, num_layers=1, history_len=10, gate="gru", identity=True, pos="none"),
      dict(batch=2, T=16, mask=-5), (64, 16)),
+    # head widths that are not instantiated: every head padded to the next one that is (12 -> 16, 24 -> 32, 6 -> 8, 20 -> 32), softmax scale
+    # of the real width; the last one also gets an extra head
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=4, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (64, 4)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=30, discrete=True, vocab_sizes=9, pos="sin", gate="gru"),
+     dict(batch=2, T=40, mask=8), (128, 4)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=8, num_layers=1, history_len=70, identity=True), dict(batch=2, T=90, mask=-5), (64, 8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=60, num_heads=3, num_layers=1, history_len=12), dict(batch=2, T=20, mask=-5), (128, 4)),
+    # widths 16 / 32 beyond the row counts their whole-sequence kernels exist for: padded to 64 columns with extra heads
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, num_layers=1, history_len=40), dict(batch=2, T=50, mask=-5), (64, 8)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=1, num_layers=1, history_len=8), dict(batch=2, T=14, mask=-5), (64, 2)),
 ]
 
 
@@ -37,7 +47,8 @@ def test_td_update_of_a_width_padded_network(emu, kw, run, padded):
     cfg = O.NetCfg(**kw)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=19, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
     assert (net.d_real, net.heads_real) == (cfg.inner_embed_size, cfg.num_heads) and (net.d_model, net.num_heads) == padded
-    assert net.tiled == 1 and net.head_dim == cfg.inner_embed_size // cfg.num_heads
+    hd = cfg.inner_embed_size // cfg.num_heads
+    assert net.tiled == 1 and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64) if w >= hd)
     assert padding_mask(net).sum() > 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)      # incl.: padded gradient entries == 0, padded parameters stay 0
 
@@ -63,7 +74,8 @@ def test_forward_on_context_prefixes(emu):
 def test_what_padding_does_not_cover_is_refused(emu):
     ok = dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=1, history_len=10)
     assert B.make_net(emu, **ok).d_real == 48
-    for bad in (dict(num_heads=4),                    # head width 12: no attention instantiation
+    for bad in (dict(inner_embed_size=140, num_heads=2),   # head width 70: beyond the widest attention instantiation (64)
+                dict(inner_embed_size=240, num_heads=6),   # six heads of 40 -> 64 columns each: 384 > 256
                 dict(action_dim=4),                   # the action embedding's columns sit at the END of a token: not a prefix of the padded row
                 dict(dropout=0.1),                    # keep masks are keyed by the element index at the buffer's width
                 dict(bag_size=4),
@@ -72,14 +84,17 @@ def test_what_padding_does_not_cover_is_refused(emu):
             B.make_net(emu, **{**ok, **bad})
     again = B.make_net(emu, **ok)                     # a padded struct initialised again keeps the caller's width
     assert emu.dtqn_net_init(ctypes.byref(again)) == 0 and (again.d_real, again.d_model, again.heads_real, again.num_heads) == (48, 64, 6, 8)
+    twin = B.DtqnNet()                                 # ... and so does its row-block twin
+    assert emu.dtqn_net_tiled_twin(ctypes.byref(again), ctypes.byref(twin)) == 0 and (twin.d_real, twin.d_model, twin.hd_real) == (48, 64, 8)
 
 
-def test_module_speaks_the_reference_shapes(emu):
+@pytest.mark.parametrize("heads", [6, 4])                # 6 heads of 8: two extra heads; 4 heads of 12: every head padded to 16
+def test_module_speaks_the_reference_shapes(emu, heads):
     """DTQN(inner_embed_size=48, num_heads=6): state_dict() has the reference's shapes, a reference-shaped state_dict loads, the forward
     equals the oracle at width 48, and everything outside the real entries of the flat buffer is zero."""
     from dtqn_amd.networks.dtqn import DTQN
-    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=12, gate="gru")
-    m = DTQN(3, 3, 8, 0, 48, 6, 2, 12, gate="gru", _test_lib=emu)
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=heads, num_layers=2, history_len=12, gate="gru")
+    m = DTQN(3, 3, 8, 0, 48, heads, 2, 12, gate="gru", _test_lib=emu)
     m._allow_cpu = True
     params = O.init_params(cfg, seed=7, perturb=True)
     sd = m.state_dict()
@@ -100,7 +115,7 @@ def test_module_speaks_the_reference_shapes(emu):
         ref = O.forward(params, cfg, obs, act)
     assert (m(obs, act) - ref).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
     # a second module takes the first one's state_dict (DqnAgent.target_update, dqn.py:208-210)
-    m2 = DTQN(3, 3, 8, 0, 48, 6, 2, 12, gate="gru", _test_lib=emu)
+    m2 = DTQN(3, 3, 8, 0, 48, heads, 2, 12, gate="gru", _test_lib=emu)
     m2.load_state_dict(m.state_dict())
     assert torch.equal(m2.flat, m.flat)
 
