@@ -144,3 +144,39 @@ def test_agent_trains_at_a_padded_width(emu):
         assert not flat[:net.n_trainable][pad].any()
     assert not torch.equal(theta0, agent.policy_network.flat)
     assert tuple(agent.policy_network.state_dict()["transformer_layers.0.attention.in_proj_weight"].shape) == (144, 48)
+
+
+def test_pad_and_unpad_are_inverse_on_every_tensor_kind():
+    """_binding.pad_param / unpad_param over random (heads, head width, padded heads, padded head width): unpad(pad(x)) == x bit for bit,
+    the padding is zero, and along the head-structured axes every head's real entries sit in front of its own block."""
+    import types
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 6), st.integers(1, 24), st.integers(0, 3), st.sampled_from([4, 8, 16, 32, 64]), st.booleans())
+    def run(H, hd, extra_heads, hdp, as_torch):
+        if hdp < hd:
+            hdp = next(w for w in (4, 8, 16, 32, 64) if w >= hd)
+        Hp, D, Dp = H + extra_heads, H * hd, (H + extra_heads) * hdp
+        if D == Dp:
+            return
+        net = types.SimpleNamespace(d_real=D, heads_real=H, hd_real=hd, num_heads=Hp, head_dim=hdp, d_model=Dp)
+        rng = np.random.default_rng(H * 100 + hd)
+        cases = {"transformer_layers.0.attention.in_proj_weight": ((3 * D, D), (3 * Dp, Dp)),
+                 "transformer_layers.0.attention.in_proj_bias": ((3 * D,), (3 * Dp,)),
+                 "transformer_layers.0.attention.out_proj.weight": ((D, D), (Dp, Dp)),
+                 "transformer_layers.0.ffn.0.weight": ((4 * D, D), (4 * Dp, Dp)),
+                 "position_embedding.position_encoding": ((1, 5, D), (1, 5, Dp)),
+                 "ffn.2.weight": ((3, D), (3, Dp))}
+        for key, (rs, ps) in cases.items():
+            x = rng.standard_normal(rs).astype(np.float32) + 3.0             # no zeros in the real part
+            x = torch.from_numpy(x) if as_torch else x
+            p = B.pad_param(net, key, x, ps)
+            assert tuple(p.shape) == ps and int((p != 0).sum()) == int(np.prod(rs))
+            back = B.unpad_param(net, key, p, rs)
+            assert (torch.equal(back, x) if as_torch else np.array_equal(back, x)), key
+        w = np.arange(3 * D * D, dtype=np.float32).reshape(3 * D, D) + 1
+        p = B.pad_param(net, "transformer_layers.0.attention.in_proj_weight", w, (3 * Dp, Dp))
+        blk, h, i = 2, H - 1, hd - 1                                        # v block, last real head, last real column of the head
+        assert np.array_equal(p[blk * Dp + h * hdp + i, :D], w[blk * D + h * hd + i])
+    run()
