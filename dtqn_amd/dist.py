@@ -111,7 +111,12 @@ class P2PExchange:
                             mine = dev.index if dev.index is not None else torch.cuda.current_device()
                             if not torch.cuda.can_device_access_peer(mine, p.device.index):
                                 raise RuntimeError(f"device {mine} has no peer access to device {p.device.index}")
-                            p[:1].to(dev)
+                            # torch enables peer access lazily, per direction, inside its device-to-device copies -- for the SOURCE
+                            # device of the copy towards the destination's memory (the copy kernel runs on the source).  The reduce
+                            # kernel runs HERE and reads THERE: the copy that enables that direction goes from this device to the peer's
+                            # (the other one is made too, so that either runtime convention is covered)
+                            self.buf[2 * n + 8:2 * n + 9].to(p.device)
+                            p[2 * n + 8:2 * n + 9].to(dev)
         except Exception as exc:
             self.error = f"mapping: {type(exc).__name__}: {exc}"[:200]
             self.peers = [self.buf] * self.world
