@@ -46,8 +46,9 @@ class _AdamHandle:
     """Stand-in for `agent.optimizer` (dqn.py:64): the Adam state lives in the engine's flat m / v
     buffers; this exposes it for checkpoints in plain-array form."""
 
-    def __init__(self, eng: TdEngine):
+    def __init__(self, eng: TdEngine, before_load: Optional[Callable[[], None]] = None):
         self._eng = eng
+        self._before_load = before_load            # the agent's side of a reload: its statistics ring restarts with the device's counter
 
     def state_dict(self) -> dict:
         e = self._eng
@@ -56,6 +57,8 @@ class _AdamHandle:
 
     def load_state_dict(self, sd: dict) -> None:
         e = self._eng
+        if self._before_load is not None:
+            self._before_load()
         e.adam_m.copy_(torch.as_tensor(sd["exp_avg"])); e.adam_v.copy_(torch.as_tensor(sd["exp_avg_sq"]))
         e.step_counter[:2] = int(sd["step"])     # optimizer steps: published | next
         e.step_counter[2:] = 0         # statistics-ring call counter (DtqnAgent.load_checkpoint restarts its host side too) | skip flag
@@ -97,7 +100,7 @@ class DtqnAgent:
                                theta_pol=self.policy_network.flat, theta_tgt=self.target_network.flat)
         self.target_update()
         self.target_network.eval()
-        self.optimizer = _AdamHandle(self.engine)
+        self.optimizer = _AdamHandle(self.engine, self._restart_stats_ring)
         self.replay_buffer = ReplayBuffer(buffer_size, env_obs_length=env_obs_length, obs_mask=obs_mask,
                                           max_episode_steps=max_env_steps, context_len=context_len, device=self.device, lib=lib)
         # one process per GPU under torch.distributed: the gradient exchange joins the update (data_parallel=False keeps this agent a
@@ -393,6 +396,20 @@ class DtqnAgent:
         elif backlog >= self.STATS_DRAIN_EVERY:     # readers (DeferredRunningAverage.mean, checkpoints) force a full drain themselves
             self._drain_stats(block=False)
 
+    def _restart_stats_ring(self, abandon: bool = False) -> None:
+        """In front of a reload of the optimizer state (optimizer.load_state_dict resets the device's call counter): finish and consume
+        the outstanding updates, then restart the statistics ring -- host counters and slot tags -- with it.  abandon: the run so far is
+        being replaced by a checkpoint, so an error it still had pending is not this load's business."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        try:
+            self._drain_stats(block=True)
+        except RuntimeError:
+            if not abandon:
+                raise
+        self._calls_issued = self._calls_read = 0
+        self.engine.stats_ring.zero_()
+
     def _drain_stats(self, block: bool) -> None:
         eng = self.engine
         ring, slots = eng.stats_ring_np, eng.RING_SLOTS
@@ -480,16 +497,7 @@ class DtqnAgent:
 
     def load_checkpoint(self, checkpoint_dir: str) -> Tuple[str, RunningAverage, RunningAverage, RunningAverage, float]:
         ck = torch.load(checkpoint_dir + "_checkpoint.pt", weights_only=False)
-        # an agent that has already trained: finish and consume its outstanding updates, then restart the statistics
-        # ring (host counters, device call counter -- reset by optimizer.load_state_dict -- and the slot tags) together
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        try:
-            self._drain_stats(block=True)
-        except RuntimeError:
-            pass                                       # a non-finite norm of the abandoned run is not this load's business
-        self._calls_issued = self._calls_read = 0
-        self.engine.stats_ring.zero_()
+        self._restart_stats_ring(abandon=True)
         self._actor_inflight = False
         self.num_train_steps = ck["step"]
         shard, r = ck, ddp.rank()

@@ -536,3 +536,60 @@ def test_pipelined_update_equals_inline_target_pass_in_a_live_loop(emu, monkeypa
     for x, y in zip(a[:3], b[:3]):
         assert torch.equal(x, y)
     assert a[3] == b[3] and len(a[3]) == 36
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pipelined_update_under_a_random_schedule_of_everything_that_can_invalidate_it(emu, monkeypatch, tmp_path, seed):
+    """The pass computed ahead must never be used after anything that changes what it read.  A seeded random schedule throws every such event
+    between updates -- episode commits, hard target syncs by count and by call, load_state_dict on the target and on the policy module,
+    an optimizer-state reload, a checkpoint save + load into the SAME agent, a replay re-import, a change of batch statistics range --
+    and the run must be BIT-equal to the same schedule with the target pass always inline (DTQN_PIPELINE=inline)."""
+    import run as runpy
+    from dtqn_amd import envs
+    from dtqn_amd.utils.epsilon_anneal import LinearAnneal
+    from dtqn_amd.utils.logging_utils import RunningAverage
+    from dtqn_amd.utils.random import set_global_seed
+
+    def go(pipe):
+        monkeypatch.setenv("DTQN_PIPELINE", pipe)
+        env = envs.make("DiscreteCarFlag-v0")
+        set_global_seed(30 + seed, env)
+        agent = make_agent(emu, env, batch=2, L=50, D=64, H=8, tuf=7, sampler="device", sample_seed=30 + seed)
+        assert agent.pipelined
+        runpy.prepopulate(agent, 500, [env])
+        eps = LinearAnneal(1.0, 1.0, 10)
+        sched = np.random.default_rng(seed)                   # the schedule's own stream: identical in both runs
+        agent.context_reset(env.reset())
+        events = []
+        for it in range(30):
+            ev = int(sched.integers(0, 10))
+            events.append(ev)
+            if ev == 0:
+                agent.target_network.load_state_dict(agent.policy_network.state_dict())
+            elif ev == 1:
+                agent.target_update()
+            elif ev == 2:
+                sd = {k: v.clone() for k, v in agent.policy_network.state_dict().items()}
+                agent.policy_network.load_state_dict(sd)          # same values: must change nothing, whatever the engine does about it
+            elif ev == 3:
+                agent.optimizer.load_state_dict(agent.optimizer.state_dict())
+            elif ev == 4:
+                ras = [RunningAverage(10) for _ in range(3)]
+                agent.save_checkpoint(str(tmp_path / f"ck{pipe}{seed}"), "w", ras[0], ras[1], ras[2], eps)
+                agent.load_checkpoint(str(tmp_path / f"ck{pipe}{seed}"))
+            elif ev == 5:
+                agent.replay_buffer.import_arrays(agent.replay_buffer.export_arrays())
+            # 6 .. 9: nothing but the loop itself (commits at episode ends, syncs every 7 updates)
+            if runpy.step(agent, env, eps) or agent.context.timestep >= 9:
+                agent.replay_buffer.flush()
+                agent.context_reset(env.reset())
+            agent.train()
+        agent._drain_stats(block=True)
+        e = agent.engine
+        return e.theta_pol.clone(), e.theta_tgt.clone(), e.adam_m.clone(), list(agent.td_errors.q), (e._pipe["used"], e._pipe["inline"]), events
+    a, b = go("1"), go("inline")
+    assert a[5] == b[5] and len(set(a[5])) >= 6                      # the schedule really mixed the events
+    assert a[4][0] >= 5 and b[4][0] == 0, (a[4], b[4])               # ... and passes computed ahead were used in between
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3]
