@@ -23,7 +23,7 @@ def _episodes():
     return st.lists(st.tuples(st.integers(0, 6), st.integers(0, 2 ** 16 - 1), st.booleans()), min_size=1, max_size=14)
 
 
-@settings(max_examples=150, deadline=None)
+@settings(max_examples=300, deadline=None, derandomize=True)
 @given(_episodes(), st.sampled_from([(3, -5.0, False), (2, 7.0, True)]), st.integers(0, 2 ** 31 - 1))
 def _run(emu, episodes, kind, seed):
     from dtqn_amd.buffers.replay_buffer import ReplayBuffer
