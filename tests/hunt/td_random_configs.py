@@ -1,6 +1,6 @@
 """Random-configuration hunt (not collected by pytest): `python tests/hunt/td_random_configs.py <seed> <trials>` draws network shapes / variants /
 batch geometry at random, runs two TD updates on the test-only emulation and compares every stage with the oracle (tests/helpers.check_td_updates).
-Prints FAIL lines and a count.  End of round 4: 245 accepted configurations over 7 seeds, no failure; with HUNT_DROPOUT=1 (dropout 0.1 / 0.3 on native shapes) 44 accepted, the three
+Prints FAIL lines and a count.  End of round 4: 245 accepted configurations over 7 seeds, no failure; HUNT_BAG=1 adds a persistent-memory bag of 1 .. 13 entries (end of round 4: see DESIGN.md); with HUNT_DROPOUT=1 (dropout 0.1 / 0.3 on native shapes) 44 accepted, the three
 failures all in the GRU + identity, d_model 128, two-layer family, 1e-4 relative -- see conditioning_fp64.py."""
 import sys, itertools, traceback
 import os
@@ -33,6 +33,10 @@ for trial in range(int(sys.argv[2])):
         kw.update(discrete=True, vocab_sizes=int(rng.integers(3, 12)))
     if drop:
         kw.update(dropout=float(rng.choice([0.1, 0.3])))
+    if os.environ.get("HUNT_BAG") == "1":         # persistent-memory bag (row-block path; widths 64 / 128 / 256, no padding)
+        if D not in (64, 128) or D // H not in (4, 8, 16, 32, 64):
+            continue
+        kw.update(bag_size=int(rng.integers(1, 14)))
     cfg = O.NetCfg(**kw)
     batch = int(rng.integers(1, 4)); T = L + int(rng.integers(2, 20)); hist = int(rng.integers(1, L + 1))
     try:
