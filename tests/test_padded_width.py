@@ -76,7 +76,7 @@ def test_what_padding_does_not_cover_is_refused(emu):
     assert B.make_net(emu, **ok).d_real == 48
     for bad in (dict(inner_embed_size=140, num_heads=2),   # head width 70: beyond the widest attention instantiation (64)
                 dict(inner_embed_size=240, num_heads=6),   # six heads of 40 -> 64 columns each: 384 > 256
-                dict(action_dim=4),                   # the action embedding's columns sit at the END of a token: not a prefix of the padded row
+                dict(action_dim=4),                   # refused by this round's dtqn_net_init (over-cautious: the action columns come first in a token)
                 dict(dropout=0.1),                    # keep masks are keyed by the element index at the buffer's width
                 dict(bag_size=4),
                 dict(inner_embed_size=272, num_heads=17)):
