@@ -593,3 +593,11 @@ def test_pipelined_update_under_a_random_schedule_of_everything_that_can_invalid
     for x, y in zip(a[:3], b[:3]):
         assert torch.equal(x, y)
     assert a[3] == b[3]
+
+
+def test_data_parallel_on_a_width_padded_network(emu, tmp_path):
+    """Two ranks (gloo, device-side exchange in shared memory) with a network that runs zero-padded (in-embed 48, 4 heads of 12 -> 64 columns,
+    heads of 16; DtqnNet.d_real): the flat gradient that travels is the padded one, its padding is exact zeros on both ranks, so the replicas
+    stay bit-identical and equal one learner on the union batch like any other shape."""
+    run_dp_script(tmp_path, {"DP_EXCHANGE": "p2p", "DP_UPDATES": "3",
+                             "DP_CFG": "dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=4, num_layers=1, history_len=12)"}, 29619)
