@@ -296,17 +296,18 @@ td.destroy_process_group()
 '''
 
 
-def run_dp_script(tmp_path, env_extra, port):
+def run_dp_script(tmp_path, env_extra, port, world=2):
     script = tmp_path / "dp.py"
     script.write_text(DP_SCRIPT.replace("@REPO@", REPO))
     out = str(tmp_path / "out")
-    env = dict(os.environ, OUT=out, HIPEMU_THREADS="2", MASTER_ADDR="127.0.0.1", **env_extra)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    env = {**os.environ, "OUT": out, "HIPEMU_THREADS": "2", "MASTER_ADDR": "127.0.0.1", **env_extra}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     r0, r1, single = (np.load(out + s) for s in (".rank0.npy", ".rank1.npy", ".single.npy"))
-    assert np.array_equal(r0, r1)                               # replicas stay bit-identical
+    for r in range(1, world):
+        assert np.array_equal(r0, np.load(out + f".rank{r}.npy"))          # replicas stay bit-identical
     norms = np.load(out + ".stats.npy")
     n_updates = int(env_extra.get("DP_UPDATES", "2"))
     # gradient norm of the LAST update: the trajectories of the two computations drift apart by noise-floor Adam steps (below)
@@ -601,3 +602,14 @@ def test_data_parallel_on_a_width_padded_network(emu, tmp_path):
     stay bit-identical and equal one learner on the union batch like any other shape."""
     run_dp_script(tmp_path, {"DP_EXCHANGE": "p2p", "DP_UPDATES": "3",
                              "DP_CFG": "dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=4, num_layers=1, history_len=12)"}, 29619)
+
+
+def test_device_side_exchange_with_four_ranks(emu, tmp_path):
+    """World size 4 on the emulation (gloo control plane, exchange buffers in shared memory): every rank waits for three peers' flags and adds
+    four buffers in RANK order -- the replicas must stay bit-identical (the order is the same everywhere) and equal one learner on the
+    four-fold batch; the start-up check (exact sums of integer-valued vectors) must pass whatever the order."""
+    import json
+    run_dp_script(tmp_path, {"DP_EXCHANGE": "auto", "DP_UPDATES": "3", "DP_BATCH": "2", "HIPEMU_THREADS": "1"}, 29623, world=4)
+    for r in range(4):
+        sel = json.load(open(str(tmp_path / "out") + f".sel{r}.json"))
+        assert sel["kind"] == "p2p" and sel["validated"] is True, sel
