@@ -52,7 +52,10 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         if (native && d < 64 && dtqn_ws_pick(d, hd, up16(L) / 16, nullptr) == 0) native = false;
         if (!native) {
             const int dmin = h * hdp, dp = dmin <= 64 ? 64 : dmin <= 128 ? 128 : 256;
-            if (hd > 64 || dmin > 256 || a != 0 || net->bag_size != 0 || net->img_c > 0 || net->dropout != 0.f) return DTQN_ERR_CONFIG;
+            // (an action embedding is fine: a token is [action embedding (a) | observation embedding (D - a)], dtqn.py:192 -- the action
+            //  columns come FIRST, so the real columns stay a prefix of the padded row and the padded rows of the observation Linear land
+            //  behind them)
+            if (hd > 64 || dmin > 256 || net->bag_size != 0 || net->img_c > 0 || net->dropout != 0.f) return DTQN_ERR_CONFIG;
             net->d_real = d;
             net->heads_real = h;
             net->hd_real = hd;

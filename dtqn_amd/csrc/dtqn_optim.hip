@@ -317,8 +317,9 @@ extern "C" int dtqn_td_xreduce(const DtqnNet* net, const DtqnTd* td, const void*
     a.gsum = gsum_dev; a.norm_partial = td->norm_partial; a.status = status_dev;
     a.n = net->n_trainable; a.n_parts = dtqn_td_norm_partials(net); a.world = world; a.gen = gen; a.own_flag = own_flag_dev;
     // DTQN_XCH_TIMEOUT_MS: how long a block waits for a peer's flag before it sets *status_dev (default 5000; tests use less)
+    // DtqnTd.xch_timeout_ms (per engine) first, then the environment, then 5 s
     const char* tmo = getenv("DTQN_XCH_TIMEOUT_MS");
-    const long long ms = tmo != nullptr && atoll(tmo) > 0 ? atoll(tmo) : 5000ll;
+    const long long ms = td->xch_timeout_ms > 0 ? (long long)td->xch_timeout_ms : tmo != nullptr && atoll(tmo) > 0 ? atoll(tmo) : 5000ll;
     a.timeout_ticks = ms * 100000ll;
     (void)hipGetLastError();
     hipLaunchKernelGGL(dtqn_xreduce_kernel, dim3(td->n_norm_blocks), dim3(kOptThreads), 0, (hipStream_t)stream, a);

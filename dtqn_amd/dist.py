@@ -10,10 +10,30 @@ learner on the union batch because the loss is a mean over equally sized shards.
 """
 from __future__ import annotations
 
+import logging
 import os
 
 import torch
 import torch.distributed as td
+
+log = logging.getLogger("dtqn_amd.dist")
+
+
+def _inject(what: str, rank: int) -> bool:
+    """Fault injection for the start-up checks of the gradient exchange (tests only): DTQN_DP_INJECT=<what>:<rank>[,<what>:<rank>...],
+    what = mapping | sum | local -- `mapping`: this rank fails to map its peers' buffers; `sum`: its device-side exchange returns one wrong
+    element; `local`: its local check work raises.  The point of all three: EVERY rank must then land on the collective together."""
+    spec = os.environ.get("DTQN_DP_INJECT", "")
+    return any(tok.strip() == f"{what}:{rank}" for tok in spec.split(",") if tok)
+
+
+def peer_access_row(device) -> list:
+    """can_device_access_peer(this device, d) for every visible device d (1 on the diagonal): one row of the matrix bench.py prints."""
+    if torch.device(device).type != "cuda":
+        return []
+    dev = torch.device(device)
+    mine = dev.index if dev.index is not None else torch.cuda.current_device()
+    return [1 if d == mine else int(torch.cuda.can_device_access_peer(mine, d)) for d in range(torch.cuda.device_count())]
 
 
 def is_distributed() -> bool:
@@ -88,19 +108,27 @@ class P2PExchange:
         import pickle
         from multiprocessing.reduction import ForkingPickler
         payload = None
+        prev_strategy = None
         try:
             if dev.type != "cuda":
-                torch.multiprocessing.set_sharing_strategy("file_system")      # handles that survive pickling through a collective
+                # handles that survive pickling through a collective; the process-wide setting is put back below
+                prev_strategy = torch.multiprocessing.get_sharing_strategy()
+                torch.multiprocessing.set_sharing_strategy("file_system")
                 self.buf.share_memory_()
             payload = bytes(ForkingPickler.dumps(self.buf))
         except Exception as exc:
             self.error = f"export: {type(exc).__name__}: {exc}"[:200]
+        finally:
+            if prev_strategy is not None:
+                torch.multiprocessing.set_sharing_strategy(prev_strategy)
         handles = [None] * self.world
         td.all_gather_object(handles, payload, group=group)
         self.peers = [self.buf] * self.world
         try:
             if self.error is None and any(h is None for h in handles):
                 raise RuntimeError("a peer could not export its exchange buffer")
+            if self.error is None and _inject("mapping", self.rank):
+                raise RuntimeError("injected mapping failure (DTQN_DP_INJECT)")
             if self.error is None:
                 self.peers = [self.buf if r == self.rank else pickle.loads(h) for r, h in enumerate(handles)]
                 if dev.type == "cuda":
@@ -180,19 +208,32 @@ class DataParallel:
         err = self.p2p.error
         mapped = agree_all(err is None, self._vote_device())
         if not mapped:
+            self._drop_p2p()             # (also in front of the raise: engine.td.xstatus must not keep pointing at a discarded buffer)
             if kind == "p2p":
                 raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p but the peers' exchange buffers could not be mapped on every rank ({err})")
-            self._drop_p2p()
             self.selection = {"kind": "rccl", "validated": False, "reason": f"peer mapping failed on some rank ({err or 'another rank'})"}
+            self._log_selection()
             return
         ok, why = self._validate_p2p()
         if ok:
             self.selection = {"kind": "p2p", "validated": True, "reason": why}
-        elif kind == "p2p":
-            raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p failed its start-up check: {why}")
         else:
             self._drop_p2p()
+            if kind == "p2p":
+                raise RuntimeError(f"DTQN_DP_EXCHANGE=p2p failed its start-up check: {why}")
             self.selection = {"kind": "rccl", "validated": False, "reason": f"device-side exchange failed its start-up check: {why}"}
+        self._log_selection()
+
+    def _log_selection(self) -> None:
+        """Once, on rank 0: which exchange the job runs and why (a fall-back to the collective is a warning: it is slower, and the only
+        other place that says so is bench.py's line)."""
+        if td.get_rank(self.group) != 0:
+            return
+        sel = self.selection
+        if sel["kind"] == "rccl" and sel["reason"] != "requested":
+            log.warning("gradient exchange: falling back to the all_reduce collective -- %s", sel["reason"])
+        else:
+            log.info("gradient exchange: %s (%s)", sel["kind"], sel["reason"])
 
     def _vote_device(self):
         # same-device smoke mode runs the collectives over gloo (host tensors)
@@ -205,25 +246,39 @@ class DataParallel:
 
     def _validate_p2p(self):
         """Two exchanges (one per buffer generation) of vectors whose sums are exact in any order: rank r contributes
-        (r + 1) * (i mod 7 + g) -- small integers --, so the rank-ordered device-side sum must EQUAL the collective's."""
+        (r + 1) * (i mod 7 + g) -- small integers --, so the rank-ordered device-side sum must EQUAL the collective's.
+        Every rank issues the SAME collectives whatever happens locally: exceptions are caught around the local work only (copy,
+        reduce launch, compare), the all_reduce of each generation and the closing vote are unconditional."""
         e, p = self.engine, self.p2p
         n = p.n
-        had = "DTQN_XCH_TIMEOUT_MS" in os.environ                 # the user's own bound, if any, stays
-        os.environ.setdefault("DTQN_XCH_TIMEOUT_MS", "2000")      # a start-up check must not sit out the 5 s of a training run
+        # a start-up check must not sit out the 5 s of a training run: 2 s through the DtqnTd field (per engine; the process
+        # environment is left alone), unless the user set a bound of their own
+        user_bound = "DTQN_XCH_TIMEOUT_MS" in os.environ
+        if not user_bound:
+            e.td.xch_timeout_ms = 2000
         ok, why = True, "two generations equal to all_reduce on every rank"
-        try:
-            base = torch.arange(n, dtype=torch.float32, device=e.device) % 7
-            for g in (1, 2):
-                # no early exit: every rank walks through the same collectives whatever its own findings are
-                vec = (base + g) * float(p.rank + 1)
+        host_side = same_device() or e.device.type != "cuda"
+        base = torch.arange(n, dtype=torch.float32, device=e.device) % 7
+        for g in (1, 2):
+            vec = (base + g) * float(p.rank + 1)
+            got = None
+            try:
+                if _inject("local", p.rank):
+                    raise RuntimeError("injected local failure (DTQN_DP_INJECT)")
                 p.k += 1
                 p.own[p.k & 1].copy_(vec)
                 p.reduce()
-                want = vec.clone() if not (same_device() or e.device.type != "cuda") else vec.cpu()
-                td.all_reduce(want, op=td.ReduceOp.SUM, group=self.group)
-                got = e.grad.to(want.device)
-                if not ok:
-                    continue
+                if _inject("sum", p.rank):
+                    e.grad[5] += 1.0
+                got = e.grad.cpu() if host_side else e.grad.clone()
+            except Exception as exc:            # local: this rank still walks through the collectives below
+                if ok:
+                    ok, why = False, f"generation {g}: {type(exc).__name__}: {exc}"[:200]
+            want = vec.cpu() if host_side else vec.clone()
+            td.all_reduce(want, op=td.ReduceOp.SUM, group=self.group)         # unconditional, every generation, every rank
+            if not ok or got is None:
+                continue
+            try:
                 if int(p.status.item()) != 0:
                     ok, why = False, f"generation {g}: a peer's flag never arrived (bounded wait expired)"
                 elif not torch.equal(got, want):
@@ -234,11 +289,10 @@ class DataParallel:
                     norm_want = float((want.double() ** 2).sum().item())
                     if abs(norm_got - norm_want) > 1e-5 * norm_want:
                         ok, why = False, f"generation {g}: sum of squares {norm_got} != {norm_want}"
-        except Exception as exc:
-            ok, why = False, f"{type(exc).__name__}: {exc}"[:200]
-        finally:
-            if not had:
-                os.environ.pop("DTQN_XCH_TIMEOUT_MS", None)
+            except Exception as exc:
+                ok, why = False, f"generation {g}: {type(exc).__name__}: {exc}"[:200]
+        if not user_bound:
+            e.td.xch_timeout_ms = 0
         all_ok = agree_all(ok, self._vote_device())
         if not all_ok and ok:
             why = "another rank's check failed"

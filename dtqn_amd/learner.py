@@ -295,10 +295,12 @@ class TdEngine:
     # that needs on the update's stream cost 11.6 us per update -- more than the gain.)  A pass computed ahead is only USED if what it
     # read is still what the update would read: same (n_valid, exclude, seed), same draw step, no replay write and no target sync
     # since; otherwise the target pass runs inline (same kernel, same slices: the numbers do not depend on which way it went).
-    def enable_pipeline(self, replay_version=lambda: 0) -> bool:
+    def enable_pipeline(self, replay_version) -> bool:
         """Switch the update to {policy passes as four row slices, next update's target pass inside the backward launch}.  Returns
-        False (and changes nothing) where the shape is not covered.  `replay_version`: callable that changes whenever the replay arrays
-        are written (ReplayBuffer.version)."""
+        False (and changes nothing) where the shape is not covered.  `replay_version` (required): callable that changes whenever the
+        replay arrays are written (ReplayBuffer.version) -- a pass computed ahead on an older replay must not be used."""
+        if not callable(replay_version):
+            raise TypeError("enable_pipeline needs a callable that changes whenever the replay arrays are written")
         import os
         if self.net.bag_size > 0 or self.img is not None or self.net.dropout > 0 or os.environ.get("DTQN_PIPELINE", "1") == "0":
             return False
@@ -428,6 +430,12 @@ class TdEngine:
             self._pipe["steps"] += 1
             return
         self._check(self.lib.dtqn_td_update(self._net_ref, replay.view_ref, self._td_ref, s), "dtqn_td_update")
+        if getattr(self, "_pipe", None) is not None:
+            # the one-call update stepped the device's optimizer counter too (host-drawn windows on an engine whose pipeline is
+            # enabled): the mirror follows, so the next in-kernel draw and the predicted hard target sync stay keyed by the device's
+            # step; whatever was computed ahead was keyed by the step this update has just used up
+            self._pipe["steps"] += 1
+            self._pipe["ahead"] = None
 
     def _img_encode_windows(self, replay: DeviceReplay, s):
         """Image nets, in front of dtqn_td_forward: token lists of the sampled windows, then the convolutional embedding of the

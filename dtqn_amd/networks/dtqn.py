@@ -167,9 +167,14 @@ class DTQN(nn.Module):
             # the encoder's first layer gathers uint8 pixels (the reference's replay and context hold images as uint8 and the
             # network sees their float VALUES, dtqn/agents/dtqn.py:199): integral values in 0..255 of any dtype are accepted,
             # anything else (normalised 0..1 images, negative values) would be silently truncated or wrapped by a cast
-            o = obss.to(torch.float32)
-            if not bool(((o >= 0) & (o <= 255) & (o == o.round())).all()):
-                raise ValueError("image observations must be integral pixel values in 0..255 (uint8 in the replay and the context)")
+            # Checked where it costs nothing to ask: host-side inputs every time (no device round trip), device-side inputs on the
+            # first such call only (the check is a full pass over the pixels and a blocking read-back: not for the actor's hot path)
+            if obss.device.type == "cpu" or not getattr(self, "_img_range_checked", False):
+                o = obss.to(torch.float32)
+                if not bool(((o >= 0) & (o <= 255) & (o == o.round())).all()):
+                    raise ValueError("image observations must be integral pixel values in 0..255 (uint8 in the replay and the context)")
+                if obss.device.type != "cpu":
+                    self._img_range_checked = True
         imgs = obss.to(device=dev).to(torch.uint8).reshape(Bn * seq, -1).contiguous()
         enc = getattr(self, "_img_enc", None)
         if enc is None or enc.device != dev:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 15
+#define DTQN_ABI_VERSION 16
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -214,7 +214,9 @@ typedef struct DtqnReplayRecord {
 } DtqnReplayRecord;
 
 /* Applies n records (device memory; staged by the host through pinned memory + hipMemcpyAsync)
- * to the replay arrays, in order. */
+ * to the replay arrays, in order.  obs_rows_dev holds one observation row [O] per RECORD, record i's row at index
+ * recs[i].obs_index, and must be at least n rows long with obs_index == i for float observations of up to 16 values (the
+ * kernel stages rows [c0, c0 + m) of a chunk of records in LDS in one pass; rows outside a chunk are fetched one by one). */
 int dtqn_replay_apply(const DtqnReplay* rp, const DtqnReplayRecord* recs_dev, const float* obs_rows_dev,
                       int n, void* stream);
 /* Draws `batch` (episode, start) pairs on the device with the reference's distribution
@@ -312,6 +314,9 @@ typedef struct DtqnTd {
                                * site, layer, element): recomputed by the backward, nothing stored */
     int32_t row_split;        /* workgroups per sequence in the forward / backward kernels: the value
                                * dtqn_td_row_split(net, B) returned (1 = one workgroup per sequence) */
+    int32_t xch_timeout_ms;   /* bounded wait of dtqn_td_xreduce for a peer's flag, in milliseconds; 0 = DTQN_XCH_TIMEOUT_MS from the
+                               * environment, else 5000.  Per engine: a start-up check can use a short bound without touching the
+                               * process environment */
     float gamma;
     float lr;
     float beta1;

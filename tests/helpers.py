@@ -88,14 +88,23 @@ def flat_from_params(net, params, keys):
     return flat
 
 
-def make_td_case(lib, cfg, *, seed, batch, T, n_eps, mask, history=None, tuf=10_000, lr=3e-4, device="cpu", test_lib=True):
-    """Oracle learner + dtqn_amd TdEngine on identical parameters and an identical synthetic replay."""
+def make_td_case(lib, cfg, *, seed, batch, T, n_eps, mask, history=None, tuf=10_000, lr=3e-4, device="cpu", test_lib=True,
+                 weight_scale=1.0):
+    """Oracle learner + dtqn_amd TdEngine on identical parameters and an identical synthetic replay.
+    weight_scale: factor on every weight MATRIX of the perturbed parameter set (0.1: std 0.2 -> 0.02, the init_weights scale of
+    utils/torch_utils.py:4-15, with biases / LayerNorm / positions still moved off their init values: |Q| < 1, so the Q tolerance of
+    check_td_updates is the ABSOLUTE 1e-4 of north_star there)."""
     import random as pyrandom
     from dtqn_amd.learner import DeviceReplay, TdEngine
     from oracle.replay_oracle import ReplayOracle, synth_fill
     net = net_from_cfg(lib, cfg)
     pol = O.init_params(cfg, seed=seed, perturb=True)
     tgt = O.init_params(cfg, seed=seed + 1, perturb=True)
+    if weight_scale != 1.0:
+        for params in (pol, tgt):
+            for k, v in params.items():
+                if v.dim() >= 2 and not k.endswith("attn_mask") and k != "position_embedding.position_encoding":
+                    v.mul_(weight_scale)
     hist = cfg.history_len if history is None else history
     oracle = O.OracleLearner(cfg, pol, lr=lr, gamma=0.99, history=hist, tuf=tuf, target=tgt)
     host = ReplayOracle((n_eps + 2) * T, cfg.obs_dim, mask, T, cfg.history_len)
@@ -143,18 +152,39 @@ def engine_probe(cfg, net, eng):
     return {"masks": masks, "argmax": torch.from_numpy(q3[1].argmax(-1))}
 
 
-def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False, q_rel=False):
+def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, grad_rtol=2e-4, one_call=False, q_rel=False,
+                     pipelined=False, draw_seed=1234, report_as=None):
     """Run n_updates on both sides from identical (episode, start) draws and compare every stage:
     the three Q tensors, pre-clip gradients, statistics, parameters after the step.
     one_call: the whole update through dtqn_td_update, as the agent's train() issues it, instead of stage by stage;
-    everything compared is still left behind by that call."""
+    everything compared is still left behind by that call.
+    pipelined: the update as DtqnAgent.train() issues it with the device sampler (dtqn_amd/learner.py: the window draw inside the
+    kernels, policy passes as four row slices, the next update's target pass inside this update's backward launch -- or on the side
+    stream for row-block nets): the engine draws its own windows, the oracle batch is built from the (episode, start) pairs the
+    kernels left in ep_idx / start, everything else is compared as in the other modes.  The caller has enabled the pipeline.
+    report_as: name under which the worst absolute Q error / gradient error of the run go to gpurun_out/parity_report.json."""
     keys = O.trainable_keys(cfg)
     Bn, L, A = eng.batch, cfg.history_len, cfg.num_actions
     net = eng.net                  # the net the update runs on: the caller's, or its row-block twin (dtqn_td_prefers_tiled)
+    worst = {"q_abs_err": 0.0, "q_abs_max": 0.0, "grad_err_over_max": 0.0, "updates": n_updates}
     for it in range(n_updates):
-        eps, starts = host.sample_indices(Bn)
-        batch = oracle_batch(host, eps, starts, cfg.discrete)
-        eng.set_indices(eps, starts)
+        if pipelined:
+            assert getattr(eng, "_pipe", None) is not None and cfg.bag_size == 0 and cfg.dropout == 0
+            n_valid, exclude = min(host.pos[0], host.max_size), host.pos[0] % host.max_size
+            eng.sample_in_forward(n_valid, exclude, draw_seed)
+            pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+            eng.update(rep)        # dtqn_td_update_pipelined (ride) / staged launches with the side stream (row-block nets)
+            idx = eng._idx_dev.cpu().numpy()
+            eps, starts = idx[0].astype(np.int64), idx[1].astype(np.int64)
+            # the draw is the reference's distribution (replay_buffer.py:141-158): finished slots minus the one in progress,
+            # start on {0 .. max(0, len - L)}
+            assert ((eps >= 0) & (eps < n_valid) & (eps != exclude)).all(), eps
+            assert ((starts >= 0) & (starts <= np.maximum(0, host.episode_lengths[eps] - L))).all(), (eps, starts)
+            batch = oracle_batch(host, eps, starts, cfg.discrete)
+        else:
+            eps, starts = host.sample_indices(Bn)
+            batch = oracle_batch(host, eps, starts, cfg.discrete)
+            eng.set_indices(eps, starts)
         if cfg.bag_size > 0:       # a synthetic bag per window (the engine takes whatever the sampler hands it)
             rng = np.random.Generator(np.random.PCG64(77 + it))
             bo = rng.integers(0, cfg.vocab_sizes, (Bn, cfg.bag_size, cfg.obs_dim)).astype(np.float32) if cfg.discrete \
@@ -163,11 +193,14 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
             eng.set_bag(bo, ba)
             batch.bag_obss = torch.as_tensor(bo, dtype=torch.long if cfg.discrete else torch.float32)
             batch.bag_actions = torch.as_tensor(ba, dtype=torch.long)
-        pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
-        if one_call:
-            eng.update(rep)
+        if pipelined:
+            pass                   # the whole update ran above
         else:
-            eng.forward_backward(rep)
+            pre = eng.theta_pol.cpu().numpy()[:net.n_trainable].copy()
+            if one_call:
+                eng.update(rep)
+            else:
+                eng.forward_backward(rep)
         # --- Q-values of the three forwards
         # The gradient is discontinuous at every ReLU kink and at ties of the double-DQN argmax; two
         # correct fp32 implementations can sit on different sides of a kink whose pre-activation is
@@ -193,17 +226,19 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
             # synthetic cases use weights of std 0.2 -- ten times the init scale -- to make every term count; |Q| reaches 1e1 - 1e2
             # there and two correct fp32 summation orders differ by a few 1e-5 * |Q|max, so the bound scales with |Q|max beyond 1.
             qmax = float(ref.detach().abs().max())
+            worst["q_abs_err"], worst["q_abs_max"] = max(worst["q_abs_err"], float(err)), max(worst["q_abs_max"], qmax)
             assert err <= q_tol * max(1.0, qmax), (it, w, err, qmax)
         # --- gradients (flat, engine layout), relative to the largest entry as in the oracle's own golden check
         ref_flat = flat_from_params(net, grads, keys)
         got = eng.grad.cpu().numpy().copy()
         gerr = np.abs(got - ref_flat).max()
+        worst["grad_err_over_max"] = max(worst["grad_err_over_max"], float(gerr / np.abs(ref_flat).max()))
         assert gerr <= grad_rtol * np.abs(ref_flat).max(), (it, gerr, np.abs(ref_flat).max(), probe)
         pad = padding_mask(net)
         if pad.any():                  # width-padded network: the padding takes no gradient at all
             assert not got[:net.n_trainable][pad].any(), (it, int(np.count_nonzero(got[:net.n_trainable][pad])))
         # --- optimizer step + statistics
-        if not one_call:
+        if not one_call and not pipelined:
             eng.clip_adam()
         st = eng.read_stats()
         # teacher-force the oracle from the engine's pre-step parameters?  No: both sides started
@@ -242,3 +277,25 @@ def check_td_updates(cfg, net, oracle, host, eng, rep, n_updates, q_tol=1e-4, gr
         else:
             assert st["target_synced"] == 0.0
             assert np.abs(tgt_got - tgt_ref).max() == 0.0
+    if pipelined:
+        worst["pipeline"] = {"used": int(eng._pipe["used"]), "inline": int(eng._pipe["inline"]), "ride": bool(eng._pipe["ride"])}
+    if report_as is not None:
+        parity_report(report_as, worst)
+    return worst
+
+
+def parity_report(name: str, payload: dict) -> None:
+    """Measured error margins of a parity check -> gpurun_out/parity_report.json (merged back from the GPU box; committed per round
+    under profiles/)."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, "parity_report.json")
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except (OSError, ValueError):
+        data = {}
+    data[name] = payload
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)

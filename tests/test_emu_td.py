@@ -456,3 +456,39 @@ def test_every_accepted_shape_has_kernels(emu):
             ref = O.forward(params, cfg, obs, act.long().unsqueeze(-1)).numpy()
         assert np.abs(q.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (D, H, L)
     assert accepted >= 45
+
+
+@pytest.mark.parametrize("heads,tuf", [(8, 10_000), (4, 2)])
+def test_pipelined_update_vs_oracle(emu, heads, tuf):
+    """The update exactly as DtqnAgent.train() issues it with the device sampler (dtqn_td_update_pipelined: in-kernel window draw,
+    policy passes as four 16-row slices, the NEXT update's target pass inside this update's backward launch and used from the second
+    update on) against the oracle on the windows the kernels drew: Q x 3, conditional gradients, statistics, the Adam step, target
+    syncs (tuf = 2: a sync invalidates the pass computed ahead, which then runs inline)."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=heads, num_layers=2, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=12, batch=3, T=120, n_eps=8, mask=-5, tuf=tuf)
+    assert eng.enable_pipeline(lambda: 0) and eng._pipe["ride"]
+    w = check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=4, pipelined=True)
+    assert w["pipeline"]["used"] >= (3 if tuf > 4 else 1) and w["pipeline"]["used"] + w["pipeline"]["inline"] == 4
+    assert int(eng.xflags.sum()) == 0 and int(eng._next_xflags.sum()) == 0
+
+
+def test_host_drawn_update_on_a_pipelined_engine_keeps_the_step_mirror(emu):
+    """dtqn_td_update through set_indices on an engine whose pipeline is enabled steps the device's optimizer counter; the
+    host mirror that keys the in-kernel draw and predicts the hard target sync must follow, and what was computed ahead is dropped."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=13, batch=3, T=120, n_eps=8, mask=-5, tuf=3)
+    assert eng.enable_pipeline(lambda: 0)
+    eng.sample_in_forward(8, 3, 77)
+    eng.update(rep)                                   # pipelined: step 0 -> 1, target pass for step 1 launched ahead
+    assert eng._pipe["steps"] == 1 and eng._pipe["ahead"] is not None
+    eps, starts = host.sample_indices(3)
+    eng.set_indices(eps, starts)
+    eng.update(rep)                                   # host-drawn windows: the plain one-call update, step 1 -> 2
+    assert eng._pipe["steps"] == 2 == int(eng.step_counter[1]) and eng._pipe["ahead"] is None
+    eng.sample_in_forward(8, 3, 77)
+    eng.update(rep)                                   # step 2 -> 3: the hard sync (tuf = 3) is predicted from the right step
+    assert eng._pipe["steps"] == 3 == int(eng.step_counter[1]) and eng._pipe["ahead"] is None
+    assert float(eng.read_stats()["target_synced"]) == 1.0
+    assert torch.equal(eng.theta_tgt[:net.n_trainable], eng.theta_pol[:net.n_trainable])
+    with pytest.raises(TypeError):
+        eng.enable_pipeline(None)

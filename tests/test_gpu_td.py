@@ -79,6 +79,11 @@ CASES += [
      dict(batch=4, T=120, mask=8, n_eps=10)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=60, num_heads=3, num_layers=1, history_len=50, identity=True), dict(batch=4, T=200, mask=-5, n_eps=12)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, num_layers=1, history_len=50), dict(batch=8, T=200, mask=-5, n_eps=20)),
+    # ... and width padding next to an action embedding (round 5: the action columns come first in a token, dtqn.py:192)
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=48, num_heads=6, num_layers=2, history_len=50, action_dim=8), dict(batch=16, T=200, mask=-5, n_eps=30, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=100, discrete=True, vocab_sizes=9, pos="sin", gate="gru", action_dim=4),
+     dict(batch=4, T=120, mask=8, n_eps=10)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=40, num_heads=5, num_layers=1, history_len=50, identity=True, action_dim=12), dict(batch=4, T=200, mask=-5, n_eps=12)),
 ]
 
 

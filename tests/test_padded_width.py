@@ -33,6 +33,11 @@ PADDED = [
     # widths 16 / 32 beyond the row counts their whole-sequence kernels exist for: padded to 64 columns with extra heads
     (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, num_layers=1, history_len=40), dict(batch=2, T=50, mask=-5), (64, 8)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=1, num_layers=1, history_len=8), dict(batch=2, T=14, mask=-5), (64, 2)),
+    # next to an action embedding (round 5): a token is [action embedding | observation embedding] (dtqn.py:192), the real columns stay a prefix
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=48, num_heads=6, num_layers=2, history_len=20, action_dim=8), dict(batch=2, T=30, mask=-5, tuf=2), (64, 8)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=30, discrete=True, vocab_sizes=9, pos="sin", gate="gru", action_dim=4),
+     dict(batch=2, T=40, mask=8), (128, 4)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=40, num_heads=5, num_layers=1, history_len=70, identity=True, action_dim=12), dict(batch=2, T=90, mask=-5), (64, 8)),
 ]
 
 
@@ -76,7 +81,6 @@ def test_what_padding_does_not_cover_is_refused(emu):
     assert B.make_net(emu, **ok).d_real == 48
     for bad in (dict(inner_embed_size=140, num_heads=2),   # head width 70: beyond the widest attention instantiation (64)
                 dict(inner_embed_size=240, num_heads=6),   # six heads of 40 -> 64 columns each: 384 > 256
-                dict(action_dim=4),                   # refused by this round's dtqn_net_init (over-cautious: the action columns come first in a token)
                 dict(dropout=0.1),                    # keep masks are keyed by the element index at the buffer's width
                 dict(bag_size=4),
                 dict(inner_embed_size=272, num_heads=17)):
