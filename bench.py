@@ -628,6 +628,21 @@ def main():
     if args.batch is None:
         args.batch = c["B"]
     agent = make_agent(c, args.batch, device, rank, args.sampler)
+    if world > 1:
+        # self-diagnosing start-up of a multi-GPU run (stderr; the JSON line stays the one line on stdout): which gradient exchange
+        # the start-up check selected and why, and who can reach whom -- row r = can_device_access_peer(rank r's device, d)
+        row = torch.tensor(ddp.peer_access_row(device) + [0] * max(0, 16 - torch.cuda.device_count()), dtype=torch.int32,
+                           device="cpu" if ddp.same_device() else device)[:16]
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        torch.distributed.all_gather(rows, row)
+        if rank == 0:
+            sel = agent.dp.selection if agent.dp is not None else {"kind": "none", "validated": False, "reason": "not distributed"}
+            n_dev = torch.cuda.device_count()
+            print(f"[bench] world={world} devices_visible={n_dev} exchange={sel['kind']} validated={sel['validated']} reason={sel['reason']!r}",
+                  file=sys.stderr)
+            for r, t in enumerate(rows):
+                print(f"[bench] peer access from rank {r}: {t.tolist()[:n_dev]}", file=sys.stderr)
+            sys.stderr.flush()
     # Device pre-warm, untimed and on a scratch learner of the same shape: a fresh box idles at low clocks and loads every code object
     # on first use; W warm-up steps of 0.1 ms each are over before either has settled.  The measured agent still takes its W steps.
     if args.prewarm > 0:

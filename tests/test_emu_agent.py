@@ -282,6 +282,8 @@ if on_gpu:
 if dp.p2p is not None:
     dp.p2p.check()
     assert dp.p2p.k == n_updates + 2 and "p2p" in dp.exchange_kind()      # + the two generations of the start-up check
+else:
+    assert not eng.td.xstatus and eng.td.grad == eng.grad.data_ptr() and eng.td.xch_timeout_ms == 0   # nothing of a dropped exchange is left
 np.save(os.environ["OUT"] + f".rank{rank}.npy", eng.theta_pol.cpu().numpy())
 if rank == 0:
     # single learner on the union batch
@@ -350,6 +352,17 @@ def test_exchange_is_selected_and_validated_at_start_up(emu, tmp_path):
     sel = [json.load(open(str(tmp_path / "c" / "out") + f".sel{r}.json")) for r in (0, 1)]
     assert all(s["kind"] == "rccl" and not s["validated"] and "start-up check" in s["reason"] for s in sel), sel
     assert np.array_equal(broken, ref)
+
+
+@pytest.mark.parametrize("inject,needle", [("mapping:1", "peer mapping failed"), ("local:0", "start-up check"), ("sum:0", "start-up check")])
+def test_injected_exchange_failure_lands_on_the_collective_everywhere(emu, tmp_path, inject, needle):
+    """DTQN_DP_INJECT (dist._inject): a peer mapping that fails on ONE rank, local check work that raises on ONE rank, one wrong sum on ONE
+    rank -- every rank walks through the same collectives of the start-up check, both land on the all_reduce with the reason recorded, the
+    engine's exchange pointers are reset, training continues (replicas identical, equal to one learner on the union batch)."""
+    import json
+    run_dp_script(tmp_path, {"DP_EXCHANGE": "auto", "DP_UPDATES": "3", "DTQN_DP_INJECT": inject}, 29623 + 2 * ["mapping:1", "local:0", "sum:0"].index(inject))
+    sel = [json.load(open(str(tmp_path / "out") + f".sel{r}.json")) for r in (0, 1)]
+    assert all(s["kind"] == "rccl" and not s["validated"] and needle in s["reason"] for s in sel), sel
 
 
 def test_vector_actor_matches_single_actor_and_reference_buffer(emu):

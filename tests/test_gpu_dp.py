@@ -62,3 +62,32 @@ def test_run_py_two_ranks_overlapped_on_one_gpu(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=150, cwd=str(tmp_path), env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert out.stdout.count("Training Steps: 2000") == 1
+
+
+@pytest.mark.parametrize("inject,needle", [("mapping:1", "peer mapping failed"), ("sum:1", "start-up check"), ("local:0", "start-up check")])
+def test_injected_exchange_failure_sends_every_rank_to_the_collective(tmp_path, inject, needle):
+    """harden the FALL-BACK.  Two processes on one GPU, DTQN_DP_EXCHANGE=auto, and a fault injected on ONE rank
+    (DTQN_DP_INJECT): its peer mapping fails / its device-side exchange returns one wrong sum / its local check work raises.  Both ranks
+    must land on the collective TOGETHER (a rank left alone in a collective hangs: the subprocess timeout is that assertion), say why in
+    `selection`, leave the engine's xstatus / grad pointers reset, and keep training: replicas bit-identical and equal to one learner on
+    the union batch."""
+    import json
+    from test_emu_agent import run_dp_script
+    run_dp_script(tmp_path, {"DP_DEVICE": "cuda", "DP_SAME_DEVICE": "1", "DP_EXCHANGE": "auto", "DP_UPDATES": "4", "DP_BATCH": "32", "DP_T": "120",
+                             "HSA_ENABLE_IPC_MODE_LEGACY": "0", "DTQN_DP_INJECT": inject,
+                             "DP_CFG": "dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)"},
+                  29661 + 2 * ["mapping:1", "sum:1", "local:0"].index(inject))
+    sel = [json.load(open(str(tmp_path / "out") + f".sel{r}.json")) for r in (0, 1)]
+    assert all(s["kind"] == "rccl" and not s["validated"] and needle in s["reason"] for s in sel), sel
+    assert "injected" in sel[int(inject[-1])]["reason"] or inject.startswith("sum"), sel
+
+
+def test_auto_selects_the_device_side_exchange_when_nothing_is_wrong(tmp_path):
+    import json
+    from test_emu_agent import run_dp_script
+    run_dp_script(tmp_path, {"DP_DEVICE": "cuda", "DP_SAME_DEVICE": "1", "DP_EXCHANGE": "auto", "DP_UPDATES": "3", "DP_BATCH": "32", "DP_T": "120",
+                             "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                             "DP_CFG": "dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)"},
+                  29669)
+    sel = [json.load(open(str(tmp_path / "out") + f".sel{r}.json")) for r in (0, 1)]
+    assert all(s["kind"] == "p2p" and s["validated"] for s in sel), sel
