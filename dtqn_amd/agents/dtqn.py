@@ -417,16 +417,18 @@ class DtqnAgent:
         rows, why = [], 0
         while self._calls_read < self._calls_issued:
             k = self._calls_read + 1
-            row = ring[(k - 1) % slots]
-            tag = float(k & 0x7FFFFF)                 # the kernel writes the call index modulo 2^23 (exact in f32)
-            if row[9] != tag:
+            row = ring[(k - 1) % slots]               # [12][2]: {value, tag} granules, each one 8-byte store of the kernel
+            tag = float(k & 0x7FFFFF)                 # the kernel tags with the call index modulo 2^23 (exact in f32)
+            if not (row[:, 1] == tag).all():
                 if not block:
                     break
                 if self.device.type == "cuda":
                     (self._main_stream if self._main_stream is not None else torch.cuda.current_stream(self.device)).synchronize()
-                if row[9] != tag:
-                    raise RuntimeError(f"statistics of update call {k} never arrived (ring tag {row[9]})")
-            vals = row.copy()
+                if not (row[:, 1] == tag).all():
+                    raise RuntimeError(f"statistics of update call {k} never arrived (ring tags {row[:, 1].tolist()})")
+            vals = row[:, 0].copy()
+            if not (row[:, 1] == tag).all():          # overwritten while it was copied (the ring is 256 calls deep: cannot happen
+                raise RuntimeError(f"statistics ring slot of call {k} was overwritten while it was read")      # with the drain cadence)
             self._calls_read = k
             rows.append(vals)
             if vals[i_nonfinite] != 0.0:

@@ -25,6 +25,9 @@ struct FwdArgs {
     const uint8_t* actions;     // (ep, r) at actions + ep*act_ep_stride + r
     long long obs_ep_stride;
     long long act_ep_stride;
+    const float* rewards;       // TD update only (nullptr otherwise): rewards / dones of the replay, (ep, r) at + ep*rew_ep_stride + r -- the
+    const uint8_t* dones;       // training pass leaves {action, reward, done} of its window rows in the act record (DtqnNet.ao_loss)
+    long long rew_ep_stride;
     const int32_t* ep_idx;      // nullptr: ep = sequence index, start = 0
     const int32_t* start;
     int n;                      // real sequence length (<= ctx_len)
@@ -166,6 +169,19 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const int row0 = st + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
+    if (TRAIN) {
+        // loss record: {action, reward, done} of this slice's rows of the window (which == 0: row0 = st + R0), for the loss stage of the
+        // backward kernel -- it then needs no address that depends on (ep, st): ONE round trip in front of its chain instead of two
+        if (a.rewards != nullptr && net.ao_loss >= 0 && t.tid < LP) {
+            const int r = t.tid;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n) {
+                const size_t wr = (size_t)ep * a.rew_ep_stride + row0 + r;
+                v = make_float4((float)act_rows[r], a.rewards[wr], a.dones[wr] ? 1.f : 0.f, 0.f);
+            }
+            st4(rf(rec, net.ao_loss, 4) + 4 * r, v);
+        }
+    }
     const int KE = net.ke, KEP = net.kep;
     const float* __restrict__ We = theta + net.off_obs_w;
     const float* __restrict__ be = theta + net.off_obs_b;
@@ -482,6 +498,9 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     TileRegs<NW, 3 * D, D> tw_in;
     TileRegs<NW, D, D> tw_hd;                          // the head's first matrix takes W_in's place after the last layer
     float4 ps_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 h2_reg = make_float4(0.f, 0.f, 0.f, 0.f);   // head.2 weight / bias, staged in LDS behind the last layer when they fit
+    float b2_reg = 0.f;
+    const bool h2_lds = A * D / 4 <= NT && A <= NT && A * D + A <= wl_arena_floats(D) - OFF_B;
     {
         const float* __restrict__ th0 = layer_theta(net, theta, 0);
         tw_in.load(th0 + net.lo_in_w, D, t);
@@ -489,6 +508,27 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     }
 
     // ---------------- window gather + embedding (as forward_body) ----------------
+    // Row slices of 16 rows (two elements of the stream per thread), continuous observations: the operands of the embedding that do NOT
+    // depend on the window -- bias, position row, the KE weights of the element's column -- go in flight in front of the window draw,
+    // whose episode-length load is a round trip of its own (embedding stage: draw -> rows -> operands was three dependent trips)
+    constexpr bool HOIST = LP * D <= 2 * NT;
+    constexpr int HN = HOIST ? (LP * D + NT - 1) / NT : 1;
+    float hb[HN], hp[HN], hw[HN][8];
+    const bool hoisted = HOIST && !net.discrete && net.ke <= 8;
+    if (hoisted) {
+        const float* __restrict__ We_ = theta + net.off_obs_w;
+        const float* __restrict__ be_ = theta + net.off_obs_b;
+#pragma unroll
+        for (int k = 0; k < HN; ++k) {
+            const int idx = t.tid + k * NT, r = idx / D, d = idx - r * D;
+            const int dd = d >= adim ? d - adim : 0;
+            const int prow = R0 + r < net.ctx_len ? R0 + r : net.ctx_len - 1;       // rows past the context are never used: stay inside the table
+            hb[k] = be_[dd];
+            hp[k] = theta[net.off_pos + (size_t)prow * D + d];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hw[k][j] = We_[(size_t)dd * net.ke + (j < net.ke ? j : 0)];
+        }
+    }
     int ep, st;
     if (a.ep_len != nullptr) {
         replay_draw(a.ep_len, a.s_n_valid, a.s_exclude, net.ctx_len, a.s_seed, a.draw_step >= 0 ? (uint32_t)a.draw_step : (uint32_t)a.step_counter[1], b, ep, st);
@@ -500,11 +540,56 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const int row0 = st + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
+    if (TRAIN) {
+        // loss record: {action, reward, done} of this slice's rows of the window (which == 0: row0 = st + R0), for the loss stage of the
+        // backward kernel -- it then needs no address that depends on (ep, st): ONE round trip in front of its chain instead of two
+        if (a.rewards != nullptr && net.ao_loss >= 0 && t.tid < LP) {
+            const int r = t.tid;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n) {
+                const size_t wr = (size_t)ep * a.rew_ep_stride + row0 + r;
+                v = make_float4((float)act_rows[r], a.rewards[wr], a.dones[wr] ? 1.f : 0.f, 0.f);
+            }
+            st4(rf(rec, net.ao_loss, 4) + 4 * r, v);
+        }
+    }
     const int KE = net.ke, KEP = net.kep;
     const float* __restrict__ We = theta + net.off_obs_w;
     const float* __restrict__ be = theta + net.off_obs_b;
     const float* __restrict__ pos = theta + net.off_pos + (size_t)R0 * D;
-    if (!net.discrete && KE <= 8) {
+    if (hoisted) {
+        // same arithmetic as below (same fmaf chain per element), operands already in registers
+#pragma unroll
+        for (int kk = 0; kk < HN; ++kk) {
+            const int idx = t.tid + kk * NT;
+            if (idx < LP * D) {
+                const int r = idx / D, d = idx - r * D;
+                float v = 0.f;
+                if (r < n) {
+                    if (d < adim) {
+                        if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                        else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                    } else {
+                        const float* e = obs_rows + (size_t)r * O;
+                        float acc = hb[kk];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < KE) acc = fmaf(e[k], hw[kk][k], acc);
+                        v = acc;
+                    }
+                    v += hp[kk];
+                    v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
+                }
+                Xs[r * LDX + d] = v;
+                if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
+            }
+        }
+        if (TRAIN)
+            for (int idx = t.tid; idx < LP * KEP; idx += NT) {
+                const int r = idx / KEP, k = idx - r * KEP;
+                rf(rec, net.ao_ein, KEP)[idx] = (r < n && k < KE) ? obs_rows[(size_t)r * O + k] : 0.f;
+            }
+    } else if (!net.discrete && KE <= 8) {
         for (int idx = t.tid; idx < LP * D; idx += NT) {
             const int r = idx / D, d = idx - r * D;
             float v = 0.f;
@@ -675,6 +760,9 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 } else {
                     tw_hd.load(theta + net.off_head1_w, D, t);
                     if (t.tid < D / 4) ps_reg = ld4(theta + net.off_head1_b + 4 * t.tid);
+                    // the head's second matrix [A][D] and bias ride along (region B of the arena is free behind the last FFN)
+                    h2_reg = ld4(theta + net.off_head2_w + 4 * (h2_lds && t.tid < A * D / 4 ? t.tid : 0));
+                    b2_reg = theta[net.off_head2_b + (t.tid < A ? t.tid : 0)];
                 }
             }
         }
@@ -705,6 +793,10 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         } else {
             tw_hd.to_lds(Ar, LWD, t);
             if (t.tid < D / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
+            if (h2_lds) {
+                if (t.tid < A * D / 4) st4(Ar + OFF_B + 4 * t.tid, h2_reg);
+                if (t.tid < A) Ar[OFF_B + A * D + t.tid] = b2_reg;
+            }
         }
         if (!ident) {  // x = LN2(x)
             layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
@@ -722,22 +814,25 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     __syncthreads();
     if (TRAIN) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
     {
-        const float* __restrict__ W2 = theta + net.off_head2_w;
-        const float* __restrict__ b2 = theta + net.off_head2_b;
         float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride + (size_t)R0 * a.q_row_stride;
-        for (int idx = t.tid; idx < (n < LP ? n : LP) * A; idx += NT) {
-            const int r = idx / A, ac = idx - r * A;
-            const float* hrow = Ws + r * LDW;
-            const float* w = W2 + (size_t)ac * D;
-            float acc = b2[ac];
+        // (one instance per address space of W_2 / b_2: LDS when they were staged, else global)
+        auto q_rows = [&](const float* __restrict__ W2, const float* __restrict__ b2) {
+            for (int idx = t.tid; idx < (n < LP ? n : LP) * A; idx += NT) {
+                const int r = idx / A, ac = idx - r * A;
+                const float* hrow = Ws + r * LDW;
+                const float* w = W2 + (size_t)ac * D;
+                float acc = b2[ac];
 #pragma unroll 8
-            for (int k = 0; k < D; k += 4) {
-                const float4 hv = ld4(hrow + k), wv = ld4(w + k);
-                acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+                for (int k = 0; k < D; k += 4) {
+                    const float4 hv = ld4(hrow + k), wv = ld4(w + k);
+                    acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc); acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+                }
+                q[r * a.q_row_stride + ac] = acc;
+                if (a.q_last_host != nullptr && R0 + r == (a.last_rows != nullptr ? a.last_rows[seq] - 1 : nfull - 1)) a.q_last_host[seq * A + ac] = acc;
             }
-            q[r * a.q_row_stride + ac] = acc;
-            if (a.q_last_host != nullptr && R0 + r == (a.last_rows != nullptr ? a.last_rows[seq] - 1 : nfull - 1)) a.q_last_host[seq * A + ac] = acc;
-        }
+        };
+        if (h2_lds) q_rows(Ar + OFF_B, Ar + OFF_B + A * D);
+        else q_rows(theta + net.off_head2_w, theta + net.off_head2_b);
     }
     DTQN_PROF(a.prof, ps++);       // end
 }

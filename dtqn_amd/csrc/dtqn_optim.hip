@@ -215,6 +215,7 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
         // dtqn.py:245-253,263, reduced over the per-sequence partials, the step counters and the host-visible ring slot -- a chain
         // of reductions and a PCIe write that used to sit behind block 0's Adam work and set the kernel's length
         float se = 0.f, sq = 0.f, sy = 0.f, mxq = -INFINITY, mnq = INFINITY, mxy = -INFINITY, mny = INFINITY;
+        const int call_prev = a.step_counter[2];          // in flight with the partials: not a round trip of its own behind the reductions
         for (int b = tid; b < a.n_stat_parts; b += kOptThreads) {
             const float* sp = a.stats_partial + (size_t)b * 8;
             se += sp[0]; sq += sp[1]; mxq = fmaxf(mxq, sp[2]); mnq = fminf(mnq, sp[3]);
@@ -243,15 +244,18 @@ __global__ __launch_bounds__(kOptThreads) void dtqn_clip_adam_kernel(AdamArgs a)
             a.stats[11] = (float)why;         // 0 applied | 1 non-finite norm | 2 exchange timed out | 3 skipped behind an earlier 1 / 2
             if (finite) a.step_counter[1] = k;
             else a.step_counter[3] = 1;
-            const int call = a.step_counter[2] + 1;       // every call counts, also a skipped (non-finite) one
+            const int call = call_prev + 1;               // every call counts, also a skipped (non-finite) one
             a.step_counter[2] = call;
             if (a.stats_ring != nullptr) {
-                // host-visible copy: payload first, fence, then the tag the host polls
-                float* slot = a.stats_ring + (size_t)((call - 1) % a.ring_slots) * 12;
-                for (int i = 0; i < 12; ++i)
-                    if (i != 9) slot[i] = a.stats[i];
-                __threadfence_system();
-                slot[9] = (float)(call & 0x7fffff);       // exact in f32 for any call count; the host compares modulo 2^23
+                // Host-visible copy: twelve 8-byte granules {value, tag}, each written by ONE system-scope store, tag = the call index
+                // modulo 2^23 (exact in f32).  The host takes a slot when all twelve tags match: no fence between payload and tag.
+                // (Rounds 1-4 wrote the payload, __threadfence_system(), then one tag: that fence is a write-back of this XCD's whole L2
+                // -- dirty with the parameters / moments the Adam blocks have just stored -- in front of the kernel's last store.)
+                unsigned long long* slot = reinterpret_cast<unsigned long long*>(a.stats_ring) + (size_t)((call - 1) % a.ring_slots) * 12;
+                const unsigned long long tag = (unsigned long long)__float_as_uint((float)(call & 0x7fffff)) << 32;
+                const float vals[12] = {se / cnt, norm, mxq, sq / cnt, mnq, mxy, sy / cnt, mny, fminf(1.0f, a.clip / (norm + 1e-6f)), (float)k,
+                                        sync_target ? 1.f : 0.f, (float)why};
+                for (int i = 0; i < 12; ++i) DTQN_SYSTEM_STORE(slot + i, tag | (unsigned long long)__float_as_uint(vals[i]));
             }
         }
     }

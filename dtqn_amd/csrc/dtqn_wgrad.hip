@@ -279,6 +279,7 @@ struct WgradDirectArgs {
     int slots;              // tile workgroups per XCD: workgroup b (on XCD b % 8) takes tile xcd_tile0[b % 8] + b / 8
     int xcd_tile0[8], xcd_ntiles[8];
     int xcd_map;            // 0: tile = workgroup index (A/B timing)
+    int small_per;          // per-sequence-partial elements per workgroup: kDSmall, or 2 kDSmall where that brings the grid down to one round
 };
 
 __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(WgradDirectArgs a) {
@@ -295,7 +296,9 @@ __global__ __launch_bounds__(kDirectThreads) void dtqn_wgrad_direct_kernel(Wgrad
     const int tile = b >= tile_blocks ? a.n_tiles : !a.xcd_map ? b : b / 8 < a.xcd_ntiles[b % 8] ? a.xcd_tile0[b % 8] + b / 8 : a.n_tiles;
     const DirectCtx ctx{a.act, a.grd, a.small, a.grad, a.batch, a.row_split, a.n_small};
     if (b >= tile_blocks) {
-        ss = direct_small<false, kDSmall, kDirectWaves>(net, ctx, b - tile_blocks, slabs, t);
+        // (same sums in the same order whatever the block size: an element's records are added wave by wave, then the waves in order)
+        ss = a.small_per == 2 * kDSmall ? direct_small<false, 2 * kDSmall, kDirectWaves>(net, ctx, b - tile_blocks, slabs, t)
+                                        : direct_small<false, kDSmall, kDirectWaves>(net, ctx, b - tile_blocks, slabs, t);
     } else if (tile < a.n_tiles) {
         int j = 0;
         for (int k = 1; k < a.n_jobs; ++k)
@@ -317,6 +320,8 @@ static int direct_tiles(const DtqnNet* net, const DtqnWJob* jobs, int* dtile0) {
 struct DirectPlan {
     int dtile0[kMaxWJobs];
     int n_tiles, slots, grid;
+    int small_per;          // elements of the per-sequence partials per workgroup
+    int grid_max;           // the grid with the smaller blocks (what norm_partial is sized for)
     int xcd_tile0[8], xcd_ntiles[8];
 };
 // Which tiles each XCD takes: eight equal runs of consecutive tiles.  (Measured at cfg 1, batch 32: tile = workgroup
@@ -331,7 +336,17 @@ static DirectPlan direct_plan(const DtqnNet* net, const DtqnWJob* jobs) {
         p.xcd_ntiles[x] = p.n_tiles - p.xcd_tile0[x] < per ? p.n_tiles - p.xcd_tile0[x] : per;
     }
     p.slots = per;
-    p.grid = p.slots * 8 + (small_elems(net) + kDSmall - 1) / kDSmall;
+    // The blocks that sum the per-sequence partials are short; with kDSmall elements each, BASELINE config 1 is 240 + 29 = 269
+    // workgroups on 256 compute units -- 13 of them wait for a second round.  Twice the elements per block (255 workgroups) is one
+    // round; taken only when it makes that difference.  DTQN_DSMALL=<kDSmall | 2 kDSmall> overrides (A/B timing).
+    static_assert(2 * kDSmall / 64 <= kDirectWaves && (size_t)(2 * kDSmall / 64) * kDirectWaves * 64 <= kDirectLdsFloats - kDirectWaves, "small-partial block fits");
+    const int n_small = small_elems(net), g1 = p.slots * 8 + (n_small + kDSmall - 1) / kDSmall, g2 = p.slots * 8 + (n_small + 2 * kDSmall - 1) / (2 * kDSmall);
+    const int cus = fuse_cu_count();
+    p.small_per = (cus > 0 && g1 > cus && g2 <= cus) ? 2 * kDSmall : kDSmall;
+    const char* e = getenv("DTQN_DSMALL");
+    if (e != nullptr && (atoi(e) == kDSmall || atoi(e) == 2 * kDSmall)) p.small_per = atoi(e);
+    p.grid = p.small_per == kDSmall ? g1 : g2;
+    p.grid_max = g1;
     return p;
 }
 
@@ -360,7 +375,7 @@ extern "C" int dtqn_td_norm_partials(const DtqnNet* net) {
     if (!net || net->n_wjobs > kMaxWJobs) return 0;
     DtqnWJob jobs[kMaxWJobs];
     if (dtqn_net_wjobs(net, jobs) != DTQN_OK) return 0;
-    const int opt = (net->n_trainable + 1023) / 1024, dir = direct_plan(net, jobs).grid;
+    const int opt = (net->n_trainable + 1023) / 1024, dir = direct_plan(net, jobs).grid_max;
     return opt > dir ? opt : dir;
 }
 
@@ -371,7 +386,7 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
     for (int j = 0; j < net->n_wjobs; ++j)      // a wave's units must fit the register buffers direct_tile was compiled with
         if ((long long)td->batch * net->lp * a.jobs[j].n_layers > kDirectMaxTokens) return DTQN_ERR_CONFIG;
     const DirectPlan plan = direct_plan(net, a.jobs);
-    a.n_tiles = plan.n_tiles; a.slots = plan.slots;
+    a.n_tiles = plan.n_tiles; a.slots = plan.slots; a.small_per = plan.small_per;
     for (int j = 0; j < net->n_wjobs; ++j) a.dtile0[j] = plan.dtile0[j];
     for (int x = 0; x < 8; ++x) { a.xcd_tile0[x] = plan.xcd_tile0[x]; a.xcd_ntiles[x] = plan.xcd_ntiles[x]; }
     a.act = td->act; a.grd = td->grd; a.grad = td->grad; a.small = td->small;

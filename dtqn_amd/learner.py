@@ -121,7 +121,7 @@ class TdEngine:
         self.stats = torch.zeros(len(STAT_NAMES), **f32)
         self.step_counter = torch.zeros(4, dtype=torch.int32, device=dev)
         self.RING_SLOTS = 256
-        ring = torch.zeros(self.RING_SLOTS, len(STAT_NAMES), dtype=torch.float32)
+        ring = torch.zeros(self.RING_SLOTS, len(STAT_NAMES), 2, dtype=torch.float32)      # {value, tag} granules (include/dtqn_hip.h)
         self.stats_ring = ring.pin_memory() if dev.type == "cuda" else ring      # written by the optimizer kernel, polled by the host
         self.stats_ring_np = self.stats_ring.numpy()
         # (episode, start) pairs: one [2][B] device array, so host-drawn pairs travel in ONE copy out of a small pinned ring

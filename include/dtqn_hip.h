@@ -124,6 +124,10 @@ typedef struct DtqnNet {
     /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
     int32_t act_stride;       /* floats per sequence */
     int32_t ao_ein, ao_x0, ao_layer0, act_layer_stride, ao_xf, ao_hh;
+    int32_t ao_loss;          /* whole-sequence kernels: [LP][4] {action, reward, done, 0} of the sampled window's rows, written by the training
+                               * forward (which has the window's position anyway) so that the loss stage of dtqn_td_backward reads them at
+                               * addresses that do not depend on the draw -- one memory round trip instead of two in front of the chain
+                               * (replay_buffer.py:160-167 gather of actions / rewards / dones); -1 on the row-block tiled path */
     int32_t al_u1, al_qkv, al_lse, al_o, al_m1, al_s1, al_st1, al_u2, al_h, al_mh, al_m2, al_s2, al_st2;
     /* al_m1 / al_mh / al_m2: ReLU activation patterns as wave ballots, one 64-bit word per
      * (16-row tile, 16-column tile, r): bit (kq*16 + i) <-> row tile*16 + kq*4 + r, column ctile*16 + i */
@@ -279,10 +283,11 @@ typedef struct DtqnTd {
     float* norm_partial;      /* [dtqn_td_norm_partials()] per-workgroup sums of squares of grad */
     float* stats_partial;     /* [B * row_split][8] */
     float* stats;             /* [12]: loss, grad_norm, q max/mean/min, target max/mean/min, clip coef, step, target-synced, non-finite flag */
-    float* stats_ring;        /* optional [stats_ring_slots][12] in PINNED HOST memory (device-visible): every call of
-                               * dtqn_td_clip_adam also writes its statistics to slot ((call_index - 1) % slots), entry 9 (the
-                               * 1-based call index modulo 2^23 -- exact in f32 --, written last) being the completion tag; the host polls it instead of
-                               * enqueueing a device->host copy and an event per update */
+    float* stats_ring;        /* optional [stats_ring_slots][12][2] in PINNED HOST memory (device-visible): every call of
+                               * dtqn_td_clip_adam also writes its statistics to slot ((call_index - 1) % slots) as twelve 8-byte granules
+                               * {value, tag}, tag = the 1-based call index modulo 2^23 (exact in f32), each granule ONE system-scope
+                               * store: a slot is complete when all twelve tags carry the call's index.  The host polls it instead of
+                               * enqueueing a device->host copy and an event per update; the kernel needs no fence */
     int32_t* step_counter;    /* [4]: [0] optimizer steps (published), [1] optimizer steps (next), [2] clip_adam calls, [3] poisoned: set by the
                                * first call that skipped its update (non-finite norm, exchange time-out); every later call skips too */
     const DtqnWJob* wjobs;    /* device copy of the job table */

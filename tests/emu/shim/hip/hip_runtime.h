@@ -218,6 +218,8 @@ using std::isfinite;
 /* 100 MHz wall clock like the device's (bounded spins of the gradient exchange must be able to run out here too) */
 static inline long long wall_clock64() { return (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10); }
 static inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned v; std::memcpy(&v, &f, 4); return v; }
+static inline float __uint_as_float(unsigned v) { float f; std::memcpy(&f, &v, 4); return f; }
 static inline long long clock64() { return 0; }
 
 // ---- atomics ----------------------------------------------------------------
