@@ -130,12 +130,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     auto mf = [&](const float* base, int off, int ctiles) -> const float* { return base + off + (size_t)(R0 / 16) * ctiles * 8; };
     // record stores: plain, or write-through through a descriptor of this sequence's record (FUSE)
     const DtqnRsrc grs = DTQN_XCH_RSRC(grec, (size_t)net.grd_stride * 4);
+    constexpr bool WT = FUSE || kOptBwdWT;           // gradient records as write-through (sc1) stores
     auto g_store4 = [&](float* p, float4 v) {
-        if constexpr (FUSE) dtqn_xch_store4(grs, (int)(p - grec) * 4, v);
+        if constexpr (WT) dtqn_xch_store4(grs, (int)(p - grec) * 4, v);
         else st4(p, v);
     };
     auto g_tile_store = [&](const float* s_, int ld_, float* g_, int rows, int cols, int gld = 0) {
-        if constexpr (FUSE) {
+        if constexpr (WT) {
             const int c4 = cols >> 2;
             if (gld == 0) gld = cols;
             const int base = (int)(g_ - grec);
@@ -162,10 +163,6 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
     float* st_s = red + PARTS * 2 * D;                 // LayerNorm (mean, rstd) of this layer [2][LP][2]
     float* DU = st_s + 4 * LP;                         // identity only: branch grad    [LP][LDX]
-    float* gam_s = DU + (net.identity != 0 ? LP * LDX : 0);   // LayerNorm gammas of this layer [2][D] (ln1 | ln2)
-    constexpr int NWORDS = MT * (D / 16) * 4;          // 64-bit ballot words of one [LP][D] ReLU pattern of this slice
-    unsigned long long* mk_s = reinterpret_cast<unsigned long long*>(gam_s + 2 * D);   // ReLU patterns of this layer [2][NWORDS] (m2 | m1)
-    static_assert(2 * NWORDS <= NT && 2 * D <= NT, "one prefetched word / gamma per thread");
 
     const int ep = a.ep_idx[b], st0 = a.start[b] + R0;
     Drop dr = drop_off();
@@ -190,27 +187,6 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         return t.tid < 2 * LP ? rf(lr, net.al_st1, 2)[t.tid] : rf(lr, net.al_st2, 2)[t.tid - 2 * LP];
     };
     float st_next = st_fetch(net.num_layers - 1);
-    // The same for every other small operand the chain used to fetch right where it needed it (each an exposed round trip on the one
-    // workgroup's critical path): the two LayerNorm gammas of a layer, its two [LP][D] ReLU patterns (64-bit ballot words), the
-    // log-sum-exp rows of a head group (with the group's q | k | v tiles), the head's second matrix.  One value per thread, a whole
-    // layer ahead, dropped into LDS at the top of the layer and published by its first barrier.
-    auto gam_fetch = [&](int l) -> float {
-        const float* th_ = layer_theta(net, theta, l);
-        const int i_ = t.tid < 2 * D ? t.tid : 0;
-        return i_ < D ? th_[net.lo_ln1_w + i_] : th_[net.lo_ln2_w + i_ - D];
-    };
-    auto mk_fetch = [&](int l) -> unsigned long long {
-        const float* lr = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
-        const int i_ = t.tid < 2 * NWORDS ? t.tid : 0;
-        const unsigned long long* m2w = reinterpret_cast<const unsigned long long*>(mf(lr, net.al_m2, D / 16));
-        const unsigned long long* m1w = reinterpret_cast<const unsigned long long*>(mf(lr, net.al_m1, D / 16));
-        return i_ < NWORDS ? m2w[i_] : m1w[i_ - NWORDS];
-    };
-    float gam_next = gam_fetch(net.num_layers - 1);
-    unsigned long long mk_next = mk_fetch(net.num_layers - 1);
-    // head: W_2 [A][D] -> the LayerNorm scratch (free until the first layer), when it fits
-    const bool w2_lds = A * D <= PARTS * 2 * D && A * D / 4 <= NT;
-    const float4 w2r = ld4(theta + net.off_head2_w + 4 * (w2_lds && t.tid < A * D / 4 ? t.tid : 0));
 
     // ---------------- B0: double-DQN target, loss, dL/dQ, statistics (dtqn.py:219-253) ----------------
     {
@@ -218,16 +194,18 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         const float* q1 = a.q3 + (((size_t)1 * a.batch + b) * LPF + R0) * AP;
         const float* q2 = a.q3 + (((size_t)2 * a.batch + b) * LPF + R0) * AP;
         const float inv_count = 1.0f / ((float)a.batch * (float)a.history);
+        DTQN_PROF(a.prof, 24);   // (finer marks of the stages that carry a first-trip penalty: slots 24..30, printed raw by stage_profile.py)
         for (int idx = t.tid; idx < LP * AP; idx += NT) dq_s[idx] = 0.f;
         __syncthreads();
+        DTQN_PROF(a.prof, 25);
         if (t.wave == 0)
             td_loss_wave(q0, q1, q2, AP, A, Lfull - R0, LP, a.history, a.gamma, inv_count,     // window test in slice-local rows
                          a.actions + (size_t)ep * a.act_ep_stride + st0, a.rewards + (size_t)ep * a.rew_ep_stride + st0,
-                         a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + ((size_t)b * RS + slice) * 8, t.lane,
-                         net.ao_loss >= 0 ? rf(rec, net.ao_loss, 4) : nullptr);
-        if (w2_lds && t.tid < A * D / 4) st4(red + 4 * t.tid, w2r);
+                         a.dones + (size_t)ep * a.rew_ep_stride + st0, dq_s, a.stats_partial + ((size_t)b * RS + slice) * 8, t.lane);
+        DTQN_PROF(a.prof, 26);
         __syncthreads();
-        if constexpr (FUSE) {
+        DTQN_PROF(a.prof, 27);
+        if constexpr (WT) {
             for (int idx = t.tid; idx < LP * AP / 4; idx += NT) g_store4(gf(grec, net.go_dq, AP) + 4 * idx, ld4(dq_s + 4 * idx));   // AP = up4(A)
         } else {
             for (int idx = t.tid; idx < LP * AP; idx += NT) gf(grec, net.go_dq, AP)[idx] = dq_s[idx];
@@ -241,29 +219,25 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     // the LDS tile, issued at the start of the NEXT stage after the prefetched fragment has been
     // retired, so that no s_waitcnt ever sits behind a freshly issued store.
     {
-        // (two instances of the loop, one per address space of W_2: a pointer chosen at run time would make every load a flat one)
-        auto head2_back = [&](const float* __restrict__ W2) {
-            constexpr int C4 = D / 4;
+        const float* __restrict__ W2 = theta + net.off_head2_w;
+        constexpr int C4 = D / 4;
 #pragma unroll
-            for (int k4 = 0; k4 < TileRegs<NW, LP, D>::N; ++k4) {
-                const int idx4 = t.tid + k4 * NT;
-                if (idx4 < LP * C4) {
-                    const int r = idx4 / C4, c0 = (idx4 - r * C4) * 4;
-                    const float hv[4] = {trh.v[k4].x, trh.v[k4].y, trh.v[k4].z, trh.v[k4].w};
-                    float g4[4];
+        for (int k4 = 0; k4 < TileRegs<NW, LP, D>::N; ++k4) {
+            const int idx4 = t.tid + k4 * NT;
+            if (idx4 < LP * C4) {
+                const int r = idx4 / C4, c0 = (idx4 - r * C4) * 4;
+                const float hv[4] = {trh.v[k4].x, trh.v[k4].y, trh.v[k4].z, trh.v[k4].w};
+                float g4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float g = 0.f;
-                        if (hv[e] > 0.f)
-                            for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + c0 + e], g);
-                        g4[e] = g;
-                    }
-                    st4(T2 + r * LDX + c0, make_float4(g4[0], g4[1], g4[2], g4[3]));
+                for (int e = 0; e < 4; ++e) {
+                    float g = 0.f;
+                    if (hv[e] > 0.f)
+                        for (int c = 0; c < A; ++c) g = fmaf(dq_s[r * AP + c], W2[c * D + c0 + e], g);
+                    g4[e] = g;
                 }
+                st4(T2 + r * LDX + c0, make_float4(g4[0], g4[1], g4[2], g4[3]));
             }
-        };
-        if (w2_lds) head2_back(red);
-        else head2_back(theta + net.off_head2_w);
+        }
     }
     __syncthreads();
     g_h1.retire();
@@ -294,15 +268,15 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         // reads of st_s ended behind a barrier, and the next layer's values go in flight now
         if (t.tid < 4 * LP) st_s[t.tid] = st_next;
         if (l > 0) st_next = st_fetch(l - 1);
-        if (t.tid < 2 * D) gam_s[t.tid] = gam_next;
-        if (t.tid < 2 * NWORDS) mk_s[t.tid] = mk_next;
-        if (l > 0) { gam_next = gam_fetch(l - 1); mk_next = mk_fetch(l - 1); }
-        if (ident && !gru) __syncthreads();            // (post-LN nets: the barrier inside the LayerNorm stage below publishes them)
 
         if (!ident) {   // x_out = LN2(s2): dL/ds2   (s2 was put in flight one stage ago)
+            if (l == net.num_layers - 1) DTQN_PROF(a.prof, 28);
             tr.to_lds(T2, LDX, t);
+            if (l == net.num_layers - 1) DTQN_PROF(a.prof, 29);
             __syncthreads();
-            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, gam_s + D, lsm + 2 * D, red, t);
+            if (l == net.num_layers - 1) DTQN_PROF(a.prof, 30);
+            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            if (l == net.num_layers - 1) DTQN_PROF(a.prof, 31);
             __syncthreads();
         }
         DTQN_PROF(a.prof, ps++);   // LN2 bwd done
@@ -314,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
             __syncthreads();
         }
         {
-            const float* m2 = reinterpret_cast<const float*>(mk_s);           // this slice's words, prefetched (mk_fetch)
+            const float* m2 = mf(lrec, net.al_m2, D / 16);
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
@@ -404,10 +378,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         constexpr int NLSE = (GW / HD) * LPF, LSE_N = (NLSE + NT - 1) / NT;      // log-sum-exp rows of a head group, in flight with its tiles
         float lse_r[LSE_N];
         auto load_group = [&](int g) {
+            if constexpr (kOptLse) {
 #pragma unroll
-            for (int k = 0; k < LSE_N; ++k) {
-                const int idx = t.tid + k * NT;
-                lse_r[k] = lrec[net.al_lse + g * NLSE + (idx < NLSE ? idx : 0)];
+                for (int k = 0; k < LSE_N; ++k) {
+                    const int idx = t.tid + k * NT;
+                    lse_r[k] = lrec[net.al_lse + g * NLSE + (idx < NLSE ? idx : 0)];
+                }
             }
             const float* qkv0 = lrec + net.al_qkv + g * GW;
             tq.load(qkv0 + (size_t)R0 * 3 * D, 3 * D, t);
@@ -432,9 +408,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
-            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s, gam_s, lsm, red, t);
+            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
         else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
-            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, gam_s + D, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
         // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
@@ -443,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
             __syncthreads();
         }
         {
-            const float* m1 = reinterpret_cast<const float*>(mk_s + NWORDS);
+            const float* m1 = mf(lrec, net.al_m1, D / 16);
             for (int idx = t.tid; idx < LP * D; idx += NT) {
                 const int r = idx / D, c = idx - r * D;
                 const float dy = gru ? T2[r * LDX + c] : DX[r * LDX + c];
@@ -479,10 +455,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                     }
                 if (OST) to.to_lds(W5r + 5 * GW, LD5, t);
                 // log-sum-exp of this group's heads -> LDS
+                if constexpr (kOptLse) {
 #pragma unroll
-                for (int k = 0; k < LSE_N; ++k) {
-                    const int idx = t.tid + k * NT;
-                    if (idx < NLSE) lse_s[idx] = lse_r[k];
+                    for (int k = 0; k < LSE_N; ++k) {
+                        const int idx = t.tid + k * NT;
+                        if (idx < NLSE) lse_s[idx] = lse_r[k];
+                    }
+                } else {
+                    for (int idx = t.tid; idx < NLSE; idx += NT) lse_s[idx] = lrec[net.al_lse + g * NLSE + idx];
                 }
                 __syncthreads();                   // da (T2) visible
                 g_do.retire();
@@ -661,7 +641,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s, gam_s, lsm, red, t);
+            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
             __syncthreads();
         }
     }
@@ -732,7 +712,6 @@ static size_t bwd_lds_bytes(const DtqnNet* net) {
     size_t fl = 2 * (size_t)LP * (D + 4) + (size_t)LP * (W5C + 4) + (size_t)LP * net->ap + 2 * (size_t)(GW / HD) * LP +
                 (size_t)PARTS * 2 * D + 4 * (size_t)LP;
     if (net->identity) fl += (size_t)LP * (D + 4);
-    fl += 2 * (size_t)D + (size_t)LP * D / 16;            // prefetched LayerNorm gammas [2][D], ReLU ballot words [2][LP / 16 * D / 16 * 4] (8 bytes each)
     return fl * sizeof(float);
 }
 

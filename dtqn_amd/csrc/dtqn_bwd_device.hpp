@@ -420,25 +420,16 @@ __device__ __forceinline__ void attention_backward_group(float* W5, int ld, int 
 //   q0 / q1 / q2: Q_pol(o), Q_pol(o'), Q_tgt(o') rows of this sequence, row stride AP
 //   dq: [rows][AP] output (LDS or global), must be zero-filled by the caller beforehand
 //   sp: 8 floats of per-sequence statistics partials
-//   lossrec != nullptr: [rows][4] {action, reward, done, 0} left by the training forward (DtqnNet.ao_loss) -- read instead of the
-//   replay rows act / rew / don, whose addresses depend on the window's position (a loaded value: a round trip of its own)
 __device__ __forceinline__ void td_loss_wave(const float* q0, const float* q1, const float* q2, int AP, int A, int L, int LPB,
                                              int history, float gamma, float inv_count, const uint8_t* act, const float* rew,
-                                             const uint8_t* don, float* dq, float* sp, int lane, const float* lossrec = nullptr) {
+                                             const uint8_t* don, float* dq, float* sp, int lane) {
     float sq = 0.f, mnq = INFINITY, mxq = -INFINITY, sy = 0.f, mny = INFINITY, mxy = -INFINITY, se = 0.f;
     for (int r = lane; r < LPB; r += 64) {
         if (r < L && r >= L - history) {
             // one round trip: none of these addresses depends on a loaded value
-            int at;
-            float rw, dn;
-            if (lossrec != nullptr) {
-                const float4 lv = ld4(lossrec + 4 * r);
-                at = (int)lv.x; rw = lv.y; dn = lv.z;
-            } else {
-                at = (int)act[r];
-                rw = rew[r];
-                dn = don[r] ? 1.f : 0.f;
-            }
+            const int at = (int)act[r];
+            const float rw = rew[r];
+            const float dn = don[r] ? 1.f : 0.f;
             float q = 0.f, best = q1[r * AP], qt = q2[r * AP];
             for (int c = 0; c < A; ++c) {          // torch.argmax: first maximal index
                 const float v0 = q0[r * AP + c], v1 = q1[r * AP + c], v2 = q2[r * AP + c];

@@ -17,6 +17,21 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Critical-path options of the whole-sequence TD kernels (round 5), one bit each so that tools/build_variant.py can build any subset
+// for an A/B on the GPU (-DDTQN_OPT=<mask>).  Nine were built and traced one by one (profiles/r05_option_attribution_cfg1.txt); the four
+// that paid are kept, the five that did not (LayerNorm gammas / ReLU ballots / head.2 weights prefetched into LDS: more live registers
+// in a kernel that already spills; a loss record written by the forward: +0.6 us there for -0.2 us in the loss stage) are gone:
+//   4   backward: log-sum-exp rows of a head group in flight with the group's tiles (-0.7 us)
+//   32  backward: gradient records leave as write-through (sc1) stores (-0.5 us)
+//   64  forward: activation records likewise (-2.5 us: the kernel no longer ends with 17 MB of dirty lines to write back)
+//   128 forward: window-independent embedding operands in flight ahead of the window draw (-0.3 us)
+#ifndef DTQN_OPT
+#define DTQN_OPT (4 | 32 | 64 | 128)
+#endif
+namespace dtqn {
+constexpr bool kOptLse = (DTQN_OPT & 4) != 0, kOptBwdWT = (DTQN_OPT & 32) != 0, kOptFwdWT = (DTQN_OPT & 64) != 0, kOptHoist = (DTQN_OPT & 128) != 0;
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
 
 extern "C" void* dtqn_debug_profile_buffer(void);
@@ -499,7 +514,8 @@ struct StageDyW {
 // SAVE = false: st_out / save_in / save_out are ignored at compile time (no conditional stores in the instruction stream)
 // PAD (width-padded networks, DtqnNet.d_real): the statistics run over the first d_real columns; the columns behind them hold zeros
 // (and get zeros back: their gamma / beta are zero).
-template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true, bool PAD = false>
+// WTS: the save_in / save_out records leave as write-through (sc1) 16-byte stores (see rec_tile_store)
+template <int D, int NW, int LPT = DTQN_MAX_LP, bool SAVE = true, bool PAD = false, bool WTS = false>
 __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int ld, int LP,
                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float* __restrict__ st_out, const Thr& t,
@@ -523,8 +539,14 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
         if (SAVE && save_in != nullptr && valid) {   // dense [LP][D] record of the LN input
+            if constexpr (WTS) {
+                const DtqnRsrc rs = DTQN_XCH_RSRC(save_in, LP * D * 4);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) st4(save_in + (size_t)row * D + part * 4 + 4 * LPR * j, v[j]);
+                for (int j = 0; j < NV; ++j) dtqn_xch_store4(rs, (row * D + part * 4 + 4 * LPR * j) * 4, v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) st4(save_in + (size_t)row * D + part * 4 + 4 * LPR * j, v[j]);
+            }
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
@@ -553,7 +575,10 @@ __device__ __forceinline__ void layernorm_rows(const float* src, float* dst, int
                 o.z = (v[j].z - mean) * rstd * g.z + b.z;
                 o.w = (v[j].w - mean) * rstd * g.w + b.w;
                 st4(dp + 4 * LPR * j, o);
-                if (SAVE && save_out != nullptr) st4(save_out + (size_t)row * D + part * 4 + 4 * LPR * j, o);
+                if (SAVE && save_out != nullptr) {
+                    if constexpr (WTS) dtqn_xch_store4(DTQN_XCH_RSRC(save_out, LP * D * 4), (row * D + part * 4 + 4 * LPR * j) * 4, o);
+                    else st4(save_out + (size_t)row * D + part * 4 + 4 * LPR * j, o);
+                }
             }
             if (SAVE && st_out != nullptr && part == 0) {
                 st_out[row * 2 + 0] = mean;
@@ -874,6 +899,22 @@ __device__ __forceinline__ void tile_store(const float* s, int ld, float* __rest
     for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
         const int r = idx / c4, c = (idx - r * c4) * 4;
         st4(g + (size_t)r * gld + c, ld4(s + r * ld + c));
+    }
+}
+// ... the same with write-through (sc1) 16-byte stores: the tile is on its way to memory while the kernel still computes, instead of
+// sitting dirty in this XCD's L2 until the kernel boundary writes it back (records another launch reads)
+template <int NW, bool WT>
+__device__ __forceinline__ void rec_tile_store(const float* s, int ld, float* __restrict__ g, int rows, int cols, const Thr& t, int gld = 0) {
+    if constexpr (WT) {
+        const int c4 = cols >> 2;
+        if (gld == 0) gld = cols;
+        const DtqnRsrc rs = DTQN_XCH_RSRC(g, (rows - 1) * gld * 4 + cols * 4);
+        for (int idx = t.tid; idx < rows * c4; idx += NW * 64) {
+            const int r = idx / c4, c = (idx - r * c4) * 4;
+            dtqn_xch_store4(rs, (r * gld + c) * 4, ld4(s + r * ld + c));
+        }
+    } else {
+        tile_store<NW>(s, ld, g, rows, cols, t, gld);
     }
 }
 template <int NW>

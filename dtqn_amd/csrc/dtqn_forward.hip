@@ -80,7 +80,6 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
     a.net = *net;
     a.theta_a = theta; a.theta_b = theta;
     a.obs = obs; a.actions = actions;
-    a.rewards = nullptr; a.dones = nullptr; a.rew_ep_stride = 0;
     if (in_rows <= 0) in_rows = n;              // rows per sequence in the input arrays (the batched actor packs whole contexts)
     if (in_rows < n) return DTQN_ERR_ARG;
     a.obs_ep_stride = (long long)in_rows * net->obs_dim;
@@ -125,7 +124,6 @@ void dtqn::td_forward_args(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     a.obs = rp->obs; a.actions = rp->actions;
     a.obs_ep_stride = (long long)(rp->max_steps + 1) * rp->obs_dim;
     a.act_ep_stride = rp->max_steps + 1;
-    a.rewards = rp->rewards; a.dones = rp->dones; a.rew_ep_stride = rp->max_steps;
     a.ep_idx = td->ep_idx; a.start = td->start;
     a.ep_len = draw ? rp->ep_len : nullptr; a.step_counter = td->step_counter;
     a.ep_out = td->ep_idx; a.start_out = td->start;

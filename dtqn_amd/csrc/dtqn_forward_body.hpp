@@ -25,9 +25,6 @@ struct FwdArgs {
     const uint8_t* actions;     // (ep, r) at actions + ep*act_ep_stride + r
     long long obs_ep_stride;
     long long act_ep_stride;
-    const float* rewards;       // TD update only (nullptr otherwise): rewards / dones of the replay, (ep, r) at + ep*rew_ep_stride + r -- the
-    const uint8_t* dones;       // training pass leaves {action, reward, done} of its window rows in the act record (DtqnNet.ao_loss)
-    long long rew_ep_stride;
     const int32_t* ep_idx;      // nullptr: ep = sequence index, start = 0
     const int32_t* start;
     int n;                      // real sequence length (<= ctx_len)
@@ -169,19 +166,6 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
     const int row0 = st + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
-    if (TRAIN) {
-        // loss record: {action, reward, done} of this slice's rows of the window (which == 0: row0 = st + R0), for the loss stage of the
-        // backward kernel -- it then needs no address that depends on (ep, st): ONE round trip in front of its chain instead of two
-        if (a.rewards != nullptr && net.ao_loss >= 0 && t.tid < LP) {
-            const int r = t.tid;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < n) {
-                const size_t wr = (size_t)ep * a.rew_ep_stride + row0 + r;
-                v = make_float4((float)act_rows[r], a.rewards[wr], a.dones[wr] ? 1.f : 0.f, 0.f);
-            }
-            st4(rf(rec, net.ao_loss, 4) + 4 * r, v);
-        }
-    }
     const int KE = net.ke, KEP = net.kep;
     const float* __restrict__ We = theta + net.off_obs_w;
     const float* __restrict__ be = theta + net.off_obs_b;
@@ -498,9 +482,6 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     TileRegs<NW, 3 * D, D> tw_in;
     TileRegs<NW, D, D> tw_hd;                          // the head's first matrix takes W_in's place after the last layer
     float4 ps_reg = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 h2_reg = make_float4(0.f, 0.f, 0.f, 0.f);   // head.2 weight / bias, staged in LDS behind the last layer when they fit
-    float b2_reg = 0.f;
-    const bool h2_lds = A * D / 4 <= NT && A <= NT && A * D + A <= wl_arena_floats(D) - OFF_B;
     {
         const float* __restrict__ th0 = layer_theta(net, theta, 0);
         tw_in.load(th0 + net.lo_in_w, D, t);
@@ -508,25 +489,26 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     }
 
     // ---------------- window gather + embedding (as forward_body) ----------------
-    // Row slices of 16 rows (two elements of the stream per thread), continuous observations: the operands of the embedding that do NOT
-    // depend on the window -- bias, position row, the KE weights of the element's column -- go in flight in front of the window draw,
-    // whose episode-length load is a round trip of its own (embedding stage: draw -> rows -> operands was three dependent trips)
-    constexpr bool HOIST = LP * D <= 2 * NT;
-    constexpr int HN = HOIST ? (LP * D + NT - 1) / NT : 1;
-    float hb[HN], hp[HN], hw[HN][8];
+    // Continuous observations: a thread's elements of the stream share their column (NT is a multiple of D), so the operands that do
+    // NOT depend on the window -- the KE weights and the bias of that column, the position entries of the thread's rows -- go in flight
+    // in front of the window draw (whose episode-length load is a round trip of its own), and the rows of all of the thread's
+    // elements are fetched together behind it: draw -> rows, two dependent trips, where the plain loop (below, kept for the other
+    // shapes) made one trip per element -- 8 at a 64-row tile (9.5 us of the 62 us pass at BASELINE config 2's shapes).
+    constexpr int EIT = (LP * D + NT - 1) / NT;      // elements of the [LP][D] stream per thread
+    constexpr bool HOIST = kOptHoist && NT % D == 0 && (LP * D) % NT == 0 && EIT <= 8;
+    constexpr int HN = HOIST ? EIT : 1, RSTEP = NT / D;
+    float hb = 0.f, hp[HN], hw[8];
     const bool hoisted = HOIST && !net.discrete && net.ke <= 8;
+    const int hd_ = t.tid % D, hr0 = t.tid / D;
     if (hoisted) {
-        const float* __restrict__ We_ = theta + net.off_obs_w;
-        const float* __restrict__ be_ = theta + net.off_obs_b;
+        const int dd = hd_ >= adim ? hd_ - adim : 0;
+        hb = theta[net.off_obs_b + dd];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hw[j] = theta[net.off_obs_w + (size_t)dd * net.ke + (j < net.ke ? j : 0)];
 #pragma unroll
         for (int k = 0; k < HN; ++k) {
-            const int idx = t.tid + k * NT, r = idx / D, d = idx - r * D;
-            const int dd = d >= adim ? d - adim : 0;
-            const int prow = R0 + r < net.ctx_len ? R0 + r : net.ctx_len - 1;       // rows past the context are never used: stay inside the table
-            hb[k] = be_[dd];
-            hp[k] = theta[net.off_pos + (size_t)prow * D + d];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hw[k][j] = We_[(size_t)dd * net.ke + (j < net.ke ? j : 0)];
+            const int prow = R0 + hr0 + k * RSTEP < net.ctx_len ? R0 + hr0 + k * RSTEP : net.ctx_len - 1;   // rows past the context are never used
+            hp[k] = theta[net.off_pos + (size_t)prow * D + hd_];
         }
     }
     int ep, st;
@@ -540,49 +522,42 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const int row0 = st + (which > 0 ? 1 : 0) + R0;
     const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row0 * O;
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row0 : nullptr;
-    if (TRAIN) {
-        // loss record: {action, reward, done} of this slice's rows of the window (which == 0: row0 = st + R0), for the loss stage of the
-        // backward kernel -- it then needs no address that depends on (ep, st): ONE round trip in front of its chain instead of two
-        if (a.rewards != nullptr && net.ao_loss >= 0 && t.tid < LP) {
-            const int r = t.tid;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < n) {
-                const size_t wr = (size_t)ep * a.rew_ep_stride + row0 + r;
-                v = make_float4((float)act_rows[r], a.rewards[wr], a.dones[wr] ? 1.f : 0.f, 0.f);
-            }
-            st4(rf(rec, net.ao_loss, 4) + 4 * r, v);
-        }
-    }
     const int KE = net.ke, KEP = net.kep;
     const float* __restrict__ We = theta + net.off_obs_w;
     const float* __restrict__ be = theta + net.off_obs_b;
     const float* __restrict__ pos = theta + net.off_pos + (size_t)R0 * D;
     if (hoisted) {
-        // same arithmetic as below (same fmaf chain per element), operands already in registers
+        // same arithmetic as the plain loop below (same fmaf chain per element), operands already in registers
+        float ev[HN][8];
+#pragma unroll
+        for (int kk = 0; kk < HN; ++kk) {              // all rows of this thread's elements in flight together
+            const int r = hr0 + kk * RSTEP;
+            // unconditional loads (a load under a branch hides the count of outstanding loads from the compiler): rows past the live
+            // ones read row 0 of the episode, which always exists, and are not used
+            const float* e = r < n ? obs_rows + (size_t)r * O : a.obs + (size_t)ep * a.obs_ep_stride;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ev[kk][k] = e[k < KE ? k : 0];
+        }
 #pragma unroll
         for (int kk = 0; kk < HN; ++kk) {
-            const int idx = t.tid + kk * NT;
-            if (idx < LP * D) {
-                const int r = idx / D, d = idx - r * D;
-                float v = 0.f;
-                if (r < n) {
-                    if (d < adim) {
-                        if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
-                        else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
-                    } else {
-                        const float* e = obs_rows + (size_t)r * O;
-                        float acc = hb[kk];
+            const int r = hr0 + kk * RSTEP, d = hd_, idx = r * D + d;
+            float v = 0.f;
+            if (r < n) {
+                if (d < adim) {
+                    if (single) v = theta[net.off_act_emb + (int)act_rows[0] * adim + d];
+                    else if (R0 + r > 0) v = theta[net.off_act_emb + (int)act_rows[r - 1] * adim + d];
+                } else {
+                    float acc = hb;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (k < KE) acc = fmaf(e[k], hw[kk][k], acc);
-                        v = acc;
-                    }
-                    v += hp[kk];
-                    v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
+                    for (int k = 0; k < 8; ++k)
+                        if (k < KE) acc = fmaf(ev[kk][k], hw[k], acc);
+                    v = acc;
                 }
-                Xs[r * LDX + d] = v;
-                if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
+                v += hp[kk];
+                v = drop_apply(dr, DROP_EMB, 0, (uint32_t)((R0 + r) * D + d), v);
             }
+            Xs[r * LDX + d] = v;
+            if (TRAIN) rf(rec, net.ao_x0, D)[idx] = v;
         }
         if (TRAIN)
             for (int idx = t.tid; idx < LP * KEP; idx += NT) {
@@ -674,12 +649,12 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_o.load(th + net.lo_out_w, D, t);              // in flight during the in-projection
         __syncthreads();                                 // (a) residual stream, W_in and the parameter block visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
                                   nullptr, rf(lrec, net.al_u1, D));
             __syncthreads();
             src = Us;
         }
-        if (TRAIN && !ident) tile_store<NW>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
+        if (TRAIN && !ident) rec_tile_store<NW, kOptFwdWT>(src, LDX, rf(lrec, net.al_u1, D), LP, D, t);
         GQkv::run(src, LDX, Ar, sm + P_INB, t, [&](int r, int c, float v) { AW[r * LDW + c] = v; });
         tw_o.to_lds(Ar + OFF_WO, LWD, t);                // behind W_in's last row: free since the previous layer's FFN
         TileRegs<NW, NC, D> tw_1;
@@ -687,7 +662,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         __syncthreads();                                 // (b) q | k | v visible; region A free
         DTQN_PROF(a.prof, ps++);   // qkv done
         if (TRAIN) {
-            tile_store<NW>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
+            rec_tile_store<NW, kOptFwdWT>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
         if (RS > 1)                                      // K | V of the rows below this slice (kv_handover)
@@ -699,7 +674,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
         __syncthreads();                                 // (c) attention output visible
         DTQN_PROF(a.prof, ps++);   // attention done
-        if (TRAIN) tile_store<NW>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
+        if (TRAIN) rec_tile_store<NW, kOptFwdWT>(AW, LDW, rf(lrec, net.al_o, D), LP, D, t);
         {   // out-projection, ReLU, residual gate:  x <- x + relu(o W_o^T + b_o)   (transformer.py:72 / :96)
             float* m_g = mf(lrec, net.al_m1, D / 16);
             GOut::run(AW, LDW, Ar + OFF_WO, sm + P_OUTB, t, [&](int r, int c, float v) {
@@ -713,11 +688,11 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_2.to_lds(Ar + OFF_B, LWC, t);
         tw_1.load(th + net.lo_f1_w + (size_t)NC * D, D, t);   // FFN-1 chunk 1, in flight during LayerNorm + FFN chunk 0
         if (!ident) {  // x = LN1(x)
-            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW, LP, TRAIN>(Xs, Us, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
             src = Us;
         }
@@ -743,7 +718,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 tw_1.to_lds(Ar, LWD, t);                 // FFN-1 chunk 1
                 tw_2.load(th + net.lo_f2_w + NC, 4 * D, t);   // FFN-2 chunk 1, in flight during FFN-2 chunk 0
             }
-            if (TRAIN) tile_store<NW>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
+            if (TRAIN) rec_tile_store<NW, kOptFwdWT>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
 #pragma unroll
             for (int q = 0; q < Own::PER_WAVE; ++q)
                 if (Own::valid_fast(t.wave, q))
@@ -760,9 +735,6 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 } else {
                     tw_hd.load(theta + net.off_head1_w, D, t);
                     if (t.tid < D / 4) ps_reg = ld4(theta + net.off_head1_b + 4 * t.tid);
-                    // the head's second matrix [A][D] and bias ride along (region B of the arena is free behind the last FFN)
-                    h2_reg = ld4(theta + net.off_head2_w + 4 * (h2_lds && t.tid < A * D / 4 ? t.tid : 0));
-                    b2_reg = theta[net.off_head2_b + (t.tid < A ? t.tid : 0)];
                 }
             }
         }
@@ -793,29 +765,24 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         } else {
             tw_hd.to_lds(Ar, LWD, t);
             if (t.tid < D / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
-            if (h2_lds) {
-                if (t.tid < A * D / 4) st4(Ar + OFF_B + 4 * t.tid, h2_reg);
-                if (t.tid < A) Ar[OFF_B + A * D + t.tid] = b2_reg;
-            }
         }
         if (!ident) {  // x = LN2(x)
-            layernorm_rows<D, NW, LP, TRAIN>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
                                   rf(lrec, net.al_s2, D), nullptr);
         } else if (TRAIN) {
-            tile_store<NW>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
+            rec_tile_store<NW, kOptFwdWT>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
         }
     }
 
     // ---------------- Q head: Linear(D,D) -> ReLU -> Linear(D,A)  (dtqn.py:149-153,216) ----------------
     __syncthreads();
     DTQN_PROF(a.prof, ps++);       // layers done
-    if (TRAIN) tile_store<NW>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
+    if (TRAIN) rec_tile_store<NW, kOptFwdWT>(Xs, LDX, rf(rec, net.ao_xf, D), LP, D, t);
     GOut::run(Xs, LDX, Ar, Ps + (net.num_layers & 1) * PSN, t, [&](int r, int c, float v) { Ws[r * LDW + c] = fmaxf(v, 0.f); });
     __syncthreads();
-    if (TRAIN) tile_store<NW>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
+    if (TRAIN) rec_tile_store<NW, kOptFwdWT>(Ws, LDW, rf(rec, net.ao_hh, D), LP, D, t);
     {
         float* q = a.q_out + (size_t)which * a.q_which_stride + (size_t)b * a.q_seq_stride + (size_t)R0 * a.q_row_stride;
-        // (one instance per address space of W_2 / b_2: LDS when they were staged, else global)
         auto q_rows = [&](const float* __restrict__ W2, const float* __restrict__ b2) {
             for (int idx = t.tid; idx < (n < LP ? n : LP) * A; idx += NT) {
                 const int r = idx / A, ac = idx - r * A;
@@ -831,8 +798,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 if (a.q_last_host != nullptr && R0 + r == (a.last_rows != nullptr ? a.last_rows[seq] - 1 : nfull - 1)) a.q_last_host[seq * A + ac] = acc;
             }
         };
-        if (h2_lds) q_rows(Ar + OFF_B, Ar + OFF_B + A * D);
-        else q_rows(theta + net.off_head2_w, theta + net.off_head2_b);
+        q_rows(theta + net.off_head2_w, theta + net.off_head2_b);
     }
     DTQN_PROF(a.prof, ps++);       // end
 }

