@@ -171,7 +171,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     DTQN_PROF(a.prof, ps++);
     // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
     static_assert(HD <= 16, "delta-in-epilogue needs a head inside one 16-column tile");
-    StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16> g_h1;
+    // (16-row slices: D / 16 column tiles on twice as many waves -> two waves per tile, half the contraction each)
+    constexpr bool SPLITS = kOptSplitS && MT == 1 && 2 * (D / 16) == NW && 2 * (GW / 16) == NW;
+    std::conditional_t<SPLITS, StageDyWSplit<D, NW, D / 16>, StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16>> g_h1;
     g_h1.prefetch(theta + net.off_head1_w, D, t);
     TileRegs<NW, LP, D> tr;                                // saved-activation tile in flight
     TileRegs<NW, LP, D> trh;
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     __syncthreads();
     g_h1.retire();
     g_tile_store(T2, LDX, gf(grec, net.go_dhh, D), LP, D);
-    g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
+    if constexpr (SPLITS) g_h1.run(T2, LDX, t, red, [&](int r, int c, float v) { DX[r * LDX + c] = v; });      // (red: free until the first LayerNorm)
+    else g_h1.run(T2, LDX, t, [&](int r, int c, float v) { DX[r * LDX + c] = v; });
     __syncthreads();
     DTQN_PROF(a.prof, ps++);   // head done
 
@@ -306,6 +309,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float w1f[2][NC / 4];
+            // 16-row slices (four column tiles of du2 on eight waves): wave w takes tile w % 4 and half w / 4 of the chunk's hidden
+            // columns; the halves are summed through W5 behind the loop
+            constexpr bool SPLITK = kOptSplitK && Own::ITEMS * 2 == NW && Own::PER_WAVE == 1 && MGX == 1 && NC % 32 == 0;
+            const int sk_it = t.wave % Own::ITEMS, sk_kh = t.wave / Own::ITEMS;
             const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(mf(lrec, net.al_mh, 4 * D / 16));
             constexpr int MGH = pick_mg(NC / 16, MT, NW);
 #pragma clang loop unroll_count(D >= 128 ? 1 : 4)
@@ -326,7 +333,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                              const unsigned long long w = mw[(r >> 4) % MGH][r & 3];
                              W5[r * LD5 + c] = ((w >> t.lane) & 1ull) ? v : 0.f;
                          });
-                if (DTQN_BWD_GUARD(t.wave, 0))
+                if constexpr (SPLITK) {
+                    float (&wh)[NC / 8] = *reinterpret_cast<float (*)[NC / 8]>(&w1f[0][0]);
+                    frag_dyw_fetch<NC / 2>(wh, W1 + (size_t)(c0 + sk_kh * (NC / 2)) * D + sk_it * 16 + t.i, D, t);
+                } else if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 if constexpr (FUSE) {
                     // the layer above is complete in memory once every wave has drained its vmcnt here: its last record stores (dq | dk | dv)
@@ -338,20 +348,36 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 if constexpr (FUSE) {
                     if (c0 == 0 && l + 1 < net.num_layers) fuse_arrive(a.fuse.counters, net.num_layers - 2 - l, t);
                 }
-                if (DTQN_BWD_GUARD(t.wave, 0)) {
+                if (SPLITK || DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
-                    for (int q = 0; q < NC / 4; ++q) DTQN_ASM_KEEP(w1f[0][q]);
+                    for (int q = 0; q < (SPLITK ? NC / 8 : NC / 4); ++q) DTQN_ASM_KEEP(w1f[0][q]);
                 }
                 g_tile_store(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, 4 * D);
+                if constexpr (SPLITK) {
+                    const float (&wh)[NC / 8] = *reinterpret_cast<const float (*)[NC / 8]>(&w1f[0][0]);
+                    frag_dyw_mma<NC / 2, 1>(W5 + sk_kh * (NC / 2), LD5, wh, t, xacc[0]);
+                } else {
 #pragma unroll
-                for (int q = 0; q < Own::PER_WAVE; ++q) {
-                    if (q + 1 < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, q + 1))
-                        frag_dyw_fetch<NC>(w1f[(q + 1) & 1], W1 + (size_t)c0 * D + Own::nt(t.wave, q + 1) * 16 + t.i, D, t);
-                    if (DTQN_BWD_GUARD(t.wave, q))
-                        frag_dyw_mma<NC, MGX>(W5 + Own::mg(t.wave, q) * MGX * 16 * LD5, LD5, w1f[q & 1], t, xacc[q]);
+                    for (int q = 0; q < Own::PER_WAVE; ++q) {
+                        if (q + 1 < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, q + 1))
+                            frag_dyw_fetch<NC>(w1f[(q + 1) & 1], W1 + (size_t)c0 * D + Own::nt(t.wave, q + 1) * 16 + t.i, D, t);
+                        if (DTQN_BWD_GUARD(t.wave, q))
+                            frag_dyw_mma<NC, MGX>(W5 + Own::mg(t.wave, q) * MGX * 16 * LD5, LD5, w1f[q & 1], t, xacc[q]);
+                    }
                 }
                 if (c0 + NC < 4 * D) g_dh.prefetch(W2 + c0 + NC, 4 * D, t);
                 __syncthreads();
+            }
+            if constexpr (SPLITK) {      // (W5 is free: the loop ended on a barrier)
+                if (t.wave >= Own::ITEMS) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) W5[((t.wave - Own::ITEMS) * 4 + r4) * 64 + t.lane] = xacc[0][0][r4];
+                }
+                __syncthreads();
+                if (t.wave < Own::ITEMS) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) xacc[0][0][r4] += W5[(t.wave * 4 + r4) * 64 + t.lane];
+                }
             }
             float* dst = ident ? DU : DX;
 #pragma unroll
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         load_group(0);
         const float* __restrict__ Wo = th + net.lo_out_w;
         const float* __restrict__ Win = th + net.lo_in_w;
-        StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16> g_do;         // dO = da W_o[:, group]
+        std::conditional_t<SPLITS, StageDyWSplit<D, NW, GW / 16>, StageDyW<D, MT, pick_mg(GW / 16, MT, NW), NW, GW / 16>> g_do;   // dO = da W_o[:, group]
         g_do.prefetch(Wo, D, t);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
@@ -435,6 +461,16 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
 #pragma unroll
                 for (int m = 0; m < MGX; ++m) xacc[q][m] = zero4();
             float winf[2][GW / 4];
+            // 16-row slices: the 3 GW contraction rows of du1 = [dq | dk | dv] W_in (q, k, v rows of W_in) as six pieces of GW / 2 rows,
+            // three per half of the waves (wave w: column tile w % 4, pieces 3 (w / 4) ...): half the rows, half the fragment per wave
+            constexpr bool SPLITW = kOptSplitW && Own::ITEMS * 2 == NW && Own::PER_WAVE == 1 && MGX == 1 && GW % 32 == 0;
+            constexpr int WPC = GW / 2;                                      // rows of a piece
+            const int sw_it = t.wave % Own::ITEMS, sw_kh = t.wave / Own::ITEMS;
+            float wpc[2][WPC / 4];
+            auto piece_fetch = [&](float (&wf)[WPC / 4], int g_, int j) {      // piece j = 0..2 of this wave's half
+                const int u = sw_kh * 3 + j, part = u >> 1, off = (u & 1) * WPC;
+                frag_dyw_fetch<WPC>(wf, Win + (size_t)(part * D + g_ * GW + off) * D + sw_it * 16 + t.i, D, t);
+            };
             const float* o_g = rf(lrec, net.al_o, D);
             float* W5r = W5 + R0 * LD5;                // this slice's rows of the attention tiles
             constexpr int MGO = pick_mg(GW / 16, MT, NW);
@@ -466,28 +502,30 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 }
                 __syncthreads();                   // da (T2) visible
                 g_do.retire();
-                if (g == 0) g_tile_store(T2, LDX, gf(lgrd, net.gl_da, D), LP, D);
+                if (g == 0 && !DOX) g_tile_store(T2, LDX, gf(lgrd, net.gl_da, D), LP, D);      // (dO broadcast: behind the send, below)
                 // do = da W_o restricted to this group's columns -> W5[:, 3GW:4GW];  delta = do . o per (row, head)
                 float ov[MGO][4];
-                g_do.run(T2, LDX, t,
-                         [&](int kt, int mg) {
-                             if (!OST) {
+                auto do_pre = [&](int kt, int mg) {
+                    if (!OST) {
 #pragma unroll
-                                 for (int m = 0; m < MGO; ++m)
+                        for (int m = 0; m < MGO; ++m)
 #pragma unroll
-                                     for (int r = 0; r < 4; ++r)
-                                         ov[m][r] = o_g[(size_t)((mg * MGO + m) * 16 + t.kq * 4 + r) * D + g * GW + kt * 16 + t.i];
-                             }
-                         },
-                         [&](int r, int c, float v) {
-                             W5r[r * LD5 + 3 * GW + c] = v;
-                             float p = v * (OST ? W5r[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
+                            for (int r = 0; r < 4; ++r)
+                                ov[m][r] = o_g[(size_t)((mg * MGO + m) * 16 + t.kq * 4 + r) * D + g * GW + kt * 16 + t.i];
+                    }
+                };
+                auto do_epi = [&](int r, int c, float v) {
+                    W5r[r * LD5 + 3 * GW + c] = v;
+                    float p = v * (OST ? W5r[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
 #pragma unroll
-                             for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
-                             if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
-                         });
+                    for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
+                    if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
+                };
+                if constexpr (SPLITS) g_do.run(T2, LDX, t, red, do_pre, do_epi);      // (red: the LayerNorm scratch, idle during the attention stage)
+                else g_do.run(T2, LDX, t, do_pre, do_epi);
                 // first W_in fragment of this wave in flight during the attention passes
-                if (DTQN_BWD_GUARD(t.wave, 0))
+                if constexpr (SPLITW) piece_fetch(wpc[0], g, 0);
+                else if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<GW>(winf[0], Win + (size_t)(0 * D + g * GW) * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 __syncthreads();
                 DTQN_PROF(a.prof, ps++);   // qkv load + dO gemm done
@@ -581,10 +619,16 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 }
                 }
                 DTQN_PROF(a.prof, ps++);   // attention bwd done
-                if (DTQN_BWD_GUARD(t.wave, 0)) {
+                if constexpr (SPLITW) {
+#pragma unroll
+                    for (int q = 0; q < WPC / 4; ++q) DTQN_ASM_KEEP(wpc[0][q]);
+                } else if (DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
                     for (int q = 0; q < GW / 4; ++q) DTQN_ASM_KEEP(winf[0][q]);
                 }
+                // (dO broadcast: the da record leaves HERE, behind the hand-overs -- in front of them the sender's drain before its flags
+                //  and the receivers' loads would queue behind the acknowledgements of these write-through stores)
+                if (g == 0 && DOX) g_tile_store(T2, LDX, gf(lgrd, net.gl_da, D), LP, D);
                 // dq | dk | dv of the group -> grd record (columns of the packed [LP][3D] layout)
                 for (int idx = t.tid; idx < LP * 3 * (GW / 4); idx += NT) {
                     const int r = idx / (3 * (GW / 4)), rem = idx - r * (3 * (GW / 4));
@@ -593,6 +637,14 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                     g_store4(gf(lgrd, net.gl_dqkv, 3 * D) + (size_t)r * 3 * D + which * D + g * GW + c, ld4(sp));
                 }
                 // du1 += dq W_in[q rows] + dk W_in[k rows] + dv W_in[v rows]: 3 fragments per owned item, double-buffered
+                if constexpr (SPLITW) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (j + 1 < 3) piece_fetch(wpc[(j + 1) & 1], g, j + 1);
+                        const int u = sw_kh * 3 + j, part = u >> 1, off = (u & 1) * WPC;
+                        frag_dyw_mma<WPC, 1>(W5r + (part == 0 ? 4 * GW : part * GW) + off, LD5, wpc[j & 1], t, xacc[0]);
+                    }
+                } else
 #pragma unroll
                 for (int q = 0; q < Own::PER_WAVE; ++q) {
 #pragma unroll
@@ -619,6 +671,17 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 if (l > 0) tr.load(rf(rec, net.ao_layer0 + (l - 1) * net.act_layer_stride + net.al_s2, D), D, t);
             } else {
                 tr.load(l == 0 ? rf(rec, net.ao_x0, D) : rf(rec, net.ao_layer0 + (l - 1) * net.act_layer_stride + net.al_s2, D), D, t);
+            }
+            if constexpr (SPLITW) {      // (W5 is free: the group loop ended on a barrier)
+                if (t.wave >= Own::ITEMS) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) W5[((t.wave - Own::ITEMS) * 4 + r4) * 64 + t.lane] = xacc[0][0][r4];
+                }
+                __syncthreads();
+                if (t.wave < Own::ITEMS) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) xacc[0][0][r4] += W5[(t.wave * 4 + r4) * 64 + t.lane];
+                }
             }
             float* dst = ident ? DU : DX;
 #pragma unroll

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "dtqn_hip.h"
 #include "dtqn_limits.h"
@@ -25,11 +26,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   32  backward: gradient records leave as write-through (sc1) stores (-0.5 us)
 //   64  forward: activation records likewise (-2.5 us: the kernel no longer ends with 17 MB of dirty lines to write back)
 //   128 forward: window-independent embedding operands in flight ahead of the window draw (-0.3 us)
+// 16-row slices, products whose output is only D / 16 = 4 column tiles wide on a workgroup of 8 waves: the contraction is split over the two
+// halves of the waves instead of leaving four of them idle (half the weight-fragment registers and half the fragment's fetch per wave):
+//   1024 backward dh W_1 (-3.6 us: 42.9 -> 39.3 us per launch)      2048 forward FFN-2 (+0.5 us: the extra barrier costs more than the
+//   16 MFMAs it saves; off)      4096 backward dqkv W_in      8192 backward head.1 and dO products
 #ifndef DTQN_OPT
-#define DTQN_OPT (4 | 32 | 64 | 128)
+#define DTQN_OPT (4 | 32 | 64 | 128 | 1024 | 4096 | 8192)
 #endif
 namespace dtqn {
 constexpr bool kOptLse = (DTQN_OPT & 4) != 0, kOptBwdWT = (DTQN_OPT & 32) != 0, kOptFwdWT = (DTQN_OPT & 64) != 0, kOptHoist = (DTQN_OPT & 128) != 0;
+constexpr bool kOptSplitK = (DTQN_OPT & 1024) != 0, kOptSplitKFwd = (DTQN_OPT & 2048) != 0, kOptSplitW = (DTQN_OPT & 4096) != 0;
+constexpr bool kOptSplitS = (DTQN_OPT & 8192) != 0;
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
@@ -501,6 +508,44 @@ struct StageDyW {
                     for (int r = 0; r < 4; ++r) epi((mg * MG + m) * 16 + t.kq * 4 + r, kt * 16 + t.i, acc[m][r]);
             }
         }
+    }
+};
+
+// StageDyW for ONE 16-row tile whose KTILES column tiles are half as many as the workgroup has waves: wave w takes tile w % KTILES and
+// half w / KTILES of the NN contraction rows (half the fragment: NN / 8 registers, NN / 8 loads), the upper waves hand their sums to
+// the lower ones through `scratch` (KTILES * 256 floats of LDS, free for the duration of run()), which then run the epilogue.
+// run() contains one __syncthreads(): every wave calls it.
+template <int NN, int NW, int KTILES>
+struct StageDyWSplit {
+    static_assert(2 * KTILES == NW && NN % 32 == 0, "two waves per column tile");
+    float bf[NN / 8];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ W, int ldw, const Thr& t) {
+        const int item = t.wave % KTILES, kh = t.wave / KTILES;
+        frag_dyw_fetch<NN / 2>(bf, W + (size_t)(kh * (NN / 2)) * ldw + item * 16 + t.i, ldw, t);
+    }
+    __device__ __forceinline__ void retire() {
+#pragma unroll
+        for (int q = 0; q < NN / 8; ++q) DTQN_ASM_KEEP(bf[q]);
+    }
+    template <typename Pre, typename Epi>
+    __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, float* scratch, Pre pre, Epi epi) {
+        const int item = t.wave % KTILES, kh = t.wave / KTILES;
+        f32x4 acc[1] = {zero4()};
+        if (kh == 0) pre(item, 0);
+        frag_dyw_mma<NN / 2, 1>(dYs + kh * (NN / 2), lda, bf, t, acc);
+        if (kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[(item * 4 + r) * 64 + t.lane] = acc[0][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi(t.kq * 4 + r, item * 16 + t.i, acc[0][r] + scratch[(item * 4 + r) * 64 + t.lane]);
+        }
+    }
+    template <typename Epi>
+    __device__ __forceinline__ void run(const float* dYs, int lda, const Thr& t, float* scratch, Epi epi) {
+        run(dYs, lda, t, scratch, [](int, int) {}, epi);
     }
 };
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ int lds_ldw(int D) { return 3 * D + 4; }
 // slice sends first, then receives.  Senders always have the lower blockIdx of a pair, on the receiver's XCD (slice_block_map).
 // Pair (s, r), s < r: flag r (r - 1) / 2 + s.
 template <int NW, int RS>
-__device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
+__device__ __forceinline__ void kv_send(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
     const int cols = 2 * D, c4 = cols >> 2;
     if (slice < RS - 1) {
         const DtqnRsrc rs = DTQN_XCH_RSRC(xb + (size_t)slice * LP * cols, LP * cols * 4);
@@ -83,6 +83,10 @@ __device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, i
         const int r = slice + 1 + t.tid;               // ... before the flags are raised
         if (t.tid < RS - 1 - slice) DTQN_AGENT_STORE(flags + r * (r - 1) / 2 + slice, (int32_t)1);
     }
+}
+template <int NW, int RS>
+__device__ __forceinline__ void kv_recv(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
+    const int cols = 2 * D, c4 = cols >> 2;
     if (slice > 0) {
         if (t.tid < slice)
             while (DTQN_AGENT_LOAD(flags + slice * (slice - 1) / 2 + t.tid) == 0) DTQN_SPIN_PAUSE();
@@ -95,6 +99,11 @@ __device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, i
         __syncthreads();
         if (t.tid < slice) DTQN_AGENT_STORE(flags + slice * (slice - 1) / 2 + t.tid, (int32_t)0);
     }
+}
+template <int NW, int RS>
+__device__ __forceinline__ void kv_handover(float* Ws, int ldw, int D, int LP, int slice, float* xb, int32_t* flags, const Thr& t) {
+    kv_send<NW, RS>(Ws, ldw, D, LP, slice, xb, flags, t);
+    kv_recv<NW, RS>(Ws, ldw, D, LP, slice, xb, flags, t);
 }
 
 // floats / flag words of one (sequence, layer) hand-over record for RS slices of LP rows
@@ -637,6 +646,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     // ---------------- transformer layers ----------------
     constexpr int MG2 = pick_mg(D / 16, MT, NW);
     using Own = Owned<D, MT, MG2, NW>;
+    constexpr bool SPLITK = kOptSplitKFwd && Own::ITEMS * 2 == NW && Own::PER_WAVE == 1 && MG2 == 1 && NC % 32 == 0;
     using GQkv = StageXwL<D, MT, pick_mg(3 * D / 16, MT, NW), NW, 3 * D / 16>;
     using GOut = StageXwL<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16>;
     using GF1 = StageXwL<D, MT, pick_mg(NC / 16, MT, NW), NW, NC / 16>;
@@ -661,13 +671,20 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_1.load(th + net.lo_f1_w, D, t);               // FFN-1 chunk 0, in flight during attention
         __syncthreads();                                 // (b) q | k | v visible; region A free
         DTQN_PROF(a.prof, ps++);   // qkv done
-        if (TRAIN) {
+        // K | V of the rows below this slice.  The hand-over goes FIRST: the slices above wait for it, and the sender's drain of its
+        // vector-memory queue in front of the flags would otherwise also sit out the acknowledgements of the q | k | v record's
+        // write-through stores (a microsecond on the training pass's critical path); the record leaves behind the receive, whose loads
+        // must not queue behind those stores either (vmcnt counts both, in order).
+        if (RS > 1) {
+            float* xb = a.xch + ((size_t)seq * net.num_layers + l) * kv_xch_floats(RS, LP, D);
+            int32_t* xf = a.xflags + ((size_t)seq * net.num_layers + l) * kv_xch_flags(RS);
+            kv_send<NW, RS>(Ws, LDW, D, LP, slice, xb, xf, t);
+            kv_recv<NW, RS>(Ws, LDW, D, LP, slice, xb, xf, t);
+        }
+        if (TRAIN) {                                     // q | k | v -> record before attention overwrites q
             rec_tile_store<NW, kOptFwdWT>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        if (RS > 1)                                      // K | V of the rows below this slice (kv_handover)
-            kv_handover<NW, RS>(Ws, LDW, D, LP, slice, a.xch + ((size_t)seq * net.num_layers + l) * kv_xch_floats(RS, LP, D),
-                                a.xflags + ((size_t)seq * net.num_layers + l) * kv_xch_flags(RS), t);
         attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS >= 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         tw_1.to_lds(Ar, LWD, t);
         TileRegs<NW, D, NC> tw_2;
@@ -719,11 +736,17 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                 tw_2.load(th + net.lo_f2_w + NC, 4 * D, t);   // FFN-2 chunk 1, in flight during FFN-2 chunk 0
             }
             if (TRAIN) rec_tile_store<NW, kOptFwdWT>(Ws, LDW, rf(lrec, net.al_h, 4 * D) + c0, LP, NC, t, 4 * D);
+            if constexpr (SPLITK) {
+                // four column tiles, eight waves: wave w takes tile w % 4 and half w / 4 of the chunk's hidden columns (summed below)
+                const int it = t.wave % Own::ITEMS, kh = t.wave / Own::ITEMS;
+                frag_xwl_mma<NC / 2, 1>(Ws + kh * (NC / 2), LDW, Ar + OFF_B + (it * 16 + t.i) * LWC + kh * (NC / 2), t, facc[0]);
+            } else {
 #pragma unroll
-            for (int q = 0; q < Own::PER_WAVE; ++q)
-                if (Own::valid_fast(t.wave, q))
-                    frag_xwl_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW,
-                                          Ar + OFF_B + (Own::nt(t.wave, q) * 16 + t.i) * LWC, t, facc[q]);
+                for (int q = 0; q < Own::PER_WAVE; ++q)
+                    if (Own::valid_fast(t.wave, q))
+                        frag_xwl_mma<NC, MG2>(Ws + Own::mg(t.wave, q) * MG2 * 16 * LDW, LDW,
+                                              Ar + OFF_B + (Own::nt(t.wave, q) * 16 + t.i) * LWC, t, facc[q]);
+            }
             if (c0 == 0) {
                 __syncthreads();                         // (g) chunk 0 of the hidden and of W_2 consumed; FFN-1 chunk 1 visible
                 tw_2.to_lds(Ar + OFF_B, LWC, t);
@@ -736,6 +759,18 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
                     tw_hd.load(theta + net.off_head1_w, D, t);
                     if (t.tid < D / 4) ps_reg = ld4(theta + net.off_head1_b + 4 * t.tid);
                 }
+            }
+        }
+        if constexpr (SPLITK) {
+            // the upper four waves hand their half of the sums to the lower four through region A of the arena (free since barrier (h))
+            if (t.wave >= Own::ITEMS) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Ar[((t.wave - Own::ITEMS) * 4 + r4) * 64 + t.lane] = facc[0][0][r4];
+            }
+            __syncthreads();
+            if (t.wave < Own::ITEMS) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) facc[0][0][r4] += Ar[(t.wave * 4 + r4) * 64 + t.lane];
             }
         }
         {
