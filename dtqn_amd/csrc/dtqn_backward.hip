@@ -312,6 +312,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
             // 16-row slices (four column tiles of du2 on eight waves): wave w takes tile w % 4 and half w / 4 of the chunk's hidden
             // columns; the halves are summed through W5 behind the loop
             constexpr bool SPLITK = kOptSplitK && Own::ITEMS * 2 == NW && Own::PER_WAVE == 1 && MGX == 1 && NC % 32 == 0;
+            constexpr bool HALFW = kOptHalfW && !SPLITK && NC % 32 == 0;      // half fragments in time: [2][NC / 8] registers instead of [2][NC / 4]
             const int sk_it = t.wave % Own::ITEMS, sk_kh = t.wave / Own::ITEMS;
             const unsigned long long* mh = reinterpret_cast<const unsigned long long*>(mf(lrec, net.al_mh, 4 * D / 16));
             constexpr int MGH = pick_mg(NC / 16, MT, NW);
@@ -336,6 +337,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 if constexpr (SPLITK) {
                     float (&wh)[NC / 8] = *reinterpret_cast<float (*)[NC / 8]>(&w1f[0][0]);
                     frag_dyw_fetch<NC / 2>(wh, W1 + (size_t)(c0 + sk_kh * (NC / 2)) * D + sk_it * 16 + t.i, D, t);
+                } else if constexpr (HALFW) {
+                    float (&wh)[NC / 8] = *reinterpret_cast<float (*)[NC / 8]>(&w1f[0][0]);
+                    if (DTQN_BWD_GUARD(t.wave, 0)) frag_dyw_fetch<NC / 2>(wh, W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 } else if (DTQN_BWD_GUARD(t.wave, 0))
                     frag_dyw_fetch<NC>(w1f[0], W1 + (size_t)c0 * D + Own::nt(t.wave, 0) * 16 + t.i, D, t);
                 if constexpr (FUSE) {
@@ -350,12 +354,27 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 }
                 if (SPLITK || DTQN_BWD_GUARD(t.wave, 0)) {
 #pragma unroll
-                    for (int q = 0; q < (SPLITK ? NC / 8 : NC / 4); ++q) DTQN_ASM_KEEP(w1f[0][q]);
+                    for (int q = 0; q < (SPLITK || HALFW ? NC / 8 : NC / 4); ++q) DTQN_ASM_KEEP(w1f[0][q]);
                 }
                 g_tile_store(W5, LD5, gf(lgrd, net.gl_dhp, 4 * D) + c0, LP, NC, 4 * D);
                 if constexpr (SPLITK) {
                     const float (&wh)[NC / 8] = *reinterpret_cast<const float (*)[NC / 8]>(&w1f[0][0]);
                     frag_dyw_mma<NC / 2, 1>(W5 + sk_kh * (NC / 2), LD5, wh, t, xacc[0]);
+                } else if constexpr (HALFW) {
+                    float (&wa)[NC / 8] = *reinterpret_cast<float (*)[NC / 8]>(&w1f[0][0]);
+                    float (&wb)[NC / 8] = *reinterpret_cast<float (*)[NC / 8]>(&w1f[1][0]);
+#pragma unroll
+                    for (int q = 0; q < Own::PER_WAVE; ++q) {
+                        const float* wcol = W1 + (size_t)c0 * D + Own::nt(t.wave, q) * 16 + t.i;
+                        const float* rows = W5 + Own::mg(t.wave, q) * MGX * 16 * LD5;
+                        if (DTQN_BWD_GUARD(t.wave, q)) {
+                            frag_dyw_fetch<NC / 2>(wb, wcol + (size_t)(NC / 2) * D, D, t);
+                            frag_dyw_mma<NC / 2, MGX>(rows, LD5, wa, t, xacc[q]);
+                        }
+                        if (q + 1 < Own::PER_WAVE && DTQN_BWD_GUARD(t.wave, q + 1))
+                            frag_dyw_fetch<NC / 2>(wa, W1 + (size_t)c0 * D + Own::nt(t.wave, q + 1) * 16 + t.i, D, t);
+                        if (DTQN_BWD_GUARD(t.wave, q)) frag_dyw_mma<NC / 2, MGX>(rows + NC / 2, LD5, wb, t, xacc[q]);
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < Own::PER_WAVE; ++q) {

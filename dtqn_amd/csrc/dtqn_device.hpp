@@ -31,12 +31,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   1024 backward dh W_1 (-3.6 us: 42.9 -> 39.3 us per launch)      2048 forward FFN-2 (+0.5 us: the extra barrier costs more than the
 //   16 MFMAs it saves; off)      4096 backward dqkv W_in      8192 backward head.1 and dO products
 #ifndef DTQN_OPT
-#define DTQN_OPT (4 | 32 | 64 | 128 | 1024 | 4096 | 8192)
+#define DTQN_OPT (4 | 32 | 64 | 128 | 1024 | 4096 | 8192 | 16384)
 #endif
 namespace dtqn {
 constexpr bool kOptLse = (DTQN_OPT & 4) != 0, kOptBwdWT = (DTQN_OPT & 32) != 0, kOptFwdWT = (DTQN_OPT & 64) != 0, kOptHoist = (DTQN_OPT & 128) != 0;
 constexpr bool kOptSplitK = (DTQN_OPT & 1024) != 0, kOptSplitKFwd = (DTQN_OPT & 2048) != 0, kOptSplitW = (DTQN_OPT & 4096) != 0;
 constexpr bool kOptSplitS = (DTQN_OPT & 8192) != 0;
+// 16384 backward dh W_1 on whole tiles (64-row workgroups: every wave is busy there) with HALF weight fragments in time instead of whole
+//       ones: 32 fewer registers in a kernel that spills (BASELINE config 2: 3 077 -> 3 113 TD-updates/s)
+constexpr bool kOptHalfW = (DTQN_OPT & 16384) != 0;
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dtqn_smem[];
@@ -922,7 +925,10 @@ __device__ __forceinline__ void attention_forward_valu(float* Ws, int ld, int D,
 }
 
 
-constexpr int kAttnMfmaMinHeadDim = 16;
+#ifndef DTQN_ATTN_MFMA_MIN_HD
+#define DTQN_ATTN_MFMA_MIN_HD 16
+#endif
+constexpr int kAttnMfmaMinHeadDim = DTQN_ATTN_MFMA_MIN_HD;
 template <int HD, int NW, bool MFMA = (HD >= kAttnMfmaMinHeadDim)>
 __device__ __forceinline__ void attention_forward(float* Ws, int ld, int D, int H, int LP, int n,
                                                   float* __restrict__ lse_out, const Thr& t, int row0 = 0, int lse_ld = 0,
