@@ -183,13 +183,16 @@ def time_kernels(agent, iters: int = 50) -> dict:
     return out
 
 
-def time_kernels_in_stream(agent, updates: int = 100) -> dict:
-    """The launches of the pipelined update timed INSIDE a running stream of updates: update u wraps ONE of its
-    launches in a HIP event pair (forward, backward, weight gradients, clip + Adam in turn; every fifth update an EMPTY pair between two
-    updates) and nothing is synchronised until the end.  A launch timed by itself behind a drained stream is not the kernel the pipeline
-    runs -- its predecessor's dirty lines are long written back, its operands sit in a warm L2: round 4's clip + Adam read 3.9 us that
-    way against 7.0 us in the rocprofv3 trace of the same run.  These are the figures of the line (`kernels_us`, `roofline.launch_us`);
-    the one-at-a-time readings stay in the detail file (`kernels_us_isolated`).  Mean minus the in-stream empty pair."""
+def time_kernels_in_stream(agent, plain_step_us=None, updates: int = 120) -> dict:
+    """The launches of the pipelined update timed INSIDE a running stream of updates: one HIP event behind EVERY launch
+    of every update, nothing synchronised until the end.  The interval between two consecutive events is the launch behind the second one
+    INCLUDING its kernel boundary -- the quantity whose sum over an update is the step, and what rocprofv3 --kernel-trace reports per
+    dispatch when the launches run back to back -- plus the cost of one event, which is measured in the same run as
+    (instrumented step - plain step) / launches per update (the plain step: the same calls without events, timed right before).
+    A launch timed by itself behind a drained stream is not the kernel the pipeline runs: round 4's clip + Adam read 3.9 us that way
+    against 7.0 us in the trace of the same run, and an event PAIR around one launch minus an empty pair (this round's first version) still
+    read 2 us low on every kernel -- the empty pair contains the boundary the subtraction then removes.  The one-at-a-time readings stay in
+    the detail file (`kernels_us_isolated`)."""
     eng, rep = agent.engine, agent.replay_buffer.dev
     lib = eng.lib
     n, t = eng._net_ref, eng._td_ref
@@ -200,31 +203,48 @@ def time_kernels_in_stream(agent, updates: int = 100) -> dict:
     names = ["dtqn_forward_kernel", "dtqn_backward_kernel", "dtqn_wgrad_direct_kernel", "dtqn_clip_adam_kernel"]
     stages = [lambda: eng._forward_stage(rep, s), lambda: eng._backward_stage(rep, s),
               lambda: eng._check(lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad"), lambda: eng.clip_adam()]
-    pairs = {k: [] for k in names + ["_event_pair_us"]}
     inline0 = eng._pipe["inline"]
-    for u in range(-10, updates):
-        which = u % 5 if u >= 0 else -1              # the first updates only fill the queue (and take the one inline target pass)
-        for j, fn in enumerate(stages):
-            if j == which:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                fn()
-                e1.record(stream)
-                pairs[names[j]].append((e0, e1))
-            else:
-                fn()
-        if which == 4:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            e1.record(stream)
-            pairs["_event_pair_us"].append((e0, e1))
+    # the plain step of THIS stream of launches (same calls, no events inside): two events around `updates` updates
+    for _ in range(10):
+        for fn in stages:
+            fn()
+        agent._calls_issued += 1
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    p0.record(stream)
+    for _ in range(updates):
+        for fn in stages:
+            fn()
+        agent._calls_issued += 1
+    p1.record(stream)
+    stream.synchronize()
+    agent._drain_stats(block=True)
+    plain_step_us = p0.elapsed_time(p1) * 1e3 / updates if plain_step_us is None else plain_step_us
+    evs = []
+    for u in range(-10, updates):                    # the first updates only fill the queue (and take the one inline target pass)
+        row = []
+        for fn in stages:
+            fn()
+            if u >= -1:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                row.append(e)
+        if row:
+            evs.append(row)
         agent._calls_issued += 1
     stream.synchronize()
     agent._drain_stats(block=True)
-    us = {k: float(np.mean([a.elapsed_time(b) * 1e3 for a, b in v])) for k, v in pairs.items()}
-    empty = us["_event_pair_us"]
-    out = {k: max(0.0, us[k] - empty) for k in names}
-    out["_event_pair_us"] = empty
+    iv = np.zeros((len(evs) - 1, 4))
+    for u in range(1, len(evs)):
+        prev = evs[u - 1][3]
+        for j in range(4):
+            iv[u - 1, j] = prev.elapsed_time(evs[u][j]) * 1e3
+            prev = evs[u][j]
+    step_instr = float(iv.sum(axis=1).mean())
+    per_event = max(0.0, (step_instr - plain_step_us) / 4.0)
+    out = {k: max(0.0, float(iv[:, j].mean()) - per_event) for j, k in enumerate(names)}
+    out["_event_us"] = per_event
+    out["_step_instrumented_us"] = step_instr
+    out["_step_plain_us"] = plain_step_us
     out["_inline_target_passes"] = int(eng._pipe["inline"] - inline0)      # 1: the first update of the run (nothing was computed ahead yet)
     return out
 
@@ -777,7 +797,9 @@ def main():
             kern_isolated = kern
             ins = time_kernels_in_stream(agent)
             kern = dict(kern_isolated, **{k: v for k, v in ins.items() if not k.startswith("_")})
-            kern["_event_pair_us"] = ins["_event_pair_us"]
+            kern["_event_us"] = ins["_event_us"]
+            kern["_step_instrumented_us"] = ins["_step_instrumented_us"]
+            kern["_step_plain_us"] = ins["_step_plain_us"]
             kern["_event_pair_isolated_us"] = kern_isolated.get("_event_pair_us")
         dom = max(("dtqn_forward_kernel", "dtqn_backward_kernel"), key=lambda k: kern[k])
         # algorithmic FLOPs per launch: forward kernel = 3 forwards; backward kernel = data-gradient half
@@ -795,7 +817,7 @@ def main():
         whole_frac = 5 * tokens * ft / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
         crit = {k: v for k, v in kern.items() if not k.startswith("_") and not k.endswith("_target_inline")}
         detail = {"build": build_digest(), "kernels_us": kern, "kernels_us_sum": float(sum(crit.values())), "kernels_us_isolated": kern_isolated,
-                  "kernels_us_method": "in-stream event pairs (one launch per update wrapped, nothing synchronised), minus the in-stream empty pair"
+                  "kernels_us_method": "intervals between in-stream events behind every launch (nothing synchronised), minus the per-event cost = (instrumented step - plain step) / 4"
                   if kern_isolated is not None else "one launch at a time behind a drained stream, minus the empty event pair",
                   "forward": "policy passes as 2 x B x 4 workgroups of 16 rows; the next update's target pass rides in the backward launch"
                   if "dtqn_forward_kernel_target_inline" in kern else "three passes in one launch"}
