@@ -55,7 +55,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
             // (an action embedding is fine: a token is [action embedding (a) | observation embedding (D - a)], dtqn.py:192 -- the action
             //  columns come FIRST, so the real columns stay a prefix of the padded row and the padded rows of the observation Linear land
             //  behind them)
-            if (hd > 64 || dmin > 256 || net->bag_size != 0 || net->img_c > 0 || net->dropout != 0.f) return DTQN_ERR_CONFIG;
+            if (hd > 64 || dmin > 256 || net->bag_size != 0 || net->img_c > 0) return DTQN_ERR_CONFIG;      // (dropout: the keep masks are keyed by (row, REAL column), TlDrop.dw)
             net->d_real = d;
             net->heads_real = h;
             net->hd_real = hd;

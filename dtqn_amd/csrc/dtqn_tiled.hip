@@ -45,6 +45,8 @@ struct TlDrop {
     uint32_t seed, step;
     const int32_t* step_counter;       // TD update: step = step_counter[1]; else `step`
     int batch, passes;
+    int dw;                            // width the element index of a [rows][D] mask is built with: the CALLER's d_model (DtqnNet.d_real) on a
+                                       // width-padded network, so that the keep masks are those of the reference-shaped network the oracle evaluates
 };
 static inline TlDrop tl_drop_none() { TlDrop d = {}; d.scale = 1.0f; d.batch = 1; return d; }
 static inline TlDrop tl_drop_make(const DtqnNet& net, uint32_t seed, uint32_t step, const int32_t* step_counter, int batch, int passes) {
@@ -53,6 +55,7 @@ static inline TlDrop tl_drop_make(const DtqnNet& net, uint32_t seed, uint32_t st
         d.thresh = (uint32_t)((double)net.dropout * 4294967296.0);
         d.scale = 1.0f / (1.0f - net.dropout);
         d.seed = seed; d.step = step; d.step_counter = step_counter; d.batch = batch > 0 ? batch : 1; d.passes = passes;
+        d.dw = net.d_real > 0 ? net.d_real : net.d_model;
     }
     return d;
 }
@@ -236,10 +239,11 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
                 v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
             }
             if (edr.thresh != 0u) {
-                v.x = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d), v.x);
-                v.y = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 1), v.y);
-                v.z = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 2), v.z);
-                v.w = drop_apply(edr, DROP_EMB, 0, (uint32_t)(r * D + d + 3), v.w);
+                const uint32_t e0 = (uint32_t)(r * a.drop.dw + d);       // (columns behind dw are padding: zero with or without a mask)
+                v.x = drop_apply(edr, DROP_EMB, 0, e0, v.x);
+                v.y = drop_apply(edr, DROP_EMB, 0, e0 + 1, v.y);
+                v.z = drop_apply(edr, DROP_EMB, 0, e0 + 2, v.z);
+                v.w = drop_apply(edr, DROP_EMB, 0, e0 + 3, v.w);
             }
         }
         st4(xo + (size_t)rl * a.x.ld + d, v);
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const int rl = m * 16 + t.kq * 4 + r4;
-                        const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * D + col), accO[o][m][r4] + bv);
+                        const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * a.drop.dw + col), accO[o][m][r4] + bv);
                         if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
                         Xt[rl * LDX + col] = fmaxf(v, 0.f);
                     }
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int rl = m * 16 + t.kq * 4 + r4;
-                    const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * D + col), accO[o][m][r4] + bv);
+                    const float v = drop_apply(fdr, DROP_FFN, a.layer, (uint32_t)((row0 + rl) * a.drop.dw + col), accO[o][m][r4] + bv);
                     if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
                     Hs[rl * LDH + wc] = fmaxf(v, 0.f);
                 }
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfn
                 v.w = ((w >> (b0 + 3)) & 1ull) ? v.w : 0.f;
             }
             if (bdr.thresh != 0u) {
-                const uint32_t e0 = (uint32_t)(row * D + c);
+                const uint32_t e0 = (uint32_t)(row * a.drop.dw + c);
                 v.x = drop_apply(bdr, DROP_FFN, a.layer, e0, v.x);
                 v.y = drop_apply(bdr, DROP_FFN, a.layer, e0 + 1, v.y);
                 v.z = drop_apply(bdr, DROP_FFN, a.layer, e0 + 2, v.z);
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(TNT) void tl_drop_rows_kernel(TlDropRowsArgs a) {
         const int r = row0 + idx / c4, c = (idx % c4) * 4;
         float* p = frow(a.x, s, r) + c;
         float4 v = ld4(p);
-        const uint32_t e0 = (uint32_t)(r * a.D + c);
+        const uint32_t e0 = (uint32_t)(r * a.drop.dw + c);
         v.x = drop_apply(dr, a.site, a.layer, e0, v.x);
         v.y = drop_apply(dr, a.site, a.layer, e0 + 1, v.y);
         v.z = drop_apply(dr, a.site, a.layer, e0 + 2, v.z);

@@ -73,7 +73,7 @@ typedef struct DtqnNet {
                                * forwards only; 0 = off.  Both kernel families (counter-based keep masks, recomputed in the backward) */
     int32_t d_real, heads_real, hd_real; /* width padding (0 on a fresh struct = none).  A shape outside the kernels' instantiations -- a d_model
                                * other than 64 / 128 / 256, a head width (d_model / num_heads) that is not 4, 8, 16, 32 or 64 -- is padded by
-                               * dtqn_net_init (no action embedding, bag, image or dropout; head width <= 64, padded d_model <= 256): every head
+                               * dtqn_net_init (no bag, no images; head width <= 64, padded d_model <= 256; with dropout the keep masks are keyed by (row, real column)): every head
                                * to the next of those widths, then whole extra heads up to the next of 64 / 128 / 256 columns.  d_real /
                                * heads_real / hd_real keep the caller's d_model / num_heads / head width; d_model / num_heads / head_dim
                                * become the padded ones.  Every tensor of theta has the padded shape: the real entries in front, except

@@ -352,6 +352,10 @@ DROPOUT_CASES = [
     (dict(obs_dim=10, num_actions=10, inner_embed_size=128, num_heads=8, history_len=50, discrete=True, vocab_sizes=9, gate="gru", dropout=0.2),
      dict(batch=8, T=50, mask=8, n_eps=20)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, history_len=50, identity=True, action_dim=8, dropout=0.1), dict(batch=8, T=200, mask=-5, n_eps=20)),
+    # width-padded networks with dropout (round 5: keep masks keyed by (row, real column))
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=50, dropout=0.1), dict(batch=16, T=200, mask=-5, n_eps=30)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=100, discrete=True, vocab_sizes=9, pos="sin", gate="gru", action_dim=4, dropout=0.2),
+     dict(batch=4, T=120, mask=8, n_eps=10)),
 ]
 
 

@@ -41,6 +41,16 @@ PADDED = [
 ]
 
 
+# ... with dropout (round 5): the keep masks of the embedding and of the feed-forward output are keyed by (row, REAL column) -- TlDrop.dw in
+# dtqn_tiled.hip --, so a padded network drops exactly the units the reference-shaped network of the oracle drops
+PADDED_DROPOUT = [
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=20, dropout=0.1), dict(batch=2, T=30, mask=-5, tuf=2), (64, 8)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=30, discrete=True, vocab_sizes=9, pos="sin", gate="gru", action_dim=4,
+          dropout=0.2), dict(batch=2, T=40, mask=8), (128, 4)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=40, num_heads=5, num_layers=1, history_len=70, identity=True, dropout=0.15), dict(batch=2, T=90, mask=-5), (64, 8)),
+]
+
+
 @pytest.fixture(scope="module")
 def emu():
     from emu import emu_build
@@ -56,6 +66,15 @@ def test_td_update_of_a_width_padded_network(emu, kw, run, padded):
     assert net.tiled == 1 and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64) if w >= hd)
     assert padding_mask(net).sum() > 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)      # incl.: padded gradient entries == 0, padded parameters stay 0
+
+
+@pytest.mark.parametrize("kw,run,padded", PADDED_DROPOUT)
+def test_td_update_of_a_width_padded_network_with_dropout(emu, kw, run, padded):
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=23, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
+    assert (net.d_real, net.d_model, net.num_heads) == (cfg.inner_embed_size,) + padded and net.dropout > 0
+    eng.td.dropout_seed = 9876
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
 
 
 def test_forward_on_context_prefixes(emu):
@@ -81,7 +100,6 @@ def test_what_padding_does_not_cover_is_refused(emu):
     assert B.make_net(emu, **ok).d_real == 48
     for bad in (dict(inner_embed_size=140, num_heads=2),   # head width 70: beyond the widest attention instantiation (64)
                 dict(inner_embed_size=240, num_heads=6),   # six heads of 40 -> 64 columns each: 384 > 256
-                dict(dropout=0.1),                    # keep masks are keyed by the element index at the buffer's width
                 dict(bag_size=4),
                 dict(inner_embed_size=272, num_heads=17)):
         with pytest.raises(NotImplementedError):
