@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "dtqn_hip.h"
+#include "dtqn_limits.h"
 
 extern "C" const char* dtqn_build_info(void) {
 #ifdef DTQN_BUILD_INFO
@@ -41,6 +42,8 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
 // launches).  D = 64 stays whole-sequence (cfg 2: 2898 | 1697).
 extern "C" int dtqn_td_prefers_tiled(const DtqnNet* net, int batch) {
     if (!net || batch < 1 || net->tiled) return 0;
+    // head width 32 / width-padded networks on the whole-sequence side (dtqn_limits.h, dtqn_ws_lite) train there in latency mode only
+    if (dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real)) return dtqn_td_row_split(net, batch) == 4 ? 0 : 1;
     const bool covered = net->d_model == 128 && net->gate == DTQN_GATE_RES && !net->identity && net->lp == 64 && net->dropout == 0.f &&
                          net->bag_size == 0;
     if (!covered) return 0;

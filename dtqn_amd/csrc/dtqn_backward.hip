@@ -80,13 +80,16 @@ struct BwdArgs {
 template <bool AHEAD> struct AheadArgs {};
 template <> struct AheadArgs<true> { FwdArgs f; };
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false, bool AHEAD = false>
+// PAD: width-padded network (DtqnNet.d_real > 0; four-slice residual-gate chain only): LayerNorm backward over the d_real real columns,
+// softmax scale of the real head width.
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool DROP, bool FUSE = false, bool AHEAD = false, bool PAD = false>
 __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, AheadArgs<AHEAD> ahead) {
     static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
+    static_assert(!PAD || (RS == 4 && MT == 1 && !GRU && !DROP && !FUSE && D == 64), "width padding rides with the four-slice residual-gate chain");
     if constexpr (AHEAD) {
         static_assert(RS == 4 && MT == 1 && !GRU && !DROP && !FUSE && D <= 64, "the target pass ahead rides with the four-slice residual-gate chain");
         if ((int)blockIdx.x >= a.batch * RS) {
-            forward_body_wl<D, 1, HD, NW, 4, false>(ahead.f);
+            forward_body_wl<D, 1, HD, NW, 4, false, PAD>(ahead.f);
             return;
         }
     }
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     const int Lfull = net.ctx_len, A = net.num_actions, AP = net.ap, H = net.num_heads, adim = net.action_dim;
     const int L = Lfull - R0 < LP ? Lfull - R0 : LP;   // live rows of this slice (may be <= 0)
     const bool ident = RS > 1 ? false : net.identity != 0;     // row slices are dispatched for post-LN nets only: folds away
+    const int dreal = PAD ? net.d_real : D;                    // LayerNorm width
     constexpr bool gru = GRU;                      // gate type is a template parameter: the ResGate build carries no GRU code
     const float* __restrict__ theta = a.theta;
     const float* rec = a.act + (size_t)b * net.act_stride;
@@ -170,7 +174,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     int ps = 0;
     DTQN_PROF(a.prof, ps++);
     // everything the head stage needs goes in flight before the (latency-bound, one-wave) loss stage
-    static_assert(HD <= 16, "delta-in-epilogue needs a head inside one 16-column tile");
+    // delta = dO . o per (row, head) comes out of the dO product's epilogue: a head inside one 16-column tile is summed across its lanes;
+    // head width 32 spans two tiles (two different waves): each adds its half into the zero-filled entry -- two addends, so the sum
+    // does not depend on who comes first
+    static_assert(HD <= 16 || (HD == 32 && RS == 4 && MT == 1), "delta-in-epilogue: a head inside one 16-column tile, or two tiles wide on the four-slice chain");
     // (16-row slices: D / 16 column tiles on twice as many waves -> two waves per tile, half the contraction each)
     constexpr bool SPLITS = kOptSplitS && MT == 1 && 2 * (D / 16) == NW && 2 * (GW / 16) == NW;
     std::conditional_t<SPLITS, StageDyWSplit<D, NW, D / 16>, StageDyW<D, MT, pick_mg(D / 16, MT, NW), NW, D / 16>> g_h1;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
             if (l == net.num_layers - 1) DTQN_PROF(a.prof, 29);
             __syncthreads();
             if (l == net.num_layers - 1) DTQN_PROF(a.prof, 30);
-            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW, FUSE, PAD>(DX, T2, DX, false, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t, false, dreal);
             if (l == net.num_layers - 1) DTQN_PROF(a.prof, 31);
             __syncthreads();
         }
@@ -453,9 +460,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // FFN bwd done
         if (!ident)   // u2 = LN1(s1): DX currently holds dL/du2 (skip + FFN branch)
-            layernorm_backward<D, NW, FUSE>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW, FUSE, PAD>(DX, T2, DX, false, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t, false, dreal);
         else          // u2 = LN2(s1) feeds only the FFN branch: stream grad += LN2'(DU)
-            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t);
+            layernorm_backward<D, NW, FUSE, PAD>(DU, T2, DX, true, LDX, LP, st_s + 2 * LP, th + net.lo_ln2_w, lsm + 2 * D, red, t, false, dreal);
         __syncthreads();
         DTQN_PROF(a.prof, ps++);   // LN1 bwd done
         // attention gate.  res: s1 = x_in + relu(attn)  ->  da = ds1 * [y1 > 0]; gru as above.
@@ -519,6 +526,9 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                 } else {
                     for (int idx = t.tid; idx < NLSE; idx += NT) lse_s[idx] = lrec[net.al_lse + g * NLSE + idx];
                 }
+                if constexpr (HD > 16) {           // delta of this slice's rows is summed up from two column tiles (the dO epilogue below)
+                    for (int idx = t.tid; idx < (GW / HD) * LP; idx += NT) delta_s[(idx / LP) * LPF + R0 + idx % LP] = 0.f;
+                }
                 __syncthreads();                   // da (T2) visible
                 g_do.retire();
                 if (g == 0 && !DOX) g_tile_store(T2, LDX, gf(lgrd, net.gl_da, D), LP, D);      // (dO broadcast: behind the send, below)
@@ -537,8 +547,12 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                     W5r[r * LD5 + 3 * GW + c] = v;
                     float p = v * (OST ? W5r[r * LD5 + 5 * GW + c] : ov[(r >> 4) % MGO][r & 3]);
 #pragma unroll
-                    for (int m = 1; m < HD; m <<= 1) p += __shfl_xor(p, m);
-                    if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
+                    for (int m = 1; m < (HD < 16 ? HD : 16); m <<= 1) p += __shfl_xor(p, m);
+                    if constexpr (HD <= 16) {
+                        if ((t.i & (HD - 1)) == 0) delta_s[(c / HD) * LPF + R0 + r] = p;
+                    } else {
+                        if (t.i == 0) atomicAdd(&delta_s[(c / HD) * LPF + R0 + r], p);
+                    }
                 };
                 if constexpr (SPLITS) g_do.run(T2, LDX, t, red, do_pre, do_epi);      // (red: the LayerNorm scratch, idle during the attention stage)
                 else g_do.run(T2, LDX, t, do_pre, do_epi);
@@ -605,6 +619,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
                             if (t.tid < nsnd) DTQN_AGENT_STORE(fg + pair_id(slice + 1 + t.tid, slice), (int32_t)0);
                         }
                     };
+                    if constexpr (PAD)      // heads zero-padded to HD columns: the scale of the real head width
+                        attention_backward_group_mfma<HD, NW>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF, dr, l, g * (GW / HD),
+                                                              true, LPF / 16, between, (float)net.hd_real);
+                    else
                     attention_backward_group_mfma<HD, NW>(W5, LD5, GW, LP, Lfull, delta_s, lse_s, t, nullptr, 0, R0, LPF, dr, l, g * (GW / HD),
                                                           true, LPF / 16, between);
                     __syncthreads();
@@ -723,7 +741,7 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         if (ident) {   // u1 = LN1(x_in): stream grad += LN1'(DU), x_in = layer input stream
             tr.to_lds(T2, LDX, t);
             __syncthreads();
-            layernorm_backward<D, NW, FUSE>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t);
+            layernorm_backward<D, NW, FUSE, PAD>(DU, T2, DX, true, LDX, LP, st_s, th + net.lo_ln1_w, lsm, red, t, false, dreal);
             __syncthreads();
         }
     }
@@ -808,18 +826,28 @@ static int launch_bwd3(const BwdArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 // the chain of this update + the target pass of the next one (four slices per sequence each: 8 * batch workgroups)
-template <int HD>
+template <int HD, bool PAD = false>
 static int launch_bwd_ahead(const BwdArgs& a, const FwdArgs& f, hipStream_t stream) {
     const size_t lb = bwd_lds_bytes(&a.net), lf = fwd_lds_bytes(&a.net, true);
     const size_t lds = lb > lf ? lb : lf;
     if (lds > 160 * 1024) return DTQN_ERR_CONFIG;
     static size_t attr_lds[kMaxDevices] = {};
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true>), lds, attr_lds);
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true, PAD>), lds, attr_lds);
     (void)hipGetLastError();
     AheadArgs<true> ah;
     ah.f = f;
     ah.f.block0 = a.batch * 4;
-    hipLaunchKernelGGL((dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true>), dim3(a.batch * 4 + f.batch * 4), dim3(8 * 64), lds, stream, a, ah);
+    hipLaunchKernelGGL((dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, true, PAD>), dim3(a.batch * 4 + f.batch * 4), dim3(8 * 64), lds, stream, a, ah);
+    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+// the chain alone of the shapes that exist as four-slice kernels only (dtqn_limits.h, dtqn_ws_lite)
+template <int HD, bool PAD>
+static int launch_bwd_lite(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = bwd_lds_bytes(&a.net);
+    static size_t attr_lds[kMaxDevices] = {};
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, false, PAD>), lds, attr_lds);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((dtqn_backward_kernel<64, 1, HD, 8, false, 4, false, false, false, PAD>), dim3(a.batch * 4), dim3(8 * 64), lds, stream, a, AheadArgs<false>{});
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
@@ -897,6 +925,27 @@ static int td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* t
     fuse_plan(net, td, &a.fuse);
     const int D = net->d_model, MT = net->lp / 16, HD = net->head_dim, NW = waves_for(*net);
     hipStream_t s = (hipStream_t)stream;
+    if (dtqn_ws_lite(net->tiled, D, HD, net->d_real)) {      // head width 32 / width-padded: the four-slice chain, alone or with the pass ahead
+        if (td->row_split != 4 || net->lp != 64 || net->identity || net->gate != DTQN_GATE_RES || !a.xch || !a.xflags || a.drop_thresh != 0u ||
+            a.fuse.n_role > 0 || NW != 8) return DTQN_ERR_CONFIG;
+        const bool pad = net->d_real > 0;
+        if (td_next != nullptr) {
+            if (!dtqn_td_fwd_slices4_ok(net) || !td_next->sample_in_kernel || td_next->batch != td->batch || !td_next->xch || !td_next->xflags ||
+                !td_next->q3) return DTQN_ERR_CONFIG;
+            FwdArgs f;
+            td_forward_args(net, rp, td_next, 2, draw_step_next, &f);
+            f.nseq = td_next->batch;
+            f.prof = nullptr;
+            if (HD == 8 && pad) return launch_bwd_ahead<8, true>(a, f, s);
+            if (HD == 16 && pad) return launch_bwd_ahead<16, true>(a, f, s);
+            if (HD == 32) return pad ? launch_bwd_ahead<32, true>(a, f, s) : launch_bwd_ahead<32, false>(a, f, s);
+            return DTQN_ERR_CONFIG;
+        }
+        if (HD == 8 && pad) return launch_bwd_lite<8, true>(a, s);
+        if (HD == 16 && pad) return launch_bwd_lite<16, true>(a, s);
+        if (HD == 32) return pad ? launch_bwd_lite<32, true>(a, s) : launch_bwd_lite<32, false>(a, s);
+        return DTQN_ERR_CONFIG;
+    }
     if (td->row_split == 2 || td->row_split == 4) {   // several workgroups per sequence (dtqn_td_row_split)
         if (net->lp != 64 || net->identity || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
         if (net->gate == DTQN_GATE_GRU) {

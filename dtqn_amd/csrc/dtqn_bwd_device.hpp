@@ -13,11 +13,13 @@ namespace dtqn {
 //   dgb  : per-sequence partial of d gamma ([D]) followed (at +D) by d beta ([D])   (global)
 // Contains two __syncthreads(); caller must sync before (inputs ready) and after (dst ready).
 // WT: dgb is read by other workgroups of the same launch (fused weight gradients): agent-scope (write-through) stores
-template <int D, int NW, bool WT = false>
+// PAD (width-padded networks, DtqnNet.d_real): the two row means run over the first d_real columns and the columns behind them get 0
+// (their dy and gamma are zero, so the column sums of pass A are zero there by themselves)
+template <int D, int NW, bool WT = false, bool PAD = false>
 __device__ __forceinline__ void layernorm_backward(const float* dy, const float* xin, float* dst, bool accumulate,
                                                    int ld, int LP, const float* __restrict__ st,
                                                    const float* __restrict__ gamma, float* __restrict__ dgb,
-                                                   float* red, const Thr& t, bool dgb_accumulate = false) {
+                                                   float* red, const Thr& t, bool dgb_accumulate = false, int d_real = D) {
     constexpr int NT = NW * 64;
     constexpr int PARTS = NT / D >= 1 ? NT / D : 1;
     // pass A: column sums  d gamma[d] = sum_r dy*xhat,  d beta[d] = sum_r dy
@@ -68,14 +70,20 @@ __device__ __forceinline__ void layernorm_backward(const float* dy, const float*
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
-        c1 *= (1.0f / D);
-        c2 *= (1.0f / D);
+        const float inv_d = PAD ? 1.0f / (float)d_real : (1.0f / D);
+        c1 *= inv_d;
+        c2 *= inv_d;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             o[j].x = rstd * (gq[j].x - c1 - xh[j].x * c2);
             o[j].y = rstd * (gq[j].y - c1 - xh[j].y * c2);
             o[j].z = rstd * (gq[j].z - c1 - xh[j].z * c2);
             o[j].w = rstd * (gq[j].w - c1 - xh[j].w * c2);
+            if constexpr (PAD) {
+                const int c0 = part * 4 + 4 * LPR * j;
+                o[j].x = c0 < d_real ? o[j].x : 0.f; o[j].y = c0 + 1 < d_real ? o[j].y : 0.f;
+                o[j].z = c0 + 2 < d_real ? o[j].z : 0.f; o[j].w = c0 + 3 < d_real ? o[j].w : 0.f;
+            }
         }
     }
     __syncthreads();   // every lane has read dy / dst before anyone overwrites dst (dst may alias dy)

@@ -1061,6 +1061,7 @@ __device__ __forceinline__ void xch_recv(float* s, int ld, const float* g, int r
 // sequence a workgroup owns (the small-batch regime is latency-bound), fewer = more registers per wave.
 // DTQN_WAVES in the environment overrides the default (tuning / tests).
 static inline int waves_for(const DtqnNet& net) {
+    if (dtqn_ws_lite(net.tiled, net.d_model, net.head_dim, net.d_real)) return 8;      // eight-wave kernels only
     int nw = 8;                        // the default wave count of the network's instantiation (dtqn_limits.h)
     dtqn_ws_pick(net.d_model, net.head_dim, net.lp / 16, &nw);
     if (nw == 0) nw = 8;

@@ -9,6 +9,7 @@ DTQN_FWD_GROUP_A(DTQN_FWD_DECL)
 DTQN_FWD_GROUP_B(DTQN_FWD_DECL)
 DTQN_FWD_GROUP_C(DTQN_FWD_DECL)
 DTQN_FWD_GROUP_D(DTQN_FWD2_DECL)
+DTQN_FWD_GROUP_E(DTQN_FWDL_DECL)
 
 static void set_dropout(FwdArgs& a, const DtqnNet* net, int passes, uint32_t seed, uint32_t step) {
     const bool on = net->dropout > 0.f && passes != 0;
@@ -23,6 +24,14 @@ static int dispatch_fwd(const FwdArgs& a, int nseq, int row_split, hipStream_t s
     const int D = a.net.d_model, HD = a.net.head_dim;
     const int MT = mt_rows > 0 ? mt_rows : a.net.lp / 16;
     const int NW = mt_rows > 0 ? 8 : waves_for(a.net);
+    if (dtqn_ws_lite(a.net.tiled, D, HD, a.net.d_real)) {      // four slices or one workgroup per sequence, nothing else (dtqn_limits.h)
+        if (a.net.identity || a.net.gate != DTQN_GATE_RES || mt_rows > 0 || (row_split == 4 && (!a.xch || !a.xflags))) return DTQN_ERR_CONFIG;
+        const bool pad = a.net.d_real > 0;
+        if (HD == 8 && pad) return launch_fwd_lite<8, true>(a, nseq, row_split, stream);
+        if (HD == 16 && pad) return launch_fwd_lite<16, true>(a, nseq, row_split, stream);
+        if (HD == 32) return pad ? launch_fwd_lite<32, true>(a, nseq, row_split, stream) : launch_fwd_lite<32, false>(a, nseq, row_split, stream);
+        return DTQN_ERR_CONFIG;
+    }
     if (row_split == 4) {      // four workgroups per sequence: 16-row slices (TD update, weights-through-LDS body)
         if (a.net.lp != 64 || a.net.identity || a.net.gate != DTQN_GATE_RES || !a.xch || !a.xflags) return DTQN_ERR_CONFIG;
         if (D == 64 && HD == 8) return launch_fwd2<64, 1, 8, 8, false, 4>(a, nseq, stream);
@@ -104,10 +113,11 @@ int dtqn::forward_infer(const DtqnNet* net, const float* theta, const float* obs
         // once (one forward of 50 rows: 38 -> 29 us per launch of the stage chain), else two 32-row ones
         const char* es = getenv("DTQN_ACTOR_SLICES");      // A/B knob: 2 = the two-slice actor of round 3
         const bool four = batch * 4 <= 256 && dtqn_td_fwd_slices4_ok(net) != 0 && a.drop_thresh == 0u && !(es != nullptr && atoi(es) == 2);
-        return dispatch_fwd(a, batch, four ? 4 : 2, (hipStream_t)stream);
+        const bool lite = dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real) != 0;       // (no two-slice kernels)
+        return dispatch_fwd(a, batch, four ? 4 : lite ? 1 : 2, (hipStream_t)stream);
     }
     // short prefix of a 64-row context: 16- or 32-row instantiation (same kernel, fewer row tiles), else the full tile
-    if (net->lp == 64 && n <= 32 && net->gate == DTQN_GATE_RES) {
+    if (net->lp == 64 && n <= 32 && net->gate == DTQN_GATE_RES && !dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real)) {
         const int rc = dispatch_fwd(a, batch, 1, (hipStream_t)stream, n <= 16 ? 1 : 2);
         if (rc != DTQN_ERR_CONFIG) return rc;
     }
@@ -173,6 +183,7 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     if (!whole && !draw) return DTQN_ERR_ARG;      // a partial launch re-derives its windows from the counter-based draw
     FwdArgs a;
     td_forward_args(net, rp, td, pass0, draw_step, &a);
+    if (dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real)) slices = 4;      // the only training flavour of those shapes
     if (slices <= 0) {
         slices = td->row_split >= 2 ? 2 : 1;               // the whole-update launch: two slices in latency mode ...
         const char* e = getenv("DTQN_FWD_SLICES");         // ... DTQN_FWD_SLICES=4: four (A/B knob; 3 B 4 workgroups do not fit the chip at once)
@@ -185,7 +196,7 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
 
 extern "C" int dtqn_td_fwd_slices4_ok(const DtqnNet* net) {
     if (!net || net->tiled || net->lp != 64 || net->identity || net->gate != DTQN_GATE_RES || net->d_model != 64 || net->dropout > 0.f) return 0;
-    if (net->head_dim != 8 && net->head_dim != 16) return 0;
+    if (net->head_dim != 8 && net->head_dim != 16 && net->head_dim != 32) return 0;
     return fwd_wl_ok(net) && fwd_lds_bytes(net, true) <= 160 * 1024 ? 1 : 0;
 }
 

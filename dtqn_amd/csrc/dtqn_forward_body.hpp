@@ -446,7 +446,8 @@ __device__ __forceinline__ void forward_body(const FwdArgs& a) {
 // trip overlaps that stage's MFMAs), written to LDS right after the barrier that frees the region, and published by the
 // next barrier.  Per-layer vectors (13 D floats) sit in one of two parameter blocks, alternating by layer parity.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int D, int MT, int HD, int NW, int RS, bool TRAIN>
+// PAD: width-padded network (DtqnNet.d_real > 0): LayerNorm statistics over the d_real real columns, softmax scale of the real head width
+template <int D, int MT, int HD, int NW, int RS, bool TRAIN, bool PAD = false>
 __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     static_assert(RS == 1 || RS == 2 || RS == 4, "one, two or four row slices");
     static_assert(D <= 64, "the weight arena is sized for D <= 64");
@@ -473,6 +474,7 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
     const int nfull = a.n, H = net.num_heads, O = net.obs_dim, adim = net.action_dim, A = net.num_actions;
     const int n = nfull - R0;
     const bool single = (a.last_rows != nullptr ? a.last_rows[seq] : nfull) == 1;      // see forward_body
+    const int dreal = PAD ? net.d_real : D;          // LayerNorm width
     const bool ident = RS > 1 ? false : net.identity != 0;
     float* rec = TRAIN ? a.act + (size_t)b * net.act_stride : nullptr;
     auto rf = [&](float* base, int off, int w) -> float* { return TRAIN ? base + off + (size_t)R0 * w : nullptr; };
@@ -659,8 +661,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_o.load(th + net.lo_out_w, D, t);              // in flight during the in-projection
         __syncthreads();                                 // (a) residual stream, W_in and the parameter block visible
         if (ident) {   // x_norm1 = LN1(x)  (transformer.py:87)
-            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
-                                  nullptr, rf(lrec, net.al_u1, D));
+            layernorm_rows<D, NW, LP, TRAIN, PAD, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+                                  nullptr, rf(lrec, net.al_u1, D), 0, dreal);
             __syncthreads();
             src = Us;
         }
@@ -685,7 +687,10 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             rec_tile_store<NW, kOptFwdWT>(AW, LDW, rf(lrec, net.al_qkv, 3 * D), LP, 3 * D, t);
             __syncthreads();
         }
-        attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS >= 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
+        if constexpr (PAD)       // heads zero-padded to HD columns: the scale is the real head width's
+            attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS >= 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l, 0, (float)net.hd_real);
+        else
+            attention_forward<HD, NW, (HD >= kAttnMfmaMinHeadDim) || (RS >= 2 && DTQN_SPLIT_ATTN_MFMA)>(Ws, LDW, D, H, LP, nfull, TRAIN ? lrec + net.al_lse : nullptr, t, R0, LPF, dr, l);
         tw_1.to_lds(Ar, LWD, t);
         TileRegs<NW, D, NC> tw_2;
         tw_2.load(th + net.lo_f2_w, 4 * D, t);           // FFN-2 chunk 0 (columns [0, NC) of W_2), in flight during the out-projection
@@ -705,12 +710,12 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
         tw_2.to_lds(Ar + OFF_B, LWC, t);
         tw_1.load(th + net.lo_f1_w + (size_t)NC * D, D, t);   // FFN-1 chunk 1, in flight during LayerNorm + FFN chunk 0
         if (!ident) {  // x = LN1(x)
-            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
-                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
+            layernorm_rows<D, NW, LP, TRAIN, PAD, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN1W, sm + P_LN1B, rf(lrec, net.al_st1, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D), 0, dreal);
             src = Xs;
         } else {       // x_norm2 = LN2(x)
-            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
-                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D));
+            layernorm_rows<D, NW, LP, TRAIN, PAD, kOptFwdWT>(Xs, Us, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s1, D), rf(lrec, net.al_u2, D), 0, dreal);
             src = Us;
         }
         __syncthreads();                                 // (e) LayerNorm output and FFN-2 chunk 0 visible
@@ -802,8 +807,8 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
             if (t.tid < D / 4) st4(Ps + ((l + 1) & 1) * PSN + 4 * t.tid, ps_reg);
         }
         if (!ident) {  // x = LN2(x)
-            layernorm_rows<D, NW, LP, TRAIN, false, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
-                                  rf(lrec, net.al_s2, D), nullptr);
+            layernorm_rows<D, NW, LP, TRAIN, PAD, kOptFwdWT>(Xs, Xs, LDX, LP, sm + P_LN2W, sm + P_LN2B, rf(lrec, net.al_st2, 2), t,
+                                  rf(lrec, net.al_s2, D), nullptr, 0, dreal);
         } else if (TRAIN) {
             rec_tile_store<NW, kOptFwdWT>(Xs, LDX, rf(lrec, net.al_s2, D), LP, D, t);
         }
@@ -840,15 +845,17 @@ __device__ __forceinline__ void forward_body_wl(const FwdArgs& a) {
 
 // WL: weights through LDS (forward_body_wl; residual gate, D <= 64, chosen by the host when the arena fits).
 // DROP: keep-mask code compiled in (register-direct stages only).
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
+// PAD: width-padded network (forward_body_wl only)
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP, bool PAD = false>
 __global__ __launch_bounds__(NW * 64) void dtqn_forward_kernel(FwdArgs a) {
     static_assert(!(WL && DROP), "dropout runs on the register-direct stages");
+    static_assert(!PAD || WL, "width padding runs on forward_body_wl");
     int seq_, slice_;
     slice_block_map((int)blockIdx.x - a.block0, a.nseq, RS, seq_, slice_);
     const int which = a.pass0 + seq_ / a.batch;                               // workgroup-uniform
     if constexpr (WL) {
-        if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true>(a);
-        else forward_body_wl<D, MT, HD, NW, RS, false>(a);
+        if (a.act != nullptr && which == 0) forward_body_wl<D, MT, HD, NW, RS, true, PAD>(a);
+        else forward_body_wl<D, MT, HD, NW, RS, false, PAD>(a);
     } else {
         if (a.act != nullptr && which == 0) forward_body<D, MT, HD, NW, GRU, RS, true, DROP>(a);
         else forward_body<D, MT, HD, NW, GRU, RS, false, DROP>(a);
@@ -875,14 +882,24 @@ inline size_t fwd_lds_bytes(const DtqnNet* net, bool wl = false) {
     return fl * sizeof(float);
 }
 
-template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP>
+template <int D, int MT, int HD, int NW, bool GRU, int RS, bool WL, bool DROP, bool PAD = false>
 int launch_fwd4(const FwdArgs& a, int nseq, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(&a.net, WL);
     static size_t attr_lds[kMaxDevices] = {};    // per instantiation and device
-    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP>), lds, attr_lds);
+    raise_lds_limit(reinterpret_cast<const void*>(&dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP, PAD>), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((dtqn_forward_kernel<D, MT, HD, NW, GRU, RS, WL, DROP, PAD>), dim3(nseq * RS), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+}
+// The shapes that exist as weights-through-LDS kernels of d_model 64 / a 64-row context only (dtqn_limits.h, dtqn_ws_lite: head width 32
+// and the width-padded networks): rs = 4 (four 16-row slices: the TD update's passes, the latency-mode actor) or 1 (one workgroup per
+// sequence: inference at any batch).  Everything else of such a network runs on its row-block twin (dtqn_td_prefers_tiled).
+template <int HD, bool PAD>
+int launch_fwd_lite(const FwdArgs& a, int nseq, int rs, hipStream_t stream) {
+    if (a.drop_thresh != 0u || !fwd_wl_ok(&a.net) || fwd_lds_bytes(&a.net, true) > 160 * 1024 || a.net.lp != 64) return DTQN_ERR_CONFIG;
+    if (rs == 4) return launch_fwd4<64, 1, HD, 8, false, 4, true, false, PAD>(a, nseq, stream);
+    if (rs == 1) return launch_fwd4<64, 4, HD, 8, false, 1, true, false, PAD>(a, nseq, stream);
+    return DTQN_ERR_CONFIG;
 }
 template <int D, int MT, int HD, int NW, bool GRU, int RS>
 int launch_fwd2(const FwdArgs& a, int nseq, hipStream_t stream) {
@@ -919,6 +936,10 @@ void td_forward_args(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td,
 // row-split (two workgroups per sequence) instantiations: (D, MT, HD, NW, GRU)
 #define DTQN_FWD_GROUP_D(X) X(64, 2, 8, 8, true, 2) X(64, 2, 16, 8, true, 2) X(64, 2, 8, 8, false, 2) X(64, 2, 16, 8, false, 2) X(128, 2, 16, 8, false, 2) \
     X(64, 1, 8, 8, false, 4) X(64, 1, 16, 8, false, 4)
+// the four-slice / whole-tile pairs of dtqn_ws_lite shapes: (HD, PAD)   (dtqn_forward_inste.hip)
+#define DTQN_FWD_GROUP_E(X) X(8, true) X(16, true) X(32, true) X(32, false)
+#define DTQN_FWDL_DECL(hd, pad) extern template int launch_fwd_lite<hd, pad>(const FwdArgs&, int, int, hipStream_t);
+#define DTQN_FWDL_DEF(hd, pad) template int launch_fwd_lite<hd, pad>(const FwdArgs&, int, int, hipStream_t);
 #define DTQN_FWD_DECL(d, mt, hd, nw) extern template int launch_fwd<d, mt, hd, nw>(const FwdArgs&, int, hipStream_t);
 #define DTQN_FWD_DEF(d, mt, hd, nw) template int launch_fwd<d, mt, hd, nw>(const FwdArgs&, int, hipStream_t);
 #define DTQN_FWD2_DECL(d, mt, hd, nw, gru, rs) extern template int launch_fwd2<d, mt, hd, nw, gru, rs>(const FwdArgs&, int, hipStream_t);

@@ -90,8 +90,14 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     net->abi_version = DTQN_ABI_VERSION;
     net->lp = up16(L);
     net->tiled = 0;
+    // head width 32 at d_model 64 and the width-padded shapes of d_model 64: the four-slice / whole-tile kernels of dtqn_limits.h
+    // (dtqn_ws_lite) where the variant is covered -- residual gate, post-LN, no dropout, a context of at most 64 rows
+    const bool lite = dtqn_ws_lite_shape(D, D / H, net->d_real > 0) && net->lp <= DTQN_MAX_LP && net->gate == DTQN_GATE_RES && !net->identity &&
+                      net->dropout == 0.f && net->bag_size == 0 && !img && getenv("DTQN_FORCE_TILED") == nullptr && net->force_tiled == 0 &&
+                      up4(img ? 0 : (net->discrete ? O * e : O)) <= 3 * D &&      // (the embedding operands of the whole-sequence kernels)
+                      getenv("DTQN_WS_LITE_OFF") == nullptr;         // (A/B knob: the row-block path of rounds 1-4)
     if (net->lp > DTQN_MAX_LP || D > DTQN_MAX_D || getenv("DTQN_FORCE_TILED") != nullptr || net->force_tiled != 0 || net->bag_size > 0 || img ||
-        net->d_real > 0) {
+        (net->d_real > 0 && !lite)) {
         // does not fit one workgroup's LDS: row-block tiled path (64-row blocks)
         net->tiled = 1;
         net->lp = (L + 63) / 64 * 64;
@@ -107,7 +113,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         // whole-sequence kernels are explicit instantiations (dtqn_limits.h): the smallest row-tile count of this (d_model, head_dim)
         // that holds the context (a context of 8 at d_model 64 runs the 16-row kernels, head_dim 16 at d_model 64 the 64-row
         // ones: rows past the context are masked like rows 50..63 of BASELINE config 1); none -> the row-block tiled path
-        const int mt = dtqn_ws_pick(D, net->head_dim, net->lp / 16, nullptr);
+        const int mt = lite ? 4 : dtqn_ws_pick(D, net->head_dim, net->lp / 16, nullptr);
         if (mt > 0) net->lp = 16 * mt;
         if (mt == 0 || ((D == 128 || D == 256) && (dtqn_lds_bytes_backward(net) == 0 || net->gate == DTQN_GATE_GRU))) {
             // ... or the whole-sequence tile set of this variant (identity-reordered layers or the GRU gate at D = 128) exceeds

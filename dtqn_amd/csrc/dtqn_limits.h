@@ -3,7 +3,7 @@
 #pragma once
 #define DTQN_MAX_LP 64          /* padded context rows held in LDS (ctx_len <= 64) */
 #define DTQN_MAX_D 128          /* d_model instantiations: 64, 128 (and 16/32 for tests) */
-#define DTQN_MAX_HEAD_DIM 64    /* 4 .. 64 in the row-block attention kernels; the whole-sequence kernels: 8 and 16 */
+#define DTQN_MAX_HEAD_DIM 64    /* 4 .. 64 in the row-block attention kernels; the whole-sequence kernels: 8, 16 (and 32: dtqn_ws_lite) */
 #define DTQN_MAX_ACTIONS 64
 #define DTQN_MAX_BAG 256        /* bag entries (bag_size <= padded context <= 256, the row-block tiled path's limit) */
 #define DTQN_THREADS 256        /* 4 wave64 per workgroup */
@@ -30,3 +30,11 @@ static inline int dtqn_ws_pick(int d, int hd, int mt_needed, int* nw_out) {
     if (nw_out) *nw_out = nw;
     return best;
 }
+
+// "Lite" whole-sequence shapes: d_model 64 (after width padding) with head width 32, or any width-padded network at head width 8 / 16 / 32
+// -- residual gate, post-LN, no dropout, context <= 64 rows (dtqn_net_init checks those).  They exist as the weights-through-LDS
+// forward (four 16-row slices or one 64-row tile per sequence) and the four-slice backward chain only: acting, inference and the
+// latency-mode TD update (dtqn_td_row_split == 4) run there; a TD update at a larger batch runs on the row-block twin
+// (dtqn_td_prefers_tiled).  Before round 5 these shapes ran on the row-block kernels throughout (2.8 x slower at batch 32).
+static inline int dtqn_ws_lite_shape(int d, int hd, int padded) { return d == 64 && (hd == 32 || (padded && (hd == 8 || hd == 16))); }
+static inline int dtqn_ws_lite(int tiled, int d, int hd, int d_real) { return !tiled && dtqn_ws_lite_shape(d, hd, d_real > 0); }

@@ -373,7 +373,8 @@ inline int fuse_cu_count() {
 // DTQN_FUSE_ROLE_WGS=<n> overrides the number of weight-gradient workgroups.
 inline bool fuse_plan(const DtqnNet* net, const DtqnTd* td, FuseArgs* f) {
     f->n_role = 0;
-    if (!net || !td || td->row_split != 4 || net->tiled || net->gate == DTQN_GATE_GRU || net->identity || net->bag_size > 0 || net->img_c > 0)
+    if (!net || !td || td->row_split != 4 || net->tiled || net->gate == DTQN_GATE_GRU || net->identity || net->bag_size > 0 || net->img_c > 0 ||
+        dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real))
         return false;
     if (!td->grad || !td->norm_partial || !td->step_counter || !td->small || !td->xflags || !td->act || !td->grd) return false;
     if (!dtqn_td_wgrad_is_direct(net, td->batch) || waves_for(*net) != kFuseWaves) return false;

@@ -82,7 +82,11 @@ typedef struct DtqnNet {
                                * 1 / sqrt(hd_real).  Padded entries are zero and stay zero: zero weights and LayerNorm affines make the padded
                                * columns 0 in every activation (an all-zero head attends uniformly over zero values), the LayerNorm
                                * statistics run over the d_real real columns, its backward writes 0 into the padded ones, so every padded
-                               * gradient entry is exactly 0 and Adam leaves the entry alone.  Row-block tiled path.  A struct that is
+                               * gradient entry is exactly 0 and Adam leaves the entry alone.  Row-block tiled path -- except a padded d_model of 64
+                               * at head width 8 / 16 / 32 with the residual gate, post-LN, no dropout and a context of at most 64 rows, which
+                               * (like the unpadded head width 32 at d_model 64) runs on the four-slice whole-sequence kernels: acting,
+                               * inference and the latency-mode TD update there, larger batches on the row-block twin
+                               * (dtqn_td_prefers_tiled; DTQN_WS_LITE_OFF=1: row-block throughout, as before round 5).  A struct that is
                                * initialised again keeps its padding (the fields are read as inputs when d_real > 0) */
     /* ---- derived: geometry ---- */
     int32_t abi_version;
@@ -380,7 +384,8 @@ int dtqn_td_row_split(const DtqnNet* net, int batch);
  * row-block tiled kernels than on the whole-sequence ones (D = 128, residual gate, post-LN, 64-row contexts, no dropout, batches
  * beyond latency mode: measured 460 -> 499 updates/s at BASELINE config 3).  The caller then trains with the twin of the net --
  * dtqn_net_tiled_twin: same parameters and theta layout, records laid out for the tiled kernels -- and keeps the original for the
- * actor's forwards.  DTQN_TRAIN_TILED=0|1 overrides. */
+ * actor's forwards.  DTQN_TRAIN_TILED=0|1 overrides.  Also 1 for the shapes that exist on the whole-sequence side as four-slice
+ * kernels only (head width 32 at d_model 64, width-padded networks of d_model 64) wherever dtqn_td_row_split is not 4. */
 int dtqn_td_prefers_tiled(const DtqnNet* net, int batch);
 int dtqn_net_tiled_twin(const DtqnNet* src, DtqnNet* dst);
 int dtqn_td_xch_floats(const DtqnNet* net, int batch);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What width / head padding costs: TD-updates/s of cfg-1-like workloads (CarFlag shapes, context 50, 2 layers, batch 32,
-synthetic replay) at shapes the kernels are instantiated for and at shapes that run zero-padded on the row-block path.
+synthetic replay) at shapes the kernels are instantiated for, at head width 32 / zero-padded widths of d_model 64 (four-slice kernels since
+round 5; DTQN_WS_LITE_OFF=1: the row-block path they ran on before) and at shapes that run zero-padded on the row-block path.
    python tests/perf/padded_rate.py            (on the GPU box; ~40 s)"""
 import os
 import sys
@@ -12,12 +13,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench  # noqa: E402
 
 
-def rate(D, H, steps=400, warm=60, force_tiled=False):
+def rate(D, H, steps=400, warm=60, force_tiled=False, lite_off=False):
     if force_tiled:
         os.environ["DTQN_FORCE_TILED"] = "1"
+    if lite_off:       # A/B knob of dtqn_net_init: head width 32 / width-padded shapes on the row-block kernels as in rounds 1-4
+        os.environ["DTQN_WS_LITE_OFF"] = "1"
     c = dict(bench.CONFIGS[1], D=D, H=H)
     agent = bench.make_agent(c, 32, torch.device("cuda", 0), 0, "device", data_parallel=False)
     os.environ.pop("DTQN_FORCE_TILED", None)
+    os.environ.pop("DTQN_WS_LITE_OFF", None)
     for _ in range(warm):
         agent.train()
     torch.cuda.synchronize()
@@ -36,11 +40,12 @@ if __name__ == "__main__":
     # GPU_MAX_HW_QUEUES hardware queues -- the fifth learner of one process measured 856 updates/s where its own process gives 3.8 k
     import subprocess
     if len(sys.argv) == 4:
-        D, H, ft = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "1"
-        r, info = rate(D, H, force_tiled=ft)
-        print(f"in-embed {D:3d} heads {H}{' (row-block path forced)' if ft else ''}: {r:8.1f} TD-updates/s   {info}", flush=True)
+        D, H, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+        r, info = rate(D, H, force_tiled=mode == 1, lite_off=mode == 2)
+        tag = {0: "", 1: " (row-block path forced)", 2: " (DTQN_WS_LITE_OFF=1: row-block path as in round 4)"}[mode]
+        print(f"in-embed {D:3d} heads {H}{tag}: {r:8.1f} TD-updates/s   {info}", flush=True)
     else:
-        for D, H, ft in ((64, 8, False), (64, 8, True), (48, 6, False), (48, 4, False), (64, 2, False), (64, 1, False), (128, 8, False), (96, 6, False),
-                         (96, 8, False), (128, 4, False)):
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), str(D), str(H), "1" if ft else "0"], capture_output=True, text=True)
+        # (what round 5 did not change -- 64/1, 128/8, 96/6, 128/4, 64/8 forced onto the row-block path -- is in profiles/r04_padded_shapes_rate.txt)
+        for D, H, mode in ((64, 8, 0), (64, 4, 0), (64, 2, 0), (64, 2, 2), (48, 6, 0), (48, 6, 2), (48, 4, 0), (40, 2, 0), (32, 4, 0)):
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), str(D), str(H), str(mode)], capture_output=True, text=True)
             print("\n".join(l for l in out.stdout.splitlines() if l.startswith("in-embed")) or out.stderr[-400:], flush=True)

@@ -407,7 +407,7 @@ ROUTED = [
     (dict(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=8, action_dim=4), dict(batch=3, T=14, mask=-5), (0, 64)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=8, gate="gru"), dict(batch=2, T=14, mask=-5), (0, 16)),
     (dict(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=10, discrete=True, vocab_sizes=9), dict(batch=2, T=16, mask=8), (0, 64)),
-    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, num_layers=1, history_len=20), dict(batch=2, T=30, mask=-5), (1, 64)),       # head_dim 32
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, num_layers=1, history_len=20), dict(batch=2, T=30, mask=-5), (0, 64)),       # head_dim 32: the four-slice kernels (round 5; dtqn_limits.h dtqn_ws_lite)
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (1, 64)),  # head_dim 64: agent_utils.py's default num_heads=1
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, num_layers=1, history_len=12, pos="sin"), dict(batch=2, T=20, mask=-5), (1, 64)),  # head_dim 4
     (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=2, num_layers=1, history_len=70, gate="gru", action_dim=8), dict(batch=2, T=90, mask=-5), (1, 128)),  # head_dim 64
@@ -458,7 +458,7 @@ def test_every_accepted_shape_has_kernels(emu):
     assert accepted >= 45
 
 
-@pytest.mark.parametrize("heads,tuf", [(8, 10_000), (4, 2)])
+@pytest.mark.parametrize("heads,tuf", [(8, 10_000), (4, 2), (2, 3)])      # (2 heads: head width 32, two column tiles per head in the delta epilogue)
 def test_pipelined_update_vs_oracle(emu, heads, tuf):
     """The update exactly as DtqnAgent.train() issues it with the device sampler (dtqn_td_update_pipelined: in-kernel window draw,
     policy passes as four 16-row slices, the NEXT update's target pass inside this update's backward launch and used from the second

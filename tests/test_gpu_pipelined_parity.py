@@ -57,6 +57,30 @@ def test_pipelined_update_head_width_16_vs_oracle(lib):
     assert w["pipeline"]["used"] >= 3
 
 
+@pytest.mark.parametrize("width,heads,shape", [(64, 2, (64, 2, 32, 0)), (48, 6, (64, 8, 8, 48)), (48, 4, (64, 4, 16, 48)), (40, 2, (64, 2, 32, 40))])
+def test_pipelined_update_head_width_32_and_padded_widths_vs_oracle(lib, width, heads, shape):
+    """Round 5: `--heads 2` and the width-padded shapes of d_model 64 on the four-slice kernels instead of the
+    row-block ones (dtqn_limits.h, dtqn_ws_lite): <64, 1, 32, 8, false, 4, ...> (a head spans two column tiles of the delta
+    epilogue) and the PAD instantiations (LayerNorm statistics over the real columns, softmax scale of the real head width), as the
+    update bench.py times, at batch 32.  check_td_updates also demands that no padded entry takes a gradient or moves."""
+    cfg = O.NetCfg(**{**CFG1, "inner_embed_size": width, "num_heads": heads})
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=24, batch=32, T=200, n_eps=40, mask=-5, tuf=3, device="cuda", test_lib=False)
+    assert (net.d_model, net.num_heads, net.head_dim, net.d_real) == shape and net.tiled == 0 and eng.net.tiled == 0
+    assert eng.row_split == 4 and eng.enable_pipeline(lambda: 0) and eng._pipe["ride"]
+    w = check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=5, pipelined=True, report_as=f"pipelined_w{width}_h{heads}")
+    assert w["pipeline"]["used"] >= 2 and w["pipeline"]["used"] + w["pipeline"]["inline"] == 5
+    assert int(eng.xflags.sum()) == 0 and int(eng._next_xflags.sum()) == 0
+
+
+def test_a_large_batch_of_a_four_slice_only_shape_trains_on_its_row_block_twin(lib):
+    """dtqn_td_prefers_tiled: beyond latency mode (batch 64) a width-padded network's update runs on the row-block twin; acting stays on
+    the whole-sequence net.  Same oracle checks."""
+    cfg = O.NetCfg(**{**CFG1, "inner_embed_size": 48, "num_heads": 6, "num_layers": 1})
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=25, batch=64, T=120, n_eps=80, mask=-5, device="cuda", test_lib=False)
+    assert net.tiled == 0 and eng.actor_net.tiled == 0 and eng.net.tiled == 1 and eng.net.d_real == 48
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+
+
 def test_four_slice_forward_through_the_staged_update_vs_oracle(lib, monkeypatch):
     """DTQN_FWD_SLICES=4 routes dtqn_td_forward (host-drawn windows) onto the four-slice kernels: the same instantiation checked
     with the reference-stream indices of the other TD cases."""

@@ -57,15 +57,43 @@ def emu():
     return B.load_library(emu_build.build())
 
 
+def four_slice_family(kw, padded):
+    """dtqn_limits.h, dtqn_ws_lite: a padded width of 64 at head width 8 / 16 / 32, residual gate, post-LN, no dropout, context <= 64 rows runs on
+    the four-slice whole-sequence kernels (round 5); everything else on the row-block kernels."""
+    return (padded[0] == 64 and padded[0] // padded[1] in (8, 16, 32) and kw.get("gate", "res") == "res" and not kw.get("identity", False)
+            and kw.get("dropout", 0.0) == 0.0 and kw["history_len"] <= 64)
+
+
+@pytest.mark.parametrize("family", ["default", "row-block"])
 @pytest.mark.parametrize("kw,run,padded", PADDED)
-def test_td_update_of_a_width_padded_network(emu, kw, run, padded):
+def test_td_update_of_a_width_padded_network(emu, kw, run, padded, family, monkeypatch):
+    lite = four_slice_family(kw, padded)
+    if family == "row-block":
+        if not lite:
+            pytest.skip("the default family of this shape is the row-block one already")
+        monkeypatch.setenv("DTQN_WS_LITE_OFF", "1")       # A/B knob read by dtqn_net_init: the row-block kernels of rounds 1-4
+        lite = False
     cfg = O.NetCfg(**kw)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=19, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
     assert (net.d_real, net.heads_real) == (cfg.inner_embed_size, cfg.num_heads) and (net.d_model, net.num_heads) == padded
     hd = cfg.inner_embed_size // cfg.num_heads
-    assert net.tiled == 1 and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64) if w >= hd)
+    assert net.tiled == (0 if lite else 1) and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64) if w >= hd)
+    if lite:
+        assert net.lp == 64 and eng.net.tiled == 0 and eng.row_split == 4
     assert padding_mask(net).sum() > 0
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)      # incl.: padded gradient entries == 0, padded parameters stay 0
+
+
+@pytest.mark.parametrize("kw,run,padded", [c for c in PADDED if four_slice_family(c[0], c[2])])
+def test_pipelined_td_update_of_a_width_padded_network(emu, kw, run, padded):
+    """... and as the timed flavour: policy passes as four slices, the next update's target pass inside the backward launch."""
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=29, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
+    assert net.tiled == 0 and net.d_real == cfg.inner_embed_size
+    assert eng.enable_pipeline(lambda: 0) and eng._pipe["ride"]
+    w = check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=4, pipelined=True)
+    assert w["pipeline"]["used"] >= 1 and w["pipeline"]["used"] + w["pipeline"]["inline"] == 4
+    assert int(eng.xflags.sum()) == 0 and int(eng._next_xflags.sum()) == 0
 
 
 @pytest.mark.parametrize("kw,run,padded", PADDED_DROPOUT)
@@ -77,10 +105,14 @@ def test_td_update_of_a_width_padded_network_with_dropout(emu, kw, run, padded):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
 
 
-def test_forward_on_context_prefixes(emu):
+@pytest.mark.parametrize("family", ["default", "row-block"])
+def test_forward_on_context_prefixes(emu, family, monkeypatch):
     from helpers import ptr
+    if family == "row-block":
+        monkeypatch.setenv("DTQN_WS_LITE_OFF", "1")
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=2, history_len=20, pos="sin")
     net = net_from_cfg(emu, cfg)
+    assert net.tiled == (1 if family == "row-block" else 0)
     params = O.init_params(cfg, seed=3, perturb=True)
     theta = torch.from_numpy(pack_theta(net, params))
     rng = np.random.default_rng(1)
@@ -89,7 +121,10 @@ def test_forward_on_context_prefixes(emu):
         obs = torch.tensor(rng.uniform(-1, 1, (3, n, 3)).astype(np.float32))
         act = torch.tensor(rng.integers(0, 3, (3, n)).astype(np.uint8))
         q = torch.full((3, n, 3), float("nan"))
-        assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 3, n, ptr(q), ptr(ws), None) == 0
+        if net.tiled:
+            assert emu.dtqn_forward_tiled(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 3, n, ptr(q), ptr(ws), None) == 0
+        else:       # one workgroup per sequence on the whole 64-row tile (the only inference flavour of these shapes besides four slices)
+            assert emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 3, n, ptr(q), None) == 0
         with torch.no_grad():
             ref = O.forward(params, cfg, obs, act.long().unsqueeze(-1)).numpy()
         assert np.abs(q.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), n
@@ -202,3 +237,15 @@ def test_pad_and_unpad_are_inverse_on_every_tensor_kind():
         blk, h, i = 2, H - 1, hd - 1                                        # v block, last real head, last real column of the head
         assert np.array_equal(p[blk * Dp + h * hdp + i, :D], w[blk * D + h * hd + i])
     run()
+
+
+def test_beyond_latency_mode_a_four_slice_only_shape_trains_on_its_row_block_twin(emu, monkeypatch):
+    """dtqn_td_prefers_tiled for the shapes of dtqn_ws_lite: where dtqn_td_row_split does not say 4 (large batches; here DTQN_ROW_SPLIT=0), the
+    update runs on the row-block twin of the net -- same theta layout -- while the caller's net stays whole-sequence."""
+    monkeypatch.setenv("DTQN_ROW_SPLIT", "0")
+    for kw in (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=1, history_len=20),
+               dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=2, num_layers=1, history_len=20)):
+        cfg = O.NetCfg(**kw)
+        net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=31, batch=2, T=30, n_eps=6, mask=-5)
+        assert net.tiled == 0 and eng.actor_net.tiled == 0 and eng.net.tiled == 1 and eng.row_split == 1
+        check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)

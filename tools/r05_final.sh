@@ -29,6 +29,15 @@ except Exception as e:
 PY
 done
 echo "quick benches t=$((SECONDS - T0))s"
+# head width 32 / width-padded shapes: rates (one process per shape) and the kernel trace of two of them
+timeout 240 python tests/perf/padded_rate.py > gpurun_out/fin/padded_shapes_rate.txt 2>&1; cat gpurun_out/fin/padded_shapes_rate.txt | cut -c1-150
+for S in "64 2" "48 6"; do
+  set -- $S
+  rocprofv3 --kernel-trace --stats -d gpurun_out/fin/ktp -- python tests/perf/padded_rate.py $1 $2 0 > gpurun_out/fin/ktp_$1_$2.log 2>&1
+  python tools/rocpd_summary.py "$(find gpurun_out/fin/ktp -name '*results.db' | head -1)" gpurun_out/fin/kernel_stats_inembed$1_heads$2.md > /dev/null 2>&1; rm -rf gpurun_out/fin/ktp
+  head -6 gpurun_out/fin/kernel_stats_inembed$1_heads$2.md | cut -c1-75,96-170
+done
+echo "padded shapes t=$((SECONDS - T0))s"
 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 32 > gpurun_out/fin/stage_cfg1.txt 2>&1
 DTQN_FWD_SLICES=4 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 32 > gpurun_out/fin/stage_cfg1_fwd4.txt 2>&1
 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 256 > gpurun_out/fin/stage_cfg2.txt 2>&1
