@@ -105,6 +105,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_forward_workspace_floats": [P(DtqnNet), i32],
         "dtqn_forward_tiled": [P(DtqnNet), vp, vp, vp, i32, i32, vp, vp, vp],
         "dtqn_td_row_split": [P(DtqnNet), i32],
+        "dtqn_td_latency_mode": [P(DtqnNet), i32],
         "dtqn_td_wgrad_is_direct": [P(DtqnNet), i32],
         "dtqn_td_wgrad_is_fused": [P(DtqnNet), P(DtqnTd)],
         "dtqn_td_norm_partials": [P(DtqnNet)],

@@ -34,7 +34,26 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
     if (e != nullptr && e[0] == '4') return 4;
     // 256 CUs: all 3*B*2 forward (and B*4 backward) workgroups resident at once.  The value is the number of row slices
     // of the BACKWARD kernel (4 x 16 rows); the forward kernel never uses more than two (2 x 32 rows).
-    return 3 * batch * 2 <= 256 ? 4 : 1;
+    if (3 * batch * 2 <= 256) return 4;
+    // Beyond latency mode (round 5) the forward runs one workgroup per sequence, and the backward chain -- half / a quarter as long per
+    // slice -- is still sliced while all its workgroups fit the chip at once.  Measured at config-1 shapes (TD-updates/s, whole |
+    // sliced backward; profiles/r05_row_split_policy.txt): batch 48 5 559 | 8 136 (four slices), 64 5 450 | 7 883 (four), 96 4 405 |
+    // 5 378 (two; four: 4 878), 128 4 245 | 5 142 (two; four: 4 683); at 192 / 256 (a round and a half / two rounds of two-slice
+    // workgroups) 0.98 / 0.99 x, so BASELINE config 2 stays whole-sequence.  d_model 64 (both gates); d_model 128 was not measured.
+    if (net->d_model == 64) {
+        if (batch * 4 <= 256) return 4;
+        if (batch * 2 <= 256) return 2;
+    }
+    return 1;
+}
+// 1: the TD update of `batch` sequences runs in latency mode -- sliced forward passes as well (two 32-row slices in the one-call update,
+// four 16-row slices in the pipelined one, dtqn_td_fwd_slices4_ok) and, pipelined, the next update's target pass inside the backward
+// launch.  0 with dtqn_td_row_split > 1: only the backward is sliced.
+extern "C" int dtqn_td_latency_mode(const DtqnNet* net, int batch) {
+    if (dtqn_td_row_split(net, batch) < 2) return 0;
+    const char* e = getenv("DTQN_ROW_SPLIT");                 // forced slices (tests / tuning) are forced in both kernels
+    if (e != nullptr) return 1;
+    return 3 * batch * 2 <= 256 ? 1 : 0;
 }
 // Both kernel families cover D = 128 / residual gate / post-LN / 64-row contexts.  Measured at BASELINE config 3 shapes (updates/s,
 // whole-sequence | row-block): B = 64 1681 | 1880, B = 128 1244 | 1391, B = 256 895 | 863, B = 512 459 | 499 -- the row-block
@@ -43,7 +62,8 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
 extern "C" int dtqn_td_prefers_tiled(const DtqnNet* net, int batch) {
     if (!net || batch < 1 || net->tiled) return 0;
     // head width 32 / width-padded networks on the whole-sequence side (dtqn_limits.h, dtqn_ws_lite) train there in latency mode only
-    if (dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real)) return dtqn_td_row_split(net, batch) == 4 ? 0 : 1;
+    if (dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real))
+        return dtqn_td_row_split(net, batch) == 4 && dtqn_td_latency_mode(net, batch) ? 0 : 1;
     const bool covered = net->d_model == 128 && net->gate == DTQN_GATE_RES && !net->identity && net->lp == 64 && net->dropout == 0.f &&
                          net->bag_size == 0;
     if (!covered) return 0;

@@ -185,9 +185,10 @@ static int td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
     td_forward_args(net, rp, td, pass0, draw_step, &a);
     if (dtqn_ws_lite(net->tiled, net->d_model, net->head_dim, net->d_real)) slices = 4;      // the only training flavour of those shapes
     if (slices <= 0) {
-        slices = td->row_split >= 2 ? 2 : 1;               // the whole-update launch: two slices in latency mode ...
+        slices = td->row_split >= 2 && dtqn_td_latency_mode(net, td->batch) ? 2 : 1;      // the whole-update launch: two slices in latency mode ...
         const char* e = getenv("DTQN_FWD_SLICES");         // ... DTQN_FWD_SLICES=4: four (A/B knob; 3 B 4 workgroups do not fit the chip at once)
         if (e != nullptr && atoi(e) == 4 && td->row_split >= 2 && dtqn_td_fwd_slices4_ok(net)) slices = 4;
+        if (e != nullptr && atoi(e) == 1) slices = 1;      // ... =1: whole 64-row workgroups under a sliced backward (A/B knob; the records do not depend on it)
     }
     if (slices == 4 && !dtqn_td_fwd_slices4_ok(net)) return DTQN_ERR_CONFIG;
     a.nseq = npasses * td->batch;

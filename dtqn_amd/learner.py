@@ -304,7 +304,10 @@ class TdEngine:
         import os
         if self.net.bag_size > 0 or self.img is not None or self.net.dropout > 0 or os.environ.get("DTQN_PIPELINE", "1") == "0":
             return False
-        ride = (not self.net.tiled and self.row_split == 4 and not self.wgrad_fused and bool(self.lib.dtqn_td_fwd_slices4_ok(self._net_ref)))
+        # (row_split 4 past latency mode -- 43 ... 64 sequences -- slices the backward only: measured 6.8 k updates/s pipelined against 7.9 k
+        #  with whole-sequence forward passes at batch 64; dtqn_td_latency_mode)
+        ride = (not self.net.tiled and self.row_split == 4 and not self.wgrad_fused and bool(self.lib.dtqn_td_fwd_slices4_ok(self._net_ref))
+                and bool(self.lib.dtqn_td_latency_mode(self._net_ref, self.batch)))
         # Row-block tiled nets at small batches (BASELINE config 5: 32 sequences x 4 row blocks = 128 workgroups per pass and per
         # launch of the backward -- half the chip): the same idea on a SECOND STREAM.  The target pass of update k + 1 runs its
         # kernels beside update k's backward kernels; update k + 1's forward launches cover two passes (one round of 256 workgroups

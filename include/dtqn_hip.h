@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 16
+#define DTQN_ABI_VERSION 17
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -380,6 +380,12 @@ int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const flo
  * the slices below it) and two in the forward.  Returns 1 when the shape / variant / batch does not profit (the chip
  * is already full) or is not covered. */
 int dtqn_td_row_split(const DtqnNet* net, int batch);
+/* 1: the update of `batch` sequences runs in latency mode -- sliced FORWARD passes too (dtqn_td_forward: two 32-row slices;
+ * dtqn_td_update_pipelined: four 16-row slices and the next update's target pass inside the backward launch).  0 while
+ * dtqn_td_row_split > 1: only the backward chain is sliced (batches past latency mode whose backward workgroups still fit the chip at
+ * once: 43 ... 64 sequences in four slices, ... 128 in two, at d_model 64), the forward runs one workgroup per sequence and the
+ * pipelined form is not used. */
+int dtqn_td_latency_mode(const DtqnNet* net, int batch);
 /* Training-path policy for shapes both kernel families cover: 1 when the TD update of `batch` sequences is faster on the
  * row-block tiled kernels than on the whole-sequence ones (D = 128, residual gate, post-LN, 64-row contexts, no dropout, batches
  * beyond latency mode: measured 460 -> 499 updates/s at BASELINE config 3).  The caller then trains with the twin of the net --

@@ -492,3 +492,19 @@ def test_host_drawn_update_on_a_pipelined_engine_keeps_the_step_mirror(emu):
     assert torch.equal(eng.theta_tgt[:net.n_trainable], eng.theta_pol[:net.n_trainable])
     with pytest.raises(TypeError):
         eng.enable_pipeline(None)
+
+
+def test_backward_stays_sliced_past_latency_mode(emu):
+    """dtqn_td_row_split / dtqn_td_latency_mode (round 5): 43 ... 64 sequences at d_model 64 run the backward chain in four slices and 65 ...
+    128 in two while the forward runs one workgroup per sequence, and the pipelined form is for latency mode only.  One update at batch
+    43 against the oracle (whole-sequence forward records under the four-slice backward)."""
+    from helpers import net_from_cfg as net_from_cfg_
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=1, history_len=50)
+    net = net_from_cfg_(emu, cfg)
+    policy = {b: (emu.dtqn_td_row_split(ctypes.byref(net), b), emu.dtqn_td_latency_mode(ctypes.byref(net), b)) for b in (32, 42, 43, 64, 65, 128, 129, 256)}
+    assert policy == {32: (4, 1), 42: (4, 1), 43: (4, 0), 64: (4, 0), 65: (2, 0), 128: (2, 0), 129: (1, 0), 256: (1, 0)}
+    wide = net_from_cfg_(emu, O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, num_layers=1, history_len=50))
+    assert emu.dtqn_td_row_split(ctypes.byref(wide), 32) == 4 and emu.dtqn_td_row_split(ctypes.byref(wide), 64) == 1
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=14, batch=43, T=80, n_eps=50, mask=-5)
+    assert eng.row_split == 4 and not eng.enable_pipeline(lambda: 0)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1, one_call=True)

@@ -154,8 +154,20 @@ def test_latency_mode_is_on_for_the_metric_config(lib):
     cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
     net = net_from_cfg(lib, cfg)
     import ctypes
-    assert lib.dtqn_td_row_split(ctypes.byref(net), 32) == 4
+    assert lib.dtqn_td_row_split(ctypes.byref(net), 32) == 4 and lib.dtqn_td_latency_mode(ctypes.byref(net), 32) == 1
     assert lib.dtqn_td_row_split(ctypes.byref(net), 256) == 1
+    # past latency mode the backward alone stays sliced while its workgroups fit the chip at once (round 5)
+    assert [(lib.dtqn_td_row_split(ctypes.byref(net), b), lib.dtqn_td_latency_mode(ctypes.byref(net), b)) for b in (64, 128)] == [(4, 0), (2, 0)]
+
+
+@pytest.mark.parametrize("batch,slices", [(64, 4), (128, 2)])
+def test_sliced_backward_under_whole_sequence_forward_vs_oracle(lib, batch, slices):
+    """Batches past latency mode (dtqn_td_row_split 4 / 2 with dtqn_td_latency_mode 0): forward passes one workgroup per sequence,
+    backward chain in four / two row slices; the update in one call, as DtqnAgent.train() issues it (no pipelined form there)."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50)
+    net, oracle, host, eng, rep = make_td_case(lib, cfg, seed=27, batch=batch, T=120, n_eps=batch + 20, mask=-5, device="cuda", test_lib=False)
+    assert eng.row_split == slices and net.tiled == 0 and not eng.enable_pipeline(lambda: 0)
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2, one_call=True, report_as=f"sliced_backward_b{batch}")
 
 
 def test_golden_G1_full_update(lib):

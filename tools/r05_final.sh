@@ -38,6 +38,15 @@ for S in "64 2" "48 6"; do
   head -6 gpurun_out/fin/kernel_stats_inembed$1_heads$2.md | cut -c1-75,96-170
 done
 echo "padded shapes t=$((SECONDS - T0))s"
+# batches past latency mode (sliced backward under whole-sequence forward passes): rate and kernel trace at 64 and 128 sequences
+for BS in 64 128; do
+  rocprofv3 --kernel-trace --stats -d gpurun_out/fin/ktb -- python bench.py --config 2 --batch $BS --steps 400 --warmup 60 $B > gpurun_out/fin/bench_batch$BS.json 2> gpurun_out/fin/bench_batch$BS.err
+  python tools/rocpd_summary.py "$(find gpurun_out/fin/ktb -name '*results.db' | head -1)" gpurun_out/fin/kernel_stats_batch$BS.md > /dev/null 2>&1; rm -rf gpurun_out/fin/ktb
+  head -6 gpurun_out/fin/kernel_stats_batch$BS.md | cut -c1-75,96-170
+  python -c "
+import json
+d = json.loads([l for l in open('gpurun_out/fin/bench_batch$BS.json') if l.startswith('{')][0]); print('batch $BS (under the tracer):', round(d['value'], 1), 'upd/s')"
+done
 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 32 > gpurun_out/fin/stage_cfg1.txt 2>&1
 DTQN_FWD_SLICES=4 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 32 > gpurun_out/fin/stage_cfg1_fwd4.txt 2>&1
 DTQN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/libdtqn_hip_prof.so timeout 60 python tests/perf/stage_profile.py 256 > gpurun_out/fin/stage_cfg2.txt 2>&1
