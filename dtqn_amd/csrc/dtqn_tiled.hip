@@ -19,6 +19,7 @@
 #include "dtqn_gru.hpp"
 
 #include "dtqn_frag16.hpp"
+#include "dtqn_wpack.hpp"
 
 namespace dtqn {
 
@@ -277,6 +278,23 @@ __device__ __forceinline__ void frag_dyw_mma_n(const float* dYs, int lda, const 
     }
 }
 
+// Weight fragments out of the fragment-major copies of dtqn_wpack.hpp: every load instruction of a wave reads 1 KB contiguous.
+//   F copy of W[N][K]: fragment (16-column tile ntile, 128-wide contraction chunk kc of K / 128) -> the 8 float4 frag16_fetch<128> loads
+__device__ __forceinline__ void wpack_fetch_f(float4 (&bf)[8], const float* __restrict__ Wp, int ntile, int kch, int kc, int lane) {
+    const float* p = Wp + ((size_t)(ntile * kch + kc) * 8) * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bf[q] = ld4(p + 256 * q);
+}
+//   B copy of W[N][K] (contraction over N): fragment (16-column tile ktile of K, chunk nc of N / 128) -> the 32 floats frag_dyw_fetch<128> loads
+__device__ __forceinline__ void wpack_fetch_b(float (&bf)[32], const float* __restrict__ Wp, int ktile, int nch, int nc, int lane) {
+    const float* p = Wp + ((size_t)(ktile * nch + nc) * 8) * 256 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = ld4(p + 256 * q);
+        bf[4 * q] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+    }
+}
+
 // ---- linear: OUT[rows][N] = f(IN[rows][K] * W[N][K]^T [+ IN2[rows][K2] * W2[N][K2]^T] + b) ----------------------
 //   mode 0: OUT = y      mode 1: OUT = relu(y)      mode 2: OUT = RES + relu(y)   (residual gate)
 //   modes 1 / 2 optionally save the ReLU pattern as wave ballots (same word layout as the whole-sequence kernels)
@@ -292,10 +310,11 @@ struct TlLinearArgs {
     const float *W2a, *W2b;
     int K2;
     Fld aux, out2, out3;
+    const float *Wpa, *Wpb;            // fragment-major F copies of Wa / Wb (dtqn_wpack.hpp), or nullptr
 };
 // (second launch bound = waves per SIMD the register budget must allow: two resident workgroups up to D = 128)
 // MR rows per workgroup: 64, or 32 when the launch would be only a few rounds of resident workgroups (launch_linear)
-template <int D, int MR>
+template <int D, int MR, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLinearArgs a) {
     constexpr int MT = MR / 16;
     constexpr int LDT = D + 4;
@@ -316,7 +335,20 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
     float4 bf0[D / 16], bf1[D / 16];
     const float* wrow = W + (size_t)(live ? col : 0) * a.K;
     const float* wrow2 = a.K2 > 0 ? W2 + (size_t)(live ? col : 0) * a.K2 : nullptr;
-    frag16_fetch<D>(bf0, wrow, t);
+    const float* __restrict__ Wp = s >= a.split ? a.Wpb : a.Wpa;
+    // chunk kc of the (first) operand's weights: D columns = D / 128 packed chunks of 8 float4
+    auto wfetch = [&](float4 (&bf)[D / 16], int kc) {
+        if constexpr (PK) {
+            if (kc < a.K / D) {
+                const float* p = Wp + ((size_t)((live ? ntile : 0) * (a.K / 128) + kc * (D / 128)) * 8) * 256 + t.lane * 4;
+#pragma unroll
+                for (int q = 0; q < D / 16; ++q) bf[q] = ld4(p + 256 * q);
+                return;
+            }
+        }
+        frag16_fetch<D>(bf, kc < a.K / D ? wrow + (size_t)kc * D : wrow2 + (size_t)(kc - a.K / D) * D, t);
+    };
+    wfetch(bf0, 0);
     const float* in0 = frow(a.in, s, row0);
     const float* in20 = a.K2 > 0 ? frow(a.in2, s, row0) : nullptr;
     const int nch1 = a.K / D, nchunks = nch1 + a.K2 / D;
@@ -328,7 +360,6 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
             st4(Xt + r * LDT + c, ld4(src + (size_t)r * ld + c));
         }
     };
-    auto wfrag = [&](int kc) { return kc < nch1 ? wrow + (size_t)kc * D : wrow2 + (size_t)(kc - nch1) * D; };
     // D = 256 (one workgroup per CU: 250 registers): the operand tile of chunk kc + 1 is pulled global -> registers while chunk
     // kc multiplies and dropped into the LDS tile once chunk kc's readers are through.  At D <= 128 two workgroups share a
     // CU and hide each other's staging; the 16 extra registers would cost that (measured: cfg 4 603 -> 581 updates/s).
@@ -359,7 +390,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
         if (PREFETCH) stage_store(); else stage(kc);
         if (kc + 1 < nchunks) {
             if (PREFETCH) stage_load(kc + 1);
-            frag16_fetch<D>(bf1, wfrag(kc + 1), t);
+            wfetch(bf1, kc + 1);
         }
         __syncthreads();
         frag16_mma<D, MT>(Xt, LDT, bf0, t, acc);
@@ -368,7 +399,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_linear_kernel(TlLine
             if (PREFETCH) stage_store(); else stage(kc + 1);
             if (kc + 2 < nchunks) {
                 if (PREFETCH) stage_load(kc + 2);
-                frag16_fetch<D>(bf0, wfrag(kc + 2), t);
+                wfetch(bf0, kc + 2);
             }
             __syncthreads();
             frag16_mma<D, MT>(Xt, LDT, bf1, t, acc);
@@ -441,21 +472,29 @@ struct TlWideArgs {
     Fld res, mask, ln_out, ln_st;
     const float *lga, *lgb, *lba, *lbb;
     int n_save;
+    const float *Wpa, *Wpb;            // fragment-major F copies of Wa / Wb (dtqn_wpack.hpp), or nullptr
+    int blk0;                          // row block of workgroup 0 (a launch may be cut into whole rounds + a rest: tl_launch_rounds)
 };
-template <int D, int MR, bool LN>
+template <int D, int MR, bool LN, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideArgs a) {
     constexpr int MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, LDX = D + 4, LDH = 128 + 4;
     static_assert(NKA == 1 || NKA == 2, "step sequence written for D in {64, 128, 256}");
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging (plain) | [MR][LDX] all columns (LN)
     Thr t = make_thr();
-    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;
+    const int blk = (int)blockIdx.x + a.blk0;
+    const int s = blk / a.rpb, row0 = (blk % a.rpb) * MR;
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W = second ? a.Wb : a.Wa;
     const float* __restrict__ bias = second ? a.bb : a.ba;
     const int wc = t.wave * 16 + t.i, NB = LN ? (D + 127) / 128 : a.N / 128;
+    const float* __restrict__ Wp = second ? a.Wpb : a.Wpa;
     auto fetch = [&](float4 (&bf)[8], int j, int kc) {                 // W [N][D]: output column j * 128 + wc, contraction chunk kc
         const int col = j * 128 + wc;
+        if constexpr (PK) {
+            wpack_fetch_f(bf, Wp, (!LN || col < D) ? j * 8 + t.wave : 0, NKA, kc, t.lane);
+            return;
+        }
         const float* wr = W + (size_t)((!LN || col < D) ? col : 0) * D + kc * KA + t.kq * 4;
 #pragma unroll
         for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
@@ -596,9 +635,11 @@ struct TlFfnArgs {
     const float *lga, *lgb, *lba, *lbb;
     TlDrop drop;                       // dropout on the block's output, before the gate's ReLU (transformer.py:38-42)
     int layer;
+    const float *W1pa, *W1pb, *W2pa, *W2pb;    // fragment-major F copies of W1 / W2 (dtqn_wpack.hpp), or nullptr
+    int blk0;                          // row block of workgroup 0 (tl_launch_rounds)
 };
 // MR rows per workgroup (64, or 32 when the launch would otherwise be a round and a half of workgroups: launch_ffn)
-template <int D, int MR>
+template <int D, int MR, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs a) {
     constexpr int MT = MR / 16;
     constexpr int KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
@@ -607,20 +648,31 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] hidden chunk / output staging
     const Thr t = make_thr();
-    const int s = (int)blockIdx.x / a.rpb, row0 = ((int)blockIdx.x % a.rpb) * MR;      // a.rpb: MR-row blocks per sequence
+    const int blk = (int)blockIdx.x + a.blk0;
+    const int s = blk / a.rpb, row0 = (blk % a.rpb) * MR;              // a.rpb: MR-row blocks per sequence
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W1 = second ? a.W1b : a.W1a;
     const float* __restrict__ W2 = second ? a.W2b : a.W2a;
     const float* __restrict__ b1 = second ? a.b1b : a.b1a;
     const float* __restrict__ b2 = second ? a.b2b : a.b2a;
     const int wc = t.wave * 16 + t.i;                                  // this lane's column inside a 128-column block
+    const float* __restrict__ W1p = second ? a.W1pb : a.W1pa;
+    const float* __restrict__ W2p = second ? a.W2pb : a.W2pa;
     auto fetchA = [&](float4 (&bf)[8], int j, int kc) {                // W1 [4D][D]: hidden unit j * 128 + wc, contraction chunk kc
+        if constexpr (PK) {
+            wpack_fetch_f(bf, W1p, j * 8 + t.wave, NKA, kc, t.lane);
+            return;
+        }
         const float* wr = W1 + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
 #pragma unroll
         for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
     };
     auto fetchB = [&](float4 (&bf)[8], int j, int ot) {                // W2 [D][4D]: output column ot * 128 + wc, hidden chunk j
         const int col = ot * 128 + wc;
+        if constexpr (PK) {
+            wpack_fetch_f(bf, W2p, col < D ? ot * 8 + t.wave : 0, NJ, j, t.lane);
+            return;
+        }
         const float* wr = W2 + (size_t)(col < D ? col : 0) * HID + j * 128 + t.kq * 4;
 #pragma unroll
         for (int q = 0; q < 8; ++q) bf[q] = ld4(wr + 16 * q);
@@ -792,8 +844,9 @@ struct TlDxArgs {
     int nsrc;
     Fld dy2, dy3;
     const float *W2, *W3;
+    const float* Wp;                   // fragment-major B copy of W (dtqn_wpack.hpp; single-operand launches), or nullptr
 };
-template <int KC, int MR>
+template <int KC, int MR, bool PK>
 __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     constexpr int MT = MR / 16;
     constexpr int LDT = KC + 4;
@@ -823,17 +876,24 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
             st4(Yt + r * LDT + c, ld4(dy0 + (size_t)r * dyf.ld + c));
         }
     };
-    frag_dyw_fetch<KC>(bf0, wchunk(0), a.KOUT, t);
+    auto wfetch = [&](float (&bf)[KC / 4], int kc) {
+        if constexpr (PK) {
+            wpack_fetch_b(bf, a.Wp, live ? ntile : 0, per, kc, t.lane);
+            return;
+        }
+        frag_dyw_fetch<KC>(bf, wchunk(kc), a.KOUT, t);
+    };
+    wfetch(bf0, 0);
     for (int kc = 0; kc < nchunks; kc += 2) {
         if (kc > 0) __syncthreads();                                  // previous chunk's tile fully consumed
         stage(kc);
-        if (kc + 1 < nchunks) frag_dyw_fetch<KC>(bf1, wchunk(kc + 1), a.KOUT, t);
+        if (kc + 1 < nchunks) wfetch(bf1, kc + 1);
         __syncthreads();
         frag_dyw_mma<KC, MT>(Yt, LDT, bf0, t, acc);
         if (kc + 1 < nchunks) {
             __syncthreads();
             stage(kc + 1);
-            if (kc + 2 < nchunks) frag_dyw_fetch<KC>(bf0, wchunk(kc + 2), a.KOUT, t);
+            if (kc + 2 < nchunks) wfetch(bf0, kc + 2);
             __syncthreads();
             frag_dyw_mma<KC, MT>(Yt, LDT, bf1, t, acc);
         }
@@ -888,8 +948,9 @@ struct TlFfnBwdArgs {
     int rpb, out_mode;
     TlDrop drop;                       // the forward's dropout on the block's output: df also takes its keep mask (and is stored
     int layer;                         // to `df` when that is given, masked or not)
+    const float *W1p, *W2p;            // fragment-major B copies of W1 / W2 (dtqn_wpack.hpp), or nullptr
 };
-template <int D, int MR>
+template <int D, int MR, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfnBwdArgs a) {
     constexpr int MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
     constexpr int LDX = D + 4, LDH = 128 + 4;
@@ -901,12 +962,20 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfn
     const int wc = t.wave * 16 + t.i;
     // phase A fragment: W2[n][j * 128 + wc], n over contraction chunk kc (KA rows); phase B: W1[j * 128 + k][ot * 128 + wc], k < 128
     auto fetchA = [&](float (&bf)[32], int j, int kc) {
+        if constexpr (PK) {                                            // W2 [D][4D]: contraction over its D rows, output = hidden columns
+            wpack_fetch_b(bf, a.W2p, j * 8 + t.wave, NKA, kc, t.lane);
+            return;
+        }
         const float* wp = a.W2 + (size_t)(kc * KA + t.kq * (KA / 4)) * HID + j * 128 + wc;
 #pragma unroll
         for (int q = 0; q < KA / 4; ++q) bf[q] = wp[(size_t)q * HID];
     };
     auto fetchB = [&](float (&bf)[32], int j, int ot) {
         const int col = ot * 128 + wc;
+        if constexpr (PK) {                                            // W1 [4D][D]: contraction over its 4D rows (chunk j), output = D columns
+            wpack_fetch_b(bf, a.W1p, col < D ? ot * 8 + t.wave : 0, NJ, j, t.lane);
+            return;
+        }
         const float* wp = a.W1 + (size_t)(j * 128 + t.kq * 32) * D + (col < D ? col : 0);
 #pragma unroll
         for (int q = 0; q < 32; ++q) bf[q] = wp[(size_t)q * D];
@@ -1671,6 +1740,19 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
         if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;                                                 \
     } while (0)
 
+// A launch of nblk row blocks on `slots` resident workgroups, cut into its whole rounds and the rest (round 6).  Where the last round
+// is half empty (BASELINE config 4 forward: 768 64-row workgroups on 512 slots), WHICH slots the hardware dispatcher gives the last 256
+// decides the kernel's time: one each on 256 compute units that have just run their pair (tl_ffn 114 us), or two each on the 128
+// units that happened to finish first (141 us) -- the traces show both, at random, launch by launch.  Launched on their own, the rest
+// land one per compute unit every time.  `launch(first block, blocks)` issues one launch; DTQN_ROUNDS=0: one launch as before.
+template <typename F>
+static int tl_launch_rounds(int nblk, int slots, F launch) {
+    const char* e = getenv("DTQN_ROUNDS");
+    const int whole = (nblk / slots) * slots;
+    if ((e != nullptr && atoi(e) == 0) || whole == 0 || whole == nblk) return launch(0, nblk);
+    const int rc = launch(0, whole);
+    return rc != DTQN_OK ? rc : launch(whole, nblk - whole);
+}
 // Rows per workgroup of the linear / dY W kernels: 64.  The 32-row instantiations (DTQN_GEMM_ROWS=32) even out short launches
 // (768 workgroups on 512 slots; 256 for the backward products into a D-wide output) but fetch every weight fragment for half
 // the MFMAs: measured cfg 4 787 -> 748, cfg 5 445 -> 408 updates/s, so they stay an experiment switch.  (The fused feed-forward
@@ -1691,67 +1773,89 @@ static int launch_linear(TlLinearArgs a, int S, hipStream_t stream) {
     if (tl_half_rows(S * a.rpb * cb, 256 * (D <= 128 ? 2 : 1))) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
-        TL_LAUNCH((tl_linear_kernel<D, 32>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        if (D % 128 == 0 && a.Wpa != nullptr && a.Wpb != nullptr) TL_LAUNCH((tl_linear_kernel<D, 32, D % 128 == 0>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_linear_kernel<D, 32, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     } else {
         const size_t lds = (size_t)64 * ((D > 16 * TNW ? D : 16 * TNW) + 4) * sizeof(float);
-        TL_LAUNCH((tl_linear_kernel<D, 64>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        if (D % 128 == 0 && a.Wpa != nullptr && a.Wpb != nullptr) TL_LAUNCH((tl_linear_kernel<D, 64, D % 128 == 0>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_linear_kernel<D, 64, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     }
     return DTQN_OK;
 }
 template <int D>
 static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream);
 // a.rpb on entry: 64-row blocks per sequence; rows per workgroup chosen like launch_ffn's (DTQN_FFN_ROWS forces)
-static bool tl_rows32(int blocks64, int slots) {
-    const char* e = getenv("DTQN_FFN_ROWS");
+// `which`: the kernel's own switch (DTQN_ROWS_FFN / _FFNB / _WIDE = 32 | 64), else DTQN_FFN_ROWS for all three, else the rule
+static bool tl_rows32(int blocks64, int slots, int D, const char* which) {
+    const char* e = getenv(which);
+    if (e == nullptr) e = getenv("DTQN_FFN_ROWS");
+    if (e != nullptr) return atoi(e) == 32;
     const int rounds = (blocks64 + slots - 1) / slots;
-    return e != nullptr ? atoi(e) == 32 : (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
+    // D = 256 (one workgroup per CU): 32 rows when the last round of 64-row workgroups would leave more than 15 % of the slots idle.
+    // D <= 128 (two per CU), round 6: tools/microbench/mfma_probe.hip shows these loops bound by the weight fragments every workgroup
+    // pulls out of L2 for its rows (the same loop with the fetches removed: 0.65 -> 0.81 of the matrix peak at 32 rows), so a 64-row
+    // workgroup -- half the fetches per MFMA -- wins even at a round and a half (config 4 forward, 768 on 512 slots: tl_ffn 155 ->
+    // 138 us); 32 rows only where 64-row workgroups would not even fill the slots once.
+    if (D <= 128) return blocks64 < slots;
+    return (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
 }
 template <int D>
 static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream) {
-    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1))) {
+    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_FFNB")) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_ffn_bwd_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        if (D % 128 == 0 && a.W1p != nullptr && a.W2p != nullptr) TL_LAUNCH((tl_ffn_bwd_kernel<D, 32, D % 128 == 0>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_ffn_bwd_kernel<D, 32, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     } else {
         const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_ffn_bwd_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        if (D % 128 == 0 && a.W1p != nullptr && a.W2p != nullptr) TL_LAUNCH((tl_ffn_bwd_kernel<D, 64, D % 128 == 0>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_ffn_bwd_kernel<D, 64, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
     }
+    return DTQN_OK;
+}
+template <int D, int MR>
+static int launch_wide_rows(TlWideArgs a, int nblk, int first, bool ln, bool pk, size_t lds, hipStream_t stream) {
+    constexpr bool CAN = D % 128 == 0;                                 // fragment-major weights exist for these widths
+    a.blk0 = first;
+    if (ln && pk) TL_LAUNCH((tl_wide_kernel<D, MR, true, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (ln) TL_LAUNCH((tl_wide_kernel<D, MR, true, false>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (pk) TL_LAUNCH((tl_wide_kernel<D, MR, false, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else TL_LAUNCH((tl_wide_kernel<D, MR, false, false>), dim3(nblk), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
 template <int D>
 static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
     const bool ln = a.ln_out.base != nullptr;
     const size_t cols = ln ? (size_t)2 * (D + 4) : (size_t)(D + 4) + (128 + 4);
-    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1))) {
+    const bool pk = D % 128 == 0 && a.Wpa != nullptr && a.Wpb != nullptr;
+    const int slots = 256 * (D <= 128 ? 2 : 1);
+    if (tl_rows32(S * a.rpb, slots, D, "DTQN_ROWS_WIDE")) {
         a.rpb *= 2;
-        const size_t lds = 32 * cols * sizeof(float);
-        if (ln) TL_LAUNCH((tl_wide_kernel<D, 32, true>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
-        else TL_LAUNCH((tl_wide_kernel<D, 32, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
-    } else {
-        const size_t lds = 64 * cols * sizeof(float);
-        if (ln) TL_LAUNCH((tl_wide_kernel<D, 64, true>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
-        else TL_LAUNCH((tl_wide_kernel<D, 64, false>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_wide_rows<D, 32>(a, n, first, ln, pk, 32 * cols * sizeof(float), stream); });
     }
-    return DTQN_OK;
+    return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_wide_rows<D, 64>(a, n, first, ln, pk, 64 * cols * sizeof(float), stream); });
 }
 // a.rpb on entry: 64-row blocks per sequence.  64-row workgroups by default; when the last round of 64-row workgroups would
 // leave more than 15 % of the launch's slots idle (resident workgroups: two per CU at D <= 128, one at D = 256), 32-row
 // workgroups even the rounds out (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3, 764 -> 788 updates/s; cfg 5: 384
 // on 256 -> 768 = 3, 437 -> 445).  DTQN_FFN_ROWS=32|64 forces one.
+template <int D, int MR>
+static int launch_ffn_rows(TlFfnArgs a, int nblk, int first, bool pk, hipStream_t stream) {
+    const size_t lds = (size_t)MR * ((D + 4) + (128 + 4)) * sizeof(float);
+    a.blk0 = first;
+    if (pk) TL_LAUNCH((tl_ffn_kernel<D, MR, D % 128 == 0>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else TL_LAUNCH((tl_ffn_kernel<D, MR, false>), dim3(nblk), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
 template <int D>
 static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     const int blocks64 = S * a.rpb, slots = 256 * (D <= 128 ? 2 : 1);
-    const char* e = getenv("DTQN_FFN_ROWS");
-    (void)e;
-    if (tl_rows32(blocks64, slots)) {
+    const bool pk = D % 128 == 0 && a.W1pa != nullptr && a.W1pb != nullptr && a.W2pa != nullptr && a.W2pb != nullptr;
+    if (tl_rows32(blocks64, slots, D, "DTQN_ROWS_FFN")) {
         a.rpb *= 2;
-        const size_t lds = (size_t)32 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_ffn_kernel<D, 32>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
-    } else {
-        const size_t lds = (size_t)64 * ((D + 4) + (128 + 4)) * sizeof(float);
-        TL_LAUNCH((tl_ffn_kernel<D, 64>), dim3(S * a.rpb), dim3(TNT), lds, stream, a);
+        return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_ffn_rows<D, 32>(a, n, first, pk, stream); });
     }
-    return DTQN_OK;
+    return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_ffn_rows<D, 64>(a, n, first, pk, stream); });
 }
 template <int KC>
 static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
@@ -1759,10 +1863,12 @@ static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
     if (tl_half_rows(S * a.rpb * cb, 512)) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
-        TL_LAUNCH((tl_dx_kernel<KC, 32>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        if (KC == 128 && a.Wp != nullptr && a.nsrc == 1) TL_LAUNCH((tl_dx_kernel<KC, 32, KC == 128>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_dx_kernel<KC, 32, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     } else {
         const size_t lds = (size_t)64 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);
-        TL_LAUNCH((tl_dx_kernel<KC, 64>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        if (KC == 128 && a.Wp != nullptr && a.nsrc == 1) TL_LAUNCH((tl_dx_kernel<KC, 64, KC == 128>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_dx_kernel<KC, 64, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     }
     return DTQN_OK;
 }
@@ -1857,7 +1963,9 @@ struct EmbedSrc {
 template <int D>
 static int forward_records(const DtqnNet& net, const float* theta_a, const float* theta_b, int split, const EmbedSrc& src,
                            int S, int n, float* rec, bool training, float* q_out, long long q_seq_stride, int q_row_stride,
-                           hipStream_t stream, const TlDrop& drop) {
+                           hipStream_t stream, const TlDrop& drop, const float* pk_a = nullptr, const float* pk_b = nullptr) {
+    // fragment-major weight copies of the two parameter sets (dtqn_wpack.hpp; nullptr: the kernels read the parameter layout)
+    const WPackPlan wplan = (pk_a != nullptr && pk_b != nullptr) ? wpack_plan(net) : WPackPlan{};
     const int lpb = net.lp, H = net.num_heads, HD = net.head_dim, rpb = lpb / TROWS;
     const RecMap rm = rec_map(net, training);
     const bool ident = net.identity != 0;
@@ -1884,6 +1992,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         a.in = in; a.out = out; a.res = res; a.mask = mask;
         a.Wa = theta_a + w_off; a.Wb = theta_b + w_off; a.ba = theta_a + b_off; a.bb = theta_b + b_off;
         a.split = split; a.K = K; a.N = N; a.rpb = rpb; a.mode = mode;
+        a.Wpa = wpack_f(wplan, pk_a, w_off); a.Wpb = wpack_f(wplan, pk_b, w_off);
         return launch_linear<D>(a, S, stream);
     };
     // out = GRUGate(x, y) (gates.py:26-31): three two-operand GEMMs with the gate arithmetic as their epilogues.
@@ -1933,6 +2042,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             wa.in = u1; wa.out = F(ab + net.al_qkv, 3 * D);
             wa.Wa = theta_a + tb + net.lo_in_w; wa.Wb = theta_b + tb + net.lo_in_w; wa.ba = theta_a + tb + net.lo_in_b; wa.bb = theta_b + tb + net.lo_in_b;
             wa.split = split; wa.rpb = rpb; wa.N = 3 * D;
+            wa.Wpa = wpack_f(wplan, pk_a, tb + net.lo_in_w); wa.Wpb = wpack_f(wplan, pk_b, tb + net.lo_in_w);
             rc = launch_wide<D>(wa, S, stream);
         } else {
             rc = linear(u1, D, 3 * D, tb + net.lo_in_w, tb + net.lo_in_b, F(ab + net.al_qkv, 3 * D), 0, nofld(), nofld());
@@ -1953,6 +2063,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             wa.in = F(ab + net.al_o, D); wa.out = s1; wa.N = D;
             wa.Wa = theta_a + tb + net.lo_out_w; wa.Wb = theta_b + tb + net.lo_out_w; wa.ba = theta_a + tb + net.lo_out_b; wa.bb = theta_b + tb + net.lo_out_b;
             wa.split = split; wa.rpb = rpb;
+            wa.Wpa = wpack_f(wplan, pk_a, tb + net.lo_out_w); wa.Wpb = wpack_f(wplan, pk_b, tb + net.lo_out_w);
             wa.res = stream_in; wa.mask = training ? F(ab + net.al_m1, 0) : nofld();
             wa.ln_out = u2; wa.ln_st = st1;
             wa.lga = theta_a + tb + net.lo_ln1_w; wa.lgb = theta_b + tb + net.lo_ln1_w; wa.lba = theta_a + tb + net.lo_ln1_b; wa.lbb = theta_b + tb + net.lo_ln1_b;
@@ -1980,6 +2091,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.W1a = theta_a + tb + net.lo_f1_w; fa.W1b = theta_b + tb + net.lo_f1_w; fa.b1a = theta_a + tb + net.lo_f1_b; fa.b1b = theta_b + tb + net.lo_f1_b;
             fa.W2a = theta_a + tb + net.lo_f2_w; fa.W2b = theta_b + tb + net.lo_f2_w; fa.b2a = theta_a + tb + net.lo_f2_b; fa.b2b = theta_b + tb + net.lo_f2_b;
             fa.split = split; fa.rpb = rpb; fa.drop = drop; fa.layer = l;
+            fa.W1pa = wpack_f(wplan, pk_a, tb + net.lo_f1_w); fa.W1pb = wpack_f(wplan, pk_b, tb + net.lo_f1_w);
+            fa.W2pa = wpack_f(wplan, pk_a, tb + net.lo_f2_w); fa.W2pb = wpack_f(wplan, pk_b, tb + net.lo_f2_w);
             fa.n_save = training ? src.batch : 0;                     // only the training third of a TD update is read again
             fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
             fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
@@ -2066,6 +2179,9 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
     auto FA = [&](int off, int ld) { return fld(act, net.act_stride, off, ld); };
     auto FG = [&](int off, int ld) { return fld(grd, net.grd_stride, off, ld); };
     const long long obs_ep_stride = (long long)(rp.max_steps + 1) * rp.obs_dim, act_ep_stride = rp.max_steps + 1;
+    // fragment-major B copies of the policy weights (dtqn_wpack.hpp), written by this update's forward
+    const float* pk = td.wpack_tgt != nullptr ? td.wpack_pol : nullptr;
+    const WPackPlan wplan = pk != nullptr ? wpack_plan(net) : WPackPlan{};
     {
         TlLossArgs a;
         a.net = net; a.q3 = td.q3; a.grd = grd; a.stats_partial = td.stats_partial;
@@ -2084,6 +2200,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
     auto dx = [&](Fld dy, int N, int w_off, int KOUT, Fld out, int mode, Fld mask) {
         TlDxArgs a = {};
         a.dy = dy; a.out = out; a.mask = mask; a.W = theta + w_off; a.N = N; a.KOUT = KOUT; a.rpb = rpb; a.mode = mode; a.nsrc = 1;
+        a.Wp = wpack_b(wplan, pk, w_off);
         return launch_dx<KC>(a, B, stream);
     };
     auto ln_bwd = [&](Fld dy, Fld xin, Fld st, int gamma_off, int dgb_off, bool accumulate) {
@@ -2174,6 +2291,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
             }
             fb.dhp = FG(gb + net.gl_dhp, 4 * D); fb.mh = FA(ab + net.al_mh, 0);
             fb.W1 = theta + tb + net.lo_f1_w; fb.W2 = theta + tb + net.lo_f2_w; fb.rpb = rpb; fb.drop = drop; fb.layer = l;
+            fb.W1p = wpack_b(wplan, pk, tb + net.lo_f1_w); fb.W2p = wpack_b(wplan, pk, tb + net.lo_f2_w);
             if (!ident) { fb.out = G; fb.out_mode = 2; } else { fb.out = T; fb.out_mode = 0; }
             if ((rc = launch_ffn_bwd<D>(fb, B, stream)) != DTQN_OK) return rc;
             if (!ident) {
@@ -2262,8 +2380,16 @@ int tiled_td_forward_part(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd
     const int split = 2 * td->batch - src.seq0 > 0 ? 2 * td->batch - src.seq0 : 0;     // sequences of passes 0 - 1 use theta_pol
     // policy(o) and policy(o') run in train mode, the target net in eval mode (dtqn.py:215-230); step = optimizer steps so far
     const TlDrop drop = tl_drop_make(*net, td->dropout_seed, 0u, td->step_counter, td->batch, 0x3);
+    // the first forward launch of an update rewrites the fragment-major weight copies from the parameters as they are NOW
+    if (pass0 == 0) {
+        const int rc = dtqn_td_wpack(net, td, stream);
+        if (rc != DTQN_OK) return rc;
+    }
+    const bool packed = td->wpack_pol != nullptr && td->wpack_tgt != nullptr;
+    const float* pk_pol = packed ? td->wpack_pol : nullptr;
+    const float* pk_tgt = packed ? td->wpack_tgt : nullptr;
 #define DTQN_TL_CASE(d) \
-    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, split, src, S, net->ctx_len, rec0, true, q0, qs, net->ap, stream, drop);
+    case d: return forward_records<d>(*net, td->theta_pol, td->theta_tgt, split, src, S, net->ctx_len, rec0, true, q0, qs, net->ap, stream, drop, pk_pol, pk_tgt);
     switch (net->d_model) {
         DTQN_TL_CASE(64)
         DTQN_TL_CASE(128)

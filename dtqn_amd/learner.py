@@ -166,6 +166,13 @@ class TdEngine:
             self._bag_rows_ring = [dict(h=torch.zeros(Bn, 2, net.bag_size, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), busy=False)
                                    for _ in range(self.IDX_RING)] if dev.type == "cuda" else []
             self._bag_rows_i = 0
+        # row-block networks: fragment-major copies of the layer matrices (include/dtqn_hip.h, dtqn_td_wpack), rewritten by every update's
+        # forward from theta_pol / theta_tgt; 0 floats where the plan does not cover the network
+        n_pack = int(self.lib.dtqn_td_wpack_floats(ctypes.byref(net)))
+        if n_pack > 0:
+            self.wpack_pol = torch.zeros(n_pack, **f32)
+            self.wpack_tgt = torch.zeros(n_pack, **f32)
+            td.wpack_pol, td.wpack_tgt = self.wpack_pol.data_ptr(), self.wpack_tgt.data_ptr()
         td.dropout_seed = int(dropout_seed) & 0xFFFFFFFF      # keep masks: hash of (seed, optimizer step, pass, sequence, site, element)
         self.img = None
         if net.img_c > 0:

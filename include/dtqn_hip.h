@@ -302,6 +302,11 @@ typedef struct DtqnTd {
     const float* xemb;        /* image nets: [3 B][padded context][D - a] observation embeddings of the three forwards, produced by
                                * dtqn_img_encode_td in front of dtqn_td_forward (whose embedding stage then only adds action embeddings,
                                * positions and dropout) */
+    float* wpack_pol;         /* optional, row-block networks: dtqn_td_wpack_floats(net) floats each -- fragment-major copies of the layer
+                               * matrices (dtqn_td_wpack rewrites them from theta_pol / theta_tgt at the start of every row-block TD
+                               * forward; the GEMM kernels then read their weight fragments 1 KB per load instruction).  NULL (either):
+                               * the kernels read the parameter layout */
+    float* wpack_tgt;
     /* hyper-parameters */
     int32_t batch;            /* B (local) */
     int32_t history;          /* loss over the last `history` positions (dtqn.py:240-241) */
@@ -426,6 +431,13 @@ int dtqn_td_backward_ahead(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
  * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
 int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
 int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch);
+/* Fragment-major weight copies of the row-block GEMM kernels (round 6; the matrices stay the reference's nn.Linear weights,
+ * dtqn/networks/transformer.py:28-61 -- only the order in which a wave finds their elements changes).  dtqn_td_wpack_floats: floats
+ * of DtqnTd.wpack_pol / wpack_tgt (0: the network is not covered -- d_model not a multiple of 128, bag networks, whole-sequence
+ * networks, DTQN_WPACK=0).  dtqn_td_wpack: rewrite both from theta_pol / theta_tgt; dtqn_td_forward calls it itself on row-block
+ * networks, so a caller only needs it in front of a dtqn_td_forward_part sequence it assembles by hand. */
+int dtqn_td_wpack_floats(const DtqnNet* net);
+int dtqn_td_wpack(const DtqnNet* net, const DtqnTd* td, void* stream);
 /* Fused weight gradients (latency mode, row_split == 4, small batches; reference: the same loss.backward(), dtqn.py:256): the
  * dtqn_td_backward launch carries extra workgroups on the compute units its row slices leave idle; they contract a layer's
  * weight gradients as soon as every sequence has published that layer's gradient records (write-through stores + event

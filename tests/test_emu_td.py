@@ -86,6 +86,8 @@ TILED = [
      dict(batch=2, T=30, mask=-5, tuf=2)),
     (dict(obs_dim=6, num_actions=5, inner_embed_size=64, num_heads=8, num_layers=2, history_len=70, discrete=True, vocab_sizes=9, action_dim=4,
           gate="gru", identity=True), dict(batch=2, T=90, mask=8, history=30)),
+    # d_model 128: the GEMM kernels read the fragment-major weight copies (dtqn_td_wpack, round 6); target sync every second update
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2)),
 ]
 
 
@@ -98,7 +100,8 @@ def test_td_update_tiled_path(emu, kw, run, monkeypatch):
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=33, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
                                                history=run.get("history"), tuf=run.get("tuf", 10_000))
     assert net.tiled == 1 and net.lp % 64 == 0
-    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    assert (emu.dtqn_td_wpack_floats(ctypes.byref(net)) > 0) == (cfg.inner_embed_size % 128 == 0) == hasattr(eng, "wpack_pol")
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3 if cfg.inner_embed_size % 128 == 0 else 2)
 
 
 SPLIT = [
