@@ -107,6 +107,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_row_split": [P(DtqnNet), i32],
         "dtqn_td_latency_mode": [P(DtqnNet), i32],
         "dtqn_td_wgrad_is_direct": [P(DtqnNet), i32],
+        "dtqn_td_wgrad_splits": [P(DtqnNet), i32],
         "dtqn_td_wpack_floats": [P(DtqnNet)],
         "dtqn_td_wpack": [P(DtqnNet), P(DtqnTd), vp],
         "dtqn_td_wgrad_is_fused": [P(DtqnNet), P(DtqnTd)],

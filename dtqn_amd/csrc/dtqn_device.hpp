@@ -73,6 +73,18 @@ inline void raise_lds_limit(const void* fn, size_t lds, size_t (&cache)[kMaxDevi
         cache[dev] = lds;
     }
 }
+// compute units of the current device (cached per device; 0 if the runtime cannot say)
+inline int device_cu_count() {
+    static int cache[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cache[dev] = n > 0 ? n : -1;
+    }
+    return cache[dev] > 0 ? cache[dev] : 0;
+}
 }  // namespace dtqn
 
 // Stage timestamps (debug): thread 0 of workgroups 0 and 1 (two row slices of sequence 0 in latency mode), 32 slots

@@ -29,6 +29,7 @@ struct WgradArgs {
     int row_split;          // small-partial records per sequence (one per workgroup of the backward kernel)
     int small_blocks;       // blocks per split that sum the small partials
     int xcd_map;            // 1: (split, tile) pairs dealt to the XCDs in contiguous runs (see the kernel); 0: pair = block (A/B timing)
+    int n_wtiles;           // 64 x 64 tiles of the jobs in `jobs` (net.n_wtiles, or fewer when dtqn_wgrad_lds_kernel takes the large matrices)
 };
 
 // Extra blocks of the same launch: sum the backward kernel's per-sequence partials (LayerNorm gamma/beta,
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     // pair (b % 8) * ceil(P / 8) + b / 8, so every XCD works through a contiguous run of pairs: the tiles of one weight
     // matrix and one token range one after the other, which share their dY / X columns -- re-reads of the records then hit
     // that XCD's L2 instead of each of the eight L2s pulling its own copy out of MALL / HBM.
-    const int P = net.n_wtiles * a.n_split, per = (P + 7) / 8, tile_blocks = per * 8, id = (int)blockIdx.x;
+    const int P = a.n_wtiles * a.n_split, per = (P + 7) / 8, tile_blocks = per * 8, id = (int)blockIdx.x;
     if (id >= tile_blocks) {
         small_partials_block(a, (id - tile_blocks) % a.small_blocks, (id - tile_blocks) / a.small_blocks);
         return;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     const int pair = a.xcd_map ? (id % 8) * per + id / 8 : id;
     if (pair >= P) return;
     // locate the job of this block
-    const int split = pair / net.n_wtiles, tile = pair - split * net.n_wtiles;
+    const int split = pair / a.n_wtiles, tile = pair - split * a.n_wtiles;
     int j = 0;
     for (int k = 1; k < a.n_jobs; ++k)
         if (a.jobs[k].tile0 <= tile) j = k;
@@ -254,6 +255,119 @@ __global__ __launch_bounds__(DTQN_THREADS, 2) void dtqn_wgrad_kernel(WgradArgs a
     }
 }
 
+// ---- large matrices of the row-block networks: 128 x 128 output tiles, operands staged through LDS (round 6) -------------------------
+// dtqn_wgrad_kernel above gives every WAVE its own pair of operand loads per 16 MFMAs: 64 x 64 tiles straight out of L2, 8 waves per
+// compute unit (160 registers each), 0.55 of the f32 matrix peak at BASELINE configs 3 - 5, where it is 15 - 17 % of the update.  Here a
+// workgroup of 8 waves owns a 128 x 128 block of one dW and one split of the batch; a chunk of 32 tokens of its dY columns
+// ([32][128]) and X columns ([32][128]) is loaded ONCE by the whole workgroup as whole 512-byte row pieces -- twice the MACs per byte
+// fetched -- into registers while the previous chunk multiplies, dropped into LDS between two barriers, and read from there as MFMA
+// operands: wave (wn, wk) owns rows [64 wn, 64 wn + 64) x columns [32 wk, 32 wk + 32) of the block as 4 x 2 interleaved 16 x 16 tiles
+// (tile cn holds rows 4 i + cn, tile ck columns 2 i + ck), so that one 16-byte and one 8-byte LDS read feed 8 MFMAs.  Leading
+// dimensions 128 / 160 words: the lane groups of ds_read_b128 / ds_read_b64 each cover the 64 banks once (MI355X_MICROARCH.md, LDS).
+// Same contraction as loss.backward() (dtqn/agents/dtqn.py:256); splits are summed by dtqn_td_reduce in a fixed order.
+constexpr int kLdsTK = 32, kLdsLDY = 128, kLdsLDX = 160, kLdsThreads = 512;
+struct WgradLdsJob {
+    DtqnWJob j;
+    int tile0;              // first 128 x 128 tile of this job in the launch
+};
+struct WgradLdsArgs {
+    DtqnNet net;
+    WgradLdsJob jobs[kMaxWJobs];
+    const float* act;
+    const float* grd;
+    float* gsplit;
+    int batch, n_split, n_jobs, n_tiles;
+};
+__global__ __launch_bounds__(kLdsThreads, 2) void dtqn_wgrad_lds_kernel(WgradLdsArgs a) {
+    const Thr t = make_thr();
+    const DtqnNet& net = a.net;
+    const int LP = net.lp;
+    float* Ys = reinterpret_cast<float*>(dtqn_smem);               // [32][128] dY columns of the chunk
+    float* Xs = Ys + kLdsTK * kLdsLDY;                             // [32][160] X columns of the chunk
+    const int pair = (int)blockIdx.x, split = pair / a.n_tiles, tile = pair - split * a.n_tiles;
+    int jx = 0;
+    for (int k = 1; k < a.n_jobs; ++k)
+        if (a.jobs[k].tile0 <= tile) jx = k;
+    const DtqnWJob& job = a.jobs[jx].j;
+    const int local = tile - a.jobs[jx].tile0, tk = job.K / 128;
+    const int bn = local / tk, bk = local - bn * tk, nbase = bn * 128, kbase = bk * 128;
+    const float* xbase = (job.x_in_act ? a.act : a.grd) + job.x_off + kbase;
+    const size_t xstride = job.x_in_act ? (size_t)net.act_stride : (size_t)net.grd_stride;
+    const float* ybase = a.grd + job.dy_off + nbase;
+    const size_t ystride = (size_t)net.grd_stride;
+    const int b_lo = (int)((long long)a.batch * split / a.n_split), b_hi = (int)((long long)a.batch * (split + 1) / a.n_split);
+    // chunks of 32 rows; the rows behind the context carry zero gradients (the loss runs over the L real positions): chunks that
+    // hold none of the first L rows are skipped (a bag network's embedding job contracts up to LP bag entries: it keeps every chunk)
+    const int live_rows = net.bag_size > 0 ? LP : net.ctx_len;
+    const int cps = (live_rows + kLdsTK - 1) / kLdsTK, nb = b_hi - b_lo, nchunks = job.n_layers * nb * cps;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int cn = 0; cn < 4; ++cn) { acc[cn][0] = zero4(); acc[cn][1] = zero4(); }
+    float bsum = 0.f;
+    const bool want_bias = job.b_off >= 0 && bk == 0;
+    // staging: thread -> (row, 16-byte piece) of each tile, two pieces per tile
+    const int sr = t.tid >> 5, sc = (t.tid & 31) * 4;
+    float4 yr[2], xr[2];
+    auto chunk_load = [&](int c) {
+        const int lyr = c / (nb * cps), rem = c - lyr * nb * cps, b = rem / cps, r0 = (rem - b * cps) * kLdsTK;
+        const float* yp = ybase + (size_t)(b_lo + b) * ystride + (size_t)lyr * job.dy_lstride + (size_t)r0 * job.ldy + sc;
+        const float* xp = xbase + (size_t)(b_lo + b) * xstride + (size_t)lyr * job.x_lstride + (size_t)r0 * job.ldx + sc;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            yr[k] = ld4(yp + (size_t)(sr + 16 * k) * job.ldy);
+            xr[k] = ld4(xp + (size_t)(sr + 16 * k) * job.ldx);
+        }
+    };
+    const int wn = t.wave >> 2, wk = t.wave & 3;
+    const float* ya = Ys + t.kq * kLdsLDY + 64 * wn + 4 * t.i;
+    const float* xa = Xs + t.kq * kLdsLDX + 32 * wk + 2 * t.i;
+    if (nchunks > 0) chunk_load(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                               // the previous chunk's tiles are consumed
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            st4(Ys + (sr + 16 * k) * kLdsLDY + sc, yr[k]);
+            st4(Xs + (sr + 16 * k) * kLdsLDX + sc, xr[k]);
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) chunk_load(c + 1);                        // in flight while this chunk multiplies
+#pragma unroll
+        for (int s = 0; s < kLdsTK / 4; ++s) {
+            const float4 a4 = ld4(ya + 4 * s * kLdsLDY);
+            const float2 b2 = *reinterpret_cast<const float2*>(xa + 4 * s * kLdsLDX);
+            const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int cn = 0; cn < 4; ++cn) {
+                acc[cn][0] = mfma16(aa[cn], b2.x, acc[cn][0]);
+                acc[cn][1] = mfma16(aa[cn], b2.y, acc[cn][1]);
+            }
+        }
+        if (want_bias && t.tid < 128) {
+#pragma unroll 8
+            for (int r = 0; r < kLdsTK; ++r) bsum += Ys[r * kLdsLDY + t.tid];
+        }
+    }
+    // acc[cn][ck][r] at lane (i, kq) = dW[nbase + 64 wn + 4 (4 kq + r) + cn][kbase + 32 wk + 2 i + ck]
+    float* out = a.gsplit + (size_t)split * net.n_trainable;
+#pragma unroll
+    for (int cn = 0; cn < 4; ++cn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nbase + 64 * wn + 4 * (4 * t.kq + r) + cn, k = kbase + 32 * wk + 2 * t.i;
+            *reinterpret_cast<float2*>(out + job.w_off + (size_t)n * job.K + k) = make_float2(acc[cn][0][r], acc[cn][1][r]);
+        }
+    if (want_bias && t.tid < 128) out[job.b_off + nbase + t.tid] = bsum;
+}
+// jobs dtqn_wgrad_lds_kernel takes: both dimensions whole 128-blocks (in_proj, out_proj, ffn.0, ffn.2, the first head matrix and
+// the GRU gate matrices of a row-block network with d_model 128 / 256)
+static inline bool wgrad_lds_job(const DtqnNet& net, const DtqnWJob& j) {
+    return net.tiled && j.N % 128 == 0 && j.K % 128 == 0 && j.ldy % 4 == 0 && j.ldx % 4 == 0;
+}
+static inline bool wgrad_lds_enabled(const DtqnNet& net) {
+    const char* e = getenv("DTQN_WGRAD_LDS");
+    return net.tiled && net.d_model % 128 == 0 && net.img_c <= 0 && !(e != nullptr && atoi(e) == 0);
+}
+
 // ---- small batches: one launch, no split-K -----------------------------------------------------------------------------
 // With B * LP <= kDirectMaxTokens (2048) the token axis is short enough for ONE workgroup to contract it all, so the splits and
 // the dtqn_td_reduce launch disappear: the output is cut into many SMALL tiles instead (16 dY columns x 32 X columns, a
@@ -354,6 +468,30 @@ static DirectPlan direct_plan(const DtqnNet* net, const DtqnWJob* jobs) {
 
 using namespace dtqn;
 
+// Batch splits of the large-batch weight-gradient launches that fill the chip once: with dtqn_wgrad_lds_kernel in play (row-block
+// networks of d_model 128 / 256) as many as put one round of its 128 x 128 tiles on the 2 x 256 slots; else min(batch, 16).
+extern "C" int dtqn_td_wgrad_splits(const DtqnNet* net, int batch) {
+    if (!net || batch < 1) return 1;
+    int n = batch < 16 ? batch : 16;
+    if (net->n_wjobs <= kMaxWJobs && wgrad_lds_enabled(*net)) {
+        DtqnWJob jobs[kMaxWJobs];
+        if (dtqn_net_wjobs(net, jobs) == DTQN_OK) {
+            int tiles = 0;
+            for (int j = 0; j < net->n_wjobs; ++j)
+                if (wgrad_lds_job(*net, jobs[j])) tiles += (jobs[j].N / 128) * (jobs[j].K / 128);
+            if (tiles > 0) {
+                const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+                const char* e = getenv("DTQN_WGRAD_SLOTS");            // resident workgroups per compute unit the split count aims at (A/B timing)
+                const int per_cu = e != nullptr && atoi(e) > 0 ? atoi(e) : 2;
+                n = per_cu * cus / tiles;
+                n = n < 1 ? 1 : (n > batch ? batch : n);
+                n = n > 64 ? 64 : n;
+            }
+        }
+    }
+    return n;
+}
+
 // One launch, no splits, no dtqn_td_reduce: when the whole batch is at most kDirectMaxTokens tokens (DTQN_WGRAD_DIRECT=0/1
 // overrides, for A/B timing).
 extern "C" int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch) {
@@ -411,8 +549,38 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     WgradArgs a;
     a.net = *net;
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
+    a.n_jobs = net->n_wjobs;
+    a.n_wtiles = net->n_wtiles;
+    if (wgrad_lds_enabled(*net)) {
+        // the large matrices go to dtqn_wgrad_lds_kernel, the rest (embedding, last head matrix) stay here with their tiles renumbered
+        WgradLdsArgs la;
+        la.net = *net;
+        la.n_jobs = 0; la.n_tiles = 0;
+        int keep = 0, tiles = 0;
+        for (int j = 0; j < net->n_wjobs; ++j) {
+            if (wgrad_lds_job(*net, a.jobs[j])) {
+                la.jobs[la.n_jobs].j = a.jobs[j];
+                la.jobs[la.n_jobs].tile0 = la.n_tiles;
+                la.n_tiles += (a.jobs[j].N / 128) * (a.jobs[j].K / 128);
+                ++la.n_jobs;
+            } else {
+                a.jobs[keep] = a.jobs[j];
+                a.jobs[keep].tile0 = tiles;
+                tiles += a.jobs[keep].tiles_n * a.jobs[keep].tiles_k;
+                ++keep;
+            }
+        }
+        if (la.n_jobs > 0) {
+            a.n_jobs = keep; a.n_wtiles = tiles;
+            la.act = td->act; la.grd = td->grd; la.gsplit = td->gsplit; la.batch = td->batch; la.n_split = td->n_split;
+            const size_t llds = (size_t)kLdsTK * (kLdsLDY + kLdsLDX) * sizeof(float);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(dtqn_wgrad_lds_kernel, dim3(la.n_tiles * td->n_split), dim3(kLdsThreads), llds, (hipStream_t)stream, la);
+            if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;
+        }
+    }
     a.act = td->act; a.grd = td->grd; a.gsplit = td->gsplit; a.small = td->small;
-    a.batch = td->batch; a.n_split = td->n_split; a.n_jobs = net->n_wjobs;
+    a.batch = td->batch; a.n_split = td->n_split;
     a.row_split = td->row_split > 1 ? td->row_split : 1;
     a.n_small = net->num_layers * 4 * net->d_model + (net->discrete ? net->vocab * net->embed_per_obs : 0) +
                 (net->action_dim > 0 ? net->num_actions * net->action_dim : 0) +
@@ -421,7 +589,7 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     a.small_blocks = small_blocks;
     const char* xm = getenv("DTQN_WGRAD_XCD");
     a.xcd_map = xm != nullptr ? atoi(xm) : 1;
-    const int tile_blocks = (net->n_wtiles * td->n_split + 7) / 8 * 8;
+    const int tile_blocks = (a.n_wtiles * td->n_split + 7) / 8 * 8;
     const size_t lds = (size_t)DTQN_WAVES * 65 * 68 * sizeof(float);
     static size_t attr_lds[kMaxDevices] = {};    // per device
     raise_lds_limit(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), lds, attr_lds);

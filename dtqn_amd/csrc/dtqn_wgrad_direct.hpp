@@ -354,17 +354,7 @@ __device__ __forceinline__ void fuse_arrive(int32_t* counters, int e, const Thr&
 }
 
 // ---- host: which launches fuse, and the readiness-ordered item list --------------------------------------------------------
-inline int fuse_cu_count() {
-    static int cache[kMaxDevices] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
-    if (cache[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        cache[dev] = n > 0 ? n : -1;
-    }
-    return cache[dev] > 0 ? cache[dev] : 0;
-}
+inline int fuse_cu_count() { return device_cu_count(); }
 // Fused when: four row slices per sequence (latency mode of the backward), residual gates, the plain context network, the whole batch
 // short enough for the one-launch weight gradients, and at least eight compute units left over behind the chain's workgroups (every
 // workgroup of the launch has a CU of its own: the weight-gradient workgroups spin on the chain's events).  OPT-IN with DTQN_WGRAD_FUSED=1

@@ -100,8 +100,8 @@ class TdEngine:
         self.adam_m = torch.zeros(nt, **f32)
         self.adam_v = torch.zeros(nt, **f32)
         Bn = self.batch
-        if n_split is None:   # enough workgroups to fill 256 CUs; the 4 waves of a block split sequences x token quarters
-            n_split = max(1, min(Bn, 16))
+        if n_split is None:   # enough workgroups to fill the chip once (include/dtqn_hip.h: min(batch, 16), or one round of the 128 x 128 tiles)
+            n_split = max(1, int(self.lib.dtqn_td_wgrad_splits(ctypes.byref(net), Bn)))
         self.n_split = int(n_split)
         self.n_norm_blocks = (nt + OPT_BLOCK_ELEMS - 1) // OPT_BLOCK_ELEMS
         # the tiled path keeps the records of all three forwards (policy(o), policy(o'), target(o')); the

@@ -431,6 +431,11 @@ int dtqn_td_backward_ahead(const DtqnNet* net, const DtqnReplay* rp, const DtqnT
  * (dtqn_td_wgrad_is_direct): one launch writes grad and norm_partial itself and dtqn_td_reduce is a no-op. */
 int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream);
 int dtqn_td_wgrad_is_direct(const DtqnNet* net, int batch);
+/* Recommended DtqnTd.n_split (token splits of the large-batch weight-gradient launches; gsplit holds n_split * n_trainable floats):
+ * min(batch, 16), or -- row-block networks of d_model 128 / 256, whose large matrices are contracted in 128 x 128 tiles with the
+ * operands staged through LDS (dtqn_wgrad_lds_kernel) -- as many as put one round of those tiles on the chip.  Any n_split >= 1 is
+ * valid; the sums are deterministic for a given n_split. */
+int dtqn_td_wgrad_splits(const DtqnNet* net, int batch);
 /* Fragment-major weight copies of the row-block GEMM kernels (round 6; the matrices stay the reference's nn.Linear weights,
  * dtqn/networks/transformer.py:28-61 -- only the order in which a wave finds their elements changes).  dtqn_td_wpack_floats: floats
  * of DtqnTd.wpack_pol / wpack_tgt (0: the network is not covered -- d_model not a multiple of 128, bag networks, whole-sequence

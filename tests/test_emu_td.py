@@ -104,6 +104,22 @@ def test_td_update_tiled_path(emu, kw, run, monkeypatch):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3 if cfg.inner_embed_size % 128 == 0 else 2)
 
 
+def test_td_update_tiled_lds_weight_gradients(emu, monkeypatch):
+    """Row-block network of d_model 128 on the LARGE-batch weight-gradient path (forced at a small batch): the layer matrices and the
+    first head matrix through dtqn_wgrad_lds_kernel (128 x 128 tiles, operands staged through LDS), the embedding and the last head
+    matrix through dtqn_wgrad_kernel, both into the same splits; against the oracle like every other case."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_WGRAD_DIRECT", "0")
+    cfg = O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=2, history_len=40, discrete=True, vocab_sizes=9)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=5, batch=3, T=50, n_eps=6, mask=8, tuf=2)
+    assert net.tiled == 1 and emu.dtqn_td_wgrad_is_direct(ctypes.byref(net), 3) == 0
+    assert eng.n_split == emu.dtqn_td_wgrad_splits(ctypes.byref(net), 3) == 3
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    monkeypatch.setenv("DTQN_WGRAD_LDS", "0")           # the same update with every job on the 64 x 64 kernel
+    net2, oracle2, host2, eng2, rep2 = make_td_case(emu, cfg, seed=5, batch=3, T=50, n_eps=6, mask=8, tuf=2)
+    check_td_updates(cfg, net2, oracle2, host2, eng2, rep2, n_updates=1)
+
+
 SPLIT = [
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50),
     dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=8, num_layers=2, history_len=50, gate="gru", action_dim=4),
