@@ -23,6 +23,28 @@
 
 namespace dtqn {
 
+// Start skew of a launch that runs a round and a half (round 6).  Where the last round is half empty (BASELINE config 4 forward: 768
+// 64-row workgroups on 2 x 256 slots), WHICH slots the hardware dispatcher gives the last 256 decides the kernel's time: one each on
+// 256 compute units that have just run a pair (tl_ffn 114 us), or two each on the 128 units whose pair happened to finish first
+// (141 us) -- the traces show both, at random, launch by launch, because the two workgroups of a unit start and finish together.
+// The workgroups that fill the SECOND slot of every unit (dispatch order 256 .. 511) therefore start `ticks` 100-MHz ticks late (6 us):
+// their partners have the unit's matrix pipe to themselves meanwhile (the delay is not lost), the two slots of a unit no longer free
+// up together, and the last half round lands one per unit every time: 143 -> 129 us in tools/microbench/ffn_bench.hip, against 134 us
+// for cutting the launch into its whole rounds and the rest.
+__device__ __forceinline__ void tl_start_skew(int ticks) {
+    if (ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < ticks) DTQN_SPIN_PAUSE_LONG();
+    }
+}
+// skew of a launch of nblk workgroups on `slots` resident ones: only where the last round is between a quarter and three quarters full
+static inline int tl_skew_ticks(int nblk, int slots) {
+    const char* e = getenv("DTQN_SKEW_TICKS");
+    const int rest = nblk % slots;
+    if (nblk <= slots || slots != 512 || rest * 4 < slots || rest * 4 > 3 * slots) return 0;
+    return e != nullptr ? atoi(e) : 600;
+}
+
 constexpr int TNW = 8;                 // waves per workgroup of the GEMM / row-wise kernels
 constexpr int TNT = TNW * 64;
 constexpr int TROWS = 64;              // rows per block
@@ -473,7 +495,7 @@ struct TlWideArgs {
     const float *lga, *lgb, *lba, *lbb;
     int n_save;
     const float *Wpa, *Wpb;            // fragment-major F copies of Wa / Wb (dtqn_wpack.hpp), or nullptr
-    int blk0;                          // row block of workgroup 0 (a launch may be cut into whole rounds + a rest: tl_launch_rounds)
+    int skew;                          // start skew of the second-slot workgroups, 100-MHz ticks (tl_start_skew; 0: none)
 };
 template <int D, int MR, bool LN, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideArgs a) {
@@ -482,7 +504,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging (plain) | [MR][LDX] all columns (LN)
     Thr t = make_thr();
-    const int blk = (int)blockIdx.x + a.blk0;
+    const int blk = (int)blockIdx.x;
     const int s = blk / a.rpb, row0 = (blk % a.rpb) * MR;
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W = second ? a.Wb : a.Wa;
@@ -509,6 +531,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         }
     }
     float* mrec = LN && save && a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
+    tl_start_skew(a.skew);
     __syncthreads();
     // one column block: `cur` holds its first fragment on entry; on exit the first fragment of block j + 1 sits in `nxt`
     // (NKA == 1: the buffers swap roles from block to block) or in `cur` again (NKA == 2)
@@ -636,7 +659,7 @@ struct TlFfnArgs {
     TlDrop drop;                       // dropout on the block's output, before the gate's ReLU (transformer.py:38-42)
     int layer;
     const float *W1pa, *W1pb, *W2pa, *W2pb;    // fragment-major F copies of W1 / W2 (dtqn_wpack.hpp), or nullptr
-    int blk0;                          // row block of workgroup 0 (tl_launch_rounds)
+    int skew;                          // start skew of the second-slot workgroups, 100-MHz ticks (tl_start_skew; 0: none)
 };
 // MR rows per workgroup (64, or 32 when the launch would otherwise be a round and a half of workgroups: launch_ffn)
 template <int D, int MR, bool PK>
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
     float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] input rows
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] hidden chunk / output staging
     const Thr t = make_thr();
-    const int blk = (int)blockIdx.x + a.blk0;
+    const int blk = (int)blockIdx.x;
     const int s = blk / a.rpb, row0 = (blk % a.rpb) * MR;              // a.rpb: MR-row blocks per sequence
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W1 = second ? a.W1b : a.W1a;
@@ -692,6 +715,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
 #pragma unroll
         for (int m = 0; m < MT; ++m) accO[o][m] = zero4();
     float* mrec_h = save && a.mh.base != nullptr ? a.mh.base + (size_t)s * a.mh.stride : nullptr;
+    tl_start_skew(a.skew);
     __syncthreads();
     for (int j = 0; j < NJ; ++j) {
         f32x4 accA[MT];
@@ -1740,19 +1764,6 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
         if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;                                                 \
     } while (0)
 
-// A launch of nblk row blocks on `slots` resident workgroups, cut into its whole rounds and the rest (round 6).  Where the last round
-// is half empty (BASELINE config 4 forward: 768 64-row workgroups on 512 slots), WHICH slots the hardware dispatcher gives the last 256
-// decides the kernel's time: one each on 256 compute units that have just run their pair (tl_ffn 114 us), or two each on the 128
-// units that happened to finish first (141 us) -- the traces show both, at random, launch by launch.  Launched on their own, the rest
-// land one per compute unit every time.  `launch(first block, blocks)` issues one launch; DTQN_ROUNDS=0: one launch as before.
-template <typename F>
-static int tl_launch_rounds(int nblk, int slots, F launch) {
-    const char* e = getenv("DTQN_ROUNDS");
-    const int whole = (nblk / slots) * slots;
-    if ((e != nullptr && atoi(e) == 0) || whole == 0 || whole == nblk) return launch(0, nblk);
-    const int rc = launch(0, whole);
-    return rc != DTQN_OK ? rc : launch(whole, nblk - whole);
-}
 // Rows per workgroup of the linear / dY W kernels: 64.  The 32-row instantiations (DTQN_GEMM_ROWS=32) even out short launches
 // (768 workgroups on 512 slots; 256 for the backward products into a D-wide output) but fetch every weight fragment for half
 // the MFMAs: measured cfg 4 787 -> 748, cfg 5 445 -> 408 updates/s, so they stay an experiment switch.  (The fused feed-forward
@@ -1795,8 +1806,9 @@ static bool tl_rows32(int blocks64, int slots, int D, const char* which) {
     // D <= 128 (two per CU), round 6: tools/microbench/mfma_probe.hip shows these loops bound by the weight fragments every workgroup
     // pulls out of L2 for its rows (the same loop with the fetches removed: 0.65 -> 0.81 of the matrix peak at 32 rows), so a 64-row
     // workgroup -- half the fetches per MFMA -- wins even at a round and a half (config 4 forward, 768 on 512 slots: tl_ffn 155 ->
-    // 138 us); 32 rows only where 64-row workgroups would not even fill the slots once.
-    if (D <= 128) return blocks64 < slots;
+    // 138 us); 32 rows only where 64-row workgroups would not even give every compute unit one (config 4 backward, 256 blocks: 64
+    // rows 334 us per chain against 342).
+    if (D <= 128) return blocks64 * 2 < slots;
     return (rounds * slots - blocks64) * 100 > 15 * rounds * slots;
 }
 template <int D>
@@ -1814,9 +1826,9 @@ static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream) {
     return DTQN_OK;
 }
 template <int D, int MR>
-static int launch_wide_rows(TlWideArgs a, int nblk, int first, bool ln, bool pk, size_t lds, hipStream_t stream) {
+static int launch_wide_rows(TlWideArgs a, int nblk, bool ln, bool pk, size_t lds, hipStream_t stream) {
     constexpr bool CAN = D % 128 == 0;                                 // fragment-major weights exist for these widths
-    a.blk0 = first;
+    a.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1));
     if (ln && pk) TL_LAUNCH((tl_wide_kernel<D, MR, true, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
     else if (ln) TL_LAUNCH((tl_wide_kernel<D, MR, true, false>), dim3(nblk), dim3(TNT), lds, stream, a);
     else if (pk) TL_LAUNCH((tl_wide_kernel<D, MR, false, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
@@ -1828,21 +1840,20 @@ static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
     const bool ln = a.ln_out.base != nullptr;
     const size_t cols = ln ? (size_t)2 * (D + 4) : (size_t)(D + 4) + (128 + 4);
     const bool pk = D % 128 == 0 && a.Wpa != nullptr && a.Wpb != nullptr;
-    const int slots = 256 * (D <= 128 ? 2 : 1);
-    if (tl_rows32(S * a.rpb, slots, D, "DTQN_ROWS_WIDE")) {
+    if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_WIDE")) {
         a.rpb *= 2;
-        return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_wide_rows<D, 32>(a, n, first, ln, pk, 32 * cols * sizeof(float), stream); });
+        return launch_wide_rows<D, 32>(a, S * a.rpb, ln, pk, 32 * cols * sizeof(float), stream);
     }
-    return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_wide_rows<D, 64>(a, n, first, ln, pk, 64 * cols * sizeof(float), stream); });
+    return launch_wide_rows<D, 64>(a, S * a.rpb, ln, pk, 64 * cols * sizeof(float), stream);
 }
 // a.rpb on entry: 64-row blocks per sequence.  64-row workgroups by default; when the last round of 64-row workgroups would
 // leave more than 15 % of the launch's slots idle (resident workgroups: two per CU at D <= 128, one at D = 256), 32-row
 // workgroups even the rounds out (cfg 4: 768 workgroups on 512 slots = 1.5 rounds -> 1536 = 3, 764 -> 788 updates/s; cfg 5: 384
 // on 256 -> 768 = 3, 437 -> 445).  DTQN_FFN_ROWS=32|64 forces one.
 template <int D, int MR>
-static int launch_ffn_rows(TlFfnArgs a, int nblk, int first, bool pk, hipStream_t stream) {
+static int launch_ffn_rows(TlFfnArgs a, int nblk, bool pk, hipStream_t stream) {
     const size_t lds = (size_t)MR * ((D + 4) + (128 + 4)) * sizeof(float);
-    a.blk0 = first;
+    a.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1));
     if (pk) TL_LAUNCH((tl_ffn_kernel<D, MR, D % 128 == 0>), dim3(nblk), dim3(TNT), lds, stream, a);
     else TL_LAUNCH((tl_ffn_kernel<D, MR, false>), dim3(nblk), dim3(TNT), lds, stream, a);
     return DTQN_OK;
@@ -1853,9 +1864,9 @@ static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     const bool pk = D % 128 == 0 && a.W1pa != nullptr && a.W1pb != nullptr && a.W2pa != nullptr && a.W2pb != nullptr;
     if (tl_rows32(blocks64, slots, D, "DTQN_ROWS_FFN")) {
         a.rpb *= 2;
-        return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_ffn_rows<D, 32>(a, n, first, pk, stream); });
+        return launch_ffn_rows<D, 32>(a, S * a.rpb, pk, stream);
     }
-    return tl_launch_rounds(S * a.rpb, slots, [&](int first, int n) { return launch_ffn_rows<D, 64>(a, n, first, pk, stream); });
+    return launch_ffn_rows<D, 64>(a, S * a.rpb, pk, stream);
 }
 template <int KC>
 static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {

@@ -39,6 +39,7 @@ extern "C" void* dtqn_debug_profile_buffer(void) { return nullptr; }
 extern "C" int dtqn_td_row_split(const DtqnNet*, int) { return 0; }
 extern "C" int dtqn_td_xch_floats(const DtqnNet*, int) { return 0; }
 extern "C" int dtqn_td_xch_flags(const DtqnNet*, int) { return 0; }
+extern "C" int dtqn_td_wpack(const DtqnNet*, const DtqnTd*, void*) { return 0; }
 
 // tick calibration: N dependent-free MFMAs on one wave per SIMD take 32 N shader cycles
 __global__ __launch_bounds__(256) void tick_kernel(long long* out, float* sink, int n) {
@@ -90,6 +91,9 @@ static void run(int S, int lpb, int n_save, int reps) {
     fa.split = S; fa.rpb = rpb; fa.mode = 2; fa.n_save = n_save;
     fa.ln_out = F(lnout, D); fa.ln_st = F(st, 2); fa.lga = fa.lgb = g; fa.lba = fa.lbb = be;
     fa.drop = dtqn::tl_drop_none(); fa.layer = 0;
+    if (getenv("FFN_BENCH_PACKED") != nullptr) {        // the fragment-major fetch path (timing only: the buffers hold the same bytes in another order)
+        fa.W1pa = fa.W1pb = W1; fa.W2pa = fa.W2pb = W2;
+    }
     hipStream_t stream; CK(hipStreamCreate(&stream));
     for (int i = 0; i < 3; ++i) if (dtqn::launch_ffn<D>(fa, S, stream) != 0) { printf("launch failed\n"); exit(1); }
     CK(hipStreamSynchronize(stream));
@@ -98,6 +102,16 @@ static void run(int S, int lpb, int n_save, int reps) {
     for (int i = 0; i < reps; ++i) dtqn::launch_ffn<D>(fa, S, stream);
     CK(hipEventRecord(e1, stream)); CK(hipStreamSynchronize(stream));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    {   // per-launch times (the 1.5-round launches are bimodal: which slots the last half round lands on)
+        std::vector<hipEvent_t> ev(reps + 1);
+        for (auto& e : ev) CK(hipEventCreate(&e));
+        CK(hipEventRecord(ev[0], stream));
+        for (int i = 0; i < reps; ++i) { dtqn::launch_ffn<D>(fa, S, stream); CK(hipEventRecord(ev[i + 1], stream)); }
+        CK(hipStreamSynchronize(stream));
+        printf("  per launch (us):");
+        for (int i = 0; i < reps; ++i) { float m; CK(hipEventElapsedTime(&m, ev[i], ev[i + 1])); printf(" %.0f", m * 1e3); }
+        printf("\n");
+    }
     const double us = ms * 1e3 / reps, gflop = (double)rows * 2.0 * 2.0 * D * HID / 1e9;
     const bool r32 = dtqn::tl_rows32(S * rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_FFN");
     printf("tl_ffn D=%d S=%d lpb=%d n_save=%d rows/wg=%d: %.1f us, %.1f TFLOP/s (%.3f of 157.3)\n", D, S, lpb, n_save, r32 ? 32 : 64, us, gflop / us * 1e3,
