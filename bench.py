@@ -201,6 +201,9 @@ def time_kernels_in_stream(agent, plain_step_us=None, updates: int = 120) -> dic
     n_valid, exclude = agent.replay_buffer.valid_range()
     eng.sample_in_forward(n_valid, exclude, agent.sample_seed)
     names = ["dtqn_forward_kernel", "dtqn_backward_kernel", "dtqn_wgrad_direct_kernel", "dtqn_clip_adam_kernel"]
+    # the stage list below leaves dtqn_td_reduce out: right only while the weight-gradient launch writes the flat gradient itself
+    if not lib.dtqn_td_wgrad_is_direct(n, eng.batch):
+        raise RuntimeError("time_kernels_in_stream: dtqn_td_wgrad is not direct for this batch -- add the dtqn_td_reduce stage")
     stages = [lambda: eng._forward_stage(rep, s), lambda: eng._backward_stage(rep, s),
               lambda: eng._check(lib.dtqn_td_wgrad(n, t, s), "dtqn_td_wgrad"), lambda: eng.clip_adam()]
     inline0 = eng._pipe["inline"]

@@ -242,6 +242,11 @@ def param_table(net: DtqnNet, width: int = 0) -> Dict[str, Tuple[int, Tuple[int,
     return tab
 
 
+def ws_lite(net: DtqnNet) -> bool:
+    """dtqn_limits.h dtqn_ws_lite: whole-sequence shapes that exist as four-slice (latency-mode) kernels only."""
+    return (not net.tiled) and net.d_model == 64 and (net.head_dim == 32 or (net.d_real > 0 and net.head_dim in (8, 16)))
+
+
 # ---- width-padded networks (include/dtqn_hip.h, DtqnNet.d_real) ---------------------------------------------------------------
 # theta holds every tensor at the padded shape with the real entries in front -- except along a head-structured axis, where each
 # head's real entries sit in front of that head's block: attention.in_proj_* rows are [q | k | v][head][width], attention.out_proj

@@ -23,8 +23,15 @@ extern "C" void* dtqn_debug_profile_buffer(void) { return g_profile_buffer; }
 
 // Latency mode (two workgroups per sequence): only where it pays and is covered -- the whole-sequence kernels with a
 // 64-row context tile, residual gate, post-LN, and few enough sequences that every workgroup is resident at once.
+// compute units the residency rules below are written against: the device's own count (256 on an MI355X; fewer on a partition)
+static int policy_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
 extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 1;
+    const int cus = policy_cus();
     const char* e = getenv("DTQN_ROW_SPLIT");                 // tests / tuning: 0 = never, 1 = whenever covered
     if (e != nullptr && e[0] == '0') return 1;
     const bool covered = !net->tiled && net->lp == 64 && !net->identity &&
@@ -34,15 +41,15 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
     if (e != nullptr && e[0] == '4') return 4;
     // 256 CUs: all 3*B*2 forward (and B*4 backward) workgroups resident at once.  The value is the number of row slices
     // of the BACKWARD kernel (4 x 16 rows); the forward kernel never uses more than two (2 x 32 rows).
-    if (3 * batch * 2 <= 256) return 4;
+    if (3 * batch * 2 <= cus) return 4;
     // Beyond latency mode (round 5) the forward runs one workgroup per sequence, and the backward chain -- half / a quarter as long per
     // slice -- is still sliced while all its workgroups fit the chip at once.  Measured at config-1 shapes (TD-updates/s, whole |
     // sliced backward; profiles/r05_row_split_policy.txt): batch 48 5 559 | 8 136 (four slices), 64 5 450 | 7 883 (four), 96 4 405 |
     // 5 378 (two; four: 4 878), 128 4 245 | 5 142 (two; four: 4 683); at 192 / 256 (a round and a half / two rounds of two-slice
     // workgroups) 0.98 / 0.99 x, so BASELINE config 2 stays whole-sequence.  d_model 64 (both gates); d_model 128 was not measured.
     if (net->d_model == 64) {
-        if (batch * 4 <= 256) return 4;
-        if (batch * 2 <= 256) return 2;
+        if (batch * 4 <= cus) return 4;
+        if (batch * 2 <= cus) return 2;
     }
     return 1;
 }
@@ -51,9 +58,9 @@ extern "C" int dtqn_td_row_split(const DtqnNet* net, int batch) {
 // launch.  0 with dtqn_td_row_split > 1: only the backward is sliced.
 extern "C" int dtqn_td_latency_mode(const DtqnNet* net, int batch) {
     if (dtqn_td_row_split(net, batch) < 2) return 0;
-    const char* e = getenv("DTQN_ROW_SPLIT");                 // forced slices (tests / tuning) are forced in both kernels
-    if (e != nullptr) return 1;
-    return 3 * batch * 2 <= 256 ? 1 : 0;
+    const char* e = getenv("DTQN_ROW_SPLIT");                 // forced slices (tests / tuning) are forced in both kernels:
+    if (e != nullptr && (e[0] == '1' || e[0] == '4')) return 1;   // the two values dtqn_td_row_split treats as forced, nothing else
+    return 3 * batch * 2 <= policy_cus() ? 1 : 0;
 }
 // Both kernel families cover D = 128 / residual gate / post-LN / 64-row contexts.  Measured at BASELINE config 3 shapes (updates/s,
 // whole-sequence | row-block): B = 64 1681 | 1880, B = 128 1244 | 1391, B = 256 895 | 863, B = 512 459 | 499 -- the row-block

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
     auto mf = [&](const float* base, int off, int ctiles) -> const float* { return base + off + (size_t)(R0 / 16) * ctiles * 8; };
     // record stores: plain, or write-through through a descriptor of this sequence's record (FUSE)
     const DtqnRsrc grs = DTQN_XCH_RSRC(grec, (size_t)net.grd_stride * 4);
-    constexpr bool WT = FUSE || kOptBwdWT;           // gradient records as write-through (sc1) stores
+    // gradient records as write-through (sc1) stores.  Not for the GRU-gated chain without dropout on 32- / 64-row tiles of eight waves:
+    // with the descriptor stores the register allocator ends at 2.2 - 4.6 KB of scratch per lane there (round 6 bisect over DTQN_OPT:
+    // bit 32 alone; 148 - 600 B with plain stores, profiles/r06_kernel_resources.md), and GRU nets do not ride the pipelined update
+    constexpr bool WT = FUSE || (kOptBwdWT && !(GRU && !DROP && MT >= 2 && NW == 8));
     auto g_store4 = [&](float* p, float4 v) {
         if constexpr (WT) dtqn_xch_store4(grs, (int)(p - grec) * 4, v);
         else st4(p, v);

@@ -14,6 +14,7 @@
 // Covers post-LN and identity-reordered layers, residual and GRU gates (the GRU gate as two-operand GEMMs with the gate
 // arithmetic in their epilogues); this is also where variants whose whole-sequence tile set exceeds LDS run
 // (identity or GRU at D >= 128).
+#include <cstdio>
 #include "dtqn_device.hpp"
 #include "dtqn_bwd_device.hpp"
 #include "dtqn_gru.hpp"
@@ -38,11 +39,14 @@ __device__ __forceinline__ void tl_start_skew(int ticks) {
     }
 }
 // skew of a launch of nblk workgroups on `slots` resident ones: only where the last round is between a quarter and three quarters full
-static inline int tl_skew_ticks(int nblk, int slots) {
-    const char* e = getenv("DTQN_SKEW_TICKS");
+// `ticks`: the kernel's own default -- the delay has to be a fair share of one workgroup's run time (measured at BASELINE config 4, forward
+// stage: the 60-us projection kernel 600; the fused layer kernel, 160 us: 0 -> 626 us, 600 -> 574, 1200 -> 558, 2400 -> 551, 4000 -> 575)
+static inline int tl_skew_ticks(int nblk, int slots, int ticks = 600, const char* own_env = nullptr) {
+    const char* e = own_env != nullptr ? getenv(own_env) : nullptr;
+    if (e == nullptr) e = getenv("DTQN_SKEW_TICKS");
     const int rest = nblk % slots;
     if (nblk <= slots || slots != 512 || rest * 4 < slots || rest * 4 > 3 * slots) return 0;
-    return e != nullptr ? atoi(e) : 600;
+    return e != nullptr ? atoi(e) : ticks;
 }
 
 constexpr int TNW = 8;                 // waves per workgroup of the GEMM / row-wise kernels
@@ -57,6 +61,7 @@ struct Fld {
 };
 static inline Fld fld(float* rec, long long stride, int off, int ld) { return Fld{rec + off, stride, ld}; }
 static inline Fld nofld() { return Fld{nullptr, 0, 0}; }
+__host__ __device__ __forceinline__ Fld nofld_dev() { return Fld{nullptr, 0, 0}; }
 __device__ __forceinline__ float* frow(const Fld& f, int s, int row) { return f.base + (size_t)s * f.stride + (size_t)row * f.ld; }
 
 // Dropout on the row-block path (net.dropout > 0): the keep-mask hash of the whole-sequence kernels (dtqn_device.hpp drop_keep),
@@ -857,6 +862,305 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_kernel(TlFfnArgs
     }
 }
 
+// ---- fused post-LN residual layer tail (round 6): everything of a layer behind its attention, in one launch ---------------------------
+//   s1 = RES + relu(O W_o^T + b_o);  u2 = LN1(s1);  s2 = u2 + relu(relu(u2 W_1^T + b_1) W_2^T + b_2);  ln_out = LN2(s2)
+//   (transformer.py:70-78) and, on the last layer of a network without a bag (HEAD): hh = relu(ln_out W_h1^T + b_h1), Q = hh W_h2^T + b_h2
+//   (dtqn.py:149-153, 216).
+// tl_wide_kernel<LN> + tl_ffn_kernel [+ tl_linear_kernel + tl_qhead_kernel] were two to four launches per layer whose short members ran
+// at a third of the matrix rate of the long one (BASELINE config 4: out-projection + LayerNorm 32 us for 1.6 GFLOP, head 31 + 17 us,
+// against 120 us for the 12.9 GFLOP of the feed-forward block) because a K = D product is over before its prologue is paid for, and
+// u2 / xf / hh made a round trip through memory between them.  Here the row block's tile stays in LDS from the attention output to the
+// Q rows: phase 0 leaves u2 in the input tile of the feed-forward loop, the closing LayerNorm leaves xf there for the head.  The
+// records are written exactly where the separate kernels wrote them, and only for the sequences the backward pass reads (s < n_save:
+// s1, u2, h, s2, hh, the ballots, the row statistics); ln_out always (the next layer's projection and attention read it).
+// Arithmetic: the same products in the same order as the separate kernels (same fragments, same 8-lane row butterflies, the 16-lane dot
+// products of tl_qhead_kernel), so Q does not depend on which way a layer went.
+struct TlLayerArgs {
+    Fld o, res, s1, m1, u2, st1;       // phase 0: O [LPB][D] in; RES = the stream entering the layer; s1 | m1 | u2 | st1 records out
+    const float *Woa, *Wob, *boa, *bob, *g1a, *g1b, *be1a, *be1b;
+    const float *Wopa, *Wopb;          // fragment-major F copies of W_o, or nullptr
+    TlFfnArgs f;                       // the feed-forward block and LN2 (f.in / f.res unused: the tile is u2; f.mode == 2, f.ln_out given)
+    // HEAD instantiation
+    Fld hh;
+    const float *Wh1a, *Wh1b, *bh1a, *bh1b, *Wh1pa, *Wh1pb;
+    const float *Wqa, *Wqb, *bqa, *bqb;
+    float* q;
+    long long q_seq_stride;
+    int q_row_stride, A, n;
+};
+template <int D, int MR, bool PK, bool HEAD>
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayerArgs a) {
+    constexpr int MT = MR / 16;
+    constexpr int KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
+    constexpr int LDX = D + 4, LDH = 128 + 4;
+    static_assert((NKA == 1 && NOT == 1) || (NKA == 2 && NOT == 2), "step sequence written for D in {64, 128, 256}");
+    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] o -> u2 -> s2 -> xf
+    float* Hs = Xt + MR * LDX;                                         // [MR][max(LDX, LDH)] relu(y1) | hidden chunk | hh
+    Thr t = make_thr();
+    const int blk = (int)blockIdx.x;
+    const int s = blk / a.f.rpb, row0 = (blk % a.f.rpb) * MR;
+    const bool second = s >= a.f.split, save = s < a.f.n_save;
+    int wc = t.wave * 16 + t.i;
+    float4 bf0[8], bf1[8];
+    // thread coordinates made opaque phase by phase: per-thread addresses of a later phase are recomputed there instead of living through
+    // the feed-forward loop next to two weight fragments and the accumulators (184 - 208 bytes of scratch per lane at <128, 64> otherwise)
+#define TL_LAYER_RELAUNDER() do { int tid_ = (int)threadIdx.x; DTQN_ASM_KEEP(tid_); t.tid = tid_; t.lane = tid_ & 63; t.wave = tid_ >> 6; t.i = t.lane & 15; t.kq = t.lane >> 4; wc = t.wave * 16 + t.i; } while (0)
+    // a [D][D] matrix (W_o, W_h1): output column j * 128 + wc, contraction chunk kc
+    auto fetchDD = [&](float4 (&bf)[8], const float* __restrict__ W, const float* __restrict__ Wp, int j, int kc) {
+        const int col = j * 128 + wc;
+        if constexpr (PK) {
+            wpack_fetch_f(bf, Wp, col < D ? j * 8 + t.wave : 0, NKA, kc, t.lane);
+            return;
+        }
+        const float* wr = W + (size_t)(col < D ? col : 0) * D + kc * KA + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    // [MR][D] = Xt [MR][D] * W^T, one 128-column block after the other; sink(j, col, rl, v) takes the accumulators (MFMA layout)
+    auto gemmDD = [&](const float* __restrict__ W, const float* __restrict__ Wp, auto&& sink) {
+#pragma unroll
+        for (int j = 0; j < NOT; ++j) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = zero4();
+            const int col = j * 128 + wc;
+            const bool live = col < D;
+            if (NKA == 1) {
+                if (live) frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, acc);
+            } else {
+                fetchDD(bf1, W, Wp, j, 1);
+                frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, acc);
+                if (j + 1 < NOT) fetchDD(bf0, W, Wp, j + 1, 0);
+                frag16_mma<KA, MT, 8>(Xt + KA, LDX, bf1, t, acc);
+            }
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) sink(col, m * 16 + t.kq * 4 + r4, acc[m][r4]);
+            }
+        }
+    };
+    // rows of Xt (+ `add` when given): 8 lanes per row whatever MR is (see tl_ffn_kernel), two-pass statistics, LN(row) to `dst` (global,
+    // may be null) and back into Xt when `keep`; the un-normalised row to `raw` and (mean, rstd) to `st` for the sequences the backward reads
+    auto ln_rows = [&](const float* add_tile, const Fld& res, const Fld& raw, const Fld& st, const Fld& dst, const float* gamma, const float* beta, bool keep) {
+        constexpr int LPR = 8, NV = D / (4 * LPR);
+        if (t.tid >= MR * LPR) return;
+        const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
+        float4 y[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            if (add_tile != nullptr) {
+                const float4 v = ld4(add_tile + rl * LDX + c), r = ld4(frow(res, s, row) + c);
+                y[j] = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+            } else {
+                y[j] = ld4(Xt + rl * LDX + c);
+            }
+            sum += (y[j].x + y[j].y) + (y[j].z + y[j].w);
+            if (save) st4(frow(raw, s, row) + c, y[j]);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sum += __shfl_xor(sum, m);
+        const float mean = sum * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float p = y[j].x - mean, q = y[j].y - mean, u = y[j].z - mean, w = y[j].w - mean;
+            sq += (p * p + q * q) + (u * u + w * w);
+        }
+#pragma unroll
+        for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 4 * LPR * j;
+            const float4 g = ld4(gamma + c), bb = ld4(beta + c);
+            const float4 o = make_float4((y[j].x - mean) * rstd * g.x + bb.x, (y[j].y - mean) * rstd * g.y + bb.y,
+                                         (y[j].z - mean) * rstd * g.z + bb.z, (y[j].w - mean) * rstd * g.w + bb.w);
+            if (dst.base != nullptr) st4(frow(dst, s, row) + c, o);
+            if (keep) st4(Xt + rl * LDX + c, o);
+        }
+        if (save && st.base != nullptr && part == 0) {
+            float* stp = st.base + (size_t)s * st.stride + (size_t)row * 2;
+            stp[0] = mean;
+            stp[1] = rstd;
+        }
+    };
+
+    // ---------------- phase 0: out-projection, residual gate, LayerNorm 1 ----------------
+    const float* __restrict__ Wo = second ? a.Wob : a.Woa;
+    const float* __restrict__ Wop = second ? a.Wopb : a.Wopa;
+    fetchDD(bf0, Wo, Wop, 0, 0);
+    {
+        const float* in0 = frow(a.o, s, row0);
+        for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
+            const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+            st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.o.ld + c));
+        }
+    }
+    tl_start_skew(a.f.skew);
+    __syncthreads();
+    {
+        const float* __restrict__ bo = second ? a.bob : a.boa;
+        float* mrec = save && a.m1.base != nullptr ? a.m1.base + (size_t)s * a.m1.stride : nullptr;
+        gemmDD(Wo, Wop, [&](int col, int rl, float acc) {
+            const float v = acc + bo[col];
+            if (mrec != nullptr) ballot_store(mrec, D / 16, row0 + rl, col, v > 0.f, t.lane);
+            Hs[rl * LDX + col] = fmaxf(v, 0.f);
+        });
+    }
+    const float* __restrict__ W1 = second ? a.f.W1b : a.f.W1a;
+    const float* __restrict__ W2 = second ? a.f.W2b : a.f.W2a;
+    const float* __restrict__ b1 = second ? a.f.b1b : a.f.b1a;
+    const float* __restrict__ b2 = second ? a.f.b2b : a.f.b2a;
+    const float* __restrict__ W1p = second ? a.f.W1pb : a.f.W1pa;
+    const float* __restrict__ W2p = second ? a.f.W2pb : a.f.W2pa;
+    auto fetchA = [&](float4 (&bf)[8], int j, int kc) {                // W1 [4D][D]: hidden unit j * 128 + wc, contraction chunk kc
+        if constexpr (PK) {
+            wpack_fetch_f(bf, W1p, j * 8 + t.wave, NKA, kc, t.lane);
+            return;
+        }
+        const float* wr = W1 + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    auto fetchB = [&](float4 (&bf)[8], int j, int ot) {                // W2 [D][4D]: output column ot * 128 + wc, hidden chunk j
+        const int col = ot * 128 + wc;
+        if constexpr (PK) {
+            wpack_fetch_f(bf, W2p, col < D ? ot * 8 + t.wave : 0, NJ, j, t.lane);
+            return;
+        }
+        const float* wr = W2 + (size_t)(col < D ? col : 0) * HID + j * 128 + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    fetchA(bf0, 0, 0);                                                 // in flight across the LayerNorm rows
+    __syncthreads();                                                   // relu(y1) complete; every reader of the o tile is through
+    ln_rows(Hs, a.res, a.s1, a.st1, save ? a.u2 : nofld_dev(), second ? a.g1b : a.g1a, second ? a.be1b : a.be1a, true);
+    __syncthreads();                                                   // the tile is u2
+
+    // ---------------- phase 1: feed-forward block (tl_ffn_kernel's loop) ----------------
+    TL_LAYER_RELAUNDER();
+    f32x4 accO[NOT][MT];
+#pragma unroll
+    for (int o = 0; o < NOT; ++o)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accO[o][m] = zero4();
+    float* mrec_h = save && a.f.mh.base != nullptr ? a.f.mh.base + (size_t)s * a.f.mh.stride : nullptr;
+    for (int j = 0; j < NJ; ++j) {
+        TL_LAYER_RELAUNDER();
+        f32x4 accA[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accA[m] = zero4();
+        if (NKA == 1) {
+            fetchB(bf1, j, 0);
+            frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, accA);
+        } else {
+            fetchA(bf1, j, 1);
+            frag16_mma<KA, MT, 8>(Xt, LDX, bf0, t, accA);
+            fetchB(bf0, j, 0);
+            frag16_mma<KA, MT, 8>(Xt + KA, LDX, bf1, t, accA);
+        }
+        {
+            const int hc = j * 128 + wc;
+            const float bv = b1[hc];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = m * 16 + t.kq * 4 + r4;
+                    const float v = accA[m][r4] + bv;
+                    if (mrec_h != nullptr) ballot_store(mrec_h, HID / 16, row0 + rl, hc, v > 0.f, t.lane);
+                    Hs[rl * LDH + wc] = fmaxf(v, 0.f);
+                }
+        }
+        __syncthreads();                                               // the hidden chunk is complete
+        if (save && a.f.h.base != nullptr) {
+            for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+                const int rl = idx >> 5, c = (idx & 31) * 4;
+                st4(frow(a.f.h, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+            }
+        }
+        if (NOT == 1) {
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            if (wc < D) frag16_mma<128, MT, 8>(Hs, LDH, bf1, t, accO[0]);
+        } else {
+            fetchB(bf1, j, 1);
+            frag16_mma<128, MT, 8>(Hs, LDH, bf0, t, accO[0]);
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            frag16_mma<128, MT, 8>(Hs, LDH, bf1, t, accO[NOT - 1]);
+        }
+        __syncthreads();                                               // ... and consumed
+    }
+    TL_LAYER_RELAUNDER();
+    // ---------------- phase 2: residual gate (u2 is the tile: s2 = tile + relu(y2), in place) and LayerNorm 2 ----------------
+    const float* __restrict__ Wh1 = second ? a.Wh1b : a.Wh1a;
+    const float* __restrict__ Wh1p = second ? a.Wh1pb : a.Wh1pa;
+    if constexpr (HEAD) fetchDD(bf0, Wh1, Wh1p, 0, 0);                // in flight across the LayerNorm rows
+    {
+        float* mrec_o = save && a.f.m2.base != nullptr ? a.f.m2.base + (size_t)s * a.f.m2.stride : nullptr;
+        const Drop fdr = tl_drop(a.f.drop, s);
+#pragma unroll
+        for (int o = 0; o < NOT; ++o) {
+            const int col = o * 128 + wc;
+            if (col < D) {
+                const float bv = b2[col];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int rl = m * 16 + t.kq * 4 + r4;
+                        const float v = drop_apply(fdr, DROP_FFN, a.f.layer, (uint32_t)((row0 + rl) * a.f.drop.dw + col), accO[o][m][r4] + bv);
+                        if (mrec_o != nullptr) ballot_store(mrec_o, D / 16, row0 + rl, col, v > 0.f, t.lane);
+                        Xt[rl * LDX + col] += fmaxf(v, 0.f);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    ln_rows(nullptr, a.res, a.f.out, a.f.ln_st, a.f.ln_out, second ? a.f.lgb : a.f.lga, second ? a.f.lbb : a.f.lba, HEAD);
+    if constexpr (HEAD) {
+        // ---------------- phase 3: Q head on the tile (xf) ----------------
+        __syncthreads();
+        TL_LAYER_RELAUNDER();
+        const float* __restrict__ bh = second ? a.bh1b : a.bh1a;
+        gemmDD(Wh1, Wh1p, [&](int col, int rl, float acc) { Hs[rl * LDX + col] = fmaxf(acc + bh[col], 0.f); });
+        __syncthreads();
+        if (save && a.hh.base != nullptr) {
+            for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
+                const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
+                st4(frow(a.hh, s, row0 + r) + c, ld4(Hs + r * LDX + c));
+            }
+        }
+        // 16 lanes per row (tl_qhead_kernel's arithmetic, the hidden row out of LDS)
+        const int c = t.tid & 15;
+        constexpr int NJQ = D / 64;
+        const float* Wq = (second ? a.Wqb : a.Wqa) + 4 * c;
+        const float* bq = second ? a.bqb : a.bqa;
+        for (int rr = t.tid >> 4; rr < MR; rr += TNT / 16) {
+            const int row = row0 + rr;
+            float4 hv[NJQ];
+#pragma unroll
+            for (int j = 0; j < NJQ; ++j) hv[j] = ld4(Hs + rr * LDX + 4 * c + 64 * j);
+            float* qrow = a.q + (size_t)s * a.q_seq_stride + (size_t)row * a.q_row_stride;
+            for (int ac = 0; ac < a.A; ++ac) {
+                float p = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJQ; ++j) {
+                    const float4 wv = ld4(Wq + (size_t)ac * D + 64 * j);
+                    p = fmaf(hv[j].x, wv.x, p); p = fmaf(hv[j].y, wv.y, p); p = fmaf(hv[j].z, wv.z, p); p = fmaf(hv[j].w, wv.w, p);
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) p += __shfl_xor(p, m);
+                if (row < a.n && c == (ac & 15)) qrow[ac] = p + bq[ac];
+            }
+        }
+    }
+}
+#undef TL_LAYER_RELAUNDER
+
 // ---- backward linear: dX[rows][KOUT] (op)= sum_p dY_p[rows][N] * W_p[N][KOUT],  p < nsrc <= 3 ------------------
 //   mode 0: OUT = v      mode 1: OUT = v where the saved ReLU ballot of OUT's forward twin is set, else 0
 //   mode 2: OUT += v
@@ -869,8 +1173,13 @@ struct TlDxArgs {
     Fld dy2, dy3;
     const float *W2, *W3;
     const float* Wp;                   // fragment-major B copy of W (dtqn_wpack.hpp; single-operand launches), or nullptr
+    // Q-head mode (hh.base != nullptr, round 6): dY is not read but MADE in the staging -- dhh = (dq W_q) * [hh > 0], tl_head_bwd_kernel's
+    // arithmetic -- and written to `dy` (the dhh record the weight gradients read) by the first column block: one launch instead of two
+    Fld hh, dq;
+    const float* Wq;
+    int A;
 };
-template <int KC, int MR, bool PK>
+template <int KC, int MR, bool PK, bool HEADM = false>
 __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     constexpr int MT = MR / 16;
     constexpr int LDT = KC + 4;
@@ -894,6 +1203,26 @@ __global__ __launch_bounds__(TNT) void tl_dx_kernel(TlDxArgs a) {
     auto stage = [&](int kc) {
         const int p = kc / per, j = kc - p * per;
         const Fld& dyf = p == 0 ? a.dy : p == 1 ? a.dy2 : a.dy3;
+        if constexpr (HEADM) {
+            for (int idx = t.tid; idx < MR * (KC / 4); idx += TNT) {
+                const int r = idx / (KC / 4), c0 = j * KC + (idx - r * (KC / 4)) * 4;
+                const float4 hv4 = ld4(frow(a.hh, s, row0 + r) + c0);
+                const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+                const float* dqr = frow(a.dq, s, row0 + r);
+                float g4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = 0.f;
+                    if (hv[e] > 0.f)
+                        for (int c = 0; c < a.A; ++c) g = fmaf(dqr[c], a.Wq[(size_t)c * a.N + c0 + e], g);
+                    g4[e] = g;
+                }
+                const float4 gv = make_float4(g4[0], g4[1], g4[2], g4[3]);
+                st4(Yt + r * LDT + (c0 - j * KC), gv);
+                if (blockIdx.y == 0) st4(frow(a.dy, s, row0 + r) + c0, gv);
+            }
+            return;
+        }
         const float* dy0 = frow(dyf, s, row0) + (size_t)j * KC;
         for (int idx = t.tid; idx < MR * (KC / 4); idx += TNT) {
             const int r = idx / (KC / 4), c = (idx - r * (KC / 4)) * 4;
@@ -1101,6 +1430,285 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_ffn_bwd_kernel(TlFfn
         }
         if (o + 1 < NOT) __syncthreads();
     }
+}
+
+// ---- fused backward of a post-LN residual layer's row-local half (round 6) -----------------------------------------------------------
+//   ds2 = LN2'(G);  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  t = ds2 + dh' W1;  ds1 = LN1'(t);  da = ds1 * [a > 0];  dO = da W_o
+//   (the mirror of tl_layer_kernel; loss.backward() through transformer.py:70-78)
+// tl_layernorm_bwd + tl_ffn_bwd + tl_layernorm_bwd + tl_mask + tl_dx were five launches per layer, four of them 6 - 15 us long for a
+// few MB of traffic each (BASELINE config 4: 70 us of a 332 us chain).  One workgroup per (sequence, 64-row block) -- the granularity of
+// the LayerNorm column partials (DtqnNet.sp_parts) -- keeps the block's gradient tile in LDS from the stream gradient entering the layer
+// to the attention-output gradient: the two LayerNorm backwards run on the tile with tl_layernorm_bwd_kernel's lane map (8 lanes per
+// row, row butterfly over the 8 lanes, column sums over the 8 rows of a wave and then over the waves through LDS, same order of
+// additions), the stream gradient G is rewritten in place (ds2 after the first, ds1 after the second: what flows on to the layer's
+// input), and df | dh' | da | dO and the d gamma | d beta partials go to the records the weight gradients read.
+struct TlChainBwdArgs {
+    TlFfnBwdArgs f;                    // f.dy = f.out = G (in place), f.m2, f.df, f.dhp, f.mh, W1 / W2 (+ packed), drop, layer; f.rpb = 64-row blocks per sequence
+    Fld s2, st2, s1, st1;              // LayerNorm inputs and (mean, rstd) of the forward
+    const float *gamma2, *gamma1;
+    float* small;                      // per-(sequence, row block) partial records
+    long long small_stride;
+    int dgb2_off, dgb1_off;
+    Fld m1, da, dO;
+    const float *Wo, *Wop;             // W_o [D][D]; its fragment-major B copy or nullptr
+};
+// LayerNorm backward of the 8 rows of a wave (lane = 8 * row-in-wave + part): y = dL/d(LN output), xp = this lane's piece of the LN input
+// row; out: o = dL/d(LN input), and the wave's column sums of (y * xhat, y) in red[wave][2][D]
+template <int D>
+__device__ __forceinline__ void tl_ln_bwd_rows8(const float4 (&y)[D / 32], const float* xp, float mean, float rstd, const float* gamma, int part,
+                                                float* red, const Thr& t, float4 (&o)[D / 32]) {
+    constexpr int NV = D / 32;
+    float4 xh[NV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float4 x = ld4(xp + 32 * j), gm = ld4(gamma + part * 4 + 32 * j);
+        xh[j] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+        const float4 g = make_float4(y[j].x * gm.x, y[j].y * gm.y, y[j].z * gm.z, y[j].w * gm.w);
+        c1 += (g.x + g.y) + (g.z + g.w);
+        c2 += (g.x * xh[j].x + g.y * xh[j].y) + (g.z * xh[j].z + g.w * xh[j].w);
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) { c1 += __shfl_xor(c1, m); c2 += __shfl_xor(c2, m); }
+    c1 *= (1.0f / D);
+    c2 *= (1.0f / D);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        float sg[4] = {y[j].x * xh[j].x, y[j].y * xh[j].y, y[j].z * xh[j].z, y[j].w * xh[j].w};
+        float sb[4] = {y[j].x, y[j].y, y[j].z, y[j].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int m = 8; m < 64; m <<= 1) { sg[c] += __shfl_xor(sg[c], m); sb[c] += __shfl_xor(sb[c], m); }
+        }
+        if (t.lane < 8) {
+            st4(red + (t.wave * 2 + 0) * D + part * 4 + 32 * j, make_float4(sg[0], sg[1], sg[2], sg[3]));
+            st4(red + (t.wave * 2 + 1) * D + part * 4 + 32 * j, make_float4(sb[0], sb[1], sb[2], sb[3]));
+        }
+        const float4 gm = ld4(gamma + part * 4 + 32 * j);
+        o[j].x = rstd * (y[j].x * gm.x - c1 - xh[j].x * c2);
+        o[j].y = rstd * (y[j].y * gm.y - c1 - xh[j].y * c2);
+        o[j].z = rstd * (y[j].z * gm.z - c1 - xh[j].z * c2);
+        o[j].w = rstd * (y[j].w * gm.w - c1 - xh[j].w * c2);
+    }
+}
+// v where the saved ReLU ballots of row `row`, columns c .. c + 3 are set (word layout of ballot_store), else 0
+__device__ __forceinline__ float4 tl_mask4(const unsigned long long* mrec, int ctiles, int row, int c, float4 v) {
+    const unsigned long long w = mrec[((row >> 4) * ctiles + (c >> 4)) * 4 + (row & 3)];
+    const int b0 = (((row >> 2) & 3) << 4) + (c & 15);
+    v.x = ((w >> b0) & 1ull) ? v.x : 0.f;
+    v.y = ((w >> (b0 + 1)) & 1ull) ? v.y : 0.f;
+    v.z = ((w >> (b0 + 2)) & 1ull) ? v.z : 0.f;
+    v.w = ((w >> (b0 + 3)) & 1ull) ? v.w : 0.f;
+    return v;
+}
+template <int D, bool PK>
+__global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_chain_bwd_kernel(TlChainBwdArgs ca) {
+    constexpr int MR = 64, MT = MR / 16, KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128, NV = D / 32;
+    constexpr int LDX = D + 4, LDH = 128 + 4;
+    static_assert((NKA == 1 && NOT == 1) || (NKA == 2 && NOT == 2), "step sequence written for D in {64, 128, 256}");
+    const TlFfnBwdArgs& a = ca.f;
+    float* Yt = reinterpret_cast<float*>(dtqn_smem);                   // [MR][LDX] df rows, then du -> da rows
+    float* Hs = Yt + MR * LDX;                                         // [MR][LDH] dh' chunk / dO staging
+    float* red = Hs + MR * LDH;                                        // [TNW][2][D] LayerNorm column sums
+    Thr t = make_thr();
+    const int s = (int)blockIdx.x / a.rpb, rb = (int)blockIdx.x % a.rpb, row0 = rb * MR;
+    int wc = t.wave * 16 + t.i;
+    // (thread coordinates re-derived from ONE opaque register at the phase boundaries: nothing per-thread computed before a phase lives through it)
+#define TL_CHAIN_RELAUNDER() do { int tid_ = (int)threadIdx.x; DTQN_ASM_KEEP(tid_); t.tid = tid_; t.lane = tid_ & 63; t.wave = tid_ >> 6; t.i = t.lane & 15; t.kq = t.lane >> 4; wc = t.wave * 16 + t.i; } while (0)
+    // phase A fragment: W2[n][j * 128 + wc], n over contraction chunk kc (KA rows); phase B: W1[j * 128 + k][ot * 128 + wc], k < 128
+    auto fetchA = [&](float (&bf)[32], int j, int kc) {
+        if constexpr (PK) {                                            // W2 [D][4D]: contraction over its D rows, output = hidden columns
+            wpack_fetch_b(bf, a.W2p, j * 8 + t.wave, NKA, kc, t.lane);
+            return;
+        }
+        const float* wp = a.W2 + (size_t)(kc * KA + t.kq * (KA / 4)) * HID + j * 128 + wc;
+#pragma unroll
+        for (int q = 0; q < KA / 4; ++q) bf[q] = wp[(size_t)q * HID];
+    };
+    auto fetchB = [&](float (&bf)[32], int j, int ot) {
+        const int col = ot * 128 + wc;
+        if constexpr (PK) {                                            // W1 [4D][D]: contraction over its 4D rows (chunk j), output = D columns
+            wpack_fetch_b(bf, a.W1p, col < D ? ot * 8 + t.wave : 0, NJ, j, t.lane);
+            return;
+        }
+        const float* wp = a.W1 + (size_t)(j * 128 + t.kq * 32) * D + (col < D ? col : 0);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) bf[q] = wp[(size_t)q * D];
+    };
+    // W_o [D][D], dO = da W_o: contraction over its rows (chunk kc of KA), output column ot * 128 + wc
+    auto fetchO = [&](float (&bf)[32], int ot, int kc) {
+        const int col = ot * 128 + wc;
+        if constexpr (PK) {
+            wpack_fetch_b(bf, ca.Wop, col < D ? ot * 8 + t.wave : 0, NKA, kc, t.lane);
+            return;
+        }
+        const float* wp = ca.Wo + (size_t)(kc * KA + t.kq * (KA / 4)) * D + (col < D ? col : 0);
+#pragma unroll
+        for (int q = 0; q < KA / 4; ++q) bf[q] = wp[(size_t)q * D];
+    };
+    float bf0[32], bf1[32];
+    fetchA(bf0, 0, 0);
+    float* dgb = ca.small + ((size_t)s * a.rpb + rb) * ca.small_stride;
+    // ---------------- LayerNorm-2 backward on the rows of G, the gate's ReLU mask, df ----------------
+    {
+        const int rl = t.tid >> 3, part = t.tid & 7, row = row0 + rl;
+        const float* stp = ca.st2.base + (size_t)s * ca.st2.stride + (size_t)row * 2;
+        const float mean = stp[0], rstd = stp[1];
+        float* gp = frow(a.dy, s, row) + part * 4;
+        float4 y[NV], o[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) y[j] = ld4(gp + 32 * j);
+        tl_ln_bwd_rows8<D>(y, frow(ca.s2, s, row) + part * 4, mean, rstd, ca.gamma2, part, red, t, o);
+        const unsigned long long* mrec = reinterpret_cast<const unsigned long long*>(a.m2.base + (size_t)s * a.m2.stride);
+        const Drop bdr = tl_drop(a.drop, s);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 32 * j;
+            st4(gp + 32 * j, o[j]);                                    // ds2: the skip path of the residual gate (read back in the epilogue)
+            float4 v = tl_mask4(mrec, D / 16, row, c, o[j]);
+            if (bdr.thresh != 0u) {
+                const uint32_t e0 = (uint32_t)(row * a.drop.dw + c);
+                v.x = drop_apply(bdr, DROP_FFN, a.layer, e0, v.x);
+                v.y = drop_apply(bdr, DROP_FFN, a.layer, e0 + 1, v.y);
+                v.z = drop_apply(bdr, DROP_FFN, a.layer, e0 + 2, v.z);
+                v.w = drop_apply(bdr, DROP_FFN, a.layer, e0 + 3, v.w);
+            }
+            st4(frow(a.df, s, row) + c, v);
+            st4(Yt + rl * LDX + c, v);
+        }
+    }
+    __syncthreads();
+    for (int idx = t.tid; idx < 2 * D; idx += TNT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) v += red[w * 2 * D + idx];
+        dgb[ca.dgb2_off + idx] = v;
+    }
+    // ---------------- feed-forward backward (tl_ffn_bwd_kernel's loop) ----------------
+    f32x4 accO[NOT][MT];
+#pragma unroll
+    for (int o = 0; o < NOT; ++o)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accO[o][m] = zero4();
+    const unsigned long long* mrec_h = reinterpret_cast<const unsigned long long*>(a.mh.base + (size_t)s * a.mh.stride);
+    for (int j = 0; j < NJ; ++j) {
+        TL_CHAIN_RELAUNDER();
+        f32x4 accA[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) accA[m] = zero4();
+        if (NKA == 1) {
+            fetchB(bf1, j, 0);
+            frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, accA);
+        } else {
+            fetchA(bf1, j, 1);
+            frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, accA);
+            fetchB(bf0, j, 0);
+            frag_dyw_mma_n<KA, MT>(Yt + KA, LDX, bf1, t, accA);
+        }
+        {
+            const int hc = j * 128 + wc;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = m * 16 + t.kq * 4 + r4, row = row0 + rl;
+                    const unsigned long long w = mrec_h[((row >> 4) * (HID / 16) + (hc >> 4)) * 4 + r4];
+                    Hs[rl * LDH + wc] = ((w >> t.lane) & 1ull) ? accA[m][r4] : 0.f;
+                }
+        }
+        __syncthreads();                                               // the dh' chunk is complete
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4;
+            st4(frow(a.dhp, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+        }
+        if (NOT == 1) {
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            if (wc < D) frag_dyw_mma_n<128, MT>(Hs, LDH, bf1, t, accO[0]);
+        } else {
+            fetchB(bf1, j, 1);
+            frag_dyw_mma_n<128, MT>(Hs, LDH, bf0, t, accO[0]);
+            if (j + 1 < NJ) fetchA(bf0, j + 1, 0);
+            frag_dyw_mma_n<128, MT>(Hs, LDH, bf1, t, accO[NOT - 1]);
+        }
+        __syncthreads();                                               // ... and consumed
+    }
+    TL_CHAIN_RELAUNDER();
+    fetchO(bf0, 0, 0);                                                 // first W_o fragment of the last product: in flight across the LayerNorm rows
+    // du into the (spent) df tile
+#pragma unroll
+    for (int o = 0; o < NOT; ++o) {
+        const int col = o * 128 + wc;
+        if (col < D) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Yt[(m * 16 + t.kq * 4 + r4) * LDX + col] = accO[o][m][r4];
+        }
+    }
+    __syncthreads();
+    // ---------------- dL/du2 = ds2 + du;  LayerNorm-1 backward;  G = ds1;  da = ds1 * [a > 0] (into the tile, in place) ----------------
+    TL_CHAIN_RELAUNDER();
+    {
+        const int rl = t.tid >> 3, part = t.tid & 7, row = row0 + rl;
+        const float* stp = ca.st1.base + (size_t)s * ca.st1.stride + (size_t)row * 2;
+        const float mean = stp[0], rstd = stp[1];
+        float* gp = frow(a.out, s, row) + part * 4;
+        float4 y[NV], o[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 p = ld4(gp + 32 * j), v = ld4(Yt + rl * LDX + part * 4 + 32 * j);
+            y[j] = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+        }
+        tl_ln_bwd_rows8<D>(y, frow(ca.s1, s, row) + part * 4, mean, rstd, ca.gamma1, part, red, t, o);
+        const unsigned long long* mrec = reinterpret_cast<const unsigned long long*>(ca.m1.base + (size_t)s * ca.m1.stride);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = part * 4 + 32 * j;
+            st4(gp + 32 * j, o[j]);
+            const float4 v = tl_mask4(mrec, D / 16, row, c, o[j]);
+            st4(frow(ca.da, s, row) + c, v);
+            st4(Yt + rl * LDX + c, v);
+        }
+    }
+    __syncthreads();
+    for (int idx = t.tid; idx < 2 * D; idx += TNT) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < TNW; ++w) v += red[w * 2 * D + idx];
+        dgb[ca.dgb1_off + idx] = v;
+    }
+    // ---------------- dO = da W_o, one 128-column block after the other ----------------
+    TL_CHAIN_RELAUNDER();
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) {
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = zero4();
+        const bool live = ot * 128 + wc < D;
+        if (NKA == 1) {
+            if (live) frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, acc);
+        } else {
+            fetchO(bf1, ot, 1);
+            frag_dyw_mma_n<KA, MT>(Yt, LDX, bf0, t, acc);
+            if (ot + 1 < NOT) fetchO(bf0, ot + 1, 0);
+            frag_dyw_mma_n<KA, MT>(Yt + KA, LDX, bf1, t, acc);
+        }
+        if (ot > 0) __syncthreads();                                   // the staging tile's previous block has left
+        if (live) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Hs[(m * 16 + t.kq * 4 + r4) * LDH + wc] = acc[m][r4];
+        }
+        __syncthreads();
+        for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+            const int rl = idx >> 5, c = (idx & 31) * 4, cg = ot * 128 + c;
+            if (cg >= D) continue;
+            st4(frow(ca.dO, s, row0 + rl) + cg, ld4(Hs + rl * LDH + c));
+        }
+    }
+#undef TL_CHAIN_RELAUNDER
 }
 
 // ---- attention per (sequence, head) -----------------------------------------------------------------------------
@@ -1753,8 +2361,14 @@ __global__ __launch_bounds__(TNT) void tl_copy_kernel(TlCopyArgs a) {
 }
 
 // ---- launch helpers --------------------------------------------------------------------------------------------------------
+// DTQN_TL_TRACE=1 (tests): one line per launch on stderr, so a test can tell WHICH kernels an update went through
+static inline bool tl_trace_on() {
+    const char* e = getenv("DTQN_TL_TRACE");                            // (read per launch: a test switches it on for one case)
+    return e != nullptr && e[0] == '1';
+}
 #define TL_LAUNCH(kernel, grid, block, lds, stream, args)                                                            \
     do {                                                                                                             \
+        if (tl_trace_on()) fprintf(stderr, "tl_launch %s\n", #kernel);                                               \
         if ((lds) > 48 * 1024) {            /* beyond the default dynamic-LDS limit: raise it once per kernel and device */   \
             static size_t tl_attr_lds_[kMaxDevices] = {};                                                            \
             raise_lds_limit(reinterpret_cast<const void*>(&kernel), (lds), tl_attr_lds_);                               \
@@ -1825,6 +2439,15 @@ static int launch_ffn_bwd(TlFfnBwdArgs a, int S, hipStream_t stream) {
     }
     return DTQN_OK;
 }
+template <int D>
+static int launch_chain_bwd(const TlChainBwdArgs& a, int S, hipStream_t stream) {
+    {
+        const size_t lds = ((size_t)64 * ((D + 4) + (128 + 4)) + (size_t)TNW * 2 * D) * sizeof(float);
+        if (D % 128 == 0 && a.f.W1p != nullptr && a.f.W2p != nullptr && a.Wop != nullptr) TL_LAUNCH((tl_chain_bwd_kernel<D, D % 128 == 0>), dim3(S * a.f.rpb), dim3(TNT), lds, stream, a);
+        else TL_LAUNCH((tl_chain_bwd_kernel<D, false>), dim3(S * a.f.rpb), dim3(TNT), lds, stream, a);
+        return DTQN_OK;
+    }
+}
 template <int D, int MR>
 static int launch_wide_rows(TlWideArgs a, int nblk, bool ln, bool pk, size_t lds, hipStream_t stream) {
     constexpr bool CAN = D % 128 == 0;                                 // fragment-major weights exist for these widths
@@ -1868,16 +2491,45 @@ static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     }
     return launch_ffn_rows<D, 64>(a, S * a.rpb, pk, stream);
 }
+// the fused layer tail: rows per workgroup by launch_ffn's rule (its long phase is the feed-forward loop)
+template <int D, int MR>
+static int launch_layer_rows(TlLayerArgs a, int nblk, bool pk, bool head, hipStream_t stream) {
+    constexpr int LDX = D + 4, LDH = 128 + 4;
+    const size_t lds = (size_t)MR * (LDX + (LDX > LDH ? LDX : LDH)) * sizeof(float);
+    a.f.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1), 2000, "DTQN_SKEW_LAYER");
+    constexpr bool CAN = D % 128 == 0;
+    if (pk && head) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, true>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (pk) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, false>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (head) TL_LAUNCH((tl_layer_kernel<D, MR, false, true>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else TL_LAUNCH((tl_layer_kernel<D, MR, false, false>), dim3(nblk), dim3(TNT), lds, stream, a);
+    return DTQN_OK;
+}
+template <int D>
+static int launch_layer(TlLayerArgs a, int S, bool head, hipStream_t stream) {
+    const int blocks64 = S * a.f.rpb, slots = 256 * (D <= 128 ? 2 : 1);
+    const bool pk = D % 128 == 0 && a.f.W1pa != nullptr && a.f.W1pb != nullptr && a.f.W2pa != nullptr && a.f.W2pb != nullptr &&
+                    a.Wopa != nullptr && a.Wopb != nullptr && (!head || (a.Wh1pa != nullptr && a.Wh1pb != nullptr));
+    if (tl_rows32(blocks64, slots, D, "DTQN_ROWS_FFN")) {
+        a.f.rpb *= 2;
+        return launch_layer_rows<D, 32>(a, S * a.f.rpb, pk, head, stream);
+    }
+    return launch_layer_rows<D, 64>(a, S * a.f.rpb, pk, head, stream);
+}
 template <int KC>
 static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
     const int cb = (a.KOUT + 16 * TNW - 1) / (16 * TNW);
-    if (tl_half_rows(S * a.rpb * cb, 512)) {
+    if (a.hh.base == nullptr && tl_half_rows(S * a.rpb * cb, 512)) {
         a.rpb *= 2;
         const size_t lds = (size_t)32 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);   // operand tile, reused by the epilogue tile
         if (KC == 128 && a.Wp != nullptr && a.nsrc == 1) TL_LAUNCH((tl_dx_kernel<KC, 32, KC == 128>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
         else TL_LAUNCH((tl_dx_kernel<KC, 32, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     } else {
         const size_t lds = (size_t)64 * ((KC > 16 * TNW ? KC : 16 * TNW) + 4) * sizeof(float);
+        if (a.hh.base != nullptr) {                                    // Q-head mode (64-row workgroups)
+            if (KC == 128 && a.Wp != nullptr) TL_LAUNCH((tl_dx_kernel<KC, 64, KC == 128, true>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+            else TL_LAUNCH((tl_dx_kernel<KC, 64, false, true>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
+            return DTQN_OK;
+        }
         if (KC == 128 && a.Wp != nullptr && a.nsrc == 1) TL_LAUNCH((tl_dx_kernel<KC, 64, KC == 128>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
         else TL_LAUNCH((tl_dx_kernel<KC, 64, false>), dim3(S * a.rpb, cb), dim3(TNT), lds, stream, a);
     }
@@ -2040,6 +2692,10 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     };
     // width-padded networks keep their LayerNorms in launches of their own (the fused epilogues below take the statistics over all D columns)
     const bool padded = net.d_real > 0;
+    // DTQN_LAYER_FUSE=0: the separate launches (out-projection + LayerNorm | feed-forward + LayerNorm | head | Q) for A/B timing and tests
+    const char* lfe = getenv("DTQN_LAYER_FUSE");
+    const bool fuse_tail = !gru && !ident && !padded && net.bag_size == 0 && getenv("DTQN_NO_WIDE") == nullptr && (lfe == nullptr || atoi(lfe) != 0);
+    bool head_done = false;
     for (int l = 0; l < net.num_layers; ++l) {
         const int tb = net.off_layer0 + l * net.layer_stride, ab = L0(l);
         const bool last = l + 1 == net.num_layers;
@@ -2066,6 +2722,41 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             at.D = D; at.lpb = lpb; at.n = n; at.drop = drop; at.layer = l;
             at.hd_eff = (float)(net.hd_real > 0 ? net.hd_real : HD);
             if ((rc = launch_attn(at, S, H, HD, stream)) != DTQN_OK) return rc;
+        }
+        // post-LN residual layer: everything behind the attention in ONE launch (tl_layer_kernel), with the Q head on the last layer
+        if (fuse_tail) {
+            TlLayerArgs la = {};
+            la.o = F(ab + net.al_o, D); la.res = stream_in; la.s1 = s1; la.u2 = u2;
+            la.m1 = training ? F(ab + net.al_m1, 0) : nofld(); la.st1 = st1;
+            la.Woa = theta_a + tb + net.lo_out_w; la.Wob = theta_b + tb + net.lo_out_w; la.boa = theta_a + tb + net.lo_out_b; la.bob = theta_b + tb + net.lo_out_b;
+            la.Wopa = wpack_f(wplan, pk_a, tb + net.lo_out_w); la.Wopb = wpack_f(wplan, pk_b, tb + net.lo_out_w);
+            la.g1a = theta_a + tb + net.lo_ln1_w; la.g1b = theta_b + tb + net.lo_ln1_w; la.be1a = theta_a + tb + net.lo_ln1_b; la.be1b = theta_b + tb + net.lo_ln1_b;
+            TlFfnArgs& fa = la.f;
+            fa.W1a = theta_a + tb + net.lo_f1_w; fa.W1b = theta_b + tb + net.lo_f1_w; fa.b1a = theta_a + tb + net.lo_f1_b; fa.b1b = theta_b + tb + net.lo_f1_b;
+            fa.W2a = theta_a + tb + net.lo_f2_w; fa.W2b = theta_b + tb + net.lo_f2_w; fa.b2a = theta_a + tb + net.lo_f2_b; fa.b2b = theta_b + tb + net.lo_f2_b;
+            fa.split = split; fa.rpb = rpb; fa.drop = drop; fa.layer = l;
+            fa.W1pa = wpack_f(wplan, pk_a, tb + net.lo_f1_w); fa.W1pb = wpack_f(wplan, pk_b, tb + net.lo_f1_w);
+            fa.W2pa = wpack_f(wplan, pk_a, tb + net.lo_f2_w); fa.W2pb = wpack_f(wplan, pk_b, tb + net.lo_f2_w);
+            fa.n_save = training ? src.batch : 0;
+            fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
+            fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
+            fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
+            fa.mode = 2; fa.out = s2;
+            fa.ln_out = last ? F(rm.xf, D) : F(L0(l + 1) + net.al_u1, D);
+            fa.ln_st = st2;
+            fa.lga = theta_a + tb + net.lo_ln2_w; fa.lgb = theta_b + tb + net.lo_ln2_w;
+            fa.lba = theta_a + tb + net.lo_ln2_b; fa.lbb = theta_b + tb + net.lo_ln2_b;
+            const bool head = last;
+            if (head) {
+                la.hh = F(rm.hh, D);
+                la.Wh1a = theta_a + net.off_head1_w; la.Wh1b = theta_b + net.off_head1_w; la.bh1a = theta_a + net.off_head1_b; la.bh1b = theta_b + net.off_head1_b;
+                la.Wh1pa = wpack_f(wplan, pk_a, net.off_head1_w); la.Wh1pb = wpack_f(wplan, pk_b, net.off_head1_w);
+                la.Wqa = theta_a + net.off_head2_w; la.Wqb = theta_b + net.off_head2_w; la.bqa = theta_a + net.off_head2_b; la.bqb = theta_b + net.off_head2_b;
+                la.q = q_out; la.q_seq_stride = q_seq_stride; la.q_row_stride = q_row_stride; la.A = net.num_actions; la.n = n;
+                head_done = true;
+            }
+            if ((rc = launch_layer<D>(la, S, head, stream)) != DTQN_OK) return rc;
+            continue;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
         if (!gru && !ident && !padded && getenv("DTQN_NO_WIDE") == nullptr) {
@@ -2164,7 +2855,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         if ((rc = linear(F(rm.bag_o, D), D, D, net.off_bag_out_w, net.off_bag_out_b, F(rm.xcat + D, 2 * D), 0, nofld(), nofld())) != DTQN_OK) return rc;
         if ((rc = linear(xw, 2 * D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
     } else
-    if ((rc = linear(xf, D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
+    if (!head_done && (rc = linear(xf, D, D, net.off_head1_w, net.off_head1_b, F(rm.hh, D), 1, nofld(), nofld())) != DTQN_OK) return rc;
+    if (head_done) return DTQN_OK;
     TlQArgs qa;
     qa.hh = F(rm.hh, D);
     qa.W2a = theta_a + net.off_head2_w; qa.W2b = theta_b + net.off_head2_w;
@@ -2201,7 +2893,11 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         a.ep_idx = td.ep_idx; a.start = td.start; a.batch = B; a.history = td.history; a.gamma = td.gamma;
         TL_LAUNCH(tl_loss_kernel, dim3(B), dim3(256), 0, stream, a);
     }
-    {
+    // the VALU half of the Q-head backward rides in the staging of the dL/dxf product below (TlDxArgs, Q-head mode); with a bag the head's
+    // input is [working memory | persistent memory] and the separate launch stays.  DTQN_HEAD_FUSE=0: the separate launch (A/B, tests)
+    const char* hfe = getenv("DTQN_HEAD_FUSE");
+    const bool head_fused = net.bag_size == 0 && (hfe == nullptr || atoi(hfe) != 0);
+    if (!head_fused) {
         TlHeadBwdArgs a;
         a.hh = FA(net.ao_hh, D); a.dq = FG(net.go_dq, net.ap); a.dhh = FG(net.go_dhh, D);
         a.W2 = theta + net.off_head2_w; a.D = D; a.A = net.num_actions; a.rpb = rpb;
@@ -2281,11 +2977,40 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         if ((rc = dx(FG(net.go_bag_dq, D), D, net.off_bag_in_w, D, G, 2, nofld())) != DTQN_OK) return rc;                  // + dq W_q
         if ((rc = dx(FG(net.go_bag_dkv, 2 * D), 2 * D, net.off_bag_in_w + D * D, D, FG(net.go_bag_de, D), 0, nofld())) != DTQN_OK) return rc;   // d E_bag
     } else
+    if (head_fused) {
+        TlDxArgs a = {};
+        a.dy = FG(net.go_dhh, D); a.out = G; a.W = theta + net.off_head1_w; a.N = D; a.KOUT = D; a.rpb = rpb; a.mode = 0; a.nsrc = 1;
+        a.Wp = wpack_b(wplan, pk, net.off_head1_w);
+        a.hh = FA(net.ao_hh, D); a.dq = FG(net.go_dq, net.ap); a.Wq = theta + net.off_head2_w; a.A = net.num_actions;
+        if ((rc = launch_dx<KC>(a, B, stream)) != DTQN_OK) return rc;                                    // dhh and dL/dxf
+    } else
     if ((rc = dx(FG(net.go_dhh, D), D, net.off_head1_w, D, G, 0, nofld())) != DTQN_OK) return rc;       // dL/dxf
+    // DTQN_BWD_CHAIN=0: the separate launches (A/B timing, tests).  64-row workgroups only: the LayerNorm column partials are per 64-row block
+    const char* bce = getenv("DTQN_BWD_CHAIN");
+    const char* ffb0 = getenv("DTQN_FFN_BWD");
+    // d_model 256 (one workgroup per compute unit): DTQN_BWD_CHAIN256 (the 64-row chain against the 32-row separate launches is a measured choice)
+    const char* bc256 = getenv("DTQN_BWD_CHAIN256");
+    const bool chain = !gru && !ident && net.d_real == 0 && (bce == nullptr || atoi(bce) != 0) &&
+                       (D <= 128 ? (ffb0 == nullptr || atoi(ffb0) != 0) && !tl_rows32(B * rpb, 256 * 2, D, "DTQN_ROWS_FFNB")
+                                 : (bc256 != nullptr && atoi(bc256) != 0));
     for (int l = net.num_layers - 1; l >= 0; --l) {
         const int tb = net.off_layer0 + l * net.layer_stride;
         const int ab = net.ao_layer0 + l * net.act_layer_stride, gb = net.go_layer0 + l * net.grd_layer_stride;
         const int sm = net.so_ln + l * 4 * D;
+        if (chain) {
+            // post-LN residual layer: LN2', the feed-forward block, LN1', the gate mask and dO = da W_o in one launch (tl_chain_bwd_kernel)
+            TlChainBwdArgs c = {};
+            c.f.dy = G; c.f.out = G; c.f.out_mode = 2; c.f.m2 = FA(ab + net.al_m2, 0); c.f.df = FG(gb + net.gl_df, D);
+            c.f.dhp = FG(gb + net.gl_dhp, 4 * D); c.f.mh = FA(ab + net.al_mh, 0);
+            c.f.W1 = theta + tb + net.lo_f1_w; c.f.W2 = theta + tb + net.lo_f2_w; c.f.rpb = rpb; c.f.drop = drop; c.f.layer = l;
+            c.f.W1p = wpack_b(wplan, pk, tb + net.lo_f1_w); c.f.W2p = wpack_b(wplan, pk, tb + net.lo_f2_w);
+            c.s2 = FA(ab + net.al_s2, D); c.st2 = FA(ab + net.al_st2, 2); c.s1 = FA(ab + net.al_s1, D); c.st1 = FA(ab + net.al_st1, 2);
+            c.gamma2 = theta + tb + net.lo_ln2_w; c.gamma1 = theta + tb + net.lo_ln1_w;
+            c.small = td.small; c.small_stride = net.sp_stride; c.dgb2_off = sm + 2 * D; c.dgb1_off = sm;
+            c.m1 = FA(ab + net.al_m1, 0); c.da = FG(gb + net.gl_da, D); c.dO = FG(net.go_do, D);
+            c.Wo = theta + tb + net.lo_out_w; c.Wop = wpack_b(wplan, pk, tb + net.lo_out_w);
+            if ((rc = launch_chain_bwd<D>(c, B, stream)) != DTQN_OK) return rc;
+        } else {
         // post-LN: x_out = LN2(s2)
         if (!ident && (rc = ln_bwd(G, FA(ab + net.al_s2, D), FA(ab + net.al_st2, 2), tb + net.lo_ln2_w, sm + 2 * D, false)) != DTQN_OK) return rc;
         // s2 = (u2 | s1) + relu(f):  df = ds2 * [f > 0];  dh' = (df W2) * [h > 0];  du2 = dh' W1
@@ -2327,6 +3052,7 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
         // s1 = x + relu(a):  da = ds1 * [a > 0];  dO = da W_o;  attention backward;  du1 = dqkv W_in
         if ((rc = gate_bwd(ab + net.al_gate1, gb + net.gl_gate1, net.off_gate_attn, FA(ab + net.al_m1, 0), FG(gb + net.gl_da, D))) != DTQN_OK) return rc;
         if ((rc = dx(FG(gb + net.gl_da, D), D, tb + net.lo_out_w, D, FG(net.go_do, D), 0, nofld())) != DTQN_OK) return rc;
+        }
         {
             TlAttnBwdArgs a;
             a.qkv = FA(ab + net.al_qkv, 3 * D); a.o = FA(ab + net.al_o, D); a.lse = FA(ab + net.al_lse, lpb);

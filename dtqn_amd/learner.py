@@ -79,6 +79,11 @@ class TdEngine:
             if (self.lib.dtqn_net_tiled_twin(ctypes.byref(net), ctypes.byref(twin)) == 0 and twin.n_theta == net.n_theta
                     and twin.n_trainable == net.n_trainable and twin.off_pos == net.off_pos and B.param_table(twin) == B.param_table(net)):
                 net = twin
+            elif not net.tiled and B.ws_lite(net):
+                # head width 32 / width-padded shapes have whole-sequence kernels for latency-mode batches only: without the twin the
+                # first update would end in DTQN_ERR_CONFIG with no reason given
+                raise ValueError(f"batch {self.batch} of this network shape trains on the row-block kernels only and its row-block twin "
+                                 "could not be built (dtqn_net_tiled_twin): use a batch inside latency mode or a shape the twin covers")
         self.net = net
         self._bound_stream = None
         dev = self.device
@@ -319,7 +324,8 @@ class TdEngine:
         # launch of the backward -- half the chip): the same idea on a SECOND STREAM.  The target pass of update k + 1 runs its
         # kernels beside update k's backward kernels; update k + 1's forward launches cover two passes (one round of 256 workgroups
         # instead of one and a half).  The two event operations per update that cost 11.6 us are 0.5 % of a 2 ms update here.
-        stream_flavour = (self.net.tiled == 1 and self.device.type == "cuda" and self.batch * (self.net.lp // 64) <= 128)
+        side_max = int(os.environ.get("DTQN_SIDE_STREAM_MAX", "128"))       # 64-row blocks per pass up to which the side stream is used
+        stream_flavour = (self.net.tiled == 1 and self.device.type == "cuda" and self.batch * (self.net.lp // 64) <= side_max)
         if not ride and not stream_flavour:
             return False
         self._qbuf = [self.q3, torch.zeros_like(self.q3)]

@@ -37,6 +37,14 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
     mod.register_parameter(parts[-1], param)
 
 
+def _img_check_every() -> int:
+    import os
+    try:
+        return max(0, int(os.environ.get("DTQN_IMG_CHECK_EVERY", "64")))
+    except ValueError:
+        return 64
+
+
 class DTQN(nn.Module):
     """Deep Transformer Q-Network.  Arguments as in the reference (dtqn.py:19-59); `pos` defaults
     to "learned" (the reference's default value 1 is rejected by its own PosEnum)."""
@@ -169,12 +177,16 @@ class DTQN(nn.Module):
             # anything else (normalised 0..1 images, negative values) would be silently truncated or wrapped by a cast
             # Checked where it costs nothing to ask: host-side inputs every time (no device round trip), device-side inputs on the
             # first such call only (the check is a full pass over the pixels and a blocking read-back: not for the actor's hot path)
-            if obss.device.type == "cpu" or not getattr(self, "_img_range_checked", False):
+            # Device-side inputs afterwards: every DTQN_IMG_CHECK_EVERY-th call (default 64; 1 = every call, 0 = first call only), so a
+            # caller that starts feeding normalised images later is still told, at a bounded cost
+            n_seen = getattr(self, "_img_range_calls", 0)
+            every = _img_check_every()
+            if obss.device.type == "cpu" or n_seen == 0 or (every > 0 and n_seen % every == 0):
                 o = obss.to(torch.float32)
                 if not bool(((o >= 0) & (o <= 255) & (o == o.round())).all()):
                     raise ValueError("image observations must be integral pixel values in 0..255 (uint8 in the replay and the context)")
-                if obss.device.type != "cpu":
-                    self._img_range_checked = True
+            if obss.device.type != "cpu":
+                self._img_range_calls = n_seen + 1
         imgs = obss.to(device=dev).to(torch.uint8).reshape(Bn * seq, -1).contiguous()
         enc = getattr(self, "_img_enc", None)
         if enc is None or enc.device != dev:

@@ -383,7 +383,8 @@ int dtqn_forward_tiled_strided(const DtqnNet* net, const float* theta, const flo
  * queries' dK | dV contribution to the lower slice, through `xch` guarded by `xflags` (agent-scope atomics).
  * A return value of 4 means four 16-row slices in the backward kernel (pairwise dK | dV hand-overs from every slice to
  * the slices below it) and two in the forward.  Returns 1 when the shape / variant / batch does not profit (the chip
- * is already full) or is not covered. */
+ * is already full) or is not covered.  "Fit the chip" is measured against the current device's compute-unit count
+ * (hipDeviceAttributeMultiprocessorCount; 256 on an MI355X), so a partition with fewer units slices less. */
 int dtqn_td_row_split(const DtqnNet* net, int batch);
 /* 1: the update of `batch` sequences runs in latency mode -- sliced FORWARD passes too (dtqn_td_forward: two 32-row slices;
  * dtqn_td_update_pipelined: four 16-row slices and the next update's target pass inside the backward launch).  0 while
@@ -395,7 +396,7 @@ int dtqn_td_latency_mode(const DtqnNet* net, int batch);
  * row-block tiled kernels than on the whole-sequence ones (D = 128, residual gate, post-LN, 64-row contexts, no dropout, batches
  * beyond latency mode: measured 460 -> 499 updates/s at BASELINE config 3).  The caller then trains with the twin of the net --
  * dtqn_net_tiled_twin: same parameters and theta layout, records laid out for the tiled kernels -- and keeps the original for the
- * actor's forwards.  DTQN_TRAIN_TILED=0|1 overrides.  Also 1 for the shapes that exist on the whole-sequence side as four-slice
+ * actor's forwards.  DTQN_TRAIN_TILED=0|1 overrides (not for the shapes of the next sentence: they have no other kernels).  Also 1 for the shapes that exist on the whole-sequence side as four-slice
  * kernels only (head width 32 at d_model 64, width-padded networks of d_model 64) wherever dtqn_td_row_split is not 4. */
 int dtqn_td_prefers_tiled(const DtqnNet* net, int batch);
 int dtqn_net_tiled_twin(const DtqnNet* src, DtqnNet* dst);

@@ -104,6 +104,31 @@ def test_td_update_tiled_path(emu, kw, run, monkeypatch):
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3 if cfg.inner_embed_size % 128 == 0 else 2)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("kw,run", [TILED[0], TILED[7]])
+def test_td_update_tiled_fused_layer_kernels(emu, kw, run, fused, monkeypatch, capfd):
+    """Round 6: a post-LN residual layer behind its attention is ONE launch forward (tl_layer_kernel: out-projection, LayerNorm 1,
+    feed-forward, LayerNorm 2, and the Q head on the last layer) and one backward (tl_chain_bwd_kernel: LayerNorm-2 backward, feed-forward
+    backward, LayerNorm-1 backward, gate mask, dO = da W_o).  Both against the oracle, next to the separate launches they replace
+    (DTQN_LAYER_FUSE=0 / DTQN_BWD_CHAIN=0), and the launch trace says which kernels ran."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_FFN_ROWS", "64")            # the chain kernel exists for 64-row workgroups (the small-batch rule picks 32)
+    monkeypatch.setenv("DTQN_LAYER_FUSE", fused)
+    monkeypatch.setenv("DTQN_BWD_CHAIN", fused)
+    monkeypatch.setenv("DTQN_TL_TRACE", "1")
+    cfg = O.NetCfg(**kw)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=33, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"],
+                                               history=run.get("history"), tuf=run.get("tuf", 10_000))
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+    err = capfd.readouterr().err
+    names = {"layer": "tl_layer_kernel" in err, "chain": "tl_chain_bwd_kernel" in err, "ffn": "tl_ffn_kernel" in err,
+             "ffn_bwd": "tl_ffn_bwd_kernel" in err, "ln_bwd": "tl_layernorm_bwd_kernel" in err, "qhead": "tl_qhead_kernel" in err}
+    if fused == "1":
+        assert names == {"layer": True, "chain": True, "ffn": False, "ffn_bwd": False, "ln_bwd": False, "qhead": False}, names
+    else:
+        assert names == {"layer": False, "chain": False, "ffn": True, "ffn_bwd": True, "ln_bwd": True, "qhead": True}, names
+
+
 def test_td_update_tiled_lds_weight_gradients(emu, monkeypatch):
     """Row-block network of d_model 128 on the LARGE-batch weight-gradient path (forced at a small batch): the layer matrices and the
     first head matrix through dtqn_wgrad_lds_kernel (128 x 128 tiles, operands staged through LDS), the embedding and the last head
@@ -356,15 +381,26 @@ def test_training_on_the_row_block_twin(emu, monkeypatch):
     assert eng0.net.tiled == 0
 
 
-@pytest.mark.parametrize("ffn_bwd", ["0", "1"])
-def test_td_update_tiled_path_width_256(emu, ffn_bwd, monkeypatch):
-    """D = 256 takes the two-chunk / two-column-block step sequences of the fused row-block kernels (tl_wide, tl_ffn, and with
-    DTQN_FFN_BWD=1 the fused feed-forward backward that is off by default at this width); everything else in this file runs D = 64."""
-    monkeypatch.setenv("DTQN_FFN_BWD", ffn_bwd)
+@pytest.mark.parametrize("ffn_bwd", ["0", "1", "chain", "unfused"])
+def test_td_update_tiled_path_width_256(emu, ffn_bwd, monkeypatch, capfd):
+    """D = 256 takes the two-chunk / two-column-block step sequences of the fused row-block kernels (tl_wide, tl_layer / tl_ffn, and with
+    DTQN_FFN_BWD=1 the fused feed-forward backward that is off by default at this width; "chain": tl_chain_bwd_kernel, DTQN_BWD_CHAIN256=1;
+    "unfused": every launch of rounds 1-5 -- DTQN_LAYER_FUSE=0, DTQN_HEAD_FUSE=0); everything else in this file runs D = 64 / 128."""
+    if ffn_bwd == "chain":
+        monkeypatch.setenv("DTQN_BWD_CHAIN256", "1")
+    elif ffn_bwd == "unfused":
+        monkeypatch.setenv("DTQN_LAYER_FUSE", "0")
+        monkeypatch.setenv("DTQN_HEAD_FUSE", "0")
+    else:
+        monkeypatch.setenv("DTQN_FFN_BWD", ffn_bwd)
+    monkeypatch.setenv("DTQN_TL_TRACE", "1")
     cfg = O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=256, num_heads=8, num_layers=1, history_len=12, action_dim=8)
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=43, batch=2, T=20, n_eps=5, mask=-5)
     assert net.tiled == 1
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+    err = capfd.readouterr().err
+    assert ("tl_chain_bwd_kernel" in err) == (ffn_bwd == "chain")
+    assert ("tl_layer_kernel" in err) == (ffn_bwd != "unfused") and ("tl_head_bwd_kernel" in err) == (ffn_bwd == "unfused")
 
 
 def test_bag_network_counts_both_token_sets_for_the_one_launch_weight_gradients(emu):
