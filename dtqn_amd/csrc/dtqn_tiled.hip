@@ -2451,7 +2451,7 @@ static int launch_chain_bwd(const TlChainBwdArgs& a, int S, hipStream_t stream) 
 template <int D, int MR>
 static int launch_wide_rows(TlWideArgs a, int nblk, bool ln, bool pk, size_t lds, hipStream_t stream) {
     constexpr bool CAN = D % 128 == 0;                                 // fragment-major weights exist for these widths
-    a.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1));
+    a.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1), 600, "DTQN_SKEW_WIDE");
     if (ln && pk) TL_LAUNCH((tl_wide_kernel<D, MR, true, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
     else if (ln) TL_LAUNCH((tl_wide_kernel<D, MR, true, false>), dim3(nblk), dim3(TNT), lds, stream, a);
     else if (pk) TL_LAUNCH((tl_wide_kernel<D, MR, false, CAN>), dim3(nblk), dim3(TNT), lds, stream, a);
@@ -2988,11 +2988,13 @@ static int backward_records(const DtqnNet& net, const DtqnReplay& rp, const Dtqn
     // DTQN_BWD_CHAIN=0: the separate launches (A/B timing, tests).  64-row workgroups only: the LayerNorm column partials are per 64-row block
     const char* bce = getenv("DTQN_BWD_CHAIN");
     const char* ffb0 = getenv("DTQN_FFN_BWD");
-    // d_model 256 (one workgroup per compute unit): DTQN_BWD_CHAIN256 (the 64-row chain against the 32-row separate launches is a measured choice)
+    // d_model 256 (one workgroup per compute unit): only beside a second stream (DtqnTd.side_stream; DTQN_BWD_CHAIN256=0|1 forces).  Measured at
+    // BASELINE config 5 (32 sequences = 128 64-row workgroups on 256 compute units): alone the chain is slower than the 32-row separate launches
+    // (backward stage 633 against 583 us), with the next update's target pass running on the other half of the chip it wins (522 -> 552 updates/s)
     const char* bc256 = getenv("DTQN_BWD_CHAIN256");
     const bool chain = !gru && !ident && net.d_real == 0 && (bce == nullptr || atoi(bce) != 0) &&
                        (D <= 128 ? (ffb0 == nullptr || atoi(ffb0) != 0) && !tl_rows32(B * rpb, 256 * 2, D, "DTQN_ROWS_FFNB")
-                                 : (bc256 != nullptr && atoi(bc256) != 0));
+                                 : (bc256 != nullptr ? atoi(bc256) != 0 : td.side_stream != 0));
     for (int l = net.num_layers - 1; l >= 0; --l) {
         const int tb = net.off_layer0 + l * net.layer_stride;
         const int ab = net.ao_layer0 + l * net.act_layer_stride, gb = net.go_layer0 + l * net.grd_layer_stride;

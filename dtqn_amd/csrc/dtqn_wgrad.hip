@@ -331,8 +331,12 @@ __global__ __launch_bounds__(kLdsThreads, 2) void dtqn_wgrad_lds_kernel(WgradLds
         }
         __syncthreads();
         if (c + 1 < nchunks) chunk_load(c + 1);                        // in flight while this chunk multiplies
+        // 4-row steps of this chunk that hold a live row (L = 50: rows 32 .. 49 of the second chunk -> 5 of its 8 steps; the rows behind
+        // the context carry zero gradients)
+        const int r0c = (c % cps) * kLdsTK, smax = live_rows - r0c >= kLdsTK ? kLdsTK / 4 : (live_rows - r0c + 3) / 4;
 #pragma unroll
         for (int s = 0; s < kLdsTK / 4; ++s) {
+            if (s >= smax) break;
             const float4 a4 = ld4(ya + 4 * s * kLdsLDY);
             const float2 b2 = *reinterpret_cast<const float2*>(xa + 4 * s * kLdsLDX);
             const float aa[4] = {a4.x, a4.y, a4.z, a4.w};

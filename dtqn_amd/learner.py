@@ -336,6 +336,7 @@ class TdEngine:
         self._next_xflags = torch.zeros_like(self.xflags)
         nxt.xch, nxt.xflags = self._next_xch.data_ptr(), self._next_xflags.data_ptr()
         if not ride:       # its own window indices (the multi-kernel path keeps them in memory) and stream / events
+            self.td.side_stream = 1                        # (the backward leaves the other stream's kernels room: include/dtqn_hip.h)
             self._next_idx = torch.zeros_like(self._idx_dev)
             nxt.ep_idx, nxt.start = self._next_idx[0].data_ptr(), self._next_idx[1].data_ptr()
         self._pipe = dict(nxt=nxt, nxt_ref=ctypes.byref(nxt), ahead=None, steps=int(self.step_counter[1].item()), tgt_version=0,

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DTQN_ABI_VERSION 17
+#define DTQN_ABI_VERSION 18
 #define DTQN_MAX_LAYERS 8
 
 /* status codes */
@@ -327,6 +327,10 @@ typedef struct DtqnTd {
     int32_t xch_timeout_ms;   /* bounded wait of dtqn_td_xreduce for a peer's flag, in milliseconds; 0 = DTQN_XCH_TIMEOUT_MS from the
                                * environment, else 5000.  Per engine: a start-up check can use a short bound without touching the
                                * process environment */
+    int32_t side_stream;      /* 1: the caller runs the NEXT update's target pass on a second stream beside this update's backward
+                               * (row-block networks at small batches, learner.py enable_pipeline).  The backward then keeps 64-row
+                               * workgroups where it would otherwise cut them to 32 to fill the chip (d_model 256: tl_chain_bwd_kernel,
+                               * one launch per layer half) -- the other stream's kernels take the idle compute units */
     float gamma;
     float lr;
     float beta1;

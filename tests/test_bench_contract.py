@@ -121,3 +121,25 @@ def test_two_ranks_print_one_whole_job_line_on_a_one_gpu_box():
     assert ex["selected_us"]["median"] > 0 and ex["solo_updates_per_s_rank0"] > 0 and ex["weak_scaling_efficiency"] > 0
     assert len(ex["kernels_us_sum_per_rank"]) == 2 and all(v > 0 for v in ex["kernels_us_sum_per_rank"])
     assert ex["kind"] == "p2p" and ex["validated"], ex      # no environment variable needed to take the fast path
+
+
+@pytest.mark.gpu
+def test_two_ranks_of_config_4_on_a_one_gpu_box():
+    """`python bench.py --gpus 2 --config 4` -- the first command for an 8-GPU node (README.md), BASELINE's 8 x MI355X data-parallel config
+    at its per-GPU batch of 128 -- dry-run with both ranks on cuda:0 (DTQN_DIST_SAME_DEVICE=1): the row-block kernels (fused layer
+    launches, LDS weight gradients, split-K reduce) through the gradient exchange and the rank-synchronous clip + Adam at least once on
+    a device.  The numbers are not a measurement (two processes share one GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DTQN_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "4", "--steps", "10", "--warmup", "3",
+                          "--no-other-configs", "--no-env-rate", "--no-cpu-baseline"], capture_output=True, text=True, timeout=400,
+                         cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 256 and "gv_memory" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(2 * 1000.0 / d["ms_per_step"], rel=1e-6) and d["value"] > 0
+    assert d["exchange"]["kind"] in ("p2p", "rccl")
+

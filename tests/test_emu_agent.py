@@ -626,3 +626,15 @@ def test_device_side_exchange_with_four_ranks(emu, tmp_path):
     for r in range(4):
         sel = json.load(open(str(tmp_path / "out") + f".sel{r}.json"))
         assert sel["kind"] == "p2p" and sel["validated"] is True, sel
+
+
+def test_device_side_exchange_with_eight_ranks(emu, tmp_path):
+    """World size 8 -- the node BASELINE configs 4 and 5 are defined on -- on the emulation: every rank waits for seven peers' flags and adds
+    eight buffers in rank order; replicas bit-identical and equal to one learner on the eight-fold batch, exchange selected and validated
+    at start-up on every rank.  (One emulation thread per rank: eight processes share this container's eight cores.)"""
+    import json
+    run_dp_script(tmp_path, {"DP_EXCHANGE": "auto", "DP_UPDATES": "2", "DP_BATCH": "1", "HIPEMU_THREADS": "1"}, 29627, world=8)
+    for r in range(8):
+        sel = json.load(open(str(tmp_path / "out") + f".sel{r}.json"))
+        assert sel["kind"] == "p2p" and sel["validated"] is True, sel
+
