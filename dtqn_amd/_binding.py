@@ -139,6 +139,7 @@ def load_library(path: str) -> ctypes.CDLL:
         "dtqn_td_gradients_pipelined": [P(DtqnNet), P(DtqnReplay), P(DtqnTd), P(DtqnTd), i32, i32, vp],
         "dtqn_target_sync": [P(DtqnNet), vp, vp, vp],
         "dtqn_debug_set_profile_buffer": [vp],
+        "dtqn_debug_last_packed_blocks": [],
         "dtqn_abi_version": [],
         "dtqn_build_info": [],
     }

@@ -45,7 +45,8 @@ static inline int tl_skew_ticks(int nblk, int slots, int ticks = 600, const char
     const char* e = own_env != nullptr ? getenv(own_env) : nullptr;
     if (e == nullptr) e = getenv("DTQN_SKEW_TICKS");
     const int rest = nblk % slots;
-    if (nblk <= slots || slots != 512 || rest * 4 < slots || rest * 4 > 3 * slots) return 0;
+    // (only between one and two rounds: at two and a half -- config 3's packed launches, 1312 workgroups -- the same delay costs 11 us per forward)
+    if (nblk <= slots || nblk >= 2 * slots || slots != 512 || rest * 4 < slots || rest * 4 > 3 * slots) return 0;
     return e != nullptr ? atoi(e) : ticks;
 }
 
@@ -63,6 +64,47 @@ static inline Fld fld(float* rec, long long stride, int off, int ld) { return Fl
 static inline Fld nofld() { return Fld{nullptr, 0, 0}; }
 __host__ __device__ __forceinline__ Fld nofld_dev() { return Fld{nullptr, 0, 0}; }
 __device__ __forceinline__ float* frow(const Fld& f, int s, int row) { return f.base + (size_t)s * f.stride + (size_t)row * f.ld; }
+
+// ---- packed rows of the sequences nobody reads again (round 6) -------------------------------------------------------------------------
+// A TD forward runs three passes; only the first (policy(o), sequences [0, batch)) is read by the backward.  The records stay per sequence
+// ([LPB][cols], LPB = L rounded up to 64) because the attention kernels and the backward address them that way, but the row-local kernels
+// (q | k | v projection, fused layer tail) need not walk (sequence, 64-row block of its record): for the other two passes their workgroups
+// walk the LIVE rows of consecutive sequences, 64 at a time -- BASELINE config 3 (L = 50, LPB = 64): 400 workgroups per pass instead of 512;
+// the 14 dead rows of a tile were never part of the loss (dtqn/agents/dtqn.py:215-243 runs over B * history positions).  A row's arithmetic
+// does not depend on where in a workgroup it sits (MFMA sums run over k, LayerNorm rows over 8 fixed lanes), so Q is bit-identical to the
+// unpacked walk.  Nothing is saved for these passes (no ReLU ballots, no h / s1 / s2 / statistics), which is what keeps this a matter of
+// row addresses only.  Conditions (forward_records): 32 <= L < LPB, batch * L a multiple of 64 (a workgroup never mixes the parameter sets
+// of two passes), 64-row workgroups, no dropout, no bag.
+struct TlPack {
+    int n0;                            // workgroups [0, n0) walk (sequence, row block) as ever
+    int s0;                            // workgroup n0 + k: live rows [64 k, 64 k + 64) of sequences s0, s0 + 1, ...
+    int L;                             // live rows per sequence; 0: no packing
+};
+struct TlBlk {
+    int s, row0;                       // first row of the workgroup: sequence, row in its record
+    int L;                             // 0: rows row0 .. row0 + MR - 1 of sequence s;  > 0: packed (rows run on into the next sequences)
+};
+__device__ __forceinline__ TlBlk tl_blk(int blk, int rpb, int MR, const TlPack& p) {
+    TlBlk b;
+    if (p.L == 0 || blk < p.n0) { b.s = blk / rpb; b.row0 = (blk - b.s * rpb) * MR; b.L = 0; }
+    else { const int v0 = (blk - p.n0) * 64, q = v0 / p.L; b.s = p.s0 + q; b.row0 = v0 - q * p.L; b.L = p.L; }
+    return b;
+}
+// row r of the workgroup: (sequence, row of its record); a packed workgroup of 64 rows spans at most three sequences (L >= 32)
+__device__ __forceinline__ void tl_row(const TlBlk& b, int r, int& s, int& row) {
+    row = b.row0 + r;
+    s = b.s;
+    if (b.L > 0) {
+        const int k = (row >= b.L ? 1 : 0) + (row >= 2 * b.L ? 1 : 0);
+        s += k;
+        row -= k * b.L;
+    }
+}
+__device__ __forceinline__ float* frow_b(const Fld& f, const TlBlk& b, int r) {
+    int s, row;
+    tl_row(b, r, s, row);
+    return frow(f, s, row);
+}
 
 // Dropout on the row-block path (net.dropout > 0): the keep-mask hash of the whole-sequence kernels (dtqn_device.hpp drop_keep),
 // keyed by (seed, step, pass, sequence, site, layer, element).  Sequence s of a launch belongs to pass s / batch; bit p of
@@ -118,6 +160,7 @@ struct TlEmbedArgs {
     const int32_t* lens;               // ragged prefixes in one launch (dtqn_actor_forward_batch): live rows of sequence s, or nullptr = n.
                                        // Only the "a one-row sequence keeps its action embedding" rule (dtqn.py:187) looks at it
     TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
+    const float *ptab_a, *ptab_b;      // embedding product tables of the two parameter sets (dtqn_wpack.hpp), or nullptr: tl_embed_table_kernel
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
@@ -275,6 +318,81 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
             }
         }
         st4(xo + (size_t)rl * a.x.ld + d, v);
+    }
+}
+
+// Discrete observations with the embedding product table of dtqn_wpack.hpp (TD forward of the covered row-block networks): the embedding of
+// a row is b + sum_j P[j][tok_j] -- O gathered 16-byte pieces per output piece, no LDS tiles, no matrix product.  One workgroup per (sequence,
+// 64-row block) like tl_embed_kernel, same outputs (x with positions and dropout, e_in for the sequences the backward reads).
+__global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
+    const DtqnNet& net = a.net;
+    const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n, V = net.vocab, E = net.embed_per_obs;
+    const int DO = D - adim;
+    const int s = (int)blockIdx.x / a.rpb, rb = (int)blockIdx.x % a.rpb;
+    const float* __restrict__ theta = s >= a.split ? a.theta_b : a.theta_a;
+    const float* __restrict__ P = s >= a.split ? a.ptab_b : a.ptab_a;
+    int ep = a.src_mod > 0 ? s % a.src_mod : s, row_first = 0;
+    if (a.ep_idx != nullptr) {
+        const int sg = s + a.seq0;
+        const int which = sg / a.batch, b = sg - which * a.batch;
+        ep = a.ep_idx[b];
+        row_first = a.start[b] + (which > 0 ? 1 : 0);
+    }
+    const float* obs_rows = a.obs + (size_t)ep * a.obs_ep_stride + (size_t)row_first * O;
+    const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
+    const bool single = (a.lens != nullptr ? a.lens[s] : n) == 1;
+    const int tid = (int)threadIdx.x;
+    int* tokl = reinterpret_cast<int*>(dtqn_smem);                     // [64][O] clamped tokens of the block's rows
+    const int nrows = n - rb * TROWS < TROWS ? n - rb * TROWS : TROWS;
+    for (int idx = tid; idx < TROWS * O; idx += TNT) {
+        const int rl = idx / O;
+        int tok = rl < nrows ? (int)obs_rows[(size_t)rb * TROWS * O + idx] : 0;
+        tokl[idx] = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+    }
+    __syncthreads();
+    float* xo = frow(a.x, s, rb * TROWS);
+    const Drop edr = tl_drop(a.drop, s);
+    const int c4n = D >> 2;
+    for (int idx = tid; idx < TROWS * c4n; idx += TNT) {
+        const int rl = idx / c4n, d = (idx - rl * c4n) * 4, r = rb * TROWS + rl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < nrows) {
+            if (d >= adim) {
+                const int* tk = tokl + rl * O;
+                for (int j = 0; j < O; ++j) {
+                    const float4 pv = ld4(P + ((size_t)j * V + tk[j]) * DO + (d - adim));
+                    v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+                }
+                const float4 bv = ld4(theta + net.off_obs_b + (d - adim));
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            } else {
+                // previous action's embedding, rolled by one step, zero at t = 0 (dtqn.py:184-192)
+                if (single) v = ld4(theta + net.off_act_emb + (int)act_rows[0] * adim + d);
+                else if (r > 0) v = ld4(theta + net.off_act_emb + (int)act_rows[r - 1] * adim + d);
+            }
+            const float4 pv = ld4(theta + net.off_pos + (size_t)r * D + d);
+            v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+            if (edr.thresh != 0u) {
+                const uint32_t e0 = (uint32_t)(r * a.drop.dw + d);
+                v.x = drop_apply(edr, DROP_EMB, 0, e0, v.x);
+                v.y = drop_apply(edr, DROP_EMB, 0, e0 + 1, v.y);
+                v.z = drop_apply(edr, DROP_EMB, 0, e0 + 2, v.z);
+                v.w = drop_apply(edr, DROP_EMB, 0, e0 + 3, v.w);
+            }
+        }
+        st4(xo + (size_t)rl * a.x.ld + d, v);
+    }
+    if (a.ein.base != nullptr) {                                       // the embedding linear's input, for its weight gradient
+        float* eo = frow(a.ein, s, rb * TROWS);
+        for (int idx = tid; idx < TROWS * KEP; idx += TNT) {
+            const int rl = idx / KEP, k = idx - rl * KEP;
+            float v = 0.f;
+            if (rl < nrows && k < KE) {
+                const int j = k / E;
+                v = theta[net.off_obs_tab + tokl[rl * O + j] * E + (k - j * E)];
+            }
+            eo[(size_t)rl * KEP + k] = v;
+        }
     }
 }
 
@@ -501,6 +619,7 @@ struct TlWideArgs {
     int n_save;
     const float *Wpa, *Wpb;            // fragment-major F copies of Wa / Wb (dtqn_wpack.hpp), or nullptr
     int skew;                          // start skew of the second-slot workgroups, 100-MHz ticks (tl_start_skew; 0: none)
+    TlPack pack;                       // plain instantiation, 64-row workgroups: packed rows of the sequences that are not saved (L == 0: none)
 };
 template <int D, int MR, bool LN, bool PK>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideArgs a) {
@@ -510,7 +629,8 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
     float* Hs = Xt + MR * LDX;                                         // [MR][LDH] output staging (plain) | [MR][LDX] all columns (LN)
     Thr t = make_thr();
     const int blk = (int)blockIdx.x;
-    const int s = blk / a.rpb, row0 = (blk % a.rpb) * MR;
+    const TlBlk rb = tl_blk(blk, a.rpb, MR, LN ? TlPack{0, 0, 0} : a.pack);
+    const int s = rb.s, row0 = rb.row0;                                // (packed workgroups: of their first row; every row goes through frow_b)
     const bool second = s >= a.split, save = s < a.n_save;
     const float* __restrict__ W = second ? a.Wb : a.Wa;
     const float* __restrict__ bias = second ? a.bb : a.ba;
@@ -529,10 +649,9 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
     float4 bf0[8], bf1[8];
     fetch(bf0, 0, 0);
     {
-        const float* in0 = frow(a.in, s, row0);
         for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
-            st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.in.ld + c));
+            st4(Xt + r * LDX + c, ld4(frow_b(a.in, rb, r) + c));
         }
     }
     float* mrec = LN && save && a.mask.base != nullptr ? a.mask.base + (size_t)s * a.mask.stride : nullptr;
@@ -583,7 +702,7 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_wide_kernel(TlWideAr
         __syncthreads();
         for (int idx = t.tid; idx < MR * 32; idx += TNT) {
             const int rl = idx >> 5, c = (idx & 31) * 4;
-            st4(frow(a.out, s, row0 + rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+            st4(frow_b(a.out, rb, rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
         }
         __syncthreads();                                               // staging tile free for the next block
     };
@@ -887,6 +1006,7 @@ struct TlLayerArgs {
     float* q;
     long long q_seq_stride;
     int q_row_stride, A, n;
+    TlPack pack;                       // 64-row workgroups: packed rows of the sequences that are not saved (L == 0: none)
 };
 template <int D, int MR, bool PK, bool HEAD>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayerArgs a) {
@@ -898,8 +1018,9 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
     float* Hs = Xt + MR * LDX;                                         // [MR][max(LDX, LDH)] relu(y1) | hidden chunk | hh
     Thr t = make_thr();
     const int blk = (int)blockIdx.x;
-    const int s = blk / a.f.rpb, row0 = (blk % a.f.rpb) * MR;
-    const bool second = s >= a.f.split, save = s < a.f.n_save;
+    const TlBlk rb = tl_blk(blk, a.f.rpb, MR, a.pack);
+    const int s = rb.s, row0 = rb.row0;                                // (packed workgroups: of their first row; they save nothing, and every
+    const bool second = s >= a.f.split, save = s < a.f.n_save;         //  row they touch goes through tl_row)
     int wc = t.wave * 16 + t.i;
     float4 bf0[8], bf1[8];
     // thread coordinates made opaque phase by phase: per-thread addresses of a later phase are recomputed there instead of living through
@@ -946,7 +1067,9 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
     auto ln_rows = [&](const float* add_tile, const Fld& res, const Fld& raw, const Fld& st, const Fld& dst, const float* gamma, const float* beta, bool keep) {
         constexpr int LPR = 8, NV = D / (4 * LPR);
         if (t.tid >= MR * LPR) return;
-        const int rl = t.tid / LPR, part = t.tid % LPR, row = row0 + rl;
+        const int rl = t.tid / LPR, part = t.tid % LPR;
+        int s, row;                                                    // this row's sequence and record row (shadow the workgroup's)
+        tl_row(rb, rl, s, row);
         float4 y[NV];
         float sum = 0.f;
 #pragma unroll
@@ -994,10 +1117,9 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
     const float* __restrict__ Wop = second ? a.Wopb : a.Wopa;
     fetchDD(bf0, Wo, Wop, 0, 0);
     {
-        const float* in0 = frow(a.o, s, row0);
         for (int idx = t.tid; idx < MR * (D / 4); idx += TNT) {
             const int r = idx / (D / 4), c = (idx - r * (D / 4)) * 4;
-            st4(Xt + r * LDX + c, ld4(in0 + (size_t)r * a.o.ld + c));
+            st4(Xt + r * LDX + c, ld4(frow_b(a.o, rb, r) + c));
         }
     }
     tl_start_skew(a.f.skew);
@@ -1140,11 +1262,12 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
         const float* Wq = (second ? a.Wqb : a.Wqa) + 4 * c;
         const float* bq = second ? a.bqb : a.bqa;
         for (int rr = t.tid >> 4; rr < MR; rr += TNT / 16) {
-            const int row = row0 + rr;
+            int sq, row;
+            tl_row(rb, rr, sq, row);
             float4 hv[NJQ];
 #pragma unroll
             for (int j = 0; j < NJQ; ++j) hv[j] = ld4(Hs + rr * LDX + 4 * c + 64 * j);
-            float* qrow = a.q + (size_t)s * a.q_seq_stride + (size_t)row * a.q_row_stride;
+            float* qrow = a.q + (size_t)sq * a.q_seq_stride + (size_t)row * a.q_row_stride;
             for (int ac = 0; ac < a.A; ++ac) {
                 float p = 0.f;
 #pragma unroll
@@ -2458,15 +2581,19 @@ static int launch_wide_rows(TlWideArgs a, int nblk, bool ln, bool pk, size_t lds
     else TL_LAUNCH((tl_wide_kernel<D, MR, false, false>), dim3(nblk), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
+// nblk_rows > 0: a packed launch (TlPack) of that many 64-row workgroups
 template <int D>
-static int launch_wide(TlWideArgs a, int S, hipStream_t stream) {
+static int launch_wide(TlWideArgs a, int S, hipStream_t stream, int nblk_rows = 0) {
     const bool ln = a.ln_out.base != nullptr;
     const size_t cols = ln ? (size_t)2 * (D + 4) : (size_t)(D + 4) + (128 + 4);
     const bool pk = D % 128 == 0 && a.Wpa != nullptr && a.Wpb != nullptr;
     if (tl_rows32(S * a.rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_WIDE")) {
         a.rpb *= 2;
+        a.pack = TlPack{0, 0, 0};
         return launch_wide_rows<D, 32>(a, S * a.rpb, ln, pk, 32 * cols * sizeof(float), stream);
     }
+    if (a.pack.L > 0 && !ln && nblk_rows > 0) return launch_wide_rows<D, 64>(a, nblk_rows, ln, pk, 64 * cols * sizeof(float), stream);
+    a.pack = TlPack{0, 0, 0};
     return launch_wide_rows<D, 64>(a, S * a.rpb, ln, pk, 64 * cols * sizeof(float), stream);
 }
 // a.rpb on entry: 64-row blocks per sequence.  64-row workgroups by default; when the last round of 64-row workgroups would
@@ -2491,6 +2618,7 @@ static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
     }
     return launch_ffn_rows<D, 64>(a, S * a.rpb, pk, stream);
 }
+static int g_last_packed_blocks = 0;    // grid of the last fused-layer launch if it was a packed one, else 0 (tests: dtqn_debug_last_packed_blocks)
 // the fused layer tail: rows per workgroup by launch_ffn's rule (its long phase is the feed-forward loop)
 template <int D, int MR>
 static int launch_layer_rows(TlLayerArgs a, int nblk, bool pk, bool head, hipStream_t stream) {
@@ -2505,14 +2633,18 @@ static int launch_layer_rows(TlLayerArgs a, int nblk, bool pk, bool head, hipStr
     return DTQN_OK;
 }
 template <int D>
-static int launch_layer(TlLayerArgs a, int S, bool head, hipStream_t stream) {
+static int launch_layer(TlLayerArgs a, int S, bool head, hipStream_t stream, int nblk_rows = 0) {
     const int blocks64 = S * a.f.rpb, slots = 256 * (D <= 128 ? 2 : 1);
     const bool pk = D % 128 == 0 && a.f.W1pa != nullptr && a.f.W1pb != nullptr && a.f.W2pa != nullptr && a.f.W2pb != nullptr &&
                     a.Wopa != nullptr && a.Wopb != nullptr && (!head || (a.Wh1pa != nullptr && a.Wh1pb != nullptr));
     if (tl_rows32(blocks64, slots, D, "DTQN_ROWS_FFN")) {
         a.f.rpb *= 2;
+        a.pack = TlPack{0, 0, 0};
         return launch_layer_rows<D, 32>(a, S * a.f.rpb, pk, head, stream);
     }
+    g_last_packed_blocks = a.pack.L > 0 && nblk_rows > 0 ? nblk_rows : 0;
+    if (a.pack.L > 0 && nblk_rows > 0) return launch_layer_rows<D, 64>(a, nblk_rows, pk, head, stream);
+    a.pack = TlPack{0, 0, 0};
     return launch_layer_rows<D, 64>(a, S * a.f.rpb, pk, head, stream);
 }
 template <int KC>
@@ -2647,8 +2779,13 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.pre = src.pre; e.pre_rows = src.pre_rows;
         if (net.img_c > 0 && e.pre == nullptr) return DTQN_ERR_ARG;     // image nets come through dtqn_img_encode
         e.ein = e.pre != nullptr ? nofld() : e.ein;
+        e.ptab_a = wpack_etab(wplan, pk_a); e.ptab_b = wpack_etab(wplan, pk_b);
+        if (e.ptab_a != nullptr && e.ptab_b != nullptr && net.discrete && e.pre == nullptr) {
+            TL_LAUNCH(tl_embed_table_kernel, dim3(S * rpb), dim3(TNT), (size_t)TROWS * net.obs_dim * sizeof(int), stream, e);
+        } else {
         const size_t elds = tl_embed_lds(net);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
+        }
     }
     auto linear = [&](Fld in, int K, int N, int w_off, int b_off, Fld out, int mode, Fld res, Fld mask) {
         TlLinearArgs a = {};
@@ -2696,6 +2833,19 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     const char* lfe = getenv("DTQN_LAYER_FUSE");
     const bool fuse_tail = !gru && !ident && !padded && net.bag_size == 0 && getenv("DTQN_NO_WIDE") == nullptr && (lfe == nullptr || atoi(lfe) != 0);
     bool head_done = false;
+    // sequences the backward reads: the training third of a TD update ([0, batch) of the update = [0, batch - seq0) of this launch)
+    const int n_save = training ? (src.batch - src.seq0 > 0 ? src.batch - src.seq0 : 0) : 0;
+    // packed rows for the rest (TlPack): DTQN_PACK_ROWS=0 keeps every workgroup on (sequence, row block)
+    TlPack pack = {0, 0, 0};
+    {
+        const char* pe = getenv("DTQN_PACK_ROWS");
+        const bool rows64 = !tl_rows32(S * rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_FFN") && !tl_rows32(S * rpb, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_WIDE");
+        if (training && fuse_tail && S > n_save && drop.thresh == 0u && src.lens == nullptr && n >= 32 && n < lpb && ((long long)src.batch * n) % 64 == 0 &&
+            rows64 && (3 * D) % 128 == 0 && (pe == nullptr || atoi(pe) != 0)) {
+            pack.n0 = n_save * rpb; pack.s0 = n_save; pack.L = n;
+        }
+    }
+    const int nblk_rows = pack.L > 0 ? pack.n0 + (S - n_save) * n / 64 : 0;      // workgroups of a packed launch
     for (int l = 0; l < net.num_layers; ++l) {
         const int tb = net.off_layer0 + l * net.layer_stride, ab = L0(l);
         const bool last = l + 1 == net.num_layers;
@@ -2710,7 +2860,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             wa.Wa = theta_a + tb + net.lo_in_w; wa.Wb = theta_b + tb + net.lo_in_w; wa.ba = theta_a + tb + net.lo_in_b; wa.bb = theta_b + tb + net.lo_in_b;
             wa.split = split; wa.rpb = rpb; wa.N = 3 * D;
             wa.Wpa = wpack_f(wplan, pk_a, tb + net.lo_in_w); wa.Wpb = wpack_f(wplan, pk_b, tb + net.lo_in_w);
-            rc = launch_wide<D>(wa, S, stream);
+            wa.pack = pack;
+            rc = launch_wide<D>(wa, S, stream, nblk_rows);
         } else {
             rc = linear(u1, D, 3 * D, tb + net.lo_in_w, tb + net.lo_in_b, F(ab + net.al_qkv, 3 * D), 0, nofld(), nofld());
         }
@@ -2737,7 +2888,8 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.split = split; fa.rpb = rpb; fa.drop = drop; fa.layer = l;
             fa.W1pa = wpack_f(wplan, pk_a, tb + net.lo_f1_w); fa.W1pb = wpack_f(wplan, pk_b, tb + net.lo_f1_w);
             fa.W2pa = wpack_f(wplan, pk_a, tb + net.lo_f2_w); fa.W2pb = wpack_f(wplan, pk_b, tb + net.lo_f2_w);
-            fa.n_save = training ? src.batch : 0;
+            fa.n_save = n_save;
+            la.pack = pack;
             fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
             fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
             fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
@@ -2755,7 +2907,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
                 la.q = q_out; la.q_seq_stride = q_seq_stride; la.q_row_stride = q_row_stride; la.A = net.num_actions; la.n = n;
                 head_done = true;
             }
-            if ((rc = launch_layer<D>(la, S, head, stream)) != DTQN_OK) return rc;
+            if ((rc = launch_layer<D>(la, S, head, stream, nblk_rows)) != DTQN_OK) return rc;
             continue;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it
@@ -2769,7 +2921,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             wa.res = stream_in; wa.mask = training ? F(ab + net.al_m1, 0) : nofld();
             wa.ln_out = u2; wa.ln_st = st1;
             wa.lga = theta_a + tb + net.lo_ln1_w; wa.lgb = theta_b + tb + net.lo_ln1_w; wa.lba = theta_a + tb + net.lo_ln1_b; wa.lbb = theta_b + tb + net.lo_ln1_b;
-            wa.n_save = training ? src.batch : 0;
+            wa.n_save = n_save;
             if ((rc = launch_wide<D>(wa, S, stream)) != DTQN_OK) return rc;
         } else {
             if (!gru) {
@@ -2795,7 +2947,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             fa.split = split; fa.rpb = rpb; fa.drop = drop; fa.layer = l;
             fa.W1pa = wpack_f(wplan, pk_a, tb + net.lo_f1_w); fa.W1pb = wpack_f(wplan, pk_b, tb + net.lo_f1_w);
             fa.W2pa = wpack_f(wplan, pk_a, tb + net.lo_f2_w); fa.W2pb = wpack_f(wplan, pk_b, tb + net.lo_f2_w);
-            fa.n_save = training ? src.batch : 0;                     // only the training third of a TD update is read again
+            fa.n_save = n_save;                                       // only the training third of a TD update is read again
             fa.h = training ? F(ab + net.al_h, 4 * D) : nofld();
             fa.mh = training ? F(ab + net.al_mh, 0) : nofld();
             fa.m2 = training ? F(ab + net.al_m2, 0) : nofld();
@@ -2839,6 +2991,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
             e.x = F(rm.bag_e, D);
             e.ein = training ? F(net.ao_bag_ein, net.kep) : nofld();
             e.src_mod = src.bag_batch; e.bag = 1; e.drop = tl_drop_none(); e.lens = nullptr; e.pre = nullptr; e.pre_rows = 0;
+            e.ptab_a = nullptr; e.ptab_b = nullptr;
             const size_t elds = tl_embed_lds(net);
             TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
         }
@@ -3150,6 +3303,8 @@ int tiled_td_backward(const DtqnNet* net, const DtqnReplay* rp, const DtqnTd* td
 }  // namespace dtqn
 
 using namespace dtqn;
+
+extern "C" int dtqn_debug_last_packed_blocks(void) { return g_last_packed_blocks; }
 
 extern "C" int dtqn_forward_workspace_floats(const DtqnNet* net, int batch) {
     if (!net || batch < 1) return 0;

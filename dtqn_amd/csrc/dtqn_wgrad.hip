@@ -11,6 +11,7 @@
 // of one dY row and its B operands 4 consecutive floats of one X row: every global access is a
 // coalesced 16 B/lane load, 16 MFMAs per pair of loads.  The four waves take different sequences
 // and are summed through LDS; splits are summed by dtqn_td_reduce (deterministic, no atomics).
+#include <mutex>
 #include "dtqn_device.hpp"
 #include "dtqn_wgrad_direct.hpp"
 
@@ -545,6 +546,33 @@ static int wgrad_direct(const DtqnNet* net, const DtqnTd* td, hipStream_t stream
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
 }
 
+// Fork-join lane of the split weight gradients (round 6).  The small jobs that stay on dtqn_wgrad_kernel next to dtqn_wgrad_lds_kernel
+// (embedding matrix, last head matrix, the small-partial sums) are a hundred-odd workgroups whose waves walk a split's tokens one 16-token
+// unit after the other: 37 / 66 / 52 us at BASELINE configs 4 / 3 / 5, latency-bound, on a chip the launch does not fill.  They depend
+// on nothing the large-matrix kernel writes (disjoint ranges of gsplit), so they run on a second stream BESIDE it: fork event on the
+// caller's stream, the small kernel on the lane's stream, join event back.  One lane per device, created on first use (a stream and two
+// events: no device memory); DTQN_WGRAD_SIDE=0 keeps both launches on the caller's stream.
+struct WgradLane {
+    hipStream_t s;
+    hipEvent_t fork, join;
+    int state;                         // 0: not tried, 1: ready, -1: unavailable
+};
+static WgradLane* wgrad_lane() {
+    static WgradLane lanes[kMaxDevices] = {};
+    const char* e = getenv("DTQN_WGRAD_SIDE");
+    if (e != nullptr && atoi(e) == 0) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    WgradLane& l = lanes[dev];
+    if (l.state == 0) {
+        l.state = (hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&l.join, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+        (void)hipGetLastError();
+    }
+    return l.state == 1 ? &l : nullptr;
+}
+
 extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream) {
     if (!net || !td || td->batch < 1 || td->n_split < 1) return DTQN_ERR_ARG;
     if (net->n_wjobs > kMaxWJobs) return DTQN_ERR_CONFIG;
@@ -555,9 +583,10 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     if (dtqn_net_wjobs(net, a.jobs) != DTQN_OK) return DTQN_ERR_CONFIG;
     a.n_jobs = net->n_wjobs;
     a.n_wtiles = net->n_wtiles;
+    WgradLdsArgs la;
+    bool have_lds = false;
     if (wgrad_lds_enabled(*net)) {
         // the large matrices go to dtqn_wgrad_lds_kernel, the rest (embedding, last head matrix) stay here with their tiles renumbered
-        WgradLdsArgs la;
         la.net = *net;
         la.n_jobs = 0; la.n_tiles = 0;
         int keep = 0, tiles = 0;
@@ -577,11 +606,18 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
         if (la.n_jobs > 0) {
             a.n_jobs = keep; a.n_wtiles = tiles;
             la.act = td->act; la.grd = td->grd; la.gsplit = td->gsplit; la.batch = td->batch; la.n_split = td->n_split;
-            const size_t llds = (size_t)kLdsTK * (kLdsLDY + kLdsLDX) * sizeof(float);
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(dtqn_wgrad_lds_kernel, dim3(la.n_tiles * td->n_split), dim3(kLdsThreads), llds, (hipStream_t)stream, la);
-            if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;
+            have_lds = true;
         }
+    }
+    // the small jobs first, beside the large-matrix kernel when the lane is there
+    WgradLane* lane = have_lds ? wgrad_lane() : nullptr;
+    static std::mutex lane_mu;         // fork / launch / join of one update are not interleaved with another host thread's
+    std::unique_lock<std::mutex> lk(lane_mu, std::defer_lock);
+    hipStream_t small_stream = (hipStream_t)stream;
+    if (lane != nullptr) {
+        lk.lock();
+        if (hipEventRecord(lane->fork, (hipStream_t)stream) == hipSuccess && hipStreamWaitEvent(lane->s, lane->fork, 0) == hipSuccess) small_stream = lane->s;
+        else { lane = nullptr; (void)hipGetLastError(); }
     }
     a.act = td->act; a.grd = td->grd; a.gsplit = td->gsplit; a.small = td->small;
     a.batch = td->batch; a.n_split = td->n_split;
@@ -598,6 +634,15 @@ extern "C" int dtqn_td_wgrad(const DtqnNet* net, const DtqnTd* td, void* stream)
     static size_t attr_lds[kMaxDevices] = {};    // per device
     raise_lds_limit(reinterpret_cast<const void*>(&dtqn_wgrad_kernel), lds, attr_lds);
     (void)hipGetLastError();   // drop stale errors left by other users of the runtime
-    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(tile_blocks + small_blocks * td->n_split), dim3(DTQN_THREADS), lds, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;
+    hipLaunchKernelGGL(dtqn_wgrad_kernel, dim3(tile_blocks + small_blocks * td->n_split), dim3(DTQN_THREADS), lds, small_stream, a);
+    if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;
+    if (lane != nullptr && hipEventRecord(lane->join, lane->s) != hipSuccess) return DTQN_ERR_LAUNCH;
+    if (have_lds) {
+        const size_t llds = (size_t)kLdsTK * (kLdsLDY + kLdsLDX) * sizeof(float);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(dtqn_wgrad_lds_kernel, dim3(la.n_tiles * td->n_split), dim3(kLdsThreads), llds, (hipStream_t)stream, la);
+        if (hipGetLastError() != hipSuccess) return DTQN_ERR_LAUNCH;
+    }
+    if (lane != nullptr && hipStreamWaitEvent((hipStream_t)stream, lane->join, 0) != hipSuccess) return DTQN_ERR_LAUNCH;
+    return DTQN_OK;
 }

@@ -11,11 +11,27 @@ struct WPackArgs {
     float* pk_pol;
     float* pk_tgt;
     int f4_total;                      // float4 of all F copies
+    int e_off, e_floats;               // embedding product table (dtqn_wpack.hpp), one per parameter set
+    int O, V, E, KE, DO, off_tab, off_w;
 };
 // one float4 of output per thread: segment 0 = policy F, 1 = policy B, 2 = target F
 __global__ __launch_bounds__(256) void dtqn_wpack_kernel(WPackArgs a) {
     const int per = a.f4_total, id = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (id >= 3 * per) return;
+    if (id >= 3 * per) {
+        // embedding product table, one element per thread: P[j][v][d] = sum_c T[v][c] W_e[d][j e + c]
+        int x = id - 3 * per;
+        if (x >= 2 * a.e_floats) return;
+        const bool tgt = x >= a.e_floats;
+        x -= tgt ? a.e_floats : 0;
+        const float* __restrict__ th = tgt ? a.theta_tgt : a.theta_pol;
+        const int d = x % a.DO, jv = x / a.DO, v = jv % a.V, j = jv / a.V;
+        const float* tr = th + a.off_tab + (size_t)v * a.E;
+        const float* wr = th + a.off_w + (size_t)d * a.KE + (size_t)j * a.E;
+        float p = 0.f;
+        for (int c = 0; c < a.E; ++c) p = fmaf(tr[c], wr[c], p);
+        (tgt ? a.pk_tgt : a.pk_pol)[a.e_off + x] = p;
+        return;
+    }
     const int seg = id / per;
     int o4 = id - seg * per;
     int j = 0;
@@ -55,7 +71,10 @@ extern "C" int dtqn_td_wpack(const DtqnNet* net, const DtqnTd* td, void* stream)
     if (a.plan.n == 0) return DTQN_OK;
     a.theta_pol = td->theta_pol; a.theta_tgt = td->theta_tgt; a.pk_pol = td->wpack_pol; a.pk_tgt = td->wpack_tgt;
     a.f4_total = a.plan.f_total / 4;
-    const int blocks = (3 * a.f4_total + 255) / 256;
+    a.e_off = a.plan.e_off; a.e_floats = a.plan.e_floats;
+    a.O = net->obs_dim; a.V = net->vocab; a.E = net->embed_per_obs; a.KE = net->ke; a.DO = net->d_model - net->action_dim;
+    a.off_tab = net->off_obs_tab; a.off_w = net->off_obs_w;
+    const int blocks = (3 * a.f4_total + 2 * a.e_floats + 255) / 256;
     (void)hipGetLastError();
     hipLaunchKernelGGL(dtqn_wpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? DTQN_OK : DTQN_ERR_LAUNCH;

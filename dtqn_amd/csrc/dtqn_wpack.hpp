@@ -25,9 +25,22 @@ struct WPackMat {
 constexpr int kMaxPackMats = 4 * 8 + 1;
 struct WPackPlan {
     int n;                             // matrices (0: the network is not covered)
-    int f_total, total;                // floats of all F copies; of F + B copies
+    int f_total, total;                // floats of all F copies; of everything in the buffer (F + B copies + the embedding product table)
+    int e_off, e_floats;               // embedding product table (discrete observations): offset in the buffer, floats (0: none)
     WPackMat m[kMaxPackMats];
 };
+// Embedding product table (round 6).  A discrete observation row is embedded as concat_j(T[tok_j]) W_e^T + b (representations.py:25-52): O table
+// rows of e floats each against the [D - a][O e] matrix.  Both are parameters, the tokens come from a vocabulary of V: the products
+//   P[j][v][d] = sum_{c < e} T[v][c] * W_e[d][j e + c]
+// are O V (D - a) floats (46 KB at BASELINE config 3), rewritten with the fragment-major weight copies at the start of every TD forward, and the
+// embedding of a row becomes b + sum_j P[j][tok_j] -- O gathered rows instead of a [rows][O e] x [O e][D] product whose operands are
+// gathered element by element (tl_embed_kernel: 38 / 71 us per TD forward at configs 4 / 3, an HBM-bound kernel's job).  The sum runs
+// over j in the order of the columns; inside a slot over c: the same terms as the reference's product in a different association.
+static inline int wpack_etab_floats(const DtqnNet& net) {
+    if (!net.discrete || net.img_c > 0 || net.action_dim % 4 != 0 || net.d_model % 4 != 0) return 0;
+    const long long fl = (long long)net.obs_dim * net.vocab * (net.d_model - net.action_dim);
+    return fl > 0 && fl <= (1 << 20) ? (int)fl : 0;     // (a 4 MB table would no longer stay cache-resident next to the records)
+}
 static inline WPackPlan wpack_plan(const DtqnNet& net) {
     WPackPlan p = {};
     const char* e = getenv("DTQN_WPACK");
@@ -48,6 +61,10 @@ static inline WPackPlan wpack_plan(const DtqnNet& net) {
     add(net.off_head1_w, D, D);
     for (int j = 0; j < p.n; ++j) p.m[j].b_off = p.f_total + p.m[j].f_off;
     p.total = 2 * p.f_total;
+    const char* ee = getenv("DTQN_EMBED_TABLE");
+    p.e_floats = (ee != nullptr && atoi(ee) == 0) ? 0 : wpack_etab_floats(net);
+    p.e_off = p.total;
+    p.total += p.e_floats;
     return p;
 }
 // F / B copy of the matrix at theta + w_off inside the packed buffer `pk`, or nullptr (no buffer, or not a packed matrix)
@@ -56,6 +73,9 @@ static inline const float* wpack_f(const WPackPlan& p, const float* pk, int w_of
     for (int j = 0; j < p.n; ++j)
         if (p.m[j].w_off == w_off) return pk + p.m[j].f_off;
     return nullptr;
+}
+static inline const float* wpack_etab(const WPackPlan& p, const float* pk) {
+    return pk != nullptr && p.n > 0 && p.e_floats > 0 ? pk + p.e_off : nullptr;
 }
 static inline const float* wpack_b(const WPackPlan& p, const float* pk, int w_off) {
     if (pk == nullptr) return nullptr;

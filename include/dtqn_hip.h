@@ -543,6 +543,9 @@ int dtqn_forward_tiled_pre(const DtqnNet* net, const float* theta, const float* 
  * 0..63) and backward (slots 64..127) TD kernels records the 100 MHz wall clock at its stage
  * boundaries into it.  NULL disables (default). */
 int dtqn_debug_set_profile_buffer(void* dev_buffer);
+/* Tests: workgroups of the last fused layer launch (tl_layer_kernel) if it walked packed rows (the live rows of policy(o') and target(o') 64 at
+ * a time, dtqn_tiled.hip TlPack), else 0. */
+int dtqn_debug_last_packed_blocks(void);
 
 /* Library self-description. */
 int dtqn_abi_version(void);

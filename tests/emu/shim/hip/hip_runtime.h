@@ -245,6 +245,13 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// streams / events of the fork-join launches (dtqn_wgrad.hip): the emulation runs every launch to completion in issue order
+typedef void* hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 template <typename F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };

@@ -129,6 +129,47 @@ def test_td_update_tiled_fused_layer_kernels(emu, kw, run, fused, monkeypatch, c
         assert names == {"layer": False, "chain": False, "ffn": True, "ffn_bwd": True, "ln_bwd": True, "qhead": True}, names
 
 
+@pytest.mark.parametrize("table", ["1", "0"])
+@pytest.mark.parametrize("adim", [0, 4])
+def test_td_update_tiled_embedding_product_table(emu, table, adim, monkeypatch, capfd):
+    """Round 6: discrete observations of a covered row-block network (d_model 128) are embedded in the TD forward from the product table
+    P[j][v] = T[v] W_e[:, slot j]^T that dtqn_td_wpack rewrites with the weight copies (tl_embed_table_kernel: O gathered rows per token);
+    DTQN_EMBED_TABLE=0 keeps the matrix product (tl_embed_kernel).  Both against the oracle, with and without an action embedding beside it,
+    over a target sync (the target's table follows theta_tgt)."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_EMBED_TABLE", table)
+    monkeypatch.setenv("DTQN_TL_TRACE", "1")
+    cfg = O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=20, discrete=True, vocab_sizes=9,
+                   action_dim=adim)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=11, batch=3, T=30, n_eps=6, mask=8, tuf=2)
+    assert net.tiled == 1
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
+    err = capfd.readouterr().err
+    assert ("tl_embed_table_kernel" in err) == (table == "1") and ("tl_launch tl_embed_kernel" in err) == (table == "0")
+
+
+@pytest.mark.parametrize("ctx,batch", [(48, 4), (96, 2)])
+def test_td_update_tiled_packed_rows_of_the_unsaved_passes(emu, ctx, batch, monkeypatch, capfd):
+    """Round 6: the q | k | v projection and the fused layer tail walk the LIVE rows of policy(o') and target(o') 64 at a time (TlPack: a
+    workgroup's rows run on from one sequence into the next; L = 48 / 96 in records of 64 / 128 rows), the training third stays on
+    (sequence, row block).  Against the oracle, and bit-identical in Q to the unpacked walk (DTQN_PACK_ROWS=0)."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_FFN_ROWS", "64")
+    cfg = O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=2, history_len=ctx, discrete=True, vocab_sizes=9)
+    qs = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("DTQN_PACK_ROWS", packed)
+        monkeypatch.setenv("DTQN_TL_TRACE", "1")
+        net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=13, batch=batch, T=ctx + 10, n_eps=6, mask=8, tuf=2)
+        assert net.tiled == 1 and net.lp > ctx
+        check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+        qs[packed] = eng.q3.clone()
+        capfd.readouterr()
+    assert torch.equal(qs["1"], qs["0"])
+    # the packed launches are shorter: 3 B LPB / 64 workgroups unpacked, B LPB / 64 + 2 B L / 64 packed (seen through the grid the shim is given)
+    assert emu.dtqn_debug_last_packed_blocks() == batch * (net.lp // 64) + 2 * batch * ctx // 64
+
+
 def test_td_update_tiled_lds_weight_gradients(emu, monkeypatch):
     """Row-block network of d_model 128 on the LARGE-batch weight-gradient path (forced at a small batch): the layer matrices and the
     first head matrix through dtqn_wgrad_lds_kernel (128 x 128 tiles, operands staged through LDS), the embedding and the last head
