@@ -126,8 +126,10 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
     // the bag branch is composed from the row-block kernels: as many bag entries as the records have rows
     if (net->bag_size > 0 && (net->bag_size > LP || !(D == 64 || D == 128 || D == 256))) return DTQN_ERR_CONFIG;
     if (net->tiled) {
-        // tiled kernels: D in {64, 128, 256}, context up to 256, attention tile q|k|v of one head in LDS
-        if (!(D == 64 || D == 128 || D == 256) || LP > 256) return DTQN_ERR_CONFIG;
+        // tiled kernels: D in {64, 128, 256}, context up to 512 (north_star's bound) as long as the attention tile q | k | v | dO of ONE head
+        // fits LDS (the test below): head widths up to 16 at 257 .. 512 rows, up to 32 at 256; wider heads at long contexts would need the
+        // K-blocked attention loop (out of scope)
+        if (!(D == 64 || D == 128 || D == 256) || LP > 512) return DTQN_ERR_CONFIG;
         const int hd = net->head_dim;                    // tl_attn_kernel / tl_attn_bwd_kernel instantiations
         if (!(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64)) return DTQN_ERR_CONFIG;
         if (((size_t)LP * (4 * net->head_dim + 4) + 2 * (size_t)LP) * sizeof(float) > 160 * 1024) return DTQN_ERR_CONFIG;

@@ -170,6 +170,24 @@ def test_td_update_tiled_packed_rows_of_the_unsaved_passes(emu, ctx, batch, monk
     assert emu.dtqn_debug_last_packed_blocks() == batch * (net.lp // 64) + 2 * batch * ctx // 64
 
 
+@pytest.mark.parametrize("ctx", [300, 512])
+def test_td_update_contexts_beyond_256(emu, ctx):
+    """north_star's bound is a 512-step context.  The row-block kernels take records of up to 512 rows as long as one head's q | k | v | dO
+    tile fits LDS: head width 16 here (68 floats per row: 139 KB at 512 rows).  One sequence, against the oracle."""
+    cfg = O.NetCfg(obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=ctx)
+    net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=9, batch=1, T=ctx + 8, n_eps=3, mask=-5)
+    assert net.tiled == 1 and net.lp == (ctx + 63) // 64 * 64
+    check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=1)
+
+
+def test_td_update_contexts_beyond_512_or_too_wide_heads_are_refused(emu):
+    from dtqn_amd import _binding as Bd
+    with pytest.raises(Exception):
+        Bd.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=513)
+    with pytest.raises(Exception):                                      # head width 32 at 512 rows: 270 KB tile
+        Bd.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, num_layers=1, history_len=400)
+
+
 def test_td_update_tiled_lds_weight_gradients(emu, monkeypatch):
     """Row-block network of d_model 128 on the LARGE-batch weight-gradient path (forced at a small batch): the layer matrices and the
     first head matrix through dtqn_wgrad_lds_kernel (128 x 128 tiles, operands staged through LDS), the embedding and the last head

@@ -55,6 +55,14 @@ CASES = [
 ]
 
 
+# contexts of 257 .. 512 steps (north_star's bound; round 6): records of up to 512 rows where one head's q | k | v | dO tile fits LDS (head width <= 16)
+CASES += [
+    (dict(obs_dim=6, num_actions=6, inner_embed_size=128, num_heads=8, history_len=384, discrete=True, vocab_sizes=12), dict(batch=2, T=400, mask=11, n_eps=4)),
+    (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=8, history_len=512, num_layers=1), dict(batch=2, T=520, mask=-5, n_eps=4, tuf=2)),
+    (dict(obs_dim=1, num_actions=5, inner_embed_size=64, num_heads=8, history_len=300, discrete=True, vocab_sizes=22, gate="gru", num_layers=1),
+     dict(batch=2, T=310, mask=21, n_eps=4)),
+]
+
 # shapes dtqn_net_init places on a larger instantiated row-tile count or sends to the row-block path (dtqn_limits.h): short contexts,
 # head_dim 32 / 64 / 4 (round 4; the same list runs on the emulation, tests/test_emu_td.py ROUTED)
 CASES += [
