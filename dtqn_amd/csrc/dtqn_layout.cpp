@@ -46,7 +46,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         // at the next instantiated head width, then whole extra heads (all-zero heads attend uniformly over zero values and contribute
         // nothing) up to the next instantiated d_model.
         const int d = net->d_model, h = net->num_heads, hd = d / h;
-        const int hdp = hd <= 4 ? 4 : hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : 64;
+        const int hdp = hd <= 4 ? 4 : hd <= 8 ? 8 : hd <= 16 ? 16 : hd <= 32 ? 32 : hd <= 64 ? 64 : 128;
         bool native = (d == 16 || d == 32 || d == 64 || d == 128 || d == 256) && hd == hdp;
         // widths 16 / 32 exist on the whole-sequence kernels only (a few row counts): beyond those they run padded to 64 columns
         if (native && d < 64 && dtqn_ws_pick(d, hd, up16(L) / 16, nullptr) == 0) native = false;
@@ -55,7 +55,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
             // (an action embedding is fine: a token is [action embedding (a) | observation embedding (D - a)], dtqn.py:192 -- the action
             //  columns come FIRST, so the real columns stay a prefix of the padded row and the padded rows of the observation Linear land
             //  behind them)
-            if (hd > 64 || dmin > 256 || net->bag_size != 0 || net->img_c > 0) return DTQN_ERR_CONFIG;      // (dropout: the keep masks are keyed by (row, REAL column), TlDrop.dw)
+            if (hd > 128 || dmin > 256 || net->bag_size != 0 || net->img_c > 0) return DTQN_ERR_CONFIG;      // (dropout: the keep masks are keyed by (row, REAL column), TlDrop.dw)
             net->d_real = d;
             net->heads_real = h;
             net->hd_real = hd;
@@ -131,7 +131,7 @@ extern "C" int dtqn_net_init(DtqnNet* net) {
         // K-blocked attention loop (out of scope)
         if (!(D == 64 || D == 128 || D == 256) || LP > 512) return DTQN_ERR_CONFIG;
         const int hd = net->head_dim;                    // tl_attn_kernel / tl_attn_bwd_kernel instantiations
-        if (!(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64)) return DTQN_ERR_CONFIG;
+        if (!(hd == 4 || hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128)) return DTQN_ERR_CONFIG;
         if (((size_t)LP * (4 * net->head_dim + 4) + 2 * (size_t)LP) * sizeof(float) > 160 * 1024) return DTQN_ERR_CONFIG;
     }
     if (A > DTQN_MAX_ACTIONS || (!net->tiled && net->kep > 3 * D)) return DTQN_ERR_CONFIG;

@@ -3,7 +3,7 @@
 #pragma once
 #define DTQN_MAX_LP 64          /* padded context rows held in LDS (ctx_len <= 64) */
 #define DTQN_MAX_D 128          /* d_model instantiations: 64, 128 (and 16/32 for tests) */
-#define DTQN_MAX_HEAD_DIM 64    /* 4 .. 64 in the row-block attention kernels; the whole-sequence kernels: 8, 16 (and 32: dtqn_ws_lite) */
+#define DTQN_MAX_HEAD_DIM 128   /* 4 .. 128 in the row-block attention kernels (128: contexts up to 64 rows, the LDS tile of one head); the whole-sequence kernels: 8, 16 (and 32: dtqn_ws_lite) */
 #define DTQN_MAX_ACTIONS 64
 #define DTQN_MAX_BAG 256        /* bag entries (bag_size <= padded context <= 256, the row-block tiled path's limit) */
 #define DTQN_THREADS 256        /* 4 wave64 per workgroup */

@@ -2681,7 +2681,7 @@ static int launch_ln_bwd(const TlLnBwdArgs& a, int S, hipStream_t stream) {
     return DTQN_OK;
 }
 // head_dim instantiations of the attention kernels (dtqn_net_init admits exactly these on the row-block path)
-#define TL_ATTN_HEAD_DIMS(X) X(4) X(8) X(16) X(32) X(64)
+#define TL_ATTN_HEAD_DIMS(X) X(4) X(8) X(16) X(32) X(64) X(128)
 static int launch_attn(const TlAttnArgs& a, int S, int H, int HD, hipStream_t stream) {
     const size_t lds = (size_t)a.lpb * (3 * HD + 4) * sizeof(float);
 #define TL_ATTN_CASE(hd)                                                                                             \

@@ -525,6 +525,8 @@ ROUTED = [
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=1, num_layers=2, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (1, 64)),  # head_dim 64: agent_utils.py's default num_heads=1
     (dict(obs_dim=3, num_actions=3, inner_embed_size=64, num_heads=16, num_layers=1, history_len=12, pos="sin"), dict(batch=2, T=20, mask=-5), (1, 64)),  # head_dim 4
     (dict(obs_dim=3, num_actions=4, inner_embed_size=128, num_heads=2, num_layers=1, history_len=70, gate="gru", action_dim=8), dict(batch=2, T=90, mask=-5), (1, 128)),  # head_dim 64
+    # head_dim 128 (round 6): `--heads 1 --in-embed 128`, agent_utils.py's default num_heads=1 at the next width; one head's tile fits LDS up to 64 rows
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=1, num_layers=1, history_len=20), dict(batch=2, T=30, mask=-5, tuf=2), (1, 64)),
 ]
 
 

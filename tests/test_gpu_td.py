@@ -92,6 +92,10 @@ CASES += [
     (dict(obs_dim=6, num_actions=5, inner_embed_size=96, num_heads=4, num_layers=1, history_len=100, discrete=True, vocab_sizes=9, pos="sin", gate="gru", action_dim=4),
      dict(batch=4, T=120, mask=8, n_eps=10)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=40, num_heads=5, num_layers=1, history_len=50, identity=True, action_dim=12), dict(batch=4, T=200, mask=-5, n_eps=12)),
+    # head width 128 (round 6): `--heads 1 --in-embed 128` (agent_utils.py's default num_heads=1), two heads at d_model 256, and a padded 96-wide head
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=1, num_layers=2, history_len=50), dict(batch=8, T=200, mask=-5, n_eps=20, tuf=2)),
+    (dict(obs_dim=6, num_actions=5, inner_embed_size=256, num_heads=2, num_layers=1, history_len=50, discrete=True, vocab_sizes=9, gate="gru"), dict(batch=4, T=60, mask=8, n_eps=10)),
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=96, num_heads=1, num_layers=1, history_len=50), dict(batch=4, T=200, mask=-5, n_eps=12)),
 ]
 
 

@@ -30,6 +30,8 @@ PADDED = [
      dict(batch=2, T=40, mask=8), (128, 4)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=8, num_layers=1, history_len=70, identity=True), dict(batch=2, T=90, mask=-5), (64, 8)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=60, num_heads=3, num_layers=1, history_len=12), dict(batch=2, T=20, mask=-5), (128, 4)),
+    # one head of 96 -> 128 columns (round 6: head width 128 exists for contexts up to 64 rows)
+    (dict(obs_dim=3, num_actions=3, inner_embed_size=96, num_heads=1, num_layers=1, history_len=12), dict(batch=2, T=20, mask=-5), (128, 1)),
     # widths 16 / 32 beyond the row counts their whole-sequence kernels exist for: padded to 64 columns with extra heads
     (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=4, num_layers=1, history_len=40), dict(batch=2, T=50, mask=-5), (64, 8)),
     (dict(obs_dim=3, num_actions=3, inner_embed_size=32, num_heads=1, num_layers=1, history_len=8), dict(batch=2, T=14, mask=-5), (64, 2)),
@@ -77,7 +79,7 @@ def test_td_update_of_a_width_padded_network(emu, kw, run, padded, family, monke
     net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=19, batch=run["batch"], T=run["T"], n_eps=6, mask=run["mask"], tuf=run.get("tuf", 10_000))
     assert (net.d_real, net.heads_real) == (cfg.inner_embed_size, cfg.num_heads) and (net.d_model, net.num_heads) == padded
     hd = cfg.inner_embed_size // cfg.num_heads
-    assert net.tiled == (0 if lite else 1) and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64) if w >= hd)
+    assert net.tiled == (0 if lite else 1) and net.hd_real == hd and net.head_dim == next(w for w in (4, 8, 16, 32, 64, 128) if w >= hd)
     if lite:
         assert net.lp == 64 and eng.net.tiled == 0 and eng.row_split == 4
     assert padding_mask(net).sum() > 0
@@ -133,7 +135,8 @@ def test_forward_on_context_prefixes(emu, family, monkeypatch):
 def test_what_padding_does_not_cover_is_refused(emu):
     ok = dict(obs_dim=3, num_actions=3, inner_embed_size=48, num_heads=6, num_layers=1, history_len=10)
     assert B.make_net(emu, **ok).d_real == 48
-    for bad in (dict(inner_embed_size=140, num_heads=2),   # head width 70: beyond the widest attention instantiation (64)
+    for bad in (dict(inner_embed_size=280, num_heads=2),   # head width 140: beyond the widest attention instantiation (128)
+                dict(inner_embed_size=140, num_heads=2, history_len=100),   # head width 70 -> 128: one head's tile fits LDS up to 64 rows only
                 dict(inner_embed_size=240, num_heads=6),   # six heads of 40 -> 64 columns each: 384 > 256
                 dict(bag_size=4),
                 dict(inner_embed_size=272, num_heads=17)):
@@ -213,7 +216,7 @@ def test_pad_and_unpad_are_inverse_on_every_tensor_kind():
     @given(st.integers(1, 6), st.integers(1, 24), st.integers(0, 3), st.sampled_from([4, 8, 16, 32, 64]), st.booleans())
     def run(H, hd, extra_heads, hdp, as_torch):
         if hdp < hd:
-            hdp = next(w for w in (4, 8, 16, 32, 64) if w >= hd)
+            hdp = next(w for w in (4, 8, 16, 32, 64, 128) if w >= hd)
         Hp, D, Dp = H + extra_heads, H * hd, (H + extra_heads) * hdp
         if D == Dp:
             return
