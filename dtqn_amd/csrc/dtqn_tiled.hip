@@ -161,6 +161,7 @@ struct TlEmbedArgs {
                                        // Only the "a one-row sequence keeps its action embedding" rule (dtqn.py:187) looks at it
     TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
     const float *ptab_a, *ptab_b;      // embedding product tables of the two parameter sets (dtqn_wpack.hpp), or nullptr: tl_embed_table_kernel
+    int n_save;                        // tl_embed_table_kernel: e_in is written for sequences [0, n_save) only (the ones the backward reads)
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
         }
         st4(xo + (size_t)rl * a.x.ld + d, v);
     }
-    if (a.ein.base != nullptr) {                                       // the embedding linear's input, for its weight gradient
+    if (a.ein.base != nullptr && s < a.n_save) {                       // the embedding linear's input, for its weight gradient
         float* eo = frow(a.ein, s, rb * TROWS);
         for (int idx = tid; idx < TROWS * KEP; idx += TNT) {
             const int rl = idx / KEP, k = idx - rl * KEP;
@@ -2780,6 +2781,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         if (net.img_c > 0 && e.pre == nullptr) return DTQN_ERR_ARG;     // image nets come through dtqn_img_encode
         e.ein = e.pre != nullptr ? nofld() : e.ein;
         e.ptab_a = wpack_etab(wplan, pk_a); e.ptab_b = wpack_etab(wplan, pk_b);
+        e.n_save = training ? (src.batch - src.seq0 > 0 ? src.batch - src.seq0 : 0) : 0;
         if (e.ptab_a != nullptr && e.ptab_b != nullptr && net.discrete && e.pre == nullptr) {
             TL_LAUNCH(tl_embed_table_kernel, dim3(S * rpb), dim3(TNT), (size_t)TROWS * net.obs_dim * sizeof(int), stream, e);
         } else {
