@@ -567,7 +567,7 @@ def test_every_accepted_shape_has_kernels(emu):
             rc = emu.dtqn_forward(ctypes.byref(net), ptr(theta), ptr(obs), ptr(act), 2, L, ptr(q), None)
         assert rc == 0, (D, H, L, net.tiled, net.lp)
         hd = D // H                 # width-padded (DtqnNet.d_real): widths and head widths without an instantiation, 16 / 32 beyond their row counts
-        assert (net.d_real > 0) == (D not in (16, 32, 64, 128, 256) or hd not in (4, 8, 16, 32, 64) or (D < 64 and net.d_model == 64)), (D, H, L)
+        assert (net.d_real > 0) == (D not in (16, 32, 64, 128, 256) or hd not in (4, 8, 16, 32, 64, 128) or (D < 64 and net.d_model == 64)), (D, H, L)
         with torch.no_grad():
             ref = O.forward(params, cfg, obs, act.long().unsqueeze(-1)).numpy()
         assert np.abs(q.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (D, H, L)
