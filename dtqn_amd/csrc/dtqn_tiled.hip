@@ -162,6 +162,8 @@ struct TlEmbedArgs {
     TlDrop drop;                       // x0 = dropout(embedding + position) (dtqn.py:195-199)
     const float *ptab_a, *ptab_b;      // embedding product tables of the two parameter sets (dtqn_wpack.hpp), or nullptr: tl_embed_table_kernel
     int n_save;                        // tl_embed_table_kernel: e_in is written for sequences [0, n_save) only (the ones the backward reads)
+    Fld qkv;                           // tl_embed_table_kernel<DQ > 0>: layer 0's q | k | v record and in_proj parameters (+ fragment-major copies)
+    const float *Wina, *Winb, *bina, *binb, *Winpa, *Winpb;
 };
 // One workgroup per (sequence, 64-row block).  The gathered input rows e_in [64][KE] (observation floats, or the
 // concatenated table rows of the observation tokens) and the embedding matrix go through LDS in K chunks of at most
@@ -325,7 +327,11 @@ __global__ __launch_bounds__(TNT) void tl_embed_kernel(TlEmbedArgs a) {
 // Discrete observations with the embedding product table of dtqn_wpack.hpp (TD forward of the covered row-block networks): the embedding of
 // a row is b + sum_j P[j][tok_j] -- O gathered 16-byte pieces per output piece, no LDS tiles, no matrix product.  One workgroup per (sequence,
 // 64-row block) like tl_embed_kernel, same outputs (x with positions and dropout, e_in for the sequences the backward reads).
-__global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
+__device__ __forceinline__ void wpack_fetch_f(float4 (&bf)[8], const float* __restrict__ Wp, int ntile, int kch, int kc, int lane);   // (below)
+// DQ > 0 (= d_model, 128 or 256): the block's embedded rows also stay in an LDS tile and layer 0's packed q | k | v projection runs on it right
+// here (qkv = x W_in^T + b_in, tl_wide_kernel's arithmetic): the projection launch and its read of x disappear.
+template <int DQ, bool PK>
+__global__ __launch_bounds__(TNT, DQ == 256 ? 2 : 4) void tl_embed_table_kernel(TlEmbedArgs a) {
     const DtqnNet& net = a.net;
     const int D = net.d_model, O = net.obs_dim, adim = net.action_dim, KE = net.ke, KEP = net.kep, n = a.n, V = net.vocab, E = net.embed_per_obs;
     const int DO = D - adim;
@@ -343,7 +349,10 @@ __global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
     const uint8_t* act_rows = a.actions != nullptr ? a.actions + (size_t)ep * a.act_ep_stride + row_first : nullptr;
     const bool single = (a.lens != nullptr ? a.lens[s] : n) == 1;
     const int tid = (int)threadIdx.x;
-    int* tokl = reinterpret_cast<int*>(dtqn_smem);                     // [64][O] clamped tokens of the block's rows
+    constexpr int LDXQ = DQ + 4, LDHQ = 128 + 4;
+    float* Xt = reinterpret_cast<float*>(dtqn_smem);                   // DQ > 0: [64][LDXQ] embedded rows | [64][LDHQ] projection staging
+    float* Hs = Xt + TROWS * LDXQ;
+    int* tokl = reinterpret_cast<int*>(DQ > 0 ? Hs + TROWS * LDHQ : Xt);      // [64][O] clamped tokens of the block's rows
     const int nrows = n - rb * TROWS < TROWS ? n - rb * TROWS : TROWS;
     for (int idx = tid; idx < TROWS * O; idx += TNT) {
         const int rl = idx / O;
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
             }
         }
         st4(xo + (size_t)rl * a.x.ld + d, v);
+        if constexpr (DQ > 0) st4(Xt + rl * LDXQ + d, v);
     }
     if (a.ein.base != nullptr && s < a.n_save) {                       // the embedding linear's input, for its weight gradient
         float* eo = frow(a.ein, s, rb * TROWS);
@@ -393,6 +403,59 @@ __global__ __launch_bounds__(TNT) void tl_embed_table_kernel(TlEmbedArgs a) {
                 v = theta[net.off_obs_tab + tokl[rl * O + j] * E + (k - j * E)];
             }
             eo[(size_t)rl * KEP + k] = v;
+        }
+    }
+    if constexpr (DQ > 0) {
+        // ---------------- layer 0's q | k | v projection on the tile ----------------
+        constexpr int KA = 128, NKA = DQ / KA, NB = 3 * DQ / 128, MT = TROWS / 16;
+        Thr t = make_thr();
+        int wc = t.wave * 16 + t.i;
+        const bool second = s >= a.split;
+        const float* __restrict__ Win = second ? a.Winb : a.Wina;
+        const float* __restrict__ Winp = second ? a.Winpb : a.Winpa;
+        const float* __restrict__ bin = second ? a.binb : a.bina;
+        auto fetchQ = [&](float4 (&bf)[8], int j, int kc) {
+            if constexpr (PK) {
+                wpack_fetch_f(bf, Winp, j * 8 + t.wave, NKA, kc, t.lane);
+                return;
+            }
+            const float* wr = Win + (size_t)(j * 128 + wc) * DQ + kc * KA + t.kq * 4;
+#pragma unroll
+            for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+        };
+        float4 bf0[8], bf1[8];
+        fetchQ(bf0, 0, 0);
+        __syncthreads();                                               // the tile is complete
+        auto blockq = [&](float4 (&cur)[8], float4 (&nxt)[8], int j) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = zero4();
+            if (NKA == 1) {
+                if (j + 1 < NB) fetchQ(nxt, j + 1, 0);
+                frag16_mma<KA, 2, 8>(Xt, LDXQ, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[0]));
+                frag16_mma<KA, 2, 8>(Xt + 32 * LDXQ, LDXQ, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[2]));
+            } else {
+                fetchQ(nxt, j, 1);
+                frag16_mma<KA, MT, 8>(Xt, LDXQ, cur, t, acc);
+                if (j + 1 < NB) fetchQ(cur, j + 1, 0);
+                frag16_mma<KA, MT, 8>(Xt + KA, LDXQ, nxt, t, acc);
+            }
+            const float bv = bin[j * 128 + wc];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Hs[(m * 16 + t.kq * 4 + r4) * LDHQ + wc] = acc[m][r4] + bv;
+            __syncthreads();
+            for (int idx = t.tid; idx < TROWS * 32; idx += TNT) {
+                const int rl = idx >> 5, c = (idx & 31) * 4;
+                st4(frow(a.qkv, s, rb * TROWS + rl) + j * 128 + c, ld4(Hs + rl * LDHQ + c));
+            }
+            __syncthreads();                                           // staging tile free for the next block
+        };
+        for (int j = 0; j < NB; ++j) {
+            { int tid_ = (int)threadIdx.x; DTQN_ASM_KEEP(tid_); t.tid = tid_; t.lane = tid_ & 63; t.wave = tid_ >> 6; t.i = t.lane & 15; t.kq = t.lane >> 4; wc = t.wave * 16 + t.i; }
+            if (NKA == 2 || (j & 1) == 0) blockq(bf0, bf1, j);
+            else blockq(bf1, bf0, j);
         }
     }
 }
@@ -1008,9 +1071,15 @@ struct TlLayerArgs {
     long long q_seq_stride;
     int q_row_stride, A, n;
     TlPack pack;                       // 64-row workgroups: packed rows of the sequences that are not saved (L == 0: none)
+    // TAIL == 2: the NEXT layer's packed q | k | v projection on the tile LayerNorm 2 leaves (its input u1): qkv = ln_out W_in^T + b_in
+    Fld qkv;
+    const float *Wina, *Winb, *bina, *binb, *Winpa, *Winpb;
 };
-template <int D, int MR, bool PK, bool HEAD>
+// TAIL: 0 nothing behind LayerNorm 2;  1 the Q head (last layer);  2 the next layer's q | k | v projection (d_model 128 / 256) -- the launch
+// of tl_wide_kernel it replaces read the same rows back from memory and ran at 0.55 of the matrix rate for want of length
+template <int D, int MR, bool PK, int TAIL>
 __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayerArgs a) {
+    constexpr bool HEAD = TAIL == 1, QKV = TAIL == 2 && (3 * D) % 128 == 0;
     constexpr int MT = MR / 16;
     constexpr int KA = D < 128 ? D : 128, NKA = D / KA, NOT = (D + 127) / 128, HID = 4 * D, NJ = HID / 128;
     constexpr int LDX = D + 4, LDH = 128 + 4;
@@ -1091,18 +1160,20 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
+            // (every multiply-add written out: the instantiations of this kernel must not differ in which products the compiler fuses --
+            //  with the plain expressions TAIL = 0 and TAIL = 2 came out one ulp apart in rstd on a few rows, 1e-5 apart in Q)
             const float p = y[j].x - mean, q = y[j].y - mean, u = y[j].z - mean, w = y[j].w - mean;
-            sq += (p * p + q * q) + (u * u + w * w);
+            sq += fmaf(p, p, q * q) + fmaf(u, u, w * w);
         }
 #pragma unroll
         for (int m = 1; m < LPR; m <<= 1) sq += __shfl_xor(sq, m);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / D) + 1e-5f);
+        const float rstd = 1.0f / sqrtf(fmaf(sq, 1.0f / D, 1e-5f));
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = part * 4 + 4 * LPR * j;
             const float4 g = ld4(gamma + c), bb = ld4(beta + c);
-            const float4 o = make_float4((y[j].x - mean) * rstd * g.x + bb.x, (y[j].y - mean) * rstd * g.y + bb.y,
-                                         (y[j].z - mean) * rstd * g.z + bb.z, (y[j].w - mean) * rstd * g.w + bb.w);
+            const float4 o = make_float4(fmaf((y[j].x - mean) * rstd, g.x, bb.x), fmaf((y[j].y - mean) * rstd, g.y, bb.y),
+                                         fmaf((y[j].z - mean) * rstd, g.z, bb.z), fmaf((y[j].w - mean) * rstd, g.w, bb.w));
             if (dst.base != nullptr) st4(frow(dst, s, row) + c, o);
             if (keep) st4(Xt + rl * LDX + c, o);
         }
@@ -1222,6 +1293,18 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
     const float* __restrict__ Wh1 = second ? a.Wh1b : a.Wh1a;
     const float* __restrict__ Wh1p = second ? a.Wh1pb : a.Wh1pa;
     if constexpr (HEAD) fetchDD(bf0, Wh1, Wh1p, 0, 0);                // in flight across the LayerNorm rows
+    const float* __restrict__ Win = second ? a.Winb : a.Wina;
+    const float* __restrict__ Winp = second ? a.Winpb : a.Winpa;
+    auto fetchQ = [&](float4 (&bf)[8], int j, int kc) {               // W_in [3D][D]: output column j * 128 + wc, contraction chunk kc
+        if constexpr (PK) {
+            wpack_fetch_f(bf, Winp, j * 8 + t.wave, NKA, kc, t.lane);
+            return;
+        }
+        const float* wr = Win + (size_t)(j * 128 + wc) * D + kc * KA + t.kq * 4;
+#pragma unroll
+        for (int q = 0; q < KA / 16; ++q) bf[q] = ld4(wr + 16 * q);
+    };
+    if constexpr (QKV) fetchQ(bf0, 0, 0);
     {
         float* mrec_o = save && a.f.m2.base != nullptr ? a.f.m2.base + (size_t)s * a.f.m2.stride : nullptr;
         const Drop fdr = tl_drop(a.f.drop, s);
@@ -1243,7 +1326,47 @@ __global__ __launch_bounds__(TNT, D <= 128 ? 4 : 2) void tl_layer_kernel(TlLayer
         }
     }
     __syncthreads();
-    ln_rows(nullptr, a.res, a.f.out, a.f.ln_st, a.f.ln_out, second ? a.f.lgb : a.f.lga, second ? a.f.lbb : a.f.lba, HEAD);
+    ln_rows(nullptr, a.res, a.f.out, a.f.ln_st, a.f.ln_out, second ? a.f.lgb : a.f.lga, second ? a.f.lbb : a.f.lba, HEAD || QKV);
+    if constexpr (QKV) {
+        // ---------------- phase 3': the next layer's q | k | v projection on the tile (its u1), one 128-column block after the other ----------------
+        __syncthreads();
+        TL_LAYER_RELAUNDER();
+        constexpr int NB = 3 * D / 128;
+        const float* __restrict__ bin = second ? a.binb : a.bina;
+        auto blockq = [&](float4 (&cur)[8], float4 (&nxt)[8], int j) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = zero4();
+            if (NKA == 1) {
+                if (j + 1 < NB) fetchQ(nxt, j + 1, 0);
+                if constexpr (KA == 128 && MT == 4) {                  // (two fragments + four accumulators + double-buffered A of four row tiles: see tl_wide_kernel)
+                    frag16_mma<KA, 2, 8>(Xt, LDX, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[0]));
+                    frag16_mma<KA, 2, 8>(Xt + 32 * LDX, LDX, cur, t, reinterpret_cast<f32x4(&)[2]>(acc[2]));
+                } else frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+            } else {
+                fetchQ(nxt, j, 1);
+                frag16_mma<KA, MT, 8>(Xt, LDX, cur, t, acc);
+                if (j + 1 < NB) fetchQ(cur, j + 1, 0);
+                frag16_mma<KA, MT, 8>(Xt + KA, LDX, nxt, t, acc);
+            }
+            const float bv = bin[j * 128 + wc];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) Hs[(m * 16 + t.kq * 4 + r4) * LDH + wc] = acc[m][r4] + bv;
+            __syncthreads();
+            for (int idx = t.tid; idx < MR * 32; idx += TNT) {
+                const int rl = idx >> 5, c = (idx & 31) * 4;
+                st4(frow_b(a.qkv, rb, rl) + j * 128 + c, ld4(Hs + rl * LDH + c));
+            }
+            __syncthreads();                                           // staging tile free for the next block
+        };
+        for (int j = 0; j < NB; ++j) {
+            TL_LAYER_RELAUNDER();
+            if (NKA == 2 || (j & 1) == 0) blockq(bf0, bf1, j);
+            else blockq(bf1, bf0, j);
+        }
+    }
     if constexpr (HEAD) {
         // ---------------- phase 3: Q head on the tile (xf) ----------------
         __syncthreads();
@@ -2622,31 +2745,47 @@ static int launch_ffn(TlFfnArgs a, int S, hipStream_t stream) {
 static int g_last_packed_blocks = 0;    // grid of the last fused-layer launch if it was a packed one, else 0 (tests: dtqn_debug_last_packed_blocks)
 // the fused layer tail: rows per workgroup by launch_ffn's rule (its long phase is the feed-forward loop)
 template <int D, int MR>
-static int launch_layer_rows(TlLayerArgs a, int nblk, bool pk, bool head, hipStream_t stream) {
+static int launch_layer_rows(TlLayerArgs a, int nblk, bool pk, int tail, hipStream_t stream) {
     constexpr int LDX = D + 4, LDH = 128 + 4;
     const size_t lds = (size_t)MR * (LDX + (LDX > LDH ? LDX : LDH)) * sizeof(float);
     a.f.skew = tl_skew_ticks(nblk, 256 * (D <= 128 ? 2 : 1), 2000, "DTQN_SKEW_LAYER");
     constexpr bool CAN = D % 128 == 0;
-    if (pk && head) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, true>), dim3(nblk), dim3(TNT), lds, stream, a);
-    else if (pk) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, false>), dim3(nblk), dim3(TNT), lds, stream, a);
-    else if (head) TL_LAUNCH((tl_layer_kernel<D, MR, false, true>), dim3(nblk), dim3(TNT), lds, stream, a);
-    else TL_LAUNCH((tl_layer_kernel<D, MR, false, false>), dim3(nblk), dim3(TNT), lds, stream, a);
+    if (tail == 2) {
+        if constexpr (CAN && MR == 64) {                               // (the projection tail exists for 64-row workgroups of d_model 128 / 256)
+            if (pk) TL_LAUNCH((tl_layer_kernel<D, MR, true, 2>), dim3(nblk), dim3(TNT), lds, stream, a);
+            else TL_LAUNCH((tl_layer_kernel<D, MR, false, 2>), dim3(nblk), dim3(TNT), lds, stream, a);
+            return DTQN_OK;
+        }
+        return DTQN_ERR_CONFIG;
+    }
+    const bool head = tail == 1;
+    if (pk && head) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, 1>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (pk) TL_LAUNCH((tl_layer_kernel<D, MR, CAN, 0>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else if (head) TL_LAUNCH((tl_layer_kernel<D, MR, false, 1>), dim3(nblk), dim3(TNT), lds, stream, a);
+    else TL_LAUNCH((tl_layer_kernel<D, MR, false, 0>), dim3(nblk), dim3(TNT), lds, stream, a);
     return DTQN_OK;
 }
+// can this launch carry the next layer's q | k | v projection? (64-row workgroups, d_model 128 / 256: launch_layer's row rule, asked in advance)
 template <int D>
-static int launch_layer(TlLayerArgs a, int S, bool head, hipStream_t stream, int nblk_rows = 0) {
+static bool layer_qkv_tail_ok(int blocks64) {
+    return D % 128 == 0 && !tl_rows32(blocks64, 256 * (D <= 128 ? 2 : 1), D, "DTQN_ROWS_FFN");
+}
+template <int D>
+static int launch_layer(TlLayerArgs a, int S, int tail, hipStream_t stream, int nblk_rows = 0) {
     const int blocks64 = S * a.f.rpb, slots = 256 * (D <= 128 ? 2 : 1);
+    const bool head = tail == 1;
     const bool pk = D % 128 == 0 && a.f.W1pa != nullptr && a.f.W1pb != nullptr && a.f.W2pa != nullptr && a.f.W2pb != nullptr &&
-                    a.Wopa != nullptr && a.Wopb != nullptr && (!head || (a.Wh1pa != nullptr && a.Wh1pb != nullptr));
+                    a.Wopa != nullptr && a.Wopb != nullptr && (!head || (a.Wh1pa != nullptr && a.Wh1pb != nullptr)) &&
+                    (tail != 2 || (a.Winpa != nullptr && a.Winpb != nullptr));
     if (tl_rows32(blocks64, slots, D, "DTQN_ROWS_FFN")) {
         a.f.rpb *= 2;
         a.pack = TlPack{0, 0, 0};
-        return launch_layer_rows<D, 32>(a, S * a.f.rpb, pk, head, stream);
+        return launch_layer_rows<D, 32>(a, S * a.f.rpb, pk, tail, stream);
     }
     g_last_packed_blocks = a.pack.L > 0 && nblk_rows > 0 ? nblk_rows : 0;
-    if (a.pack.L > 0 && nblk_rows > 0) return launch_layer_rows<D, 64>(a, nblk_rows, pk, head, stream);
+    if (a.pack.L > 0 && nblk_rows > 0) return launch_layer_rows<D, 64>(a, nblk_rows, pk, tail, stream);
     a.pack = TlPack{0, 0, 0};
-    return launch_layer_rows<D, 64>(a, S * a.f.rpb, pk, head, stream);
+    return launch_layer_rows<D, 64>(a, S * a.f.rpb, pk, tail, stream);
 }
 template <int KC>
 static int launch_dx(TlDxArgs a, int S, hipStream_t stream) {
@@ -2764,6 +2903,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     const WPackPlan wplan = (pk_a != nullptr && pk_b != nullptr) ? wpack_plan(net) : WPackPlan{};
     const int lpb = net.lp, H = net.num_heads, HD = net.head_dim, rpb = lpb / TROWS;
     const RecMap rm = rec_map(net, training);
+    bool qkv0_done = false;            // the embedding launch also ran layer 0's q | k | v projection
     const bool ident = net.identity != 0;
     int rc;
     auto F = [&](int off, int ld) { return fld(rec, rm.stride, off, ld); };
@@ -2783,7 +2923,27 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         e.ptab_a = wpack_etab(wplan, pk_a); e.ptab_b = wpack_etab(wplan, pk_b);
         e.n_save = training ? (src.batch - src.seq0 > 0 ? src.batch - src.seq0 : 0) : 0;
         if (e.ptab_a != nullptr && e.ptab_b != nullptr && net.discrete && e.pre == nullptr) {
-            TL_LAUNCH(tl_embed_table_kernel, dim3(S * rpb), dim3(TNT), (size_t)TROWS * net.obs_dim * sizeof(int), stream, e);
+            // ... with layer 0's q | k | v projection in the same launch (d_model 128 / 256, post-LN: the layer reads its own input; DTQN_EMBED_QKV=0: apart)
+            const char* eqe = getenv("DTQN_EMBED_QKV");
+            const int tb0 = net.off_layer0;
+            e.qkv = F(L0(0) + net.al_qkv, 3 * D);
+            e.Wina = theta_a + tb0 + net.lo_in_w; e.Winb = theta_b + tb0 + net.lo_in_w; e.bina = theta_a + tb0 + net.lo_in_b; e.binb = theta_b + tb0 + net.lo_in_b;
+            e.Winpa = wpack_f(wplan, pk_a, tb0 + net.lo_in_w); e.Winpb = wpack_f(wplan, pk_b, tb0 + net.lo_in_w);
+            bool with_qkv = false;
+            if constexpr (D % 128 == 0) {
+                // Measured (TD-updates/s, fused | apart): config 3 (1536 workgroups, three rounds) 588 | 585; config 4 (768: a round and a half,
+                // where the projection launch has its start skew) 993 | 998; config 5 (d_model 256, 384 workgroups on 256 slots) 564 | 568.
+                // So: d_model 128 and launches of two rounds and more; DTQN_EMBED_QKV=1 forces it wherever it exists, =0 never.
+                const bool pays = D == 128 && S * rpb >= 2 * 512;
+                if (!ident && net.num_layers > 0 && getenv("DTQN_NO_WIDE") == nullptr && (eqe != nullptr ? atoi(eqe) != 0 : pays)) {
+                    const size_t lds = ((size_t)TROWS * ((D + 4) + (128 + 4))) * sizeof(float) + (size_t)TROWS * net.obs_dim * sizeof(int);
+                    if (e.Winpa != nullptr && e.Winpb != nullptr) TL_LAUNCH((tl_embed_table_kernel<D, true>), dim3(S * rpb), dim3(TNT), lds, stream, e);
+                    else TL_LAUNCH((tl_embed_table_kernel<D, false>), dim3(S * rpb), dim3(TNT), lds, stream, e);
+                    with_qkv = true;
+                    qkv0_done = true;
+                }
+            }
+            if (!with_qkv) TL_LAUNCH((tl_embed_table_kernel<0, false>), dim3(S * rpb), dim3(TNT), (size_t)TROWS * net.obs_dim * sizeof(int), stream, e);
         } else {
         const size_t elds = tl_embed_lds(net);
         TL_LAUNCH(tl_embed_kernel, dim3(S * rpb), dim3(TNT), elds, stream, e);
@@ -2835,6 +2995,7 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
     const char* lfe = getenv("DTQN_LAYER_FUSE");
     const bool fuse_tail = !gru && !ident && !padded && net.bag_size == 0 && getenv("DTQN_NO_WIDE") == nullptr && (lfe == nullptr || atoi(lfe) != 0);
     bool head_done = false;
+    int qkv_done_for = qkv0_done ? 0 : -1;
     // sequences the backward reads: the training third of a TD update ([0, batch) of the update = [0, batch - seq0) of this launch)
     const int n_save = training ? (src.batch - src.seq0 > 0 ? src.batch - src.seq0 : 0) : 0;
     // packed rows for the rest (TlPack): DTQN_PACK_ROWS=0 keeps every workgroup on (sequence, row block)
@@ -2856,7 +3017,9 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
         // the residual stream entering the layer: post-LN keeps it in u1 itself; identity in x0 / the previous s2
         const Fld stream_in = !ident ? u1 : (l == 0 ? F(net.ao_x0, D) : F(L0(l - 1) + net.al_s2, D));
         if (ident && (rc = lnorm(stream_in, u1, st1, tb + net.lo_ln1_w, tb + net.lo_ln1_b)) != DTQN_OK) return rc;
-        if ((3 * D) % 128 == 0 && getenv("DTQN_NO_WIDE") == nullptr) {        // packed q | k | v projection: one workgroup per row block walks the column blocks
+        if (qkv_done_for == l) {
+            rc = DTQN_OK;                                                      // the previous layer's fused launch wrote this layer's q | k | v
+        } else if ((3 * D) % 128 == 0 && getenv("DTQN_NO_WIDE") == nullptr) {  // packed q | k | v projection: one workgroup per row block walks the column blocks
             TlWideArgs wa = {};
             wa.in = u1; wa.out = F(ab + net.al_qkv, 3 * D);
             wa.Wa = theta_a + tb + net.lo_in_w; wa.Wb = theta_b + tb + net.lo_in_w; wa.ba = theta_a + tb + net.lo_in_b; wa.bb = theta_b + tb + net.lo_in_b;
@@ -2909,7 +3072,17 @@ static int forward_records(const DtqnNet& net, const float* theta_a, const float
                 la.q = q_out; la.q_seq_stride = q_seq_stride; la.q_row_stride = q_row_stride; la.A = net.num_actions; la.n = n;
                 head_done = true;
             }
-            if ((rc = launch_layer<D>(la, S, head, stream, nblk_rows)) != DTQN_OK) return rc;
+            // ... or, on the other layers of d_model 128 / 256, the NEXT layer's q | k | v projection (DTQN_QKV_FUSE=0: its own launch)
+            const char* qfe = getenv("DTQN_QKV_FUSE");
+            const bool qkv_next = !last && layer_qkv_tail_ok<D>(S * rpb) && getenv("DTQN_NO_WIDE") == nullptr && (qfe == nullptr || atoi(qfe) != 0);
+            if (qkv_next) {
+                const int tbn = net.off_layer0 + (l + 1) * net.layer_stride;
+                la.qkv = F(L0(l + 1) + net.al_qkv, 3 * D);
+                la.Wina = theta_a + tbn + net.lo_in_w; la.Winb = theta_b + tbn + net.lo_in_w; la.bina = theta_a + tbn + net.lo_in_b; la.binb = theta_b + tbn + net.lo_in_b;
+                la.Winpa = wpack_f(wplan, pk_a, tbn + net.lo_in_w); la.Winpb = wpack_f(wplan, pk_b, tbn + net.lo_in_w);
+                qkv_done_for = l + 1;
+            }
+            if ((rc = launch_layer<D>(la, S, head ? 1 : (qkv_next ? 2 : 0), stream, nblk_rows)) != DTQN_OK) return rc;
             continue;
         }
         // s1 = gate(stream, relu(o W_o^T + b)), then the LayerNorm behind it

@@ -138,6 +138,7 @@ def test_td_update_tiled_embedding_product_table(emu, table, adim, monkeypatch, 
     over a target sync (the target's table follows theta_tgt)."""
     monkeypatch.setenv("DTQN_FORCE_TILED", "1")
     monkeypatch.setenv("DTQN_EMBED_TABLE", table)
+    monkeypatch.setenv("DTQN_EMBED_QKV", "1")            # (by default only launches of two rounds and more take the fused form)
     monkeypatch.setenv("DTQN_TL_TRACE", "1")
     cfg = O.NetCfg(obs_dim=6, num_actions=5, inner_embed_size=128, num_heads=8, num_layers=1, history_len=20, discrete=True, vocab_sizes=9,
                    action_dim=adim)
@@ -146,6 +147,17 @@ def test_td_update_tiled_embedding_product_table(emu, table, adim, monkeypatch, 
     check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=3)
     err = capfd.readouterr().err
     assert ("tl_embed_table_kernel" in err) == (table == "1") and ("tl_launch tl_embed_kernel" in err) == (table == "0")
+    # ... and with the table, layer 0's q | k | v projection rides in the embedding launch (d_model 128 / 256): no tl_wide_kernel launch at all
+    # in this one-layer network; DTQN_EMBED_QKV=0 keeps them apart with bit-identical Q
+    assert ("tl_wide_kernel" in err) == (table == "0")
+    if table == "1":
+        q_fused = eng.q3.clone()
+        monkeypatch.setenv("DTQN_EMBED_QKV", "0")
+        net2, oracle2, host2, eng2, rep2 = make_td_case(emu, cfg, seed=11, batch=3, T=30, n_eps=6, mask=8, tuf=2)
+        check_td_updates(cfg, net2, oracle2, host2, eng2, rep2, n_updates=3)
+        err2 = capfd.readouterr().err
+        assert "tl_wide_kernel" in err2 and "tl_embed_table_kernel<0, false>" in err2
+        assert torch.equal(eng2.q3, q_fused)
 
 
 @pytest.mark.parametrize("ctx,batch", [(48, 4), (96, 2)])
@@ -186,6 +198,26 @@ def test_td_update_contexts_beyond_512_or_too_wide_heads_are_refused(emu):
         Bd.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=4, num_layers=1, history_len=513)
     with pytest.raises(Exception):                                      # head width 32 at 512 rows: 270 KB tile
         Bd.make_net(emu, obs_dim=3, num_actions=4, inner_embed_size=64, num_heads=2, num_layers=1, history_len=400)
+
+
+def test_td_update_tiled_next_layers_projection_rides_in_the_layer_launch(emu, monkeypatch, capfd):
+    """Round 6: at d_model 128 / 256 the fused layer launch of layer l also runs layer l + 1's q | k | v projection on the tile its LayerNorm 2
+    leaves (tl_layer_kernel<..., TAIL = 2>): a two-layer forward launches tl_wide_kernel once (layer 0) instead of twice.  Against the oracle,
+    and bit-identical in Q to the separate launch (DTQN_QKV_FUSE=0)."""
+    monkeypatch.setenv("DTQN_FORCE_TILED", "1")
+    monkeypatch.setenv("DTQN_FFN_ROWS", "64")
+    monkeypatch.setenv("DTQN_TL_TRACE", "1")
+    cfg = O.NetCfg(obs_dim=3, num_actions=3, inner_embed_size=128, num_heads=8, num_layers=2, history_len=20)
+    qs, wide, tails = {}, {}, {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DTQN_QKV_FUSE", fuse)
+        net, oracle, host, eng, rep = make_td_case(emu, cfg, seed=19, batch=2, T=30, n_eps=6, mask=-5, tuf=2)
+        capfd.readouterr()
+        check_td_updates(cfg, net, oracle, host, eng, rep, n_updates=2)
+        err = capfd.readouterr().err
+        qs[fuse], wide[fuse], tails[fuse] = eng.q3.clone(), err.count("tl_launch (tl_wide_kernel"), err.count("true, 2>)") + err.count("false, 2>)")
+    assert torch.equal(qs["0"], qs["1"])
+    assert wide["0"] == 2 * wide["1"] > 0 and tails["0"] == 0 and tails["1"] == wide["1"]
 
 
 def test_td_update_tiled_lds_weight_gradients(emu, monkeypatch):
