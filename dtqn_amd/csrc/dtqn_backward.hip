@@ -267,7 +267,13 @@ __global__ __launch_bounds__(NW * 64) void dtqn_backward_kernel(BwdArgs a, Ahead
         // shapes).  At D <= 64 the hoisted addresses are the faster code even where they spill a little (measured round 3: the 16-row
         // slices of latency mode lose 2 us with the same trick, the full 64-row tile is unchanged), so those keep them.
         Thr t = t_outer;
-#define DTQN_RELAUNDER() do { if constexpr (D >= 128 && MT >= 4) { DTQN_ASM_KEEP(t.tid); DTQN_ASM_KEEP(t.lane); DTQN_ASM_KEEP(t.wave); DTQN_ASM_KEEP(t.i); DTQN_ASM_KEEP(t.kq); } } while (0)
+        // (round 6: the one-workgroup-per-sequence backward of d_model 64 -- BASELINE config 2 -- and the GRU-gated two-slice one re-derive the
+        //  coordinates from ONE opaque register instead: 148 - 624 B of scratch per lane -> 0.  Measured, us per update old | new
+        //  (tests/perf/time_ws_shapes.py): residual gate batch 192 297 | 287, 256 323 | 312 (config 2: 3 110 -> 3 228 TD-updates/s); GRU batch 96
+        //  402 | 334, 128 424 | 353, 192 642 | 580, 256 728 | 665.  The residual-gate two-slice kernels lose 0.6 % with it (188 | 189, 196 | 197)
+        //  and keep the hoisted addresses; the same in the weights-through-LDS forward also reaches 0 B and is slower (3 228 -> 3 131): not kept)
+#define DTQN_RELAUNDER() do { if constexpr (D >= 128 && MT >= 4) { DTQN_ASM_KEEP(t.tid); DTQN_ASM_KEEP(t.lane); DTQN_ASM_KEEP(t.wave); DTQN_ASM_KEEP(t.i); DTQN_ASM_KEEP(t.kq); } \
+        else if constexpr (D == 64 && MT >= 2 && NW <= 8 && (RS == 1 || (GRU && RS == 2))) { int tid_ = (int)threadIdx.x; DTQN_ASM_KEEP(tid_); t.tid = tid_; t.lane = tid_ & 63; t.wave = tid_ >> 6; t.i = t.lane & 15; t.kq = t.lane >> 4; } } while (0)
         DTQN_RELAUNDER();
         const float* __restrict__ th = layer_theta(net, theta, l);
         const float* lrec = rec + net.ao_layer0 + (size_t)l * net.act_layer_stride;
